@@ -1,0 +1,22 @@
+"""CPU oracle for the URGENT-2026 track-1 hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import anything from this package.  The product path
+(``urgent2026_challenge_track1_amd``) never does: it fails loudly when the HIP
+library is missing.
+
+Pinning status (see DESIGN.md "Oracle"): the reference delegates all arithmetic
+to un-vendored third-party packages (espnet==202412, pesq, pystoi,
+fast_bss_eval) that are absent here and holds no tests / golden vectors, so
+every module states its own pin:
+
+* ``flow_ref``  - pinned against the reference's own ``bsrnn_flowse.py``,
+  ``odes.py`` and ``sampling/`` imported in the build container
+  (``tests/golden/make_golden.py`` generated the committed vectors).
+* ``bsrnn_ref`` - architecture pinned by the parameter counts printed in
+  ``conf/models/BSRNN_baseline.yaml:30-31`` and, structurally, by the in-tree
+  twin ``bsrnn_flowse.py`` (same dual-path loop / BandSplit); numerics are
+  stock ``torch`` CPU ops.  espnet numerics themselves: parity unpinned.
+* ``stft_ref``, ``losses_ref``, ``metrics_ref``, ``pesq_ref`` - restated from
+  the published algorithms; parity unpinned by the reference.
+"""

@@ -1,0 +1,81 @@
+// Shared helpers for the liburse_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/urse.h"
+
+namespace urse {
+
+void set_error(const char* fmt, ...);
+
+#define URSE_CHECK_ARG(cond, ...)                      \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      ::urse::set_error(__VA_ARGS__);                  \
+      return URSE_ERR_INVALID_ARG;                     \
+    }                                                  \
+  } while (0)
+
+// Launch-error check: kernels are asynchronous, this only catches configuration errors.
+#define URSE_CHECK_LAUNCH(name)                                               \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      ::urse::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return URSE_ERR_LAUNCH;                                                 \
+    }                                                                         \
+  } while (0)
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  // plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950), round-to-nearest-even
+  __hip_bfloat16 b = __float2bfloat16(f);
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum (blockDim.x multiple of 64, <= 1024). `red` = >= 16 floats of LDS. All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); exact enough (<= 2 ulp f32) and safe for |x| large
+  const float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace urse

@@ -1,0 +1,55 @@
+"""Host-side operators of the hot path: thin torch.autograd wrappers over the C ABI.
+
+PyTorch supplies device memory, streams and autograd bookkeeping only; every
+arithmetic step runs in a hand-written gfx950 kernel of liburse_hip.so.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, require_cuda, stream_ptr
+
+WIN_RECT, WIN_HANN = 0, 1
+F32, BF16 = 0, 1
+
+
+def _f32c(t):
+    return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
+
+
+def stft_forward(wav, n_fft, hop, window=WIN_HANN, lens=None):
+    """espnet Stft.forward (bsrnn.py:37): wav f32 [B, L] -> complex64 [B, T, F]."""
+    require_cuda(wav)
+    wav = _f32c(wav)
+    B, L = wav.shape
+    T, Fb = L // hop + 1, n_fft // 2 + 1
+    spec = torch.empty(B, T, Fb, 2, device=wav.device, dtype=torch.float32)
+    if lens is not None:
+        lens = lens.to(device=wav.device, dtype=torch.int32).contiguous()
+    call("stft_fwd", wav, lens, spec, B, L, n_fft, hop, window, stream_ptr())
+    return torch.view_as_complex(spec)
+
+
+class _ISTFT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec_ri, n_fft, hop, length, window):
+        B, T, Fb, _ = spec_ri.shape
+        wav = torch.empty(B, length, device=spec_ri.device, dtype=torch.float32)
+        call("istft_fwd", spec_ri, wav, B, T, n_fft, hop, length, window, stream_ptr())
+        ctx.cfg = (B, T, Fb, n_fft, hop, length, window)
+        return wav
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, Fb, n_fft, hop, length, window = ctx.cfg
+        g = _f32c(g)
+        gs = torch.empty(B, T, Fb, 2, device=g.device, dtype=torch.float32)
+        call("istft_bwd", g, gs, B, T, n_fft, hop, length, window, stream_ptr())
+        return gs, None, None, None, None
+
+
+def istft_forward(spec, n_fft, hop, length, window=WIN_HANN):
+    """espnet Stft.inverse (bsrnn.py:40): complex64 [B, T, F] (or real [B,T,F,2]) -> wav f32 [B, length]."""
+    if spec.is_complex():
+        spec = torch.view_as_real(spec)
+    require_cuda(spec)
+    return _ISTFT.apply(_f32c(spec), n_fft, hop, int(length), window)
