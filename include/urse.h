@@ -56,6 +56,43 @@ int urse_istft_fwd(const float* spec, float* wav, int B, int T, int n_fft, int h
 int urse_istft_bwd(const float* grad_wav, float* grad_spec, int B, int T, int n_fft, int hop, int L_out,
                    int window, void* stream);
 
+/* ---- dense contractions on the matrix cores (bf16 or exact-f32 MFMA, f32 accumulate) ---------
+ * Stand behind cuBLAS under nn.Linear / nn.Conv1d(kernel 1) / the nn.LSTM input projection of
+ * espnet2 BSRNN (in-tree twin: baseline_code/models/bsrnn_flowse.py:66-81,296-307) and their
+ * autograd backward.  Leading dimensions are in elements; operands 16-byte aligned; K a multiple
+ * of 32 (bf16) / 16 (f32) -- callers keep zero-padded channel dims.
+ */
+/* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]) (+ resid[M,N] f32).  act: 0 none, 1 tanh. */
+int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
+                 const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K, int in_dtype, int out_dtype,
+                 int act, void* stream);
+/* grouped form: `descs` = device array of `groups` records of 12 int64
+ * {A, B, C, bias, resid, lda, ldb, ldc, M, N, K, ldr}; grid.x = max_blocks (largest tile count). */
+int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_dtype, int out_dtype, int act,
+                         void* stream);
+/* C[Mo,No] (f32) += sum_r A[r,Mo] * B'[r,No]  and optionally colsum[Mo] += sum_r A[r,:].
+ * B'[r] = B[r+shift], zero when period > 0 and ((r / inner) % period) == invalid_step
+ * (the h_{t-1} operand of the recurrent weight gradient). */
+int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
+                 int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner, int64_t period,
+                 int64_t invalid_step, int dtype, void* stream);
+
+/* ---- GroupNorm(1, C) on the channel-last activation stream -----------------------------------
+ * espnet2 choose_norm("GN") / choose_norm1d("GN") == nn.GroupNorm(1, N) (in-tree twin:
+ * baseline_code/models/bsrnn_flowse.py:291,302 norm_time / norm_freq; :119-136 decoder norms).
+ * x f32 [B, T, Kg, W]; a group = (b, kg) spans T rows of W values; channel = col % N;
+ * gamma/beta index = kg * gstride + channel.  y rows are [B*T*Kg*(W/N)][Np] (zero padded), dtype
+ * URSE_BF16 | URSE_F32.  stats / sums: f64 [B*Kg*2] scratch (sum, sum of squares). */
+int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, void* y, double* stats, int B, int T,
+                       int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* stream);
+/* dx = GN backward(dy) (+ dres); dgamma / dbeta are accumulated (+=). */
+int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, const float* gamma, const float* dres,
+                       float* dx, float* dgamma, float* dbeta, double* sums, int B, int T, int Kg, int W, int N,
+                       int gstride, float eps, void* stream);
+/* out[out_rows, out_cols] (pitch ldo) = zero-padded copy of in[rows, cols] (or its transpose), with cast. */
+int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int rows, int cols,
+                int out_rows, int out_cols, int transpose, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

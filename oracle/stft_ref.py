@@ -31,7 +31,7 @@ def stft(x, n_fft, hop, window="hann", ilens=None):
     Hann window of win_length=n_fft (``window=None`` -> rectangular).  Frames
     t >= olens[b] are zeroed when ``ilens`` is given.
     """
-    win = torch.hann_window(n_fft, dtype=x.dtype) if window == "hann" else None
+    win = torch.hann_window(n_fft, dtype=x.dtype) if window == "hann" else torch.ones(n_fft, dtype=x.dtype)
     X = torch.stft(x, n_fft, hop, n_fft, win, center=True, pad_mode="reflect",
                    normalized=False, onesided=True, return_complex=True)
     X = X.transpose(1, 2)  # [B, T, F]
@@ -46,7 +46,7 @@ def stft(x, n_fft, hop, window="hann", ilens=None):
 
 def istft(X, n_fft, hop, length, window="hann"):
     """espnet ``Stft.inverse``: X complex [B, T, F] -> wav [B, length]."""
-    win = torch.hann_window(n_fft, dtype=X.real.dtype) if window == "hann" else None
+    win = torch.hann_window(n_fft, dtype=X.real.dtype) if window == "hann" else torch.ones(n_fft, dtype=X.real.dtype)
     return torch.istft(X.transpose(1, 2), n_fft, hop, n_fft, win, center=True,
                        normalized=False, onesided=True, length=int(length))
 

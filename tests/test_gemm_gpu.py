@@ -1,0 +1,80 @@
+"""GPU parity: MFMA GEMM kernels vs float64 matmul on the same (bf16-rounded) operands."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 224), (128, 128, 32), (1000, 3136, 224), (77, 196, 800), (513, 1568, 416)])
+def test_gemm_nt(lib, dtype, M, N, K):
+    from urgent2026_challenge_track1_amd import ops
+    A, W = _mk((M, K), dtype, 1), _mk((N, K), dtype, 2)
+    bias = _mk((N,), torch.float32, 3)
+    ref = A.double() @ W.double().T + bias.double()
+    got = ops.gemm_nt(A.cuda(), W.cuda(), bias.cuda(), out_dtype=torch.float32).cpu()
+    tol = 2e-5 * (K ** 0.5) * 4
+    assert (got.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / 10)
+    # tanh + bf16 out
+    got2 = ops.gemm_nt(A.cuda(), W.cuda(), bias.cuda(), act=1, out_dtype=torch.bfloat16).cpu()
+    assert (got2.double() - torch.tanh(ref / 1.0)).abs().max().item() <= 1e-2
+    # residual epilogue (in place on an f32 stream) with a strided A view
+    res = _mk((M, N), torch.float32, 4)
+    Ap = torch.zeros(M, K + 32, dtype=dtype)
+    Ap[:, :K] = A
+    r = res.clone().cuda()
+    ops.gemm_nt(Ap.cuda()[:, :K], W.cuda(), bias.cuda(), resid=r, out=r)
+    assert (r.cpu().double() - (ref + res.double())).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / 10)
+
+
+def test_gemm_nt_identity_asymmetric(lib):
+    """A = I with an asymmetric B catches a transposed C write or fragment map."""
+    from urgent2026_challenge_track1_amd import ops
+    K = 64
+    A = torch.eye(K, dtype=torch.bfloat16)
+    W = (torch.arange(48 * K, dtype=torch.float32).reshape(48, K) % 251 - 100).to(torch.bfloat16)
+    got = ops.gemm_nt(A.cuda(), W.cuda(), out_dtype=torch.float32).cpu()
+    assert torch.equal(got, W.float().T)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("R,Mo,No", [(1000, 224, 800), (4096, 1568, 416), (333, 3136, 224), (70, 200, 40)])
+def test_gemm_tn(lib, dtype, R, Mo, No):
+    from urgent2026_challenge_track1_amd import ops
+    A, Bm = _mk((R, Mo), dtype, 5), _mk((R, No), dtype, 6)
+    ref = A.double().T @ Bm.double()
+    out = torch.zeros(Mo - 3, No - 5, device="cuda")
+    cs = torch.zeros(Mo - 3, device="cuda")
+    ops.gemm_tn(A.cuda(), Bm.cuda(), out, colsum=cs, Mo=Mo - 3, No=No - 5)
+    tol = 1e-4 * (R ** 0.5)
+    assert (out.cpu().double() - ref[:Mo - 3, :No - 5]).abs().max().item() <= tol
+    assert (cs.cpu().double() - A.double().sum(0)[:Mo - 3]).abs().max().item() <= tol
+    # accumulate semantics
+    ops.gemm_tn(A.cuda(), Bm.cuda(), out, Mo=Mo - 3, No=No - 5)
+    assert (out.cpu().double() - 2 * ref[:Mo - 3, :No - 5]).abs().max().item() <= 2 * tol
+
+
+@pytest.mark.parametrize("inner,period,rev", [(1, 10, False), (1, 10, True), (7, 10, False), (7, 10, True)])
+def test_gemm_tn_shifted_operand(lib, inner, period, rev):
+    """h_{t-1} operand: B'[r] = B[r -/+ inner], zero at the first/last step of each sequence."""
+    from urgent2026_challenge_track1_amd import ops
+    R = inner * period * 6
+    A, Bm = _mk((R, 64), torch.bfloat16, 7), _mk((R, 96), torch.bfloat16, 8)
+    step = (torch.arange(R) // inner) % period
+    Bs = torch.zeros_like(Bm)
+    if not rev:
+        Bs[inner:] = Bm[:-inner]
+        Bs[step == 0] = 0
+    else:
+        Bs[:-inner] = Bm[inner:]
+        Bs[step == period - 1] = 0
+    ref = A.double().T @ Bs.double()
+    out = torch.zeros(64, 96, device="cuda")
+    ops.gemm_tn(A.cuda(), Bm.cuda(), out, shift=(inner if rev else -inner), inner=inner, period=period,
+                invalid_step=(period - 1 if rev else 0))
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-3

@@ -1,0 +1,380 @@
+// Dense contractions of the BSRNN hot path on the CDNA4 matrix cores.
+//
+//   gemm_nt : C[M,N]  = epi( A[M,K] * B[N,K]^T )         forward projections, dgrads (weights pre-transposed)
+//   gemm_tn : C[Mo,No] += A[R,Mo]^T * B[R,No]            weight gradients (reduction over the row axis, split-R)
+//
+// Operands are bf16 (v_mfma_f32_16x16x32_bf16) or f32 (v_mfma_f32_16x16x4_f32, exact f32); accumulation
+// is always f32.  128x128 workgroup tiles, 4 waves of 64x64 (4x4 MFMA tiles), K staged through
+// double-buffered LDS in 64-byte slabs with register prefetch (one barrier per K-step).  Grouped
+// launches (one descriptor per band) serve the band-split / mask-decoder 1x1 convolutions.
+// They replace the cuBLAS calls under nn.Linear / nn.Conv1d(k=1) / nn.LSTM input projections of
+// espnet2's BSRNN (reference twin: baseline_code/models/bsrnn_flowse.py:66-81,296-307).
+#include "urse_common.h"
+
+namespace urse {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short short8_t __attribute__((ext_vector_type(8)));
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct GemmDesc {  // 12 x int64, mirrored by ops.py
+  const char* A;
+  const char* B;
+  char* C;
+  const float* bias;
+  const float* resid;
+  long lda, ldb, ldc;  // elements
+  long M, N, K;
+  long ldr;            // resid leading dim (elements)
+};
+
+constexpr int BM = 128, BN = 128;
+constexpr int SLAB = 64;      // bytes of K per LDS row
+constexpr int ROWB = 80;      // padded LDS row pitch (bytes)
+
+// bijective XCD-aware remap: blocks that share an XCD (bid % 8) get consecutive tile ids
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  typedef short8_t type;
+  static constexpr int KSUB = 1;
+  static __device__ __forceinline__ type load(const char* row, int lane, int) {
+    return *reinterpret_cast<const short8_t*>(row + 16 * (lane >> 4));
+  }
+  static __device__ __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
+                                                   0, 0, 0);
+  }
+};
+template <> struct Frag<float> {
+  typedef float type;
+  static constexpr int KSUB = 4;
+  static __device__ __forceinline__ type load(const char* row, int lane, int s) {
+    return *reinterpret_cast<const float*>(row + 16 * s + 4 * (lane >> 4));
+  }
+  static __device__ __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmDesc* __restrict__ descs, GemmDesc single, int act) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * ROWB];
+  const GemmDesc d = descs ? descs[blockIdx.z] : single;
+  const int tn = (int)((d.N + BN - 1) / BN), tm = (int)((d.M + BM - 1) / BM);
+  const int nblk = tm * tn;
+  if ((int)blockIdx.x >= nblk) return;
+  const int bid = xcd_remap(blockIdx.x, nblk);
+  const int tile_m = bid / tn, tile_n = bid - tile_m * tn;
+  const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+  constexpr int ES = sizeof(T);
+  const long Kb = d.K * ES;  // bytes of K
+  const int nk = (int)(Kb / SLAB);
+
+  auto As = [&](int buf) -> char* { return lds + buf * (BM + BN) * ROWB; };
+  auto Bs = [&](int buf) -> char* { return lds + buf * (BM + BN) * ROWB + BM * ROWB; };
+
+  // staging map: 2 chunks of A and 2 of B per thread
+  const int srow = tid >> 2, skc = tid & 3;
+  uint4 ra[2], rb[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long row = m0 + srow + 64 * i;
+      ra[i] = (row < d.M) ? *reinterpret_cast<const uint4*>(d.A + (row * d.lda) * ES + (long)kt * SLAB + skc * 16)
+                          : make_uint4(0, 0, 0, 0);
+      const long col = n0 + srow + 64 * i;
+      rb[i] = (col < d.N) ? *reinterpret_cast<const uint4*>(d.B + (col * d.ldb) * ES + (long)kt * SLAB + skc * 16)
+                          : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(As(buf) + (srow + 64 * i) * ROWB + skc * 16) = ra[i];
+      *reinterpret_cast<uint4*>(Bs(buf) + (srow + 64 * i) * ROWB + skc * 16) = rb[i];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const char* a_base = As(cur) + (wm * 64 + (lane & 15)) * ROWB;
+    const char* b_base = Bs(cur) + (wn * 64 + (lane & 15)) * ROWB;
+#pragma unroll
+    for (int s = 0; s < Frag<T>::KSUB; ++s) {
+      typename Frag<T>::type a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = Frag<T>::load(a_base + i * 16 * ROWB, lane, s);
+        b[i] = Frag<T>::load(b_base + i * 16 * ROWB, lane, s);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Frag<T>::mma(a[i], b[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  TO* C = reinterpret_cast<TO*>(d.C);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long col = n0 + wn * 64 + j * 16 + (lane & 15);
+    if (col >= d.N) continue;
+    const float bv = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (row >= d.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (act == 1) v = tanhf_(v);
+        if (d.resid) v += d.resid[row * d.ldr + col];
+        C[row * d.ldc + col] = from_f32<TO>(v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: C[Mo,No] += sum_r A[r,Mo] * Bsh[r,No],  Bsh[r] = valid(r) ? B[r+shift] : 0
+// valid(r): period == 0, or ((r / inner) % period) != invalid_step  (h_{t-1} of the first step is 0)
+constexpr int TROW_BF16 = 272;  // LDS row pitch for a [32 r][128 m] bf16 slab (256 + 16)
+constexpr int TROW_F32 = 528;   // [16 r][128 m] f32 slab (512 + 16)
+
+struct TnArgs {
+  const char* A; const char* B; float* C; float* colsum;
+  long lda, ldb, ldc;
+  long R, Mo, No;
+  long shift, inner, period, invalid_step;
+  long rows_per_slice;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs p) {
+  constexpr int ES = sizeof(T);
+  constexpr int BKR = (ES == 2) ? 32 : 16;  // rows per step
+  constexpr int PITCH = (ES == 2) ? TROW_BF16 : TROW_F32;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 32 * TROW_BF16];
+  const int tn = (int)((p.No + BN - 1) / BN);
+  const int tile_m = blockIdx.x / tn, tile_n = blockIdx.x - tile_m * tn;
+  const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
+  const long r_begin = (long)blockIdx.y * p.rows_per_slice;
+  long r_end = r_begin + p.rows_per_slice;
+  if (r_end > p.R) r_end = p.R;
+  if (r_begin >= r_end) return;
+  const int nk = (int)((r_end - r_begin + BKR - 1) / BKR);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+
+  auto As = [&](int buf) -> char* { return lds + buf * 2 * BKR * PITCH; };
+  auto Bs = [&](int buf) -> char* { return lds + buf * 2 * BKR * PITCH + BKR * PITCH; };
+
+  constexpr int CPR = BM * ES / 16;           // 16-B chunks per slab row (16 bf16 / 32 f32)
+  constexpr int NCH = BKR * CPR / 256;        // chunks per thread per operand (2 / 2)
+  uint4 ra[NCH], rb[NCH];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / CPR, mc = c - row * CPR;
+      const long r = r_begin + (long)kt * BKR + row;
+      const long ca = m0 + mc * (16 / ES), cb = n0 + mc * (16 / ES);
+      ra[i] = (r < r_end && ca < p.lda) ? *reinterpret_cast<const uint4*>(p.A + (r * p.lda + ca) * ES)
+                                        : make_uint4(0, 0, 0, 0);
+      bool ok = (r < r_end && cb < p.ldb);
+      const long rs = r + p.shift;
+      if (p.period) ok = ok && (((r / p.inner) % p.period) != p.invalid_step);
+      ok = ok && rs >= 0 && rs < p.R;
+      rb[i] = ok ? *reinterpret_cast<const uint4*>(p.B + (rs * p.ldb + cb) * ES) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / CPR, mc = c - row * CPR;
+      *reinterpret_cast<uint4*>(As(buf) + row * PITCH + mc * 16) = ra[i];
+      *reinterpret_cast<uint4*>(Bs(buf) + row * PITCH + mc * 16) = rb[i];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;
+  const bool do_colsum = (p.colsum != nullptr) && tile_n == 0 && tid < BM;
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    if (ES == 2) {
+      const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+      short8_t a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* pa = As(cur) + (8 * g + q) * PITCH + (wm * 64 + i * 16 + 4 * pp) * 2;
+        const char* pb = Bs(cur) + (8 * g + q) * PITCH + (wn * 64 + i * 16 + 4 * pp) * 2;
+        short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(pa));
+        short4_t a1 =
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(pa + 4 * PITCH));
+        short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(pb));
+        short4_t b1 =
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(pb + 4 * PITCH));
+        a[i] = short8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        b[i] = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+      if (do_colsum) {
+        const bf16_t* col = reinterpret_cast<const bf16_t*>(As(cur)) + tid;
+#pragma unroll 8
+        for (int r = 0; r < BKR; ++r) csum += bf16_to_f32(col[r * (PITCH / 2)]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float a[4], b[4];
+        const int rr = 4 * s + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = *reinterpret_cast<const float*>(As(cur) + rr * PITCH + (wm * 64 + i * 16 + (lane & 15)) * 4);
+          b[i] = *reinterpret_cast<const float*>(Bs(cur) + rr * PITCH + (wn * 64 + i * 16 + (lane & 15)) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = Frag<float>::mma(a[i], b[j], acc[i][j]);
+      }
+      if (do_colsum) {
+        const float* col = reinterpret_cast<const float*>(As(cur)) + tid;
+#pragma unroll 8
+        for (int r = 0; r < BKR; ++r) csum += col[r * (PITCH / 4)];
+      }
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long col = n0 + wn * 64 + j * 16 + (lane & 15);
+    if (col >= p.No) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (row < p.Mo) atomicAdd(p.C + row * p.ldc + col, acc[i][j][r]);
+      }
+  }
+  if (do_colsum && m0 + tid < p.Mo) atomicAdd(p.colsum + m0 + tid, csum);
+}
+
+}  // namespace urse
+
+using namespace urse;
+
+static int check_desc_host(const GemmDesc& d, int es, const char* who) {
+  URSE_CHECK_ARG(d.A && d.B && d.C, "%s: null operand", who);
+  URSE_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "%s: empty problem", who);
+  URSE_CHECK_ARG((d.K * es) % SLAB == 0, "%s: K (%ld) must be a multiple of %d elements", who, d.K, SLAB / es);
+  URSE_CHECK_ARG((d.lda * es) % 16 == 0 && (d.ldb * es) % 16 == 0 && ((uintptr_t)d.A % 16) == 0 &&
+                     ((uintptr_t)d.B % 16) == 0,
+                 "%s: operands must be 16-byte aligned with 16-byte-multiple row pitch", who);
+  URSE_CHECK_ARG(d.lda >= d.K && d.ldb >= d.K && d.ldc >= d.N, "%s: leading dimension too small", who);
+  return URSE_OK;
+}
+
+template <typename T, typename TO>
+static void launch_nt(const GemmDesc* descs, const GemmDesc& single, int groups, int max_blocks, int act,
+                      hipStream_t st) {
+  hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), dim3(max_blocks, 1, groups), dim3(256), 0, st, descs, single, act);
+}
+
+static int dispatch_nt(const GemmDesc* descs, const GemmDesc& single, int groups, int max_blocks, int in_dtype,
+                       int out_dtype, int act, hipStream_t st) {
+  if (in_dtype == URSE_BF16 && out_dtype == URSE_BF16) launch_nt<bf16_t, bf16_t>(descs, single, groups, max_blocks, act, st);
+  else if (in_dtype == URSE_BF16 && out_dtype == URSE_F32) launch_nt<bf16_t, float>(descs, single, groups, max_blocks, act, st);
+  else if (in_dtype == URSE_F32 && out_dtype == URSE_F32) launch_nt<float, float>(descs, single, groups, max_blocks, act, st);
+  else if (in_dtype == URSE_F32 && out_dtype == URSE_BF16) launch_nt<float, bf16_t>(descs, single, groups, max_blocks, act, st);
+  else { set_error("gemm_nt: bad dtype %d/%d", in_dtype, out_dtype); return URSE_ERR_INVALID_ARG; }
+  URSE_CHECK_LAUNCH("urse_gemm_nt");
+  return URSE_OK;
+}
+
+extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                            const float* bias, const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K,
+                            int in_dtype, int out_dtype, int act, void* stream) {
+  GemmDesc d;
+  d.A = (const char*)A; d.B = (const char*)B; d.C = (char*)C; d.bias = bias; d.resid = resid;
+  d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.ldr = ldr;
+  int rc = check_desc_host(d, in_dtype == URSE_BF16 ? 2 : 4, "urse_gemm_nt");
+  if (rc) return rc;
+  URSE_CHECK_ARG(!resid || out_dtype == URSE_F32, "urse_gemm_nt: residual epilogue writes f32");
+  const long blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  URSE_CHECK_ARG(blocks < (1L << 31), "urse_gemm_nt: too many tiles");
+  return dispatch_nt(nullptr, d, 1, (int)blocks, in_dtype, out_dtype, act, (hipStream_t)stream);
+}
+
+extern "C" int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_dtype, int out_dtype,
+                                    int act, void* stream) {
+  URSE_CHECK_ARG(descs && groups > 0 && max_blocks > 0, "urse_gemm_nt_grouped: bad argument");
+  GemmDesc dummy;
+  memset(&dummy, 0, sizeof(dummy));
+  return dispatch_nt((const GemmDesc*)descs, dummy, groups, max_blocks, in_dtype, out_dtype, act,
+                     (hipStream_t)stream);
+}
+
+extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                            float* colsum, int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner,
+                            int64_t period, int64_t invalid_step, int dtype, void* stream) {
+  URSE_CHECK_ARG(A && B && C && R > 0 && Mo > 0 && No > 0, "urse_gemm_tn: bad argument");
+  const int es = dtype == URSE_BF16 ? 2 : 4;
+  URSE_CHECK_ARG((lda * es) % 16 == 0 && (ldb * es) % 16 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+                 "urse_gemm_tn: operands must be 16-byte aligned with 16-byte-multiple row pitch");
+  URSE_CHECK_ARG(lda >= Mo && ldb >= No && ldc >= No, "urse_gemm_tn: leading dimension too small");
+  TnArgs p;
+  p.A = (const char*)A; p.B = (const char*)B; p.C = C; p.colsum = colsum;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.R = R; p.Mo = Mo; p.No = No;
+  p.shift = shift; p.inner = inner > 0 ? inner : 1; p.period = period; p.invalid_step = invalid_step;
+  const long tiles = ((Mo + BM - 1) / BM) * ((No + BN - 1) / BN);
+  const int bkr = dtype == URSE_BF16 ? 32 : 16;
+  long slices = (1024 + tiles - 1) / tiles;
+  const long max_slices = (R + 4 * bkr - 1) / (4 * bkr);
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  long rps = (R + slices - 1) / slices;
+  rps = (rps + bkr - 1) / bkr * bkr;
+  slices = (R + rps - 1) / rps;
+  p.rows_per_slice = rps;
+  dim3 grid((unsigned)tiles, (unsigned)slices);
+  if (dtype == URSE_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  URSE_CHECK_LAUNCH("urse_gemm_tn");
+  return URSE_OK;
+}

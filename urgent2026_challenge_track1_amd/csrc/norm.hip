@@ -1,0 +1,288 @@
+// GroupNorm(1, C) statistics / apply / backward for the channel-last activation layout, plus the
+// small packing kernels (cast + transpose + zero-pad) that feed the MFMA GEMMs.
+//
+// Activation layout: x f32 [B, T, Kg, W]; a "group" is (b, kg) and covers T rows of W contiguous
+// values (row pitch Kg*W).  The dual-path norms use Kg = 1, W = K*N (per-utterance statistics over
+// (N, T, K), espnet choose_norm("GN") == nn.GroupNorm(1, N) on [B,N,T,K]); the mask-decoder norms use
+// Kg = K, W = N (nn.GroupNorm(1, N) on [B,N,T] per band).  gamma/beta are indexed by
+// kg * gstride + (col % N).  HBM-bound: statistics are reduced with wave shuffles + f64 atomics,
+// the apply pass reads x once and writes the (bf16|f32) zero-padded GEMM operand once.
+// Reference twin: baseline_code/models/bsrnn_flowse.py:291,302 (norm_time / norm_freq), :119-136.
+#include "urse_common.h"
+
+namespace urse {
+
+struct GnShape {
+  int B, T, Kg, W, N, Np;  // Np = padded channel count of the output rows
+  int gstride;             // gamma/beta stride between kg groups (0 = shared)
+};
+
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats,
+                                                       GnShape s, int rows_per_block) {
+  __shared__ double red[8];
+  const int b = blockIdx.z, kg = blockIdx.y;
+  const int t0 = blockIdx.x * rows_per_block;
+  int t1 = t0 + rows_per_block;
+  if (t1 > s.T) t1 = s.T;
+  const long pitch = (long)s.Kg * s.W;
+  const float* base = x + ((long)b * s.T) * pitch + (long)kg * s.W;
+  const int w4 = s.W >> 2;
+  double sum = 0.0, sq = 0.0;
+  for (int t = t0; t < t1; ++t) {
+    const float4* row = reinterpret_cast<const float4*>(base + (long)t * pitch);
+    float ls = 0.f, lq = 0.f;
+    for (int i = threadIdx.x; i < w4; i += blockDim.x) {
+      const float4 v = row[i];
+      ls += (v.x + v.y) + (v.z + v.w);
+      lq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    sum += ls;
+    sq += lq;
+  }
+  sum = wave_sum_d(sum);
+  sq = wave_sum_d(sq);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[w] = sum; red[4 + w] = sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = red[0] + red[1] + red[2] + red[3], q = red[4] + red[5] + red[6] + red[7];
+    atomicAdd(stats + ((long)b * s.Kg + kg) * 2, a);
+    atomicAdd(stats + ((long)b * s.Kg + kg) * 2 + 1, q);
+  }
+}
+
+__device__ __forceinline__ void gn_mean_rstd(const double* stats, long g, double cnt, float eps, float* mean,
+                                             float* rstd) {
+  const double m = stats[g * 2] / cnt;
+  double var = stats[g * 2 + 1] / cnt - m * m;
+  if (var < 0.0) var = 0.0;
+  *mean = (float)m;
+  *rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// one thread per 4 channels of one N-vector; output rows are [B*T*Kg*(W/N)][Np]
+template <typename TO>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       TO* __restrict__ y, GnShape s, float eps) {
+  const int n4 = s.Np >> 2;
+  const long total = (long)s.B * s.T * s.Kg * (s.W / s.N) * n4;
+  const double cnt = (double)s.T * s.W;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long vec = idx / n4;
+    const int c = (int)(idx - vec * n4) * 4;
+    // vec indexes [B][T][Kg][W/N]
+    const int per_row = s.Kg * (s.W / s.N);
+    const long bt = vec / per_row;
+    const int rem = (int)(vec - bt * per_row);
+    const int kg = rem / (s.W / s.N);
+    const int b = (int)(bt / s.T);
+    TO o[4];
+    if (c < s.N) {
+      float mean, rstd;
+      gn_mean_rstd(stats, (long)b * s.Kg + kg, cnt, eps, &mean, &rstd);
+      const float4 v = *reinterpret_cast<const float4*>(x + vec * s.N + c);
+      const float* g = gamma + (long)kg * s.gstride + c;
+      const float* be = beta + (long)kg * s.gstride + c;
+      o[0] = from_f32<TO>((v.x - mean) * rstd * g[0] + be[0]);
+      o[1] = from_f32<TO>((v.y - mean) * rstd * g[1] + be[1]);
+      o[2] = from_f32<TO>((v.z - mean) * rstd * g[2] + be[2]);
+      o[3] = from_f32<TO>((v.w - mean) * rstd * g[3] + be[3]);
+    } else {
+      o[0] = o[1] = o[2] = o[3] = from_f32<TO>(0.f);
+    }
+    TO* dst = y + vec * s.Np + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j] = o[j];
+  }
+}
+
+// backward pass 1: per-group s1 = sum dy*gamma, s2 = sum dy*gamma*xhat (f64 atomics), per-channel
+// dgamma += sum dy*xhat, dbeta += sum dy (f32 atomics).  thread <-> channel, block <-> (row chunk, kg, b)
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const double* __restrict__ stats,
+                                                            const float* __restrict__ gamma, double* __restrict__ sums,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            GnShape s, float eps, int rows_per_block) {
+  __shared__ double red[8];
+  const int b = blockIdx.z, kg = blockIdx.y;
+  const int t0 = blockIdx.x * rows_per_block;
+  int t1 = t0 + rows_per_block;
+  if (t1 > s.T) t1 = s.T;
+  const long pitch = (long)s.Kg * s.W;
+  const long base = ((long)b * s.T) * pitch + (long)kg * s.W;
+  float mean, rstd;
+  gn_mean_rstd(stats, (long)b * s.Kg + kg, (double)s.T * s.W, eps, &mean, &rstd);
+  double s1 = 0.0, s2 = 0.0;
+  // each thread owns channels n = tid, tid + 256, ... (N <= 256 in practice) across all W/N vectors of a row
+  for (int n = threadIdx.x; n < s.N; n += blockDim.x) {
+    const float g = gamma[(long)kg * s.gstride + n];
+    float dg = 0.f, db = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      for (int v = 0; v < s.W; v += s.N) {
+        const long off = base + (long)t * pitch + v + n;
+        const float xh = (x[off] - mean) * rstd;
+        const float d = dy[off];
+        dg += d * xh;
+        db += d;
+        a1 += d * g;
+        a2 += d * g * xh;
+      }
+    }
+    atomicAdd(dgamma + (long)kg * s.gstride + n, dg);
+    atomicAdd(dbeta + (long)kg * s.gstride + n, db);
+    s1 += a1;
+    s2 += a2;
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[w] = s1; red[4 + w] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + ((long)b * s.Kg + kg) * 2, red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(sums + ((long)b * s.Kg + kg) * 2 + 1, red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
+// backward pass 2: dx = rstd * (gamma*dy - s1/n - xhat*s2/n) (+ dres), float4 per thread
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const double* __restrict__ stats,
+                                                           const double* __restrict__ sums,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ dres, float* __restrict__ dx,
+                                                           GnShape s, float eps) {
+  const int n4 = s.N >> 2;
+  const long total = (long)s.B * s.T * s.Kg * (s.W / s.N) * n4;
+  const double cnt = (double)s.T * s.W;
+  const int per_row = s.Kg * (s.W / s.N);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long vec = idx / n4;
+    const int c = (int)(idx - vec * n4) * 4;
+    const long bt = vec / per_row;
+    const int rem = (int)(vec - bt * per_row);
+    const int kg = rem / (s.W / s.N);
+    const int b = (int)(bt / s.T);
+    const long g = (long)b * s.Kg + kg;
+    float mean, rstd;
+    gn_mean_rstd(stats, g, cnt, eps, &mean, &rstd);
+    const float m1 = (float)(sums[g * 2] / cnt), m2 = (float)(sums[g * 2 + 1] / cnt);
+    const long off = vec * s.N + c;
+    const float4 xv = *reinterpret_cast<const float4*>(x + off);
+    const float4 dv = *reinterpret_cast<const float4*>(dy + off);
+    const float* ga = gamma + (long)kg * s.gstride + c;
+    float4 o;
+    o.x = rstd * (ga[0] * dv.x - m1 - (xv.x - mean) * rstd * m2);
+    o.y = rstd * (ga[1] * dv.y - m1 - (xv.y - mean) * rstd * m2);
+    o.z = rstd * (ga[2] * dv.z - m1 - (xv.z - mean) * rstd * m2);
+    o.w = rstd * (ga[3] * dv.w - m1 - (xv.w - mean) * rstd * m2);
+    if (dres) {
+      const float4 r = *reinterpret_cast<const float4*>(dres + off);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    *reinterpret_cast<float4*>(dx + off) = o;
+  }
+}
+
+// out[r, c] (TO, pitch ldo, zero outside [rows, cols]) = in[r, c] or in[c, r] (f32|bf16 source)
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) pack2d_kernel(const TI* __restrict__ in, long ldi, TO* __restrict__ out,
+                                                     long ldo, int rows, int cols, int out_rows, int out_cols,
+                                                     int transpose) {
+  const long total = (long)out_rows * out_cols;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / out_cols), c = (int)(idx - (long)r * out_cols);
+    float v = 0.f;
+    if (r < rows && c < cols) v = to_f32<TI>(transpose ? in[(long)c * ldi + r] : in[(long)r * ldi + c]);
+    out[(long)r * ldo + c] = from_f32<TO>(v);
+  }
+}
+
+}  // namespace urse
+
+using namespace urse;
+
+static int grid_for(long total) {
+  long g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+static int make_shape(GnShape* s, int B, int T, int Kg, int W, int N, int Np, int gstride, const char* who) {
+  URSE_CHECK_ARG(B > 0 && T > 0 && Kg > 0 && W > 0 && N > 0 && W % N == 0 && N % 4 == 0 && Np % 4 == 0 && Np >= N,
+                 "%s: bad shape B%d T%d Kg%d W%d N%d Np%d", who, B, T, Kg, W, N, Np);
+  s->B = B; s->T = T; s->Kg = Kg; s->W = W; s->N = N; s->Np = Np; s->gstride = gstride;
+  return URSE_OK;
+}
+
+extern "C" int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, void* y, double* stats,
+                                  int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype,
+                                  void* stream) {
+  GnShape s;
+  int rc = make_shape(&s, B, T, Kg, W, N, Np, gstride, "urse_groupnorm_fwd");
+  if (rc) return rc;
+  URSE_CHECK_ARG(x && gamma && beta && y && stats, "urse_groupnorm_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * B * Kg, st);
+  int nblk = ceil_div((long)T * W, 32768);  // ~32k values per block
+  if (nblk > T) nblk = T;
+  const int rpb = ceil_div(T, nblk);
+  dim3 grid(ceil_div(T, rpb), Kg, B);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, stats, s, rpb);
+  const long total = (long)B * T * Kg * (W / N) * (Np / 4);
+  if (out_dtype == URSE_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta,
+                       (bf16_t*)y, s, eps);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta,
+                       (float*)y, s, eps);
+  URSE_CHECK_LAUNCH("urse_groupnorm_fwd");
+  return URSE_OK;
+}
+
+extern "C" int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, const float* gamma,
+                                  const float* dres, float* dx, float* dgamma, float* dbeta, double* sums, int B,
+                                  int T, int Kg, int W, int N, int gstride, float eps, void* stream) {
+  GnShape s;
+  int rc = make_shape(&s, B, T, Kg, W, N, N, gstride, "urse_groupnorm_bwd");
+  if (rc) return rc;
+  URSE_CHECK_ARG(x && dy && stats && gamma && dx && dgamma && dbeta && sums, "urse_groupnorm_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * Kg, st);
+  int nblk = ceil_div((long)T * W, 32768);
+  if (nblk > T) nblk = T;
+  const int rpb = ceil_div(T, nblk);
+  dim3 grid(ceil_div(T, rpb), Kg, B);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, st, x, dy, stats, gamma, sums, dgamma, dbeta, s, eps,
+                     rpb);
+  const long total = (long)B * T * Kg * (W / N) * (N / 4);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, dy, stats, sums, gamma, dres,
+                     dx, s, eps);
+  URSE_CHECK_LAUNCH("urse_groupnorm_bwd");
+  return URSE_OK;
+}
+
+extern "C" int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int rows,
+                           int cols, int out_rows, int out_cols, int transpose, void* stream) {
+  URSE_CHECK_ARG(in && out && rows >= 0 && cols >= 0 && out_rows > 0 && out_cols > 0 && ldo >= out_cols,
+                 "urse_pack2d: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)out_rows * out_cols;
+  dim3 g(grid_for(total)), b(256);
+  if (in_dtype == URSE_F32 && out_dtype == URSE_BF16)
+    hipLaunchKernelGGL((pack2d_kernel<float, bf16_t>), g, b, 0, st, (const float*)in, (long)ldi, (bf16_t*)out,
+                       (long)ldo, rows, cols, out_rows, out_cols, transpose);
+  else if (in_dtype == URSE_F32 && out_dtype == URSE_F32)
+    hipLaunchKernelGGL((pack2d_kernel<float, float>), g, b, 0, st, (const float*)in, (long)ldi, (float*)out, (long)ldo,
+                       rows, cols, out_rows, out_cols, transpose);
+  else if (in_dtype == URSE_BF16 && out_dtype == URSE_BF16)
+    hipLaunchKernelGGL((pack2d_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)in, (long)ldi, (bf16_t*)out,
+                       (long)ldo, rows, cols, out_rows, out_cols, transpose);
+  else if (in_dtype == URSE_BF16 && out_dtype == URSE_F32)
+    hipLaunchKernelGGL((pack2d_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)in, (long)ldi, (float*)out,
+                       (long)ldo, rows, cols, out_rows, out_cols, transpose);
+  else { set_error("urse_pack2d: bad dtype"); return URSE_ERR_INVALID_ARG; }
+  URSE_CHECK_LAUNCH("urse_pack2d");
+  return URSE_OK;
+}

@@ -53,3 +53,41 @@ def istft_forward(spec, n_fft, hop, length, window=WIN_HANN):
         spec = torch.view_as_real(spec)
     require_cuda(spec)
     return _ISTFT.apply(_f32c(spec), n_fft, hop, int(length), window)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense contractions
+# ---------------------------------------------------------------------------------------------
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError("URSE GEMM operands are bf16 or f32, got %s" % t.dtype)
+
+
+def gemm_nt(A, W, bias=None, resid=None, act=0, out=None, out_dtype=None, N=None):
+    """out[M, N] = act(A[M, K] @ W[N, K]^T + bias) (+ resid).  A, W: 2-D, unit inner stride, same dtype."""
+    require_cuda(A, W)
+    M, K = A.shape
+    Nw = W.shape[0] if N is None else N
+    assert W.shape[1] == K and A.stride(1) == 1 and W.stride(1) == 1 and A.dtype == W.dtype
+    if out is None:
+        out = torch.empty(M, Nw, device=A.device, dtype=out_dtype or A.dtype)
+    assert out.stride(1) == 1
+    call("gemm_nt", A, A.stride(0), W, W.stride(0), out, out.stride(0), bias, resid,
+         0 if resid is None else resid.stride(0), M, Nw, K, _dt(A), _dt(out), act, stream_ptr())
+    return out
+
+
+def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=0, invalid_step=0):
+    """out[Mo, No] (f32) += A[R, Mo]^T @ B'[R, No]; optional colsum[Mo] += sum_r A[r]."""
+    require_cuda(A, Bm, out)
+    R = A.shape[0]
+    Mo = A.shape[1] if Mo is None else Mo
+    No = Bm.shape[1] if No is None else No
+    assert Bm.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and A.dtype == Bm.dtype
+    assert out.dtype == torch.float32 and out.stride(-1) == 1
+    call("gemm_tn", A, A.stride(0), Bm, Bm.stride(0), out, out.stride(0), colsum, R, Mo, No, shift, inner, period,
+         invalid_step, _dt(A), stream_ptr())
+    return out
