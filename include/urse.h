@@ -93,6 +93,25 @@ int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, con
 int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int rows, int cols,
                 int out_rows, int out_cols, int transpose, void* stream);
 
+/* ---- bidirectional LSTM recurrence ---------------------------------------------------------------
+ * Sequential part of nn.LSTM(N, 2N, batch_first, bidirectional) (cuDNN under espnet2 BSRNN; twin:
+ * baseline_code/models/bsrnn_flowse.py:296-299 rnn_time, :303-306 rnn_freq).  Gate order i,f,g,o.
+ * Rows of the [M, .] matrices are addressed as row(s,t) = (s/inner)*outer + s%inner + t*stride.
+ *  gx   [M, ldg>=8H]  gate pre-activations x*W_ih^T + b_ih + b_hh, direction d in cols [d*4H,(d+1)*4H);
+ *                     overwritten with the gate activations when save != 0
+ *  whh  [2][4H][Hp]   recurrent weights, K zero-padded to Hp (multiple of 32 bf16 / 16 f32, >= ceil16(H))
+ *  hout [M, ldh>=2H]  hidden states, direction d in cols [d*H,(d+1)*H)
+ *  c    [M, 2H] f32   cell states (written when save != 0)
+ *  rows16: sequences per workgroup / 16 (0 = automatic). */
+int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int64_t ldh, float* c, int H, int Hp,
+                        int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save, int dtype,
+                        int rows16, void* stream);
+/* Backward through time.  dh [M, ldd>=2H] = gradient w.r.t. hout; gates: in = saved activations,
+ * out = gradient w.r.t. the gate pre-activations; whhT [2][H][4H] = transposed recurrent weights. */
+int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT,
+                        int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int dtype,
+                        int rows16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

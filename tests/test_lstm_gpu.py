@@ -1,0 +1,79 @@
+"""GPU parity: LSTM recurrence kernels (fwd + BPTT) vs torch.nn.LSTM on CPU."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, T, K, N, path, dtype, seed=0):
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(seed)
+    H = 2 * N
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, K, N)                      # channel-last activations
+    if path == "time":
+        seqs = x.permute(0, 2, 1, 3).reshape(B * K, T, N)
+        n_seq, seq_len, inner, outer, stride = B * K, T, K, T * K, K
+    else:
+        seqs = x.reshape(B * T, K, N)
+        n_seq, seq_len, inner, outer, stride = B * T, K, 1, K, 1
+    seqs = seqs.clone().requires_grad_(True)
+    y, _ = lstm(seqs)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    if path == "time":
+        y_rows = y.detach().reshape(B, K, T, 2 * H).permute(0, 2, 1, 3).reshape(-1, 2 * H)
+        gy_rows = gy.reshape(B, K, T, 2 * H).permute(0, 2, 1, 3).reshape(-1, 2 * H)
+        gx_rows = seqs.grad.reshape(B, K, T, N).permute(0, 2, 1, 3).reshape(-1, N)
+    else:
+        y_rows, gy_rows, gx_rows = y.detach().reshape(-1, 2 * H), gy.reshape(-1, 2 * H), seqs.grad.reshape(-1, N)
+
+    dev = "cuda"
+    M = B * T * K
+    Np, Hp = ops.kpad(N, dtype), ops.kpad(ops.pad_to(H, 16), dtype)
+    xr = ops.pack2d(x.reshape(M, N).to(dev), M, Np, dtype)
+    wih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]).detach().to(dev)
+    bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach().to(dev)
+    wih_p = ops.pack2d(wih, 8 * H, Np, dtype)
+    whh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]).detach().to(dev)      # [2,4H,H]
+    whh_p = ops.pack2d(whh.reshape(8 * H, H), 8 * H, Hp, dtype)
+    whhT_p = torch.stack([ops.pack2d(whh[d], H, 4 * H, dtype, transpose=True) for d in range(2)])
+    gx = ops.gemm_nt(xr, wih_p, bias)
+    hout, c = ops.lstm_fwd(gx, whh_p, H, Hp, n_seq, seq_len, inner, outer, stride)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    err = (hout[:, :2 * H].float().cpu() - y_rows).abs().max().item()
+    assert err <= tol, ("fwd", err)
+    assert torch.all(hout[:, 2 * H:] == 0)
+
+    # backward through time
+    ldh = hout.shape[1]
+    dh = ops.pack2d(gy_rows.to(dev), M, ldh, dtype)
+    dg = ops.lstm_bwd(dh, gx, c, whhT_p, H, n_seq, seq_len, inner, outer, stride)
+    # dx = dgates @ W_ih
+    wihT_p = ops.pack2d(wih, N, 8 * H, dtype, transpose=True)
+    dx = ops.gemm_nt(dg, wihT_p, out_dtype=torch.float32)
+    scale = gx_rows.abs().max().item()
+    err = (dx.cpu() - gx_rows).abs().max().item()
+    assert err <= (3e-2 if dtype == torch.bfloat16 else 5e-5) * scale, ("dx", err, scale)
+    # weight grads
+    dwih = torch.zeros(8 * H, N, device=dev)
+    db = torch.zeros(8 * H, device=dev)
+    ops.gemm_tn(dg, xr, dwih, colsum=db, No=N)
+    ref_dwih = torch.cat([lstm.weight_ih_l0.grad, lstm.weight_ih_l0_reverse.grad])
+    ref_db = torch.cat([lstm.bias_ih_l0.grad, lstm.bias_ih_l0_reverse.grad])
+    wt = (3e-2 if dtype == torch.bfloat16 else 1e-4)
+    assert (dwih.cpu() - ref_dwih).abs().max().item() <= wt * ref_dwih.abs().max().item()
+    assert (db.cpu() - ref_db).abs().max().item() <= wt * ref_db.abs().max().item()
+    for d, (wname, inv, sh) in enumerate([("weight_hh_l0", 0, -stride), ("weight_hh_l0_reverse", seq_len - 1, stride)]):
+        dwhh = torch.zeros(4 * H, H, device=dev)
+        ops.gemm_tn(dg[:, d * 4 * H:(d + 1) * 4 * H], hout[:, d * H:(d + 1) * H], dwhh, shift=sh, inner=stride,
+                    period=seq_len, invalid_step=inv)
+        ref = getattr(lstm, wname).grad
+        assert (dwhh.cpu() - ref).abs().max().item() <= wt * ref.abs().max().item(), wname
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("path", ["time", "band"])
+@pytest.mark.parametrize("B,T,K,N", [(2, 9, 20, 16), (1, 33, 5, 24), (3, 7, 34, 196)])
+def test_lstm_fwd_bwd(lib, dtype, path, B, T, K, N):
+    _case(B, T, K, N, path, dtype)

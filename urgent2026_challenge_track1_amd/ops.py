@@ -91,3 +91,63 @@ def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=
     call("gemm_tn", A, A.stride(0), Bm, Bm.stride(0), out, out.stride(0), colsum, R, Mo, No, shift, inner, period,
          invalid_step, _dt(A), stream_ptr())
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GroupNorm / packing / LSTM recurrence (raw, non-autograd wrappers; bsrnn.py composes them)
+# ---------------------------------------------------------------------------------------------
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def kpad(n, dtype):
+    """zero-padded contraction length the MFMA GEMMs need: multiple of 32 (bf16) / 16 (f32)."""
+    return pad_to(n, 32 if dtype == torch.bfloat16 else 16)
+
+
+def pack2d(inp, out_rows, out_cols, dtype, transpose=False, out=None):
+    """zero-padded (optionally transposed) cast copy of a 2-D tensor."""
+    require_cuda(inp)
+    assert inp.dim() == 2 and inp.stride(1) == 1
+    rows, cols = (inp.shape[1], inp.shape[0]) if transpose else inp.shape
+    if out is None:
+        out = torch.empty(out_rows, out_cols, device=inp.device, dtype=dtype)
+    call("pack2d", inp, inp.stride(0), _dt(inp), out, out.stride(0), _dt(out), rows, cols, out_rows, out_cols,
+         int(transpose), stream_ptr())
+    return out
+
+
+def groupnorm_fwd(x, gamma, beta, B, T, Kg, W, N, Np, gstride, dtype, eps=1e-5):
+    """x f32 [B,T,Kg,W] -> (y [B*T*Kg*(W/N), Np] dtype, stats f64 [B*Kg*2])."""
+    require_cuda(x)
+    y = torch.empty(B * T * Kg * (W // N), Np, device=x.device, dtype=dtype)
+    stats = torch.empty(B * Kg * 2, device=x.device, dtype=torch.float64)
+    call("groupnorm_fwd", x, gamma, beta, y, stats, B, T, Kg, W, N, Np, gstride, float(eps), _dt(y), stream_ptr())
+    return y, stats
+
+
+def groupnorm_bwd(x, dy, stats, gamma, dres, dgamma, dbeta, B, T, Kg, W, N, gstride, eps=1e-5):
+    """returns dx f32 (same layout as x); dgamma/dbeta accumulated in place."""
+    dx = torch.empty_like(x)
+    sums = torch.empty(B * Kg * 2, device=x.device, dtype=torch.float64)
+    call("groupnorm_bwd", x, dy, stats, gamma, dres, dx, dgamma, dbeta, sums, B, T, Kg, W, N, gstride, float(eps),
+         stream_ptr())
+    return dx
+
+
+def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, rows16=0):
+    """gx [M, 8H] (overwritten by gate activations if save) -> (hout [M, kpad(2H)], c [M, 2H] f32)."""
+    M = gx.shape[0]
+    ldh = kpad(2 * H, gx.dtype)
+    hout = torch.zeros(M, ldh, device=gx.device, dtype=gx.dtype)
+    c = torch.empty(M, 2 * H, device=gx.device, dtype=torch.float32) if save else None
+    call("lstm_bidir_fwd", gx, gx.stride(0), whh, hout, ldh, c, H, Hp, n_seq, seq_len, inner, outer, stride,
+         int(save), _dt(gx), rows16, stream_ptr())
+    return hout, c
+
+
+def lstm_bwd(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride, rows16=0):
+    """gates (saved activations) is overwritten with d(pre-activations)."""
+    call("lstm_bidir_bwd", dh, dh.stride(0), gates, gates.stride(0), c, whhT, H, n_seq, seq_len, inner, outer, stride,
+         _dt(gates), rows16, stream_ptr())
+    return gates
