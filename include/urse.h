@@ -62,7 +62,8 @@ int urse_istft_bwd(const float* grad_wav, float* grad_spec, int B, int T, int n_
  * autograd backward.  Leading dimensions are in elements; operands 16-byte aligned; K a multiple
  * of 32 (bf16) / 16 (f32) -- callers keep zero-padded channel dims.
  */
-/* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]) (+ resid[M,N] f32).  act: 0 none, 1 tanh. */
+/* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]) (+ resid[M,N] f32).  act: 0 none, 1 tanh,
+ * 2 tanh-backward: C = (A*B^T) * (1 - h^2) with h [M,N] (output dtype) passed in the resid slot. */
 int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                  const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K, int in_dtype, int out_dtype,
                  int act, void* stream);
@@ -93,6 +94,11 @@ int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, con
 int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int rows, int cols,
                 int out_rows, int out_cols, int transpose, void* stream);
 
+/* `nseg` independent pack2d copies in one launch: segs = device int64 [nseg, 8]
+ * {in_off, in_rows, in_cols, in_ld, out_off, out_rows, out_cols, out_ld} (elements); f32 source. */
+int urse_pack_segments(const float* in, void* out, const void* segs, int nseg, int blocks_per_seg, int transpose,
+                       int out_dtype, void* stream);
+
 /* ---- bidirectional LSTM recurrence ---------------------------------------------------------------
  * Sequential part of nn.LSTM(N, 2N, batch_first, bidirectional) (cuDNN under espnet2 BSRNN; twin:
  * baseline_code/models/bsrnn_flowse.py:296-299 rnn_time, :303-306 rnn_freq).  Gate order i,f,g,o.
@@ -111,6 +117,28 @@ int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int6
 int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT,
                         int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int dtype,
                         int rows16, void* stream);
+
+/* ---- band split front end / mask-decoder back end ------------------------------------------------
+ * espnet2 BandSplit.forward and the tail of BSRNN.forward / MaskDecoder (in-tree twin
+ * baseline_code/models/bsrnn_flowse.py:63-86 and :311-315).  `bands` is an int32 [K, 8] table
+ * {f0, sb, xoff, xpad, goff, poff, ppad, 0}: first bin, width, column offset / padded width of the band in
+ * the xnb operand, offset into the concatenated norm gamma/beta, column offset / padded width in `pre`. */
+/* spec c64 [B,T,F] -> xnb [B*T, ldx]: per-band GroupNorm(1, 2*sb) (zero padded band tail), GEMM-ready. */
+int urse_bandsplit_norm_fwd(const float* spec, const int32_t* bands, const float* gamma, const float* beta, void* xnb,
+                            double* stats, int B, int T, int F, int K, int ldx, float eps, int out_dtype,
+                            void* stream);
+/* dgamma / dbeta (+=) of the band norms from dxnb f32 [B*T, ldx]. */
+int urse_bandsplit_norm_bwd(const float* spec, const float* dxnb, const int32_t* bands, const double* stats,
+                            float* dgamma, float* dbeta, int B, int T, int F, int K, int ldx, float eps,
+                            void* stream);
+/* out = GLU(pre_m) * x + GLU(pre_r)  (complex); pre_* f32 [rows, ldp]; f2k int32 [F] bin -> band (-1 none). */
+int urse_glu_mask_apply_fwd(const float* pre_m, const float* pre_r, const float* x, float* out,
+                            const int32_t* bands, const int32_t* f2k, int64_t rows, int F, int ldp, void* stream);
+int urse_glu_mask_apply_bwd(const float* pre_m, const float* pre_r, const float* x, const float* dout, void* dpre_m,
+                            void* dpre_r, const int32_t* bands, const int32_t* f2k, int64_t rows, int F, int ldp,
+                            int out_dtype, void* stream);
+/* y = a*x + b*y (f32). */
+int urse_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

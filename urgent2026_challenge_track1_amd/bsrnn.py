@@ -1,0 +1,608 @@
+"""BSRNN_SE on MI355X: the reference's nn.Module surface over the hand-written HIP kernels.
+
+Mirrors ``baseline_code/models/bsrnn.py:9-41`` (``BSRNN_SE(num_channel, num_layer)`` with
+sub-modules ``encoder`` / ``decoder`` / ``bsrnn`` and ``forward(speech_mix, speech_lengths, fs)
+-> (enhanced_wav, enhanced_feature)``) and the espnet2 ``BSRNNSeparator`` parameter tree it wraps
+(``bsrnn.bsrnn.{band_split,norm_time,rnn_time,fc_time,norm_freq,rnn_freq,fc_freq,mask_decoder}``),
+so reference checkpoints load by name.  The torch modules below are parameter CONTAINERS only:
+their ``forward`` is never called.  All parameters are views into one flat f32 buffer (and one
+flat gradient buffer) so the fused optimizer and the bucketed RCCL all-reduce see contiguous
+memory; activations are channel-last ``[B, T, K, N]``.
+
+Every arithmetic step is a kernel of liburse_hip.so; torch only allocates, views and records
+the autograd graph (custom Functions whose backward writes parameter gradients straight into
+the flat gradient buffer).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import call, stream_ptr
+
+SUBBANDS_481 = tuple([5] + [4] * 19 + [10] * 6 + [40] * 7 + [60])   # reference bsrnn_flowse.py:29
+GN_EPS = 1e-5
+
+
+def _ptr(t, off_elems=0):
+    return t.data_ptr() + off_elems * t.element_size()
+
+
+class _PackPlan:
+    """A set of (cast + pad [+ transpose]) copies from the flat parameter buffer, run as ONE launch."""
+
+    def __init__(self, transpose):
+        self.transpose = transpose
+        self.segs = []
+        self.size = 0
+        self._table = None
+        self._out = {}
+
+    def add(self, in_off, in_rows, in_cols, out_rows, out_cols):
+        off = self.size
+        self.segs.append([in_off, in_rows, in_cols, in_cols, off, out_rows, out_cols, out_cols])
+        self.size += (out_rows * out_cols + 31) // 32 * 32
+        return (off, out_rows, out_cols)
+
+    def run(self, flat, dtype):
+        if not self.segs:
+            return None
+        if self._table is None or self._table.device != flat.device:
+            self._table = torch.tensor(self.segs, dtype=torch.int64, device=flat.device)
+        key = (dtype, flat.device)
+        if key not in self._out:
+            self._out[key] = torch.empty(self.size, dtype=dtype, device=flat.device)
+        out = self._out[key]
+        big = max(s[5] * s[6] for s in self.segs)
+        call("pack_segments", flat, out, self._table, len(self.segs), max(1, min(64, (big + 2047) // 2048)),
+             int(self.transpose), ops._dt(out), stream_ptr())
+        return out
+
+
+def _view(buf, h):
+    off, r, c = h
+    return buf[off:off + r * c].view(r, c)
+
+
+def _descs(rows, device):
+    return torch.tensor(rows, dtype=torch.int64, device=device)
+
+
+def _tiles(M, N):
+    return ((M + 127) // 128) * ((N + 127) // 128)
+
+
+class BSRNNCore(nn.Module):
+    """espnet2 ``BSRNN`` (band split -> L x dual-path BLSTM -> mask decoder -> m*x + r), HIP-backed."""
+
+    def __init__(self, input_dim=481, num_channel=16, num_layer=6, target_fs=48000, causal=False, num_spk=1,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        if causal or num_spk != 1:
+            raise NotImplementedError("the reference uses causal=False, num_spk=1 (models/bsrnn.py:27-34)")
+        if not (input_dim == 481 and target_fs == 48000):
+            raise NotImplementedError("band table defined for input_dim=481 @ 48 kHz (bsrnn_flowse.py:23-40)")
+        if num_channel % 4:
+            raise ValueError("num_channel must be a multiple of 4")
+        self.subbands = SUBBANDS_481
+        self.input_dim, self.N, self.H, self.num_layer = input_dim, num_channel, 2 * num_channel, num_layer
+        self.compute_dtype = compute_dtype
+        N, H = self.N, self.H
+        # ---- parameter containers with the espnet names -----------------------------------------
+        bs = nn.Module()
+        bs.norm = nn.ModuleList([nn.GroupNorm(1, 2 * sb) for sb in self.subbands])
+        bs.fc = nn.ModuleList([nn.Conv1d(2 * sb, N, 1) for sb in self.subbands])
+        self.band_split = bs
+        self.norm_time = nn.ModuleList([nn.GroupNorm(1, N) for _ in range(num_layer)])
+        self.rnn_time = nn.ModuleList([nn.LSTM(N, H, batch_first=True, bidirectional=True) for _ in range(num_layer)])
+        self.fc_time = nn.ModuleList([nn.Linear(2 * H, N) for _ in range(num_layer)])
+        self.norm_freq = nn.ModuleList([nn.GroupNorm(1, N) for _ in range(num_layer)])
+        self.rnn_freq = nn.ModuleList([nn.LSTM(N, H, batch_first=True, bidirectional=True) for _ in range(num_layer)])
+        self.fc_freq = nn.ModuleList([nn.Linear(2 * H, N) for _ in range(num_layer)])
+        md = nn.Module()
+        mk = lambda sb: nn.Sequential(nn.GroupNorm(1, N), nn.Conv1d(N, 4 * N, 1), nn.Tanh(),
+                                      nn.Conv1d(4 * N, 4 * sb, 1), nn.GLU(dim=1))
+        md.mlp_mask = nn.ModuleList([mk(sb) for sb in self.subbands])
+        md.mlp_residual = nn.ModuleList([mk(sb) for sb in self.subbands])
+        self.mask_decoder = md
+        self._flat = None
+        self._flat_grad = None
+        self._off = {}
+        self._plans = None
+        self._tables = {}
+        self._packed = None
+        self._packed_version = -1
+        self.param_version = 0          # bumped by the optimizer after every update
+        self.grad_ready_hook = None     # callable(tag) fired when a parameter group's grads are final
+
+    # ------------------------------------------------------------------------------------------
+    # flat parameter / gradient buffers
+    # ------------------------------------------------------------------------------------------
+    def _ordered_params(self):
+        """Flat layout: groups that the kernels read as one matrix are made contiguous."""
+        bs, md, L = self.band_split, self.mask_decoder, self.num_layer
+        order = []
+        order += [("bs.gamma", [m.weight for m in bs.norm]), ("bs.beta", [m.bias for m in bs.norm]),
+                  ("bs.w", [m.weight for m in bs.fc]), ("bs.b", [m.bias for m in bs.fc])]
+        for l in range(L):
+            for path, norm, rnn, fc in (("t", self.norm_time[l], self.rnn_time[l], self.fc_time[l]),
+                                        ("f", self.norm_freq[l], self.rnn_freq[l], self.fc_freq[l])):
+                p = "l%d%s." % (l, path)
+                order += [(p + "gamma", [norm.weight]), (p + "beta", [norm.bias]),
+                          (p + "wih", [rnn.weight_ih_l0, rnn.weight_ih_l0_reverse]),
+                          (p + "bih", [rnn.bias_ih_l0, rnn.bias_ih_l0_reverse]),
+                          (p + "bhh", [rnn.bias_hh_l0, rnn.bias_hh_l0_reverse]),
+                          (p + "whh", [rnn.weight_hh_l0, rnn.weight_hh_l0_reverse]),
+                          (p + "wfc", [fc.weight]), (p + "bfc", [fc.bias])]
+        for tag, mlps in (("m", md.mlp_mask), ("r", md.mlp_residual)):
+            p = "md%s." % tag
+            order += [(p + "gamma", [s[0].weight for s in mlps]), (p + "beta", [s[0].bias for s in mlps]),
+                      (p + "w1", [s[1].weight for s in mlps]), (p + "b1", [s[1].bias for s in mlps]),
+                      (p + "w2", [s[3].weight for s in mlps]), (p + "b2", [s[3].bias for s in mlps])]
+        return order
+
+    def _ensure_flat(self):
+        first = next(self.parameters())
+        if self._flat is not None and self._flat.device == first.device and \
+                first.data_ptr() == self._flat.data_ptr() + 4 * self._first_off:
+            return
+        order = self._ordered_params()
+        total = 0
+        offs = {}
+        plist = []
+        for name, ps in order:
+            total = (total + 3) // 4 * 4          # 16-byte aligned group starts
+            offs[name] = total
+            for p in ps:
+                plist.append((p, total))
+                total += p.numel()
+        assert len(plist) == len(list(self.parameters()))
+        flat = torch.zeros(total, dtype=torch.float32, device=first.device)
+        grad = torch.zeros(total, dtype=torch.float32, device=first.device)
+        with torch.no_grad():
+            for p, o in plist:
+                flat[o:o + p.numel()].copy_(p.data.reshape(-1).float())
+                p.data = flat[o:o + p.numel()].view(p.shape)
+                p.grad = grad[o:o + p.numel()].view(p.shape)
+        self._flat, self._flat_grad, self._off = flat, grad, offs
+        self._first_off = [o for p, o in plist if p is first][0]
+        self._plans = None
+        self._packed_version = -1
+        self._tables = {}
+
+    @property
+    def flat_params(self):
+        self._ensure_flat()
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        self._ensure_flat()
+        return self._flat_grad
+
+    def grad_groups(self):
+        """[(tag, offset, numel)] in the order backward completes them (for bucketed all-reduce)."""
+        self._ensure_flat()
+        names = list(self._off.keys())
+        ends = [self._off[n] for n in names[1:]] + [self._flat.numel()]
+        spans = {n: (self._off[n], e - self._off[n]) for n, e in zip(names, ends)}
+        groups = []
+
+        def span(prefix):
+            ns = [n for n in names if n.startswith(prefix)]
+            lo = min(spans[n][0] for n in ns)
+            hi = max(spans[n][0] + spans[n][1] for n in ns)
+            return lo, hi - lo
+        groups.append(("md",) + span("md"))
+        for l in reversed(range(self.num_layer)):
+            groups.append(("l%df" % l,) + span("l%df." % l))
+            groups.append(("l%dt" % l,) + span("l%dt." % l))
+        groups.append(("bs",) + span("bs."))
+        return groups
+
+    def _g(self, name, numel=None, off=0):
+        o = self._off[name] + off
+        n = numel if numel is not None else 0
+        return self._flat_grad[o:o + n] if numel is not None else self._flat_grad[o:]
+
+    def _p(self, name, numel, off=0):
+        o = self._off[name] + off
+        return self._flat[o:o + numel]
+
+    def _ready(self, tag):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(tag)
+
+    # ------------------------------------------------------------------------------------------
+    # static tables / packed weights
+    # ------------------------------------------------------------------------------------------
+    def _build_plans(self, dtype):
+        N, H = self.N, self.H
+        Np, Hp = ops.kpad(N, dtype), ops.kpad(ops.pad_to(H, 16), dtype)
+        ld2H, ld4N = ops.kpad(2 * H, dtype), ops.kpad(4 * N, dtype)
+        pn, pt = _PackPlan(False), _PackPlan(True)
+        h = {}
+        o = self._off
+        f0 = 0
+        w_off = 0
+        for k, sb in enumerate(self.subbands):
+            xpad = ops.kpad(2 * sb, dtype)
+            h["bs.w", k] = pn.add(o["bs.w"] + w_off, N, 2 * sb, N, xpad)
+            h["bs.wT", k] = pt.add(o["bs.w"] + w_off, N, 2 * sb, 2 * sb, Np)
+            w_off += N * 2 * sb
+            f0 += sb
+        for l in range(self.num_layer):
+            for path in "tf":
+                p = "l%d%s." % (l, path)
+                h[p + "wih"] = pn.add(o[p + "wih"], 8 * H, N, 8 * H, Np)
+                h[p + "wihT"] = pt.add(o[p + "wih"], 8 * H, N, N, 8 * H)
+                h[p + "whh"] = pn.add(o[p + "whh"], 8 * H, H, 8 * H, Hp)
+                h[p + "whhT0"] = pt.add(o[p + "whh"], 4 * H, H, H, 4 * H)
+                h[p + "whhT1"] = pt.add(o[p + "whh"] + 4 * H * H, 4 * H, H, H, 4 * H)
+                h[p + "wfc"] = pn.add(o[p + "wfc"], N, 2 * H, N, ld2H)
+                h[p + "wfcT"] = pt.add(o[p + "wfc"], N, 2 * H, 2 * H, Np)
+        for tag in "mr":
+            p = "md%s." % tag
+            w2_off = 0
+            for k, sb in enumerate(self.subbands):
+                ppad = ops.kpad(4 * sb, dtype)
+                h[p + "w1", k] = pn.add(o[p + "w1"] + k * 4 * N * N, 4 * N, N, 4 * N, Np)
+                h[p + "w1T", k] = pt.add(o[p + "w1"] + k * 4 * N * N, 4 * N, N, N, ld4N)
+                h[p + "w2", k] = pn.add(o[p + "w2"] + w2_off, 4 * sb, 4 * N, 4 * sb, ld4N)
+                h[p + "w2T", k] = pt.add(o[p + "w2"] + w2_off, 4 * sb, 4 * N, 4 * N, ppad)
+                w2_off += 4 * sb * 4 * N
+        self._plans = (dtype, pn, pt, h)
+        self._dims = dict(Np=Np, Hp=Hp, ld2H=ld2H, ld4N=ld4N)
+
+    def _prepare(self):
+        """(re)pack the GEMM operands from the f32 master weights; once per parameter version."""
+        self._ensure_flat()
+        dtype = self.compute_dtype
+        if self._plans is None or self._plans[0] != dtype:
+            self._build_plans(dtype)
+            self._packed_version = -1
+        if self._packed_version == self.param_version:
+            return
+        _, pn, pt, h = self._plans
+        bn, bt = pn.run(self._flat, dtype), pt.run(self._flat, dtype)
+        H = self.H
+        pk = {}
+        for key, hd in h.items():
+            name = key[0] if isinstance(key, tuple) else key
+            pk[key] = _view(bt if name.endswith("T") or name.endswith("T0") or name.endswith("T1") else bn, hd)
+        bias = torch.empty(self.num_layer * 2, 8 * H, dtype=torch.float32, device=self._flat.device)
+        i = 0
+        for l in range(self.num_layer):
+            for path in "tf":
+                p = "l%d%s." % (l, path)
+                call("axpby", self._p(p + "bih", 8 * H), bias[i], 1.0, 0.0, 8 * H, stream_ptr())
+                call("axpby", self._p(p + "bhh", 8 * H), bias[i], 1.0, 1.0, 8 * H, stream_ptr())
+                pk[p + "bias"] = bias[i]
+                i += 1
+        self._packed = pk
+        self._packed_version = self.param_version
+
+    def _band_tables(self, F, dtype, device):
+        key = (F, dtype, device)
+        if key in self._tables:
+            return self._tables[key]
+        rows, f2k = [], [-1] * F
+        f0 = xoff = poff = 0
+        K = 0
+        for k, sb in enumerate(self.subbands):
+            xpad, ppad = ops.kpad(2 * sb, dtype), ops.kpad(4 * sb, dtype)
+            rows.append([f0, sb, xoff, xpad, 2 * f0, poff, ppad, 0])
+            for f in range(f0, min(F, f0 + sb)):
+                f2k[f] = k
+            f0 += sb
+            xoff += xpad
+            poff += ppad
+            K = k + 1
+            if f0 >= F:
+                break
+        tb = dict(K=K, rows=rows, ldx=xoff, P=poff,
+                  bands=torch.tensor(rows, dtype=torch.int32, device=device),
+                  f2k=torch.tensor(f2k, dtype=torch.int32, device=device))
+        self._tables[key] = tb
+        return tb
+
+    # ------------------------------------------------------------------------------------------
+    # band split
+    # ------------------------------------------------------------------------------------------
+    def bandsplit_fwd(self, spec):
+        B, T, F, _ = spec.shape
+        dt, dev, N = self.compute_dtype, spec.device, self.N
+        tb = self._band_tables(F, dt, dev)
+        K, pk = tb["K"], self._packed
+        n_gb = 2 * sum(self.subbands)
+        xnb = torch.empty(B * T, tb["ldx"], dtype=dt, device=dev)
+        stats = torch.empty(B * K * 2, dtype=torch.float64, device=dev)
+        call("bandsplit_norm_fwd", spec, tb["bands"], self._p("bs.gamma", n_gb), self._p("bs.beta", n_gb), xnb, stats,
+             B, T, F, K, tb["ldx"], GN_EPS, ops._dt(xnb), stream_ptr())
+        z = torch.empty(B, T, K, N, dtype=torch.float32, device=dev)
+        M = B * T
+        rows = []
+        for k in range(K):
+            r = tb["rows"][k]
+            w = pk["bs.w", k]
+            rows.append([_ptr(xnb, r[2]), _ptr(w), _ptr(z, k * N), _ptr(self._flat, self._off["bs.b"] + k * N), 0,
+                         tb["ldx"], w.shape[1], K * N, M, N, r[3], 0])
+        call("gemm_nt_grouped", _descs(rows, dev), K, _tiles(M, N), ops._dt(xnb), ops.F32, 0, stream_ptr())
+        return z, (xnb, stats, tb)
+
+    def bandsplit_bwd(self, spec, saved, dz):
+        xnb, stats, tb = saved
+        B, T, F, _ = spec.shape
+        dt, dev, N = self.compute_dtype, spec.device, self.N
+        K, pk, Np = tb["K"], self._packed, self._dims["Np"]
+        M = B * T
+        dzT = ops.pack2d(dz.reshape(M * K, N), M * K, Np, dt)
+        dxnb = torch.empty(M, tb["ldx"], dtype=torch.float32, device=dev)
+        rows = []
+        w_off = 0
+        for k in range(K):
+            r = tb["rows"][k]
+            sb = r[1]
+            a = dzT.view(M, K * Np)[:, k * Np:(k + 1) * Np]
+            gw = self._g("bs.w", N * 2 * sb, w_off).view(N, 2 * sb)
+            ops.gemm_tn(a, xnb[:, r[2]:r[2] + r[3]], gw, colsum=self._g("bs.b", N, k * N), Mo=N, No=2 * sb)
+            wT = pk["bs.wT", k]
+            rows.append([_ptr(dzT, k * Np), _ptr(wT), _ptr(dxnb, r[2]), 0, 0, K * Np, Np, tb["ldx"], M, 2 * sb, Np, 0])
+            w_off += N * 2 * sb
+        call("gemm_nt_grouped", _descs(rows, dev), K, _tiles(M, 128), ops._dt(dzT), ops.F32, 0, stream_ptr())
+        n_gb = 2 * sum(self.subbands)
+        call("bandsplit_norm_bwd", spec, dxnb, tb["bands"], stats, self._g("bs.gamma", n_gb), self._g("bs.beta", n_gb),
+             B, T, F, K, tb["ldx"], GN_EPS, stream_ptr())
+        self._ready("bs")
+
+    # ------------------------------------------------------------------------------------------
+    # dual-path half layer: GN -> BLSTM -> Linear -> +skip   (time: sequences along T, band: along K)
+    # ------------------------------------------------------------------------------------------
+    def _seqmap(self, path, B, T, K):
+        if path == "t":
+            return dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+        return dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+
+    def dualpath_fwd(self, skip, l, path, save):
+        B, T, K, N = skip.shape
+        H, dt, pk, d = self.H, self.compute_dtype, self._packed, self._dims
+        p = "l%d%s." % (l, path)
+        M = B * T * K
+        xn, stats = ops.groupnorm_fwd(skip, self._p(p + "gamma", N), self._p(p + "beta", N), B, T, 1, K * N, N,
+                                      d["Np"], 0, dt, GN_EPS)
+        gx = ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
+        sm = self._seqmap(path, B, T, K)
+        hout, c = ops.lstm_fwd(gx, pk[p + "whh"], H, d["Hp"], save=save, **sm)
+        out = torch.empty_like(skip)
+        ops.gemm_nt(hout, pk[p + "wfc"], self._p(p + "bfc", N), resid=skip.view(M, N), out=out.view(M, N))
+        return out, ((stats, xn, gx, c, hout) if save else None)
+
+    def dualpath_bwd(self, skip, saved, l, path, dout):
+        stats, xn, gates, c, hout = saved
+        B, T, K, N = skip.shape
+        H, dt, pk, d = self.H, self.compute_dtype, self._packed, self._dims
+        p = "l%d%s." % (l, path)
+        M = B * T * K
+        dout2 = dout.reshape(M, N)
+        doT = ops.pack2d(dout2, M, d["Np"], dt)
+        dh = torch.empty(M, d["ld2H"], dtype=dt, device=skip.device)
+        ops.gemm_nt(doT, pk[p + "wfcT"], out=dh, N=2 * H)
+        ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N,
+                    No=2 * H)
+        sm = self._seqmap(path, B, T, K)
+        whhT = pk[p + "whhT0"]  # whhT0 / whhT1 are adjacent blocks of the transposed-pack buffer: [2][H][4H]
+        dg = ops.lstm_bwd(dh, gates, c, whhT, H, **sm)
+        gb = self._g(p + "bih", 8 * H)
+        ops.gemm_tn(dg, xn, self._g(p + "wih", 8 * H * N).view(8 * H, N), colsum=gb, Mo=8 * H, No=N)
+        call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())
+        st, L = sm["stride"], sm["seq_len"]
+        for dr, (sh, inv) in enumerate(((-st, 0), (st, L - 1))):
+            ops.gemm_tn(dg[:, dr * 4 * H:(dr + 1) * 4 * H], hout[:, dr * H:(dr + 1) * H],
+                        self._g(p + "whh", 4 * H * H, dr * 4 * H * H).view(4 * H, H), Mo=4 * H, No=H, shift=sh,
+                        inner=st, period=L, invalid_step=inv)
+        dxn = ops.gemm_nt(dg, pk[p + "wihT"], out_dtype=torch.float32, N=N)
+        dskip = ops.groupnorm_bwd(skip, dxn, stats, self._p(p + "gamma", N), dout, self._g(p + "gamma", N),
+                                  self._g(p + "beta", N), B, T, 1, K * N, N, 0, GN_EPS)
+        self._ready("l%d%s" % (l, path))
+        return dskip
+
+    # ------------------------------------------------------------------------------------------
+    # mask decoder + complex mask apply
+    # ------------------------------------------------------------------------------------------
+    def maskdec_fwd(self, skip, spec, save):
+        B, T, K, N = skip.shape
+        F = spec.shape[2]
+        dt, dev, pk, d = self.compute_dtype, skip.device, self._packed, self._dims
+        tb = self._band_tables(F, dt, dev)
+        assert tb["K"] == K
+        M, Np, ld4N, P = B * T, d["Np"], d["ld4N"], tb["P"]
+        Kf = len(self.subbands)
+        xns, sts, hids, pres = [], [], [], []
+        rows1, rows2 = [], []
+        for tag in "mr":
+            p = "md%s." % tag
+            xn, st = ops.groupnorm_fwd(skip, self._p(p + "gamma", Kf * N), self._p(p + "beta", Kf * N), B, T, K, N, N,
+                                       Np, N, dt, GN_EPS)
+            hid = torch.zeros(K, M, ld4N, dtype=dt, device=dev)
+            pre = torch.empty(M, P, dtype=torch.float32, device=dev)
+            b2_off = 0
+            for k in range(K):
+                sb = self.subbands[k]
+                r = tb["rows"][k]
+                w1, w2 = pk[p + "w1", k], pk[p + "w2", k]
+                rows1.append([_ptr(xn, k * Np), _ptr(w1), _ptr(hid, k * M * ld4N),
+                              _ptr(self._flat, self._off[p + "b1"] + k * 4 * N), 0, K * Np, Np, ld4N, M, 4 * N, Np, 0])
+                rows2.append([_ptr(hid, k * M * ld4N), _ptr(w2), _ptr(pre, r[5]),
+                              _ptr(self._flat, self._off[p + "b2"] + b2_off), 0, ld4N, ld4N, P, M, 4 * sb, ld4N, 0])
+                b2_off += 4 * sb
+            xns.append(xn); sts.append(st); hids.append(hid); pres.append(pre)
+        call("gemm_nt_grouped", _descs(rows1, dev), 2 * K, _tiles(M, 4 * N), ops._dt(xns[0]), ops._dt(hids[0]), 1,
+             stream_ptr())
+        call("gemm_nt_grouped", _descs(rows2, dev), 2 * K, _tiles(M, 4 * max(self.subbands[:K])), ops._dt(hids[0]),
+             ops.F32, 0, stream_ptr())
+        out = torch.empty(B, T, F, 2, dtype=torch.float32, device=dev)
+        call("glu_mask_apply_fwd", pres[0], pres[1], spec, out, tb["bands"], tb["f2k"], M, F, P, stream_ptr())
+        return out, ((xns, sts, hids, pres, tb) if save else None)
+
+    def maskdec_bwd(self, skip, spec, saved, dout):
+        xns, sts, hids, pres, tb = saved
+        B, T, K, N = skip.shape
+        F = spec.shape[2]
+        dt, dev, pk, d = self.compute_dtype, skip.device, self._packed, self._dims
+        M, Np, ld4N, P = B * T, d["Np"], d["ld4N"], tb["P"]
+        Kf = len(self.subbands)
+        dpre = [torch.zeros(M, P, dtype=dt, device=dev) for _ in range(2)]
+        call("glu_mask_apply_bwd", pres[0], pres[1], spec, dout, dpre[0], dpre[1], tb["bands"], tb["f2k"], M, F, P,
+             ops._dt(dpre[0]), stream_ptr())
+        dhp = [torch.zeros(K, M, ld4N, dtype=dt, device=dev) for _ in range(2)]
+        dxn = [torch.empty(M * K, N, dtype=torch.float32, device=dev) for _ in range(2)]
+        rows_a, rows_b = [], []
+        for i, tag in enumerate("mr"):
+            p = "md%s." % tag
+            for k in range(K):
+                r = tb["rows"][k]
+                rows_a.append([_ptr(dpre[i], r[5]), _ptr(pk[p + "w2T", k]), _ptr(dhp[i], k * M * ld4N), 0,
+                               _ptr(hids[i], k * M * ld4N), P, r[6], ld4N, M, 4 * N, r[6], ld4N])
+                rows_b.append([_ptr(dhp[i], k * M * ld4N), _ptr(pk[p + "w1T", k]), _ptr(dxn[i], k * N), 0, 0, ld4N,
+                               ld4N, K * N, M, N, ld4N, 0])
+        call("gemm_nt_grouped", _descs(rows_a, dev), 2 * K, _tiles(M, 4 * N), ops._dt(dpre[0]), ops._dt(dhp[0]), 2,
+             stream_ptr())
+        for i, tag in enumerate("mr"):
+            p = "md%s." % tag
+            w2_off = b2_off = 0
+            for k in range(K):
+                sb = self.subbands[k]
+                r = tb["rows"][k]
+                ops.gemm_tn(dpre[i][:, r[5]:r[5] + r[6]], hids[i][k], self._g(p + "w2", 16 * sb * N, w2_off).view(4 * sb, 4 * N),
+                            colsum=self._g(p + "b2", 4 * sb, b2_off), Mo=4 * sb, No=4 * N)
+                xk = xns[i].view(M, K * Np)[:, k * Np:(k + 1) * Np]
+                ops.gemm_tn(dhp[i][k], xk, self._g(p + "w1", 4 * N * N, k * 4 * N * N).view(4 * N, N),
+                            colsum=self._g(p + "b1", 4 * N, k * 4 * N), Mo=4 * N, No=N)
+                w2_off += 16 * sb * N
+                b2_off += 4 * sb
+        call("gemm_nt_grouped", _descs(rows_b, dev), 2 * K, _tiles(M, N), ops._dt(dhp[0]), ops.F32, 0, stream_ptr())
+        dskip = None
+        for i, tag in enumerate("mr"):
+            p = "md%s." % tag
+            dskip = ops.groupnorm_bwd(skip, dxn[i].view(B, T, K, N), sts[i], self._p(p + "gamma", Kf * N), dskip,
+                                      self._g(p + "gamma", Kf * N), self._g(p + "beta", Kf * N), B, T, K, N, N, N,
+                                      GN_EPS)
+        self._ready("md")
+        return dskip
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, spec_ri):
+        """spec_ri f32 [B, T, F, 2] -> masked spectrum f32 [B, T, F, 2] (num_spk = 1 squeezed)."""
+        ops.require_cuda(spec_ri)
+        self._prepare()
+        spec_ri = spec_ri.contiguous().float()
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not train:
+            z, _ = self.bandsplit_fwd(spec_ri)
+            for l in range(self.num_layer):
+                z, _ = self.dualpath_fwd(z, l, "t", False)
+                z, _ = self.dualpath_fwd(z, l, "f", False)
+            return self.maskdec_fwd(z, spec_ri, False)[0]
+        anchor = self._flat.new_zeros((), requires_grad=True)
+        z = _BandSplitFn.apply(anchor, spec_ri, self)
+        for l in range(self.num_layer):
+            z = _DualPathFn.apply(z, self, l, "t")
+            z = _DualPathFn.apply(z, self, l, "f")
+        return _MaskDecFn.apply(z, spec_ri, self)
+
+
+class _BandSplitFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, spec, core):
+        z, saved = core.bandsplit_fwd(spec)
+        ctx.core, ctx.saved, ctx.spec = core, saved, spec
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        ctx.core.bandsplit_bwd(ctx.spec, ctx.saved, dz.contiguous())
+        ctx.saved = None
+        return None, None, None
+
+
+class _DualPathFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, core, l, path):
+        out, saved = core.dualpath_fwd(skip, l, path, True)
+        ctx.core, ctx.saved, ctx.skip, ctx.l, ctx.path = core, saved, skip, l, path
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d = ctx.core.dualpath_bwd(ctx.skip, ctx.saved, ctx.l, ctx.path, dout.contiguous())
+        ctx.saved = None
+        return d, None, None, None
+
+
+class _MaskDecFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, spec, core):
+        out, saved = core.maskdec_fwd(skip, spec, True)
+        ctx.core, ctx.saved, ctx.skip, ctx.spec = core, saved, skip, spec
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d = ctx.core.maskdec_bwd(ctx.skip, ctx.spec, ctx.saved, dout.contiguous())
+        ctx.saved = None
+        return d, None, None
+
+
+class BSRNNSeparator(nn.Module):
+    """espnet2 ``BSRNNSeparator`` surface: complex [B,T,F] -> ([complex [B,T,F]], ilens, {})."""
+
+    def __init__(self, input_dim, num_spk=1, num_channels=16, num_layers=6, target_fs=48000, causal=True,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.bsrnn = BSRNNCore(input_dim, num_channels, num_layers, target_fs, causal, num_spk, compute_dtype)
+
+    def forward(self, input, ilens=None, additional=None):
+        spec_ri = torch.view_as_real(input) if input.is_complex() else input
+        out = self.bsrnn(spec_ri)
+        return [torch.view_as_complex(out)], ilens, {}
+
+
+class _StftCfg(nn.Module):
+    """parameter-free stand-in for espnet2 STFTEncoder / STFTDecoder (keeps the attribute names)."""
+
+    def __init__(self, n_fft, hop_length, default_fs):
+        super().__init__()
+        self.n_fft, self.hop_length, self.default_fs = n_fft, hop_length, default_fs
+        self.output_dim = n_fft // 2 + 1
+
+    def reconfig(self, fs):
+        if fs is None:
+            return self.n_fft, self.hop_length
+        fs = int(fs)
+        return self.n_fft * fs // self.default_fs, self.hop_length * fs // self.default_fs
+
+
+class BSRNN_SE(nn.Module):
+    """Drop-in for ``baseline_code/models/bsrnn.py:9-41``."""
+
+    def __init__(self, num_channel=192, num_layer=6, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.encoder = _StftCfg(960, 480, 48000)
+        self.decoder = _StftCfg(960, 480, 48000)
+        self.bsrnn = BSRNNSeparator(self.encoder.output_dim, 1, num_channel, num_layer, 48000, False, compute_dtype)
+
+    @property
+    def core(self):
+        return self.bsrnn.bsrnn
+
+    def forward(self, speech_mix, speech_lengths, fs):
+        ops.require_cuda(speech_mix)
+        n_fft, hop = self.encoder.reconfig(fs)
+        lens = torch.as_tensor(speech_lengths)
+        feature_mix = ops.stft_forward(speech_mix.float(), n_fft, hop, ops.WIN_HANN, lens)
+        feature_pre, _, _ = self.bsrnn(feature_mix, None, None)
+        enhanced_feature = feature_pre[0]
+        n_fft_d, hop_d = self.decoder.reconfig(fs)
+        enhanced_wav = ops.istft_forward(enhanced_feature, n_fft_d, hop_d, int(lens.max()))
+        return enhanced_wav, enhanced_feature

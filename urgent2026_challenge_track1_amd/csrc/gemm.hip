@@ -147,7 +147,12 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmDesc* __restrict
         if (row >= d.M) continue;
         float v = acc[i][j][r] + bv;
         if (act == 1) v = tanhf_(v);
-        if (d.resid) v += d.resid[row * d.ldr + col];
+        if (act == 2) {  // tanh backward: aux (= resid slot, TO typed) holds h = tanh(.)
+          const float hv = to_f32<TO>(reinterpret_cast<const TO*>(d.resid)[row * d.ldr + col]);
+          v *= (1.f - hv * hv);
+        } else if (d.resid) {
+          v += d.resid[row * d.ldr + col];
+        }
         C[row * d.ldc + col] = from_f32<TO>(v);
       }
     }
@@ -335,7 +340,8 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
   d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.ldr = ldr;
   int rc = check_desc_host(d, in_dtype == URSE_BF16 ? 2 : 4, "urse_gemm_nt");
   if (rc) return rc;
-  URSE_CHECK_ARG(!resid || out_dtype == URSE_F32, "urse_gemm_nt: residual epilogue writes f32");
+  URSE_CHECK_ARG(!resid || act == 2 || out_dtype == URSE_F32, "urse_gemm_nt: residual epilogue writes f32");
+  URSE_CHECK_ARG(act != 2 || resid, "urse_gemm_nt: act 2 (tanh backward) needs the aux operand");
   const long blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   URSE_CHECK_ARG(blocks < (1L << 31), "urse_gemm_nt: too many tiles");
   return dispatch_nt(nullptr, d, 1, (int)blocks, in_dtype, out_dtype, act, (hipStream_t)stream);

@@ -286,3 +286,41 @@ extern "C" int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out,
   URSE_CHECK_LAUNCH("urse_pack2d");
   return URSE_OK;
 }
+
+// ---- segmented pack: S independent (cast + optional transpose + zero pad) copies in one launch -------
+namespace urse {
+struct PackSeg {  // int64 x 8, built by the host once per model / dtype
+  long in_off, in_rows, in_cols, in_ld;      // source block (elements, relative to `in`)
+  long out_off, out_rows, out_cols, out_ld;  // destination block (elements, relative to `out`)
+};
+template <typename TO>
+__global__ void __launch_bounds__(256) pack_seg_kernel(const float* __restrict__ in, TO* __restrict__ out,
+                                                       const PackSeg* __restrict__ segs, int transpose) {
+  const PackSeg s = segs[blockIdx.y];
+  const long total = s.out_rows * s.out_cols;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / s.out_cols, c = idx - r * s.out_cols;
+    float v = 0.f;
+    if (!transpose) {
+      if (r < s.in_rows && c < s.in_cols) v = in[s.in_off + r * s.in_ld + c];
+    } else {
+      if (c < s.in_rows && r < s.in_cols) v = in[s.in_off + c * s.in_ld + r];
+    }
+    out[s.out_off + r * s.out_ld + c] = from_f32<TO>(v);
+  }
+}
+}  // namespace urse
+
+extern "C" int urse_pack_segments(const float* in, void* out, const void* segs, int nseg, int blocks_per_seg,
+                                  int transpose, int out_dtype, void* stream) {
+  URSE_CHECK_ARG(in && out && segs && nseg > 0 && blocks_per_seg > 0, "urse_pack_segments: bad argument");
+  dim3 g(blocks_per_seg, nseg), b(256);
+  if (out_dtype == URSE_BF16)
+    hipLaunchKernelGGL(urse::pack_seg_kernel<urse::bf16_t>, g, b, 0, (hipStream_t)stream, in, (urse::bf16_t*)out,
+                       (const urse::PackSeg*)segs, transpose);
+  else
+    hipLaunchKernelGGL(urse::pack_seg_kernel<float>, g, b, 0, (hipStream_t)stream, in, (float*)out,
+                       (const urse::PackSeg*)segs, transpose);
+  URSE_CHECK_LAUNCH("urse_pack_segments");
+  return URSE_OK;
+}
