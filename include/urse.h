@@ -140,6 +140,31 @@ int urse_glu_mask_apply_bwd(const float* pre_m, const float* pre_r, const float*
 /* y = a*x + b*y (f32). */
 int urse_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream);
 
+/* ---- losses and optimizer ---------------------------------------------------------------------------
+ * espnet2 MultiResL1SpecLoss(window_sz, eps, normalize_variance=True, time_domain_weight) and SISNRLoss
+ * as constructed in baseline_code/d_model.py:24-25 and called at :74,:80; clip_grad_norm_ + AdamW as
+ * configured in train_se.py:78 / d_model.py:104-109. */
+/* sums f64 [B,5] = {sum t, sum t^2, sum e, sum e^2, sum e*t}. */
+int urse_pair_sums(const float* target, const float* estimate, double* sums, int B, int L, void* stream);
+/* loss f32 [B].  `windows` is a HOST array of n_windows even boxcar window sizes (hop = w/2).
+ * G (f32 [B,L], may be NULL) receives dLoss/d(a*e) for urse_mrl1_loss_bwd; acc f64 [B,2] scratch. */
+int urse_mrl1_loss_fwd(const float* target, const float* estimate, float* loss, float* G, double* sums, double* acc,
+                       int B, int L, const int32_t* windows, int n_windows, float eps, float td_weight, void* stream);
+/* grad_estimate f32 [B,L] = grad_loss[b] * dLoss_b/d estimate;  c1 f64 [B] scratch. */
+int urse_mrl1_loss_bwd(const float* target, const float* estimate, const float* G, const double* sums,
+                       const float* grad_loss, float* grad_estimate, double* c1, int B, int L, float eps,
+                       void* stream);
+/* loss f32 [B] = 10 log10((1-coh)/coh) (= -SI-SDR in dB), zero-mean. */
+int urse_sisnr_fwd(const float* ref, const float* inf, float* loss, double* sums, int B, int L, void* stream);
+/* out f64 [1] = sum g^2. */
+int urse_grad_sumsq(const float* g, double* out, int64_t n, void* stream);
+/* clip_grad_norm_(max_norm) (norm^2 read from device memory, grads pre-multiplied by grad_scale) +
+ * AdamW step `step` (1-based); grads are zeroed afterwards when zero_grad != 0; a non-finite norm skips
+ * the update. */
+int urse_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         const double* normsq, float max_norm, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

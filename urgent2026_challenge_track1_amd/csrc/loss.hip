@@ -1,0 +1,395 @@
+// Training losses and the fused optimizer step.
+//
+//  * MultiResL1SpecLoss (espnet2, ctor baseline_code/d_model.py:24, call :74): unbiased-std
+//    normalisation, alpha = <e,t>/(<e,e>+eps), L1 in time + mean over 4 boxcar-window STFT magnitude
+//    L1 terms ("sum" reduction).  With a = alpha/sigma_e and b = 1/sigma_t the loss is
+//    0.5*sum|a e - b t| + 0.125*sum_w sum | |STFT_w(a e)| - |STFT_w(b t)| |.
+//    The spectral kernel packs (a*e_frame) + i*(b*t_frame) into ONE complex FFT per frame, so no
+//    spectrogram ever reaches HBM; when gradients are wanted the same launch also produces
+//    G = dLoss/d(a e) (magnitude-sign * phase, inverse transform, overlap-add with f32 atomics folded
+//    through the reflect padding).  The backward then only applies the chain rule through a(e).
+//  * SISNRLoss (d_model.py:25,80; fast_bss_eval.si_sdr_loss): closed form from the same five sums.
+//  * clip_grad_norm_(0.5) + AdamW (train_se.py:78, d_model.py:104-109) on the flat buffers.
+#include <map>
+#include <mutex>
+#include <vector>
+#include <math.h>
+
+#include "fft_lds.h"
+
+namespace urse {
+
+struct LossTables { FftPlan plan; float2* tw; };
+static std::mutex g_lmu;
+static std::map<std::pair<int, int>, LossTables> g_ltab;
+
+static int loss_tables(int n, LossTables* out) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_lmu);
+  auto it = g_ltab.find({dev, n});
+  if (it != g_ltab.end()) { *out = it->second; return URSE_OK; }
+  LossTables t;
+  if (!make_fft_plan(n, &t.plan)) { set_error("mrl1: unsupported window size %d", n); return URSE_ERR_UNSUPPORTED; }
+  std::vector<float2> tw(n);
+  for (int j = 0; j < n; ++j) {
+    const double a = -2.0 * M_PI * (double)j / (double)n;
+    tw[j] = make_float2((float)cos(a), (float)sin(a));
+  }
+  if (hipMalloc(&t.tw, n * sizeof(float2)) != hipSuccess) { set_error("mrl1: hipMalloc failed"); return URSE_ERR_RUNTIME; }
+  (void)hipMemcpy(t.tw, tw.data(), n * sizeof(float2), hipMemcpyHostToDevice);
+  g_ltab[{dev, n}] = t;
+  *out = t;
+  return URSE_OK;
+}
+
+// sums[b][0..4] = sum t, sum t^2, sum e, sum e^2, sum e*t   (f64)
+__global__ void __launch_bounds__(256) pair_sums_kernel(const float* __restrict__ t, const float* __restrict__ e,
+                                                        double* __restrict__ sums, int L, int chunk) {
+  __shared__ double red[5][4];
+  const int b = blockIdx.y;
+  const int i0 = blockIdx.x * chunk;
+  int i1 = i0 + chunk;
+  if (i1 > L) i1 = L;
+  const float* tb = t + (long)b * L;
+  const float* eb = e + (long)b * L;
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const double tv = tb[i], ev = eb[i];
+    s[0] += tv; s[1] += tv * tv; s[2] += ev; s[3] += ev * ev; s[4] += ev * tv;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    s[j] = wave_sum_d(s[j]);
+    if (lane == 0) red[j][w] = s[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const int j = threadIdx.x;
+    atomicAdd(sums + (long)b * 5 + j, red[j][0] + red[j][1] + red[j][2] + red[j][3]);
+  }
+}
+
+struct Mrl1Scalars { float a, b; double sig_t, D, mean_e, set; };
+
+__device__ __forceinline__ Mrl1Scalars mrl1_scalars(const double* s, int L, double eps) {
+  Mrl1Scalars r;
+  const double var_t = (s[1] - s[0] * s[0] / L) / (L - 1);
+  const double var_e = (s[3] - s[2] * s[2] / L) / (L - 1);
+  r.sig_t = sqrt(var_t);
+  r.D = s[3] + eps * var_e;          // a = <e,t> / (sigma_t * D)
+  r.set = s[4];
+  r.mean_e = s[2] / L;
+  r.a = (float)(s[4] / (r.sig_t * r.D));
+  r.b = (float)(1.0 / r.sig_t);
+  return r;
+}
+
+// time-domain term; also initialises G = 0.5 * sign(a e - b t)
+__global__ void __launch_bounds__(256) mrl1_td_kernel(const float* __restrict__ t, const float* __restrict__ e,
+                                                      const double* __restrict__ sums, double* __restrict__ acc,
+                                                      float* __restrict__ G, int L, int chunk, double eps, float w_td) {
+  __shared__ double red[4];
+  const int b = blockIdx.y;
+  const Mrl1Scalars sc = mrl1_scalars(sums + (long)b * 5, L, eps);
+  const int i0 = blockIdx.x * chunk;
+  int i1 = i0 + chunk;
+  if (i1 > L) i1 = L;
+  double s = 0;
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const float d = sc.a * e[(long)b * L + i] - sc.b * t[(long)b * L + i];
+    s += fabsf(d);
+    if (G) G[(long)b * L + i] = w_td * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc + (long)b * 2, red[0] + red[1] + red[2] + red[3]);
+}
+
+__device__ __forceinline__ int reflect_idx(int p, int L) {
+  if (p < 0) p = -p;
+  if (p >= L) p = 2 * (L - 1) - p;
+  return p;
+}
+
+// one boxcar-window resolution: NF frames per workgroup, frame f: z = a*e + i*b*t -> one complex FFT
+template <bool GRAD>
+__global__ void __launch_bounds__(256) mrl1_spec_kernel(const float* __restrict__ t, const float* __restrict__ e,
+                                                        const double* __restrict__ sums, double* __restrict__ acc,
+                                                        float* __restrict__ G, int L, int T, FftPlan plan, int hop,
+                                                        const float2* __restrict__ tw_g, int NF, double eps,
+                                                        float w_spec) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[4];
+  const int n = plan.n, half = n / 2;
+  float2* tw = reinterpret_cast<float2*>(smem);
+  float2* bufA = tw + n;
+  float2* bufB = bufA + (size_t)NF * n;
+  const int b = blockIdx.y, t0 = blockIdx.x * NF;
+  const Mrl1Scalars sc = mrl1_scalars(sums + (long)b * 5, L, eps);
+  const float* tb = t + (long)b * L;
+  const float* eb = e + (long)b * L;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
+  for (int idx = threadIdx.x; idx < NF * n; idx += blockDim.x) {
+    const int f = idx / n, i = idx - f * n;
+    const int fr = t0 + f;
+    float2 v = make_float2(0.f, 0.f);
+    if (fr < T) {
+      const int p = reflect_idx(fr * hop + i - half, L);
+      v = make_float2(sc.a * eb[p], sc.b * tb[p]);
+    }
+    bufA[idx] = v;
+  }
+  __syncthreads();
+  float2* Z = fft_lds_forward(bufA, bufB, NF, plan, tw);
+  float2* Y = (Z == bufA) ? bufB : bufA;
+  double s = 0;
+  for (int idx = threadIdx.x; idx < NF * (half + 1); idx += blockDim.x) {
+    const int f = idx / (half + 1), k = idx - f * (half + 1);
+    const float2 zk = Z[f * n + k];
+    const float2 zc = Z[f * n + (k == 0 ? 0 : n - k)];
+    const float2 U = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+    const float2 Tt = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+    const float mu = sqrtf(U.x * U.x + U.y * U.y), mt = sqrtf(Tt.x * Tt.x + Tt.y * Tt.y);
+    const float d = mu - mt;
+    if (t0 + f < T) s += fabsf(d);
+    if (GRAD) {
+      const float sg = (d > 0.f ? w_spec : (d < 0.f ? -w_spec : 0.f));
+      float2 g = make_float2(0.f, 0.f);
+      if (mu > 0.f && t0 + f < T) g = make_float2(sg * U.x / mu, sg * U.y / mu);
+      const bool edge = (k == 0) || (k == half);
+      if (edge) {
+        Y[f * n + k] = make_float2(g.x, 0.f);
+      } else {
+        Y[f * n + k] = make_float2(0.5f * g.x, 0.5f * g.y);
+        Y[f * n + n - k] = make_float2(0.5f * g.x, -0.5f * g.y);
+      }
+    }
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc + (long)b * 2 + 1, red[0] + red[1] + red[2] + red[3]);
+  if (GRAD) {
+    // pair frames (2p, 2p+1): in = conj(Ya + i Yb)
+    const int NP = NF / 2;
+    for (int idx = threadIdx.x; idx < NP * n; idx += blockDim.x) {
+      const int pidx = idx / n, k = idx - pidx * n;
+      const float2 ya = Y[(2 * pidx) * n + k], yb = Y[(2 * pidx + 1) * n + k];
+      Z[idx] = make_float2(ya.x - yb.y, -(ya.y + yb.x));
+    }
+    __syncthreads();
+    const float2* R = fft_lds_forward(Z, Y, NP, plan, tw);
+    for (int idx = threadIdx.x; idx < NP * n; idx += blockDim.x) {
+      const int pidx = idx / n, i = idx - pidx * n;
+      const float2 r = R[idx];
+      const int fa = t0 + 2 * pidx;
+      if (fa < T) atomicAdd(G + (long)b * L + reflect_idx(fa * hop + i - half, L), r.x);
+      if (fa + 1 < T) atomicAdd(G + (long)b * L + reflect_idx((fa + 1) * hop + i - half, L), -r.y);
+    }
+  }
+}
+
+__global__ void mrl1_final_kernel(const double* __restrict__ acc, float* __restrict__ loss, int B, float w_td,
+                                  float w_spec) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) loss[b] = (float)(w_td * acc[b * 2] + w_spec * acc[b * 2 + 1]);
+}
+
+// c1[b] = sum_n G[n] * e[n]
+__global__ void __launch_bounds__(256) dot_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                  double* __restrict__ out, int L, int chunk) {
+  __shared__ double red[4];
+  const int b = blockIdx.y;
+  const int i0 = blockIdx.x * chunk;
+  int i1 = i0 + chunk;
+  if (i1 > L) i1 = L;
+  double s = 0;
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) s += (double)x[(long)b * L + i] * y[(long)b * L + i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out + b, red[0] + red[1] + red[2] + red[3]);
+}
+
+// de = gl[b] * ( a*G + c1 * da/de ),  da/de[n] = t[n]/(sig_t D) - (a/D) (2 e[n] + 2 eps (e[n]-mean_e)/(L-1))
+__global__ void __launch_bounds__(256) mrl1_bwd_kernel(const float* __restrict__ t, const float* __restrict__ e,
+                                                       const float* __restrict__ G, const double* __restrict__ sums,
+                                                       const double* __restrict__ c1, const float* __restrict__ gl,
+                                                       float* __restrict__ de, int L, double eps) {
+  const int b = blockIdx.y;
+  const Mrl1Scalars sc = mrl1_scalars(sums + (long)b * 5, L, eps);
+  const double a = sc.set / (sc.sig_t * sc.D);
+  const float k_t = (float)(c1[b] / (sc.sig_t * sc.D));
+  const float k_e = (float)(c1[b] * a / sc.D);
+  const float me = (float)sc.mean_e, ke2 = (float)(2.0 * eps / (L - 1));
+  const float up = gl[b];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
+    const long o = (long)b * L + i;
+    const float ev = e[o];
+    de[o] = up * (sc.a * G[o] + k_t * t[o] - k_e * (2.f * ev + ke2 * (ev - me)));
+  }
+}
+
+// SI-SNR loss = 10 log10((1-coh)/coh), zero-mean, unit-norm (norm clamped at 1e-6)
+__global__ void sisnr_final_kernel(const double* __restrict__ sums, float* __restrict__ loss, int B, int L) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* s = sums + (long)b * 5;
+  const double srr = s[1] - s[0] * s[0] / L, sii = s[3] - s[2] * s[2] / L, sri = s[4] - s[0] * s[2] / L;
+  const double nr = fmax(sqrt(fmax(srr, 0.0)), 1e-6), ni = fmax(sqrt(fmax(sii, 0.0)), 1e-6);
+  const double c = sri / (nr * ni);
+  const double coh = c * c;
+  loss[b] = (float)(10.0 * log10((1.0 - coh) / coh));
+}
+
+// ---- optimizer ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, double* __restrict__ out, long n) {
+  __shared__ double red[4];
+  double s = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double v = g[i];
+    s += v * v;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.AdamW.step(); grads zeroed on the way out.
+// A non-finite gradient norm skips the update (the reference's NaN guard, d_model.py:48-57).
+__global__ void __launch_bounds__(256) clip_adamw_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, long n,
+                                                         const double* __restrict__ normsq, float max_norm, float lr,
+                                                         float beta1, float beta2, float eps, float wd, float bc1,
+                                                         float bc2_sqrt, float grad_scale, int zero_grad) {
+  const double nsq = *normsq * (double)grad_scale * (double)grad_scale;
+  const bool finite = isfinite(nsq);
+  float coef = grad_scale;
+  if (max_norm > 0.f) {
+    const float c = max_norm / ((float)sqrt(nsq) + 1e-6f);
+    if (c < 1.f) coef *= c;
+  }
+  const float step = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if (finite) {
+      const float gr = g[i] * coef;
+      float pv = p[i] * (1.f - lr * wd);
+      const float mv = m[i] + (gr - m[i]) * (1.f - beta1);
+      const float vv = v[i] * beta2 + gr * gr * (1.f - beta2);
+      pv -= step * mv / (sqrtf(vv) / bc2_sqrt + eps);
+      p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+}  // namespace urse
+
+using namespace urse;
+
+static std::once_flag g_loss_lds_once;
+
+extern "C" int urse_pair_sums(const float* target, const float* estimate, double* sums, int B, int L, void* stream) {
+  URSE_CHECK_ARG(target && estimate && sums && B > 0 && L > 1, "urse_pair_sums: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(sums, 0, sizeof(double) * 5 * B, st);
+  const int chunk = 16384;
+  hipLaunchKernelGGL(pair_sums_kernel, dim3(ceil_div(L, chunk), B), dim3(256), 0, st, target, estimate, sums, L, chunk);
+  URSE_CHECK_LAUNCH("urse_pair_sums");
+  return URSE_OK;
+}
+
+extern "C" int urse_mrl1_loss_fwd(const float* target, const float* estimate, float* loss, float* G, double* sums,
+                                  double* acc, int B, int L, const int32_t* windows, int n_windows, float eps,
+                                  float td_weight, void* stream) {
+  URSE_CHECK_ARG(target && estimate && loss && sums && acc && windows && B > 0 && L > 1 && n_windows > 0 &&
+                     n_windows <= 8,
+                 "urse_mrl1_loss_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  std::call_once(g_loss_lds_once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mrl1_spec_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mrl1_spec_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  });
+  int rc = urse_pair_sums(target, estimate, sums, B, L, stream);
+  if (rc) return rc;
+  (void)hipMemsetAsync(acc, 0, sizeof(double) * 2 * B, st);
+  const int chunk = 16384;
+  hipLaunchKernelGGL(mrl1_td_kernel, dim3(ceil_div(L, chunk), B), dim3(256), 0, st, target, estimate, sums, acc, G, L,
+                     chunk, (double)eps, td_weight);
+  const float w_spec = (1.f - td_weight) / (float)n_windows;
+  for (int i = 0; i < n_windows; ++i) {
+    const int n = windows[i], hop = n / 2;
+    URSE_CHECK_ARG(n >= 4 && n % 2 == 0 && n / 2 < L, "urse_mrl1_loss_fwd: bad window %d", n);
+    LossTables tb;
+    rc = loss_tables(n, &tb);
+    if (rc) return rc;
+    const int T = L / hop + 1;
+    int NF = 8;
+    while (NF > 2 && (size_t)(2 * NF + 1) * n * 8 > 72 * 1024) NF -= 2;
+    const size_t lds = (size_t)(2 * NF + 1) * n * 8;
+    dim3 grid(ceil_div(T, NF), B);
+    if (G)
+      hipLaunchKernelGGL(mrl1_spec_kernel<true>, grid, dim3(256), lds, st, target, estimate, sums, acc, G, L, T,
+                         tb.plan, hop, tb.tw, NF, (double)eps, w_spec);
+    else
+      hipLaunchKernelGGL(mrl1_spec_kernel<false>, grid, dim3(256), lds, st, target, estimate, sums, acc, G, L, T,
+                         tb.plan, hop, tb.tw, NF, (double)eps, w_spec);
+  }
+  hipLaunchKernelGGL(mrl1_final_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, acc, loss, B, td_weight, w_spec);
+  URSE_CHECK_LAUNCH("urse_mrl1_loss_fwd");
+  return URSE_OK;
+}
+
+extern "C" int urse_mrl1_loss_bwd(const float* target, const float* estimate, const float* G, const double* sums,
+                                  const float* grad_loss, float* grad_estimate, double* c1, int B, int L, float eps,
+                                  void* stream) {
+  URSE_CHECK_ARG(target && estimate && G && sums && grad_loss && grad_estimate && c1 && B > 0 && L > 1,
+                 "urse_mrl1_loss_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(c1, 0, sizeof(double) * B, st);
+  const int chunk = 16384;
+  hipLaunchKernelGGL(dot_kernel, dim3(ceil_div(L, chunk), B), dim3(256), 0, st, G, estimate, c1, L, chunk);
+  hipLaunchKernelGGL(mrl1_bwd_kernel, dim3(ceil_div(L, 1024), B), dim3(256), 0, st, target, estimate, G, sums, c1,
+                     grad_loss, grad_estimate, L, (double)eps);
+  URSE_CHECK_LAUNCH("urse_mrl1_loss_bwd");
+  return URSE_OK;
+}
+
+extern "C" int urse_sisnr_fwd(const float* ref, const float* inf, float* loss, double* sums, int B, int L,
+                              void* stream) {
+  int rc = urse_pair_sums(ref, inf, sums, B, L, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sisnr_final_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, sums, loss, B, L);
+  URSE_CHECK_LAUNCH("urse_sisnr_fwd");
+  return URSE_OK;
+}
+
+extern "C" int urse_grad_sumsq(const float* g, double* out, int64_t n, void* stream) {
+  URSE_CHECK_ARG(g && out && n > 0, "urse_grad_sumsq: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(out, 0, sizeof(double), st);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, st, g, out, (long)n);
+  URSE_CHECK_LAUNCH("urse_grad_sumsq");
+  return URSE_OK;
+}
+
+extern "C" int urse_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                    const double* normsq, float max_norm, float lr, float beta1, float beta2,
+                                    float eps, float weight_decay, int step, float grad_scale, int zero_grad,
+                                    void* stream) {
+  URSE_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && normsq && n > 0 && step >= 1,
+                 "urse_clip_adamw_step: bad argument");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(clip_adamw_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, (long)n, normsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale,
+                     zero_grad);
+  URSE_CHECK_LAUNCH("urse_clip_adamw_step");
+  return URSE_OK;
+}

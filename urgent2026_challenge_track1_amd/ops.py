@@ -151,3 +151,88 @@ def lstm_bwd(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride, rows16
     call("lstm_bidir_bwd", dh, dh.stride(0), gates, gates.stride(0), c, whhT, H, n_seq, seq_len, inner, outer, stride,
          _dt(gates), rows16, stream_ptr())
     return gates
+
+
+# ---------------------------------------------------------------------------------------------
+# losses / optimizer
+# ---------------------------------------------------------------------------------------------
+import ctypes as _ct
+
+
+class _MRL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, estimate, target, windows, eps, td_weight):
+        B, L = estimate.shape
+        dev = estimate.device
+        loss = torch.empty(B, device=dev, dtype=torch.float32)
+        sums = torch.empty(B * 5, device=dev, dtype=torch.float64)
+        acc = torch.empty(B * 2, device=dev, dtype=torch.float64)
+        need = estimate.requires_grad
+        G = torch.empty(B, L, device=dev, dtype=torch.float32) if need else None
+        warr = (_ct.c_int32 * len(windows))(*windows)
+        call("mrl1_loss_fwd", target, estimate, loss, G, sums, acc, B, L, warr, len(windows), float(eps),
+             float(td_weight), stream_ptr())
+        ctx.saved = (estimate, target, G, sums, eps)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        estimate, target, G, sums, eps = ctx.saved
+        B, L = estimate.shape
+        de = torch.empty_like(estimate)
+        c1 = torch.empty(B, device=estimate.device, dtype=torch.float64)
+        call("mrl1_loss_bwd", target, estimate, G, sums, _f32c(gl), de, c1, B, L, float(eps), stream_ptr())
+        ctx.saved = None
+        return de, None, None, None, None
+
+
+def mr_l1_loss(target, estimate, window_sz=(256, 512, 768, 1024), eps=1e-6, time_domain_weight=0.5):
+    """espnet2 MultiResL1SpecLoss(normalize_variance=True, reduction='sum').forward(target, estimate) -> [B]."""
+    require_cuda(target, estimate)
+    return _MRL1.apply(_f32c(estimate), _f32c(target), tuple(int(w) for w in window_sz), eps, time_domain_weight)
+
+
+def si_snr_loss(ref, inf):
+    """espnet2 SISNRLoss()(ref, inf) -> [B] (no gradient: the reference only logs it, d_model.py:79-80)."""
+    require_cuda(ref, inf)
+    ref, inf = _f32c(ref.detach()), _f32c(inf.detach())
+    B, L = ref.shape
+    loss = torch.empty(B, device=ref.device, dtype=torch.float32)
+    sums = torch.empty(B * 5, device=ref.device, dtype=torch.float64)
+    call("sisnr_fwd", ref, inf, loss, sums, B, L, stream_ptr())
+    return loss
+
+
+class FusedClipAdamW:
+    """clip_grad_norm_(max_norm) + torch.optim.AdamW semantics on flat f32 buffers, one kernel."""
+
+    def __init__(self, flat_params, flat_grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6,
+                 max_norm=0.5):
+        require_cuda(flat_params, flat_grads)
+        self.p, self.g = flat_params, flat_grads
+        self.m = torch.zeros_like(flat_params)
+        self.v = torch.zeros_like(flat_params)
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.step_count = 0
+        self.normsq = torch.zeros(1, device=flat_params.device, dtype=torch.float64)
+
+    def step(self, grad_scale=1.0, zero_grad=True):
+        n = self.p.numel()
+        self.step_count += 1
+        call("grad_sumsq", self.g, self.normsq, n, stream_ptr())
+        call("clip_adamw_step", self.p, self.g, self.m, self.v, n, self.normsq, float(self.max_norm or 0.0),
+             float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
+             self.step_count, float(grad_scale), int(zero_grad), stream_ptr())
+
+    def grad_norm(self):
+        """global L2 norm of the gradients seen by the last step (device scalar, no sync)."""
+        return self.normsq.sqrt()
+
+    def state_dict(self):
+        return {"exp_avg": self.m, "exp_avg_sq": self.v, "step": self.step_count, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+        self.lr = float(sd.get("lr", self.lr))
