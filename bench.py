@@ -1,10 +1,12 @@
 #!/usr/bin/env python
-"""bench.py -- hot-path throughput on MI355X (see DESIGN.md "Measurement").
+"""bench.py -- BSRNN train-step throughput on MI355X (see DESIGN.md "Measurement").
 
 python bench.py --gpus N --steps K --warmup W     (N>1 is launched by torch.distributed.run)
 
-Prints ONE JSON line on rank 0.  A "step" is one pass of the hot path over one batch of synthetic
-4 s @ 48 kHz utterances that already sit in HBM when the timed region starts.
+A "step" = one full SEModel optimisation step (STFT -> band split -> 6 x dual-path BLSTM -> mask decoder
+-> iSTFT -> MR-L1 loss -> backward -> [RCCL all-reduce] -> clip + AdamW) on a per-GPU batch of synthetic
+4 s @ 48 kHz noisy/clean pairs already resident in HBM (BASELINE.json configs[1]: B=32, bf16 MFMA).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -17,18 +19,18 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (spec)
+MFMA_F32_PEAK_TF = 157.3
 
 
 def synth_batch(B, L, fs, seed, device):
-    """SURVEY 8(d) generator: low-passed noise x syllabic envelope, 0.4 s near-silence at both ends, peak 0.9;
-    noisy = clean + white noise at U(-5, 20) dB SNR, jointly peak-normalised."""
+    """SURVEY 8(d) generator: low-passed noise x 4 Hz syllabic envelope, 0.4 s near-silence at both ends, peak
+    0.9; noisy = clean + white noise at U(-5, 20) dB SNR, jointly peak-normalised.  Host-side, untimed."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     n = torch.randn(B, L, generator=g)
-    # one-pole low-pass a = 0.95 via FFT-domain response (deterministic, cheap on host)
     k = torch.fft.rfftfreq(L)
-    Hf = 1.0 / (1.0 - 0.95 * torch.exp(-2j * torch.pi * k))
+    Hf = 1.0 / (1.0 - 0.95 * torch.exp(-2j * torch.pi * k))       # one-pole low-pass a = 0.95
     clean = torch.fft.irfft(torch.fft.rfft(n) * Hf, n=L)
     clean = clean / clean.std(dim=1, keepdim=True)
     t = torch.arange(L) / fs
@@ -50,12 +52,40 @@ def synth_batch(B, L, fs, seed, device):
     return (clean * sc).to(device), (noisy * sc).to(device)
 
 
+def gate_gemm_flops(B, T, K, N, layers):
+    """BLSTM gate GEMM FLOPs of one forward: 24 directional LSTMs x 4H(I+H) MAC x T*K rows."""
+    H = 2 * N
+    return 2.0 * layers * 2 * 2 * (4 * H) * (N + H) * (B * T * K)
+
+
+def cpu_baseline(args, fs, L):
+    """The oracle's (CPU torch restatement of train_se.py) optimisation step on the host cores."""
+    from oracle import bsrnn_ref, losses_ref
+    torch.set_num_threads(os.cpu_count())
+    Bc = args.cpu_batch
+    model = bsrnn_ref.BSRNN_SE(196, 6)
+    opt = losses_ref.make_optimizer(model.parameters())
+    clean, noisy = synth_batch(Bc, L, fs, 2024, "cpu")
+    lens = torch.full((Bc,), L, dtype=torch.int32)
+    t0 = time.perf_counter()
+    losses_ref.train_step(model, opt, clean, noisy, fs, lens)
+    dt = time.perf_counter() - t0
+    return {"value": Bc / dt, "unit": "utt/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "1 oracle train step (fwd+bwd+clip+AdamW, fp32), B=%d x 4 s @ %d Hz, N=196 L=6, %d threads"
+                      % (Bc, fs, torch.get_num_threads()), "seconds": dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--channels", type=int, default=196)
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -69,64 +99,82 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from urgent2026_challenge_track1_amd import ops
-    fs, L, B = 48000, 192000, args.batch
-    n_fft, hop = 960, 480
+    from urgent2026_challenge_track1_amd.config import Config
+    from urgent2026_challenge_track1_amd.d_model import SEModel
+    from urgent2026_challenge_track1_amd.ddp import GradBucketReducer
+
+    fs, B = 48000, args.batch
+    L = int(args.seconds * fs)
+    cfg = Config(compute_dtype=args.dtype, model_configs={"num_channel": args.channels, "num_layer": args.layers},
+                 seed=2024)
+    torch.manual_seed(cfg.seed)
+    model = SEModel(cfg).to(dev)
+    core = model.se_model.core
+    (opt,), _ = model.configure_optimizers()
+    if world > 1:   # identical initial weights on every rank
+        dist.broadcast(core.flat_params, 0)
+    reducer = GradBucketReducer(core) if world > 1 else None
     clean, noisy = synth_batch(B, L, fs, 2024 + rank, dev)
+    lens = torch.full((B,), L, dtype=torch.int32)
+    fs_t = torch.tensor(fs, dtype=torch.int32)
+    batch = (clean.view(B, 1, L), noisy.view(B, 1, L), fs_t, lens)
 
     def step():
-        spec = ops.stft_forward(noisy, n_fft, hop)
-        wav = ops.istft_forward(spec, n_fft, hop, L)
-        return wav
+        loss = model.training_step(batch)
+        loss.backward()
+        model.optimizer_step(opt, reducer)
+        return loss
 
     for _ in range(args.warmup):
         step()
-    # kernel-level timing of the STFT launch with events on the launch stream
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    names = ["lstm_fwd_time", "lstm_fwd_band", "lstm_bwd_time", "lstm_bwd_band", "stft_fwd"]
+    ops.enable_timing(names)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        evs[i][0].record()
-        spec = ops.stft_forward(noisy, n_fft, hop)
-        evs[i][1].record()
-        ops.istft_forward(spec, n_fft, hop, L)
+    for _ in range(args.steps):
+        loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    timing = ops.disable_timing()
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
-    k_ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
-    T, Fb = L // hop + 1, n_fft // 2 + 1
-    alg_bytes = B * (L * 4 + T * Fb * 8)
-    ach = alg_bytes / (k_ms * 1e-3) / 1e9
+    kt = {n: (sum(a.elapsed_time(b) for a, b in v) / max(1, len(v)), len(v)) for n, v in timing.items()}
 
+    T, Fb, K = L // 480 + 1, 481, 34
+    H = 2 * args.channels
+    # dominant kernel: the BLSTM recurrences (recurrent half of the gate GEMMs, 4H x H MACs per row and direction)
+    rec_flops = {"lstm_fwd_band": 2.0 * 2 * 4 * H * H * (B * T * K), "lstm_fwd_time": 2.0 * 2 * 4 * H * H * (B * T * K)}
+    tot_ms = {n: kt[n][0] * kt[n][1] for n in kt}
+    dom = max(("lstm_fwd_band", "lstm_fwd_time", "lstm_bwd_band", "lstm_bwd_time"), key=lambda n: tot_ms[n])
+    dom_flops = 2.0 * 2 * 4 * H * H * (B * T * K)      # per launch, forward or BPTT recurrent product
+    peak = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
+    ach = dom_flops / (kt[dom][0] * 1e-3) / 1e12
+    stft_bytes = B * (L * 4 + T * Fb * 8)
     out = {
-        "metric": "utterances/sec (4 s @ 48 kHz), PARTIAL path: STFT+iSTFT only (train step under construction)",
-        "value": world * B * args.steps / dt, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "B%d x 4 s @ 48 kHz, n_fft 960 hop 480, stft->istft" % B, "per_gpu_batch": B},
-        "roofline": {"bound": "hbm", "kernel": "stft_kernel<0>", "achieved": ach, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms},
+        "metric": "utterances/sec (4 s @ 48 kHz) train step", "value": world * B * args.steps / dt, "unit": "utt/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BSRNN discriminative train step, B%d x %.0f s @ 48 kHz per GPU, N=%d L=%d, "
+                               "MR-L1 loss, clip 0.5 + AdamW" % (B, args.seconds, args.channels, args.layers),
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                     "frac": ach / peak, "traffic": None, "algorithmic_flops_per_launch": dom_flops,
+                     "kernel_ms": kt[dom][0], "launches_per_step": kt[dom][1] / args.steps},
+        "kernels_ms_per_step": {n: tot_ms[n] / args.steps for n in tot_ms},
+        "stft_roofline": {"bound": "hbm", "achieved": stft_bytes / (kt["stft_fwd"][0] * 1e-3) / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": stft_bytes / (kt["stft_fwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "gate_gemm_tflops_per_step": 3 * gate_gemm_flops(B, T, K, args.channels, args.layers) / 1e12,
+        "final_loss": float(loss),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import stft_ref
-        x = noisy[:8].cpu()
-        torch.set_num_threads(os.cpu_count())
-        stft_ref.stft(x, n_fft, hop)
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            X, _ = stft_ref.stft(x, n_fft, hop)
-            stft_ref.istft(X, n_fft, hop, L)
-        cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": 8 * reps / cdt, "unit": "utt/s", "cores": os.cpu_count(), "kind": "port",
-                               "sample": "oracle torch.stft+istft, 8 utt x %d reps" % reps}
+        out["cpu_baseline"] = cpu_baseline(args, fs, L)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -60,15 +60,18 @@ __device__ __forceinline__ void mma_slab(const uint4 (&a)[RT], const uint4& b, f
   }
 }
 
+constexpr int NW = 16;          // waves per workgroup: memory-level parallelism for the streamed weights
+constexpr int NTHR = NW * 64;
+
 template <typename T, int RT, int MAXUT>
-__global__ void __launch_bounds__(256) lstm_fwd_kernel(LstmFwdArgs p) {
+__global__ void __launch_bounds__(NTHR) lstm_fwd_kernel(LstmFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T), R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   const int dir = blockIdx.y, s0 = blockIdx.x * R;
   const int H = p.H, Hp = p.Hp, nut = (H + 15) >> 4;
   const int pitch = Hp * ES + 16;
-  for (int i = tid; i < 2 * R * pitch / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+  for (int i = tid; i < 2 * R * pitch / 4; i += NTHR) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
   float cst[MAXUT][RT][4];
 #pragma unroll
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_kernel(LstmFwdArgs p) {
     const long toff = (long)t * p.m.stride;
 #pragma unroll
     for (int ui = 0; ui < MAXUT; ++ui) {
-      const int ut = w + 4 * ui;
+      const int ut = w + NW * ui;
       if (ut < nut) {
         const int u = ut * 16 + lc;
         const bool uvalid = u < H;
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_kernel(LstmFwdArgs p) {
         const char* wr = whh + ((long)uc * Hp) * ES + 16 * lr;
         const long wg = (long)H * Hp * ES;  // gate stride
         const char* ar = hc + lc * pitch + 16 * lr;
-#pragma unroll 2
+#pragma unroll 4
         for (int ks = 0; ks < nslab; ++ks) {
           uint4 b[4], a[RT];
 #pragma unroll
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_kernel(LstmFwdArgs p) {
 }
 
 template <typename T, int RT, int MAXUT>
-__global__ void __launch_bounds__(256) lstm_bwd_kernel(LstmBwdArgs p) {
+__global__ void __launch_bounds__(NTHR) lstm_bwd_kernel(LstmBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T), R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(LstmBwdArgs p) {
     const long toff = (long)t * p.m.stride;
 #pragma unroll
     for (int ui = 0; ui < MAXUT; ++ui) {
-      const int ut = w + 4 * ui;
+      const int ut = w + NW * ui;
       if (ut < nut) {
         const int u = ut * 16 + lc;
         if (u < H) {
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(LstmBwdArgs p) {
     if (step + 1 < p.m.seq_len) {
 #pragma unroll
       for (int ui = 0; ui < MAXUT; ++ui) {
-        const int ut = w + 4 * ui;
+        const int ut = w + NW * ui;
         if (ut < nut) {
           const int u = ut * 16 + lc;
           const int uc = u < H ? u : H - 1;
@@ -282,7 +285,7 @@ static int launch_fwd(const LstmFwdArgs& p, hipStream_t st) {
   const size_t lds = (size_t)2 * R * (p.Hp * sizeof(T) + 16);
   URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_fwd: Hp %d with %d rows exceeds LDS", p.Hp, R);
   dim3 grid(ceil_div(p.m.n_seq, R), 2);
-  hipLaunchKernelGGL((lstm_fwd_kernel<T, RT, MAXUT>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((lstm_fwd_kernel<T, RT, MAXUT>), grid, dim3(NTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_fwd");
   return URSE_OK;
 }
@@ -295,7 +298,7 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
   const size_t lds = (size_t)R * (4 * p.H * sizeof(T) + 16);
   URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_bwd: H %d with %d rows exceeds LDS", p.H, R);
   dim3 grid(ceil_div(p.m.n_seq, R), 2);
-  hipLaunchKernelGGL((lstm_bwd_kernel<T, RT, MAXUT>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((lstm_bwd_kernel<T, RT, MAXUT>), grid, dim3(NTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_bwd");
   return URSE_OK;
 }
@@ -324,21 +327,16 @@ extern "C" int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void*
   if (rc) return rc;
   URSE_CHECK_ARG((Hp * es) % 64 == 0 && Hp >= ((H + 15) / 16) * 16, "urse_lstm_bidir_fwd: bad Hp %d for H %d", Hp, H);
   URSE_CHECK_ARG(ldg >= 8L * H && ldh >= 2L * H, "urse_lstm_bidir_fwd: leading dimension too small");
-  const int ut_per_wave = ((H + 15) / 16 + 3) / 4;
+  const int ut_per_wave = ((H + 15) / 16 + NW - 1) / NW;
   hipStream_t st = (hipStream_t)stream;
   int rt = rows16;
-  if (rt <= 0) rt = n_seq >= 8192 ? 4 : (n_seq >= 1024 ? 2 : 1);
+  if (rt <= 0) rt = n_seq >= 1024 ? 2 : 1;
   if (dtype == URSE_BF16) {
-    if (ut_per_wave <= 7) {
-      if (rt >= 4) return launch_fwd<bf16_t, 4, 7>(p, st);
-      if (rt == 2) return launch_fwd<bf16_t, 2, 7>(p, st);
-      return launch_fwd<bf16_t, 1, 7>(p, st);
-    }
-    if (rt >= 2) return launch_fwd<bf16_t, 2, 12>(p, st);
-    return launch_fwd<bf16_t, 1, 12>(p, st);
+    if (ut_per_wave <= 2) return rt >= 2 ? launch_fwd<bf16_t, 2, 2>(p, st) : launch_fwd<bf16_t, 1, 2>(p, st);
+    return rt >= 2 ? launch_fwd<bf16_t, 2, 3>(p, st) : launch_fwd<bf16_t, 1, 3>(p, st);
   }
-  if (ut_per_wave <= 7) return launch_fwd<float, 1, 7>(p, st);
-  return launch_fwd<float, 1, 12>(p, st);
+  if (ut_per_wave <= 2) return launch_fwd<float, 1, 2>(p, st);
+  return launch_fwd<float, 1, 3>(p, st);
 }
 
 extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c,
@@ -352,17 +350,15 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
   int rc = check_map(p.m, H, es, "urse_lstm_bidir_bwd");
   if (rc) return rc;
   URSE_CHECK_ARG(ldg >= 8L * H && ldd >= 2L * H, "urse_lstm_bidir_bwd: leading dimension too small");
-  const int ut_per_wave = ((H + 15) / 16 + 3) / 4;
+  const int ut_per_wave = ((H + 15) / 16 + NW - 1) / NW;
   hipStream_t st = (hipStream_t)stream;
   int rt = rows16;
-  if (rt <= 0) rt = n_seq >= 4096 ? 2 : 1;
+  if (rt <= 0) rt = n_seq >= 1024 ? 2 : 1;
   if (dtype == URSE_BF16) {
-    if (ut_per_wave <= 7) {
-      if (rt >= 2 && (size_t)32 * (8 * H + 16) <= 160 * 1024) return launch_bwd<bf16_t, 2, 7>(p, st);
-      return launch_bwd<bf16_t, 1, 7>(p, st);
-    }
-    return launch_bwd<bf16_t, 1, 12>(p, st);
+    const bool fits2 = (size_t)32 * (8 * H + 16) <= 160 * 1024;
+    if (ut_per_wave <= 2) return (rt >= 2 && fits2) ? launch_bwd<bf16_t, 2, 2>(p, st) : launch_bwd<bf16_t, 1, 2>(p, st);
+    return launch_bwd<bf16_t, 1, 3>(p, st);
   }
-  if (ut_per_wave <= 7) return launch_bwd<float, 1, 7>(p, st);
-  return launch_bwd<float, 1, 12>(p, st);
+  if (ut_per_wave <= 2) return launch_bwd<float, 1, 2>(p, st);
+  return launch_bwd<float, 1, 3>(p, st);
 }

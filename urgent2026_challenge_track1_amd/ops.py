@@ -11,6 +11,31 @@ from ._lib import call, require_cuda, stream_ptr
 WIN_RECT, WIN_HANN = 0, 1
 F32, BF16 = 0, 1
 
+# Optional per-kernel HIP-event timing (bench.py): name -> [(start_event, end_event), ...]
+_timing = None
+
+
+def enable_timing(names):
+    global _timing
+    _timing = {n: [] for n in names}
+
+
+def disable_timing():
+    global _timing
+    t, _timing = _timing, None
+    return t
+
+
+def timed_call(tname, name, *args):
+    if _timing is not None and tname in _timing:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        call(name, *args)
+        b.record()
+        _timing[tname].append((a, b))
+    else:
+        call(name, *args)
+
 
 def _f32c(t):
     return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
@@ -25,7 +50,7 @@ def stft_forward(wav, n_fft, hop, window=WIN_HANN, lens=None):
     spec = torch.empty(B, T, Fb, 2, device=wav.device, dtype=torch.float32)
     if lens is not None:
         lens = lens.to(device=wav.device, dtype=torch.int32).contiguous()
-    call("stft_fwd", wav, lens, spec, B, L, n_fft, hop, window, stream_ptr())
+    timed_call("stft_fwd", "stft_fwd", wav, lens, spec, B, L, n_fft, hop, window, stream_ptr())
     return torch.view_as_complex(spec)
 
 
@@ -141,15 +166,15 @@ def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, ro
     ldh = kpad(2 * H, gx.dtype)
     hout = torch.zeros(M, ldh, device=gx.device, dtype=gx.dtype)
     c = torch.empty(M, 2 * H, device=gx.device, dtype=torch.float32) if save else None
-    call("lstm_bidir_fwd", gx, gx.stride(0), whh, hout, ldh, c, H, Hp, n_seq, seq_len, inner, outer, stride,
-         int(save), _dt(gx), rows16, stream_ptr())
+    timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_bidir_fwd", gx, gx.stride(0), whh, hout, ldh,
+               c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), _dt(gx), rows16, stream_ptr())
     return hout, c
 
 
 def lstm_bwd(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride, rows16=0):
     """gates (saved activations) is overwritten with d(pre-activations)."""
-    call("lstm_bidir_bwd", dh, dh.stride(0), gates, gates.stride(0), c, whhT, H, n_seq, seq_len, inner, outer, stride,
-         _dt(gates), rows16, stream_ptr())
+    timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_bidir_bwd", dh, dh.stride(0), gates,
+               gates.stride(0), c, whhT, H, n_seq, seq_len, inner, outer, stride, _dt(gates), rows16, stream_ptr())
     return gates
 
 
