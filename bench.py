@@ -58,21 +58,43 @@ def gate_gemm_flops(B, T, K, N, layers):
     return 2.0 * layers * 2 * 2 * (4 * H) * (N + H) * (B * T * K)
 
 
-def cpu_baseline(args, fs, L):
-    """The oracle's (CPU torch restatement of train_se.py) optimisation step on the host cores."""
+CPU_SAMPLE_SECONDS = 1.0
+
+
+def _cpu_baseline_worker():
+    """child process: one oracle (CPU torch restatement of train_se.py) optimisation step on a bounded sample."""
+    import torch
     from oracle import bsrnn_ref, losses_ref
-    torch.set_num_threads(os.cpu_count())
-    Bc = args.cpu_batch
+    threads = min(os.cpu_count() or 1, 32)      # beyond ~32 threads the small per-step ops oversubscribe
+    torch.set_num_threads(threads)
+    fs = 48000
+    L = int(CPU_SAMPLE_SECONDS * fs)
     model = bsrnn_ref.BSRNN_SE(196, 6)
     opt = losses_ref.make_optimizer(model.parameters())
-    clean, noisy = synth_batch(Bc, L, fs, 2024, "cpu")
-    lens = torch.full((Bc,), L, dtype=torch.int32)
+    clean, noisy = synth_batch(1, max(L, int(0.9 * fs)), fs, 2024, "cpu")
+    clean, noisy = clean[:, :L].contiguous(), noisy[:, :L].contiguous()
+    lens = torch.full((1,), L, dtype=torch.int32)
+    losses_ref.train_step(model, opt, clean[:, :L // 4], noisy[:, :L // 4], fs, lens // 4)   # warm-up
     t0 = time.perf_counter()
     losses_ref.train_step(model, opt, clean, noisy, fs, lens)
     dt = time.perf_counter() - t0
-    return {"value": Bc / dt, "unit": "utt/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "1 oracle train step (fwd+bwd+clip+AdamW, fp32), B=%d x 4 s @ %d Hz, N=196 L=6, %d threads"
-                      % (Bc, fs, torch.get_num_threads()), "seconds": dt}
+    print(json.dumps({"dt": dt, "threads": threads}))
+
+
+def cpu_baseline(timeout_s=240):
+    """Oracle train step timed on the host cores on a BOUNDED sample (1 utterance x 1 s @ 48 kHz, full N=196 L=6
+    model, fp32); the per-step cost is linear in the number of frames, so utt/s for 4 s utterances = (1/4)/dt."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True,
+                           text=True, timeout=timeout_s)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # timeout or failure: report it, never hang the bench
+        return {"value": None, "unit": "utt/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+    return {"value": (CPU_SAMPLE_SECONDS / 4.0) / d["dt"], "unit": "utt/s", "cores": d["threads"], "kind": "port",
+            "sample": "oracle train step (fwd+bwd+clip+AdamW, fp32, N=196 L=6) on 1 utt x %.1f s @ 48 kHz = %.2f s; "
+                      "scaled to 4 s utterances (cost linear in frames); %d torch threads of %d host cpus"
+                      % (CPU_SAMPLE_SECONDS, d["dt"], d["threads"], os.cpu_count())}
 
 
 def main():
@@ -85,9 +107,12 @@ def main():
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--channels", type=int, default=196)
     ap.add_argument("--seconds", type=float, default=4.0)
-    ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true")
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        _cpu_baseline_worker()
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,10 +196,10 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": stft_bytes / (kt["stft_fwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "gate_gemm_tflops_per_step": 3 * gate_gemm_flops(B, T, K, args.channels, args.layers) / 1e12,
-        "final_loss": float(loss),
+        "final_loss": float(loss.detach()),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, fs, L)
+        out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

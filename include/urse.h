@@ -73,10 +73,12 @@ int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_d
                          void* stream);
 /* C[Mo,No] (f32) += sum_r A[r,Mo] * B'[r,No]  and optionally colsum[Mo] += sum_r A[r,:].
  * B'[r] = B[r+shift], zero when period > 0 and ((r / inner) % period) == invalid_step
- * (the h_{t-1} operand of the recurrent weight gradient). */
+ * (the h_{t-1} operand of the recurrent weight gradient).  perm_h > 0: the columns of A are in the LSTM
+ * kernels' gate-interleaved order (dir, unit, gate) and C rows / colsum are written back in nn.LSTM's
+ * (dir, gate, unit) order with H = perm_h. */
 int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
                  int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner, int64_t period,
-                 int64_t invalid_step, int dtype, void* stream);
+                 int64_t invalid_step, int64_t perm_h, int dtype, void* stream);
 
 /* ---- GroupNorm(1, C) on the channel-last activation stream -----------------------------------
  * espnet2 choose_norm("GN") / choose_norm1d("GN") == nn.GroupNorm(1, N) (in-tree twin:
@@ -99,13 +101,20 @@ int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ld
 int urse_pack_segments(const float* in, void* out, const void* segs, int nseg, int blocks_per_seg, int transpose,
                        int out_dtype, void* stream);
 
+/* Packs one nn.LSTM(bidirectional)'s f32 weights (wih [2*4H,N], whh [2*4H,H], bih/bhh [2*4H], forward then
+ * reverse) into the kernel layouts: wih_p [8H,Np] / wihT_p [N,8H] / bias [8H] (b_ih+b_hh) with gate rows
+ * permuted to (dir, unit, gate); whh_frag (2*ceil16(H)*4*Hp elements) and whhT_frag (2*ceil16(H)*4H). */
+int urse_lstm_pack(const float* wih, const float* whh, const float* bih, const float* bhh, void* wih_p, void* wihT_p,
+                   float* bias, void* whh_frag, void* whhT_frag, int N, int Np, int H, int Hp, int dtype,
+                   void* stream);
+
 /* ---- bidirectional LSTM recurrence ---------------------------------------------------------------
  * Sequential part of nn.LSTM(N, 2N, batch_first, bidirectional) (cuDNN under espnet2 BSRNN; twin:
  * baseline_code/models/bsrnn_flowse.py:296-299 rnn_time, :303-306 rnn_freq).  Gate order i,f,g,o.
  * Rows of the [M, .] matrices are addressed as row(s,t) = (s/inner)*outer + s%inner + t*stride.
- *  gx   [M, ldg>=8H]  gate pre-activations x*W_ih^T + b_ih + b_hh, direction d in cols [d*4H,(d+1)*4H);
+ *  gx   [M, ldg>=8H]  gate pre-activations x*W_ih^T + b_ih + b_hh, GATE-INTERLEAVED: col = d*4H + unit*4 + gate;
  *                     overwritten with the gate activations when save != 0
- *  whh  [2][4H][Hp]   recurrent weights, K zero-padded to Hp (multiple of 32 bf16 / 16 f32, >= ceil16(H))
+ *  whh                recurrent weights in MFMA-fragment order from urse_lstm_pack (K padded to Hp)
  *  hout [M, ldh>=2H]  hidden states, direction d in cols [d*H,(d+1)*H)
  *  c    [M, 2H] f32   cell states (written when save != 0)
  *  rows16: sequences per workgroup / 16 (0 = automatic). */
@@ -113,7 +122,8 @@ int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int6
                         int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save, int dtype,
                         int rows16, void* stream);
 /* Backward through time.  dh [M, ldd>=2H] = gradient w.r.t. hout; gates: in = saved activations,
- * out = gradient w.r.t. the gate pre-activations; whhT [2][H][4H] = transposed recurrent weights. */
+ * out = gradient w.r.t. the gate pre-activations (same interleaved layout); whhT = fragment-ordered
+ * transposed recurrent weights from urse_lstm_pack. */
 int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT,
                         int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int dtype,
                         int rows16, void* stream);

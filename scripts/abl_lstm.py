@@ -1,0 +1,47 @@
+"""Ablation timing of the LSTM recurrence kernels (diagnostic builds; not part of the product path)."""
+import ctypes, os, subprocess, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
+variants = {"base": []}
+libs = {}
+for name, fl in variants.items():
+    so = "/tmp/abl_%s.so" % name
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", *fl,
+                           os.path.join(CS, "lstm.hip"), os.path.join(CS, "api.hip"), "-o", so])
+    libs[name] = ctypes.CDLL(so)
+B, T, K, N = 32, 401, 34, 196
+H, Hp = 2 * N, 416
+M = B * T * K
+dev = "cuda"
+gx = torch.randn(M, 8 * H, device=dev).to(torch.bfloat16)
+whh = (torch.randn(2 * 400 * 4 * Hp, device=dev) * 0.05).to(torch.bfloat16)
+hout = torch.zeros(M, 800, device=dev, dtype=torch.bfloat16)
+c = torch.empty(M, 2 * H, device=dev)
+whhT = (torch.randn(2 * 400 * 4 * H, device=dev) * 0.05).to(torch.bfloat16)
+dh = torch.randn(M, 800, device=dev).to(torch.bfloat16)
+st = torch.cuda.current_stream().cuda_stream
+P = ctypes.c_void_p
+def fwd(lib, path, rt):
+    if path == "time": a = (B * K, T, K, T * K, K)
+    else: a = (B * T, K, 1, K, 1)
+    return lib.urse_lstm_bidir_fwd(P(gx.data_ptr()), ctypes.c_int64(8 * H), P(whh.data_ptr()), P(hout.data_ptr()), ctypes.c_int64(800),
+        P(c.data_ptr()), H, Hp, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 1, 1, rt, P(st))
+def bwd(lib, path, rt):
+    if path == "time": a = (B * K, T, K, T * K, K)
+    else: a = (B * T, K, 1, K, 1)
+    return lib.urse_lstm_bidir_bwd(P(dh.data_ptr()), ctypes.c_int64(800), P(gx.data_ptr()), ctypes.c_int64(8 * H), P(c.data_ptr()),
+        P(whhT.data_ptr()), H, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 1, rt, P(st))
+for fn, fname in ((fwd, "fwd"), (bwd, "bwd")):
+    for path in ("time", "band"):
+        for rt in ((1, 2, 17, 18, 20) if fname == 'fwd' else (1, 17, 18)):
+            res = []
+            for name, lib in libs.items():
+                assert fn(lib, path, rt) == 0
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2): fn(lib, path, rt)
+                torch.cuda.synchronize()
+                res.append("%s %.2f" % (name, (time.perf_counter() - t0) / 2 * 1e3))
+            print(fname, path, "rt", rt, " | ".join(res), "ms", flush=True)

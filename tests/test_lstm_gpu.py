@@ -32,14 +32,13 @@ def _case(B, T, K, N, path, dtype, seed=0):
     M = B * T * K
     Np, Hp = ops.kpad(N, dtype), ops.kpad(ops.pad_to(H, 16), dtype)
     xr = ops.pack2d(x.reshape(M, N).to(dev), M, Np, dtype)
-    wih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]).detach().to(dev)
-    bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach().to(dev)
-    wih_p = ops.pack2d(wih, 8 * H, Np, dtype)
-    whh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]).detach().to(dev)      # [2,4H,H]
-    whh_p = ops.pack2d(whh.reshape(8 * H, H), 8 * H, Hp, dtype)
-    whhT_p = torch.stack([ops.pack2d(whh[d], H, 4 * H, dtype, transpose=True) for d in range(2)])
-    gx = ops.gemm_nt(xr, wih_p, bias)
-    hout, c = ops.lstm_fwd(gx, whh_p, H, Hp, n_seq, seq_len, inner, outer, stride)
+    wih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]).detach().to(dev).contiguous()
+    whh = torch.cat([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]).detach().to(dev).contiguous()
+    bih = torch.cat([lstm.bias_ih_l0, lstm.bias_ih_l0_reverse]).detach().to(dev).contiguous()
+    bhh = torch.cat([lstm.bias_hh_l0, lstm.bias_hh_l0_reverse]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(wih, whh, bih, bhh, N, H, dtype)
+    gx = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    hout, c = ops.lstm_fwd(gx, pk["whh"], H, Hp, n_seq, seq_len, inner, outer, stride)
     tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
     err = (hout[:, :2 * H].float().cpu() - y_rows).abs().max().item()
     assert err <= tol, ("fwd", err)
@@ -48,17 +47,16 @@ def _case(B, T, K, N, path, dtype, seed=0):
     # backward through time
     ldh = hout.shape[1]
     dh = ops.pack2d(gy_rows.to(dev), M, ldh, dtype)
-    dg = ops.lstm_bwd(dh, gx, c, whhT_p, H, n_seq, seq_len, inner, outer, stride)
+    dg = ops.lstm_bwd(dh, gx, c, pk["whhT"], H, n_seq, seq_len, inner, outer, stride)
     # dx = dgates @ W_ih
-    wihT_p = ops.pack2d(wih, N, 8 * H, dtype, transpose=True)
-    dx = ops.gemm_nt(dg, wihT_p, out_dtype=torch.float32)
+    dx = ops.gemm_nt(dg, pk["wihT"], out_dtype=torch.float32)
     scale = gx_rows.abs().max().item()
     err = (dx.cpu() - gx_rows).abs().max().item()
     assert err <= (3e-2 if dtype == torch.bfloat16 else 5e-5) * scale, ("dx", err, scale)
     # weight grads
     dwih = torch.zeros(8 * H, N, device=dev)
     db = torch.zeros(8 * H, device=dev)
-    ops.gemm_tn(dg, xr, dwih, colsum=db, No=N)
+    ops.gemm_tn(dg, xr, dwih, colsum=db, No=N, perm_h=H)
     ref_dwih = torch.cat([lstm.weight_ih_l0.grad, lstm.weight_ih_l0_reverse.grad])
     ref_db = torch.cat([lstm.bias_ih_l0.grad, lstm.bias_ih_l0_reverse.grad])
     wt = (3e-2 if dtype == torch.bfloat16 else 1e-4)
@@ -67,7 +65,7 @@ def _case(B, T, K, N, path, dtype, seed=0):
     for d, (wname, inv, sh) in enumerate([("weight_hh_l0", 0, -stride), ("weight_hh_l0_reverse", seq_len - 1, stride)]):
         dwhh = torch.zeros(4 * H, H, device=dev)
         ops.gemm_tn(dg[:, d * 4 * H:(d + 1) * 4 * H], hout[:, d * H:(d + 1) * H], dwhh, shift=sh, inner=stride,
-                    period=seq_len, invalid_step=inv)
+                    period=seq_len, invalid_step=inv, perm_h=H)
         ref = getattr(lstm, wname).grad
         assert (dwhh.cpu() - ref).abs().max().item() <= wt * ref.abs().max().item(), wname
 

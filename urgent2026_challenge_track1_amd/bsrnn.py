@@ -235,11 +235,6 @@ class BSRNNCore(nn.Module):
         for l in range(self.num_layer):
             for path in "tf":
                 p = "l%d%s." % (l, path)
-                h[p + "wih"] = pn.add(o[p + "wih"], 8 * H, N, 8 * H, Np)
-                h[p + "wihT"] = pt.add(o[p + "wih"], 8 * H, N, N, 8 * H)
-                h[p + "whh"] = pn.add(o[p + "whh"], 8 * H, H, 8 * H, Hp)
-                h[p + "whhT0"] = pt.add(o[p + "whh"], 4 * H, H, H, 4 * H)
-                h[p + "whhT1"] = pt.add(o[p + "whh"] + 4 * H * H, 4 * H, H, H, 4 * H)
                 h[p + "wfc"] = pn.add(o[p + "wfc"], N, 2 * H, N, ld2H)
                 h[p + "wfcT"] = pt.add(o[p + "wfc"], N, 2 * H, 2 * H, Np)
         for tag in "mr":
@@ -270,16 +265,19 @@ class BSRNNCore(nn.Module):
         pk = {}
         for key, hd in h.items():
             name = key[0] if isinstance(key, tuple) else key
-            pk[key] = _view(bt if name.endswith("T") or name.endswith("T0") or name.endswith("T1") else bn, hd)
-        bias = torch.empty(self.num_layer * 2, 8 * H, dtype=torch.float32, device=self._flat.device)
-        i = 0
+            pk[key] = _view(bt if name.endswith("T") else bn, hd)
+        N = self.N
+        if not hasattr(self, "_lstm_bufs") or self._lstm_bufs.get("key") != (dtype, self._flat.device):
+            self._lstm_bufs = {"key": (dtype, self._flat.device)}
         for l in range(self.num_layer):
             for path in "tf":
                 p = "l%d%s." % (l, path)
-                call("axpby", self._p(p + "bih", 8 * H), bias[i], 1.0, 0.0, 8 * H, stream_ptr())
-                call("axpby", self._p(p + "bhh", 8 * H), bias[i], 1.0, 1.0, 8 * H, stream_ptr())
-                pk[p + "bias"] = bias[i]
-                i += 1
+                lp = ops.lstm_pack(self._p(p + "wih", 8 * H * N), self._p(p + "whh", 8 * H * H),
+                                   self._p(p + "bih", 8 * H), self._p(p + "bhh", 8 * H), N, H, dtype,
+                                   out=self._lstm_bufs.get(p))
+                self._lstm_bufs[p] = lp
+                pk[p + "wih"], pk[p + "wihT"], pk[p + "bias"] = lp["wih"], lp["wihT"], lp["bias"]
+                pk[p + "whh"], pk[p + "whhT"] = lp["whh"], lp["whhT"]
         self._packed = pk
         self._packed_version = self.param_version
 
@@ -391,16 +389,15 @@ class BSRNNCore(nn.Module):
         ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N,
                     No=2 * H)
         sm = self._seqmap(path, B, T, K)
-        whhT = pk[p + "whhT0"]  # whhT0 / whhT1 are adjacent blocks of the transposed-pack buffer: [2][H][4H]
-        dg = ops.lstm_bwd(dh, gates, c, whhT, H, **sm)
+        dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, **sm)   # dgates, gate-interleaved columns
         gb = self._g(p + "bih", 8 * H)
-        ops.gemm_tn(dg, xn, self._g(p + "wih", 8 * H * N).view(8 * H, N), colsum=gb, Mo=8 * H, No=N)
+        ops.gemm_tn(dg, xn, self._g(p + "wih", 8 * H * N).view(8 * H, N), colsum=gb, Mo=8 * H, No=N, perm_h=H)
         call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())
         st, L = sm["stride"], sm["seq_len"]
         for dr, (sh, inv) in enumerate(((-st, 0), (st, L - 1))):
             ops.gemm_tn(dg[:, dr * 4 * H:(dr + 1) * 4 * H], hout[:, dr * H:(dr + 1) * H],
                         self._g(p + "whh", 4 * H * H, dr * 4 * H * H).view(4 * H, H), Mo=4 * H, No=H, shift=sh,
-                        inner=st, period=L, invalid_step=inv)
+                        inner=st, period=L, invalid_step=inv, perm_h=H)
         dxn = ops.gemm_nt(dg, pk[p + "wihT"], out_dtype=torch.float32, N=N)
         dskip = ops.groupnorm_bwd(skip, dxn, stats, self._p(p + "gamma", N), dout, self._g(p + "gamma", N),
                                   self._g(p + "beta", N), B, T, 1, K * N, N, 0, GN_EPS)

@@ -171,7 +171,14 @@ struct TnArgs {
   long R, Mo, No;
   long shift, inner, period, invalid_step;
   long rows_per_slice;
+  long perm_h;   // > 0: A columns are gate-interleaved (dir, unit, gate); C rows / colsum are written as (dir, gate, unit)
 };
+
+__device__ __forceinline__ long tn_perm(long m, long h) {
+  if (h <= 0) return m;
+  const long g4 = 4 * h, d = m / g4, r = m - d * g4;
+  return d * g4 + (r & 3) * h + (r >> 2);
+}
 
 template <typename T>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs p) {
@@ -294,10 +301,10 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (row < p.Mo) atomicAdd(p.C + row * p.ldc + col, acc[i][j][r]);
+        if (row < p.Mo) atomicAdd(p.C + tn_perm(row, p.perm_h) * p.ldc + col, acc[i][j][r]);
       }
   }
-  if (do_colsum && m0 + tid < p.Mo) atomicAdd(p.colsum + m0 + tid, csum);
+  if (do_colsum && m0 + tid < p.Mo) atomicAdd(p.colsum + tn_perm(m0 + tid, p.perm_h), csum);
 }
 
 }  // namespace urse
@@ -358,7 +365,7 @@ extern "C" int urse_gemm_nt_grouped(const void* descs, int groups, int max_block
 
 extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                             float* colsum, int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner,
-                            int64_t period, int64_t invalid_step, int dtype, void* stream) {
+                            int64_t period, int64_t invalid_step, int64_t perm_h, int dtype, void* stream) {
   URSE_CHECK_ARG(A && B && C && R > 0 && Mo > 0 && No > 0, "urse_gemm_tn: bad argument");
   const int es = dtype == URSE_BF16 ? 2 : 4;
   URSE_CHECK_ARG((lda * es) % 16 == 0 && (ldb * es) % 16 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
@@ -368,6 +375,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   p.A = (const char*)A; p.B = (const char*)B; p.C = C; p.colsum = colsum;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.R = R; p.Mo = Mo; p.No = No;
   p.shift = shift; p.inner = inner > 0 ? inner : 1; p.period = period; p.invalid_step = invalid_step;
+  p.perm_h = perm_h;
   const long tiles = ((Mo + BM - 1) / BM) * ((No + BN - 1) / BN);
   const int bkr = dtype == URSE_BF16 ? 32 : 16;
   long slices = (1024 + tiles - 1) / tiles;

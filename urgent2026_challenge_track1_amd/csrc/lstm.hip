@@ -8,6 +8,11 @@
 // and no grid barrier.  Gate order i,f,g,o and the two-bias convention follow nn.LSTM (cuDNN) as used
 // by espnet2 BSRNN (twin: baseline_code/models/bsrnn_flowse.py:296-299 time path, :303-306 band path).
 //
+// Layouts chosen for the memory system: gate columns are interleaved per hidden unit
+// (col = dir*4H + u*4 + gate) so a lane touches its four gates with ONE 8-byte access and 16 lanes cover
+// a full 128-byte line; the recurrent weights are pre-packed in MFMA-fragment order (1 KiB per
+// wave-instruction, fully coalesced) by urse_lstm_pack.
+//
 // row(s, t) = (s / inner) * outer + (s % inner) + t * stride   maps (sequence, step) to a row of the
 // [B*T*K, .] channel-last activation matrices: time path inner=K, outer=T*K, stride=K; band path
 // inner=1, outer=K, stride=1.
@@ -25,7 +30,7 @@ struct SeqMap {
 
 struct LstmFwdArgs {
   void* gx; long ldg;        // [M, ldg] T: gate pre-activations (both directions, 2*4H); overwritten with activations
-  const void* whh;           // [2][4H][Hp] T
+  const void* whh;           // fragment-ordered [2][nut][nslab][4][64][16 B]
   void* hout; long ldh;      // [M, ldh] T: h (dir 0 cols [0,H), dir 1 cols [H,2H))
   float* c;                  // [M, 2H] f32 cell state (saved when `save`)
   int H, Hp, save;
@@ -36,9 +41,29 @@ struct LstmBwdArgs {
   const void* dh; long ldd;  // [M, ldd] T: gradient w.r.t. hout
   void* gates; long ldg;     // in: saved gate activations; out: gradient w.r.t. gate pre-activations
   const float* c;            // [M, 2H]
-  const void* whhT;          // [2][H][4H] T
+  const void* whhT;          // fragment-ordered [2][nut][nslabT][64][16 B]
   int H;
   SeqMap m;
+};
+
+template <typename T> struct Vec4;
+template <> struct Vec4<bf16_t> {
+  typedef uint2 raw;
+  static __device__ __forceinline__ void unpack(raw v, float (&o)[4]) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ raw pack(const float (&i)[4]) {
+    raw v;
+    v.x = (unsigned)f32_to_bf16(i[0]) | ((unsigned)f32_to_bf16(i[1]) << 16);
+    v.y = (unsigned)f32_to_bf16(i[2]) | ((unsigned)f32_to_bf16(i[3]) << 16);
+    return v;
+  }
+};
+template <> struct Vec4<float> {
+  typedef float4 raw;
+  static __device__ __forceinline__ void unpack(raw v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+  static __device__ __forceinline__ raw pack(const float (&i)[4]) { return make_float4(i[0], i[1], i[2], i[3]); }
 };
 
 template <typename T, int RT>
@@ -60,13 +85,13 @@ __device__ __forceinline__ void mma_slab(const uint4 (&a)[RT], const uint4& b, f
   }
 }
 
-constexpr int NW = 16;          // waves per workgroup: memory-level parallelism for the streamed weights
-constexpr int NTHR = NW * 64;
-
-template <typename T, int RT, int MAXUT>
-__global__ void __launch_bounds__(NTHR) lstm_fwd_kernel(LstmFwdArgs p) {
+// NW = waves per workgroup (16: most memory-level parallelism, 128 VGPRs; 8: 256 VGPRs for bigger row tiles)
+template <typename T, int RT, int MAXUT, int NW>
+__global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
+  constexpr int NTHR = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T), R = 16 * RT;
+  typedef typename Vec4<T>::raw V4;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   const int dir = blockIdx.y, s0 = blockIdx.x * R;
   const int H = p.H, Hp = p.Hp, nut = (H + 15) >> 4;
@@ -91,10 +116,11 @@ __global__ void __launch_bounds__(NTHR) lstm_fwd_kernel(LstmFwdArgs p) {
       if (seq >= p.m.n_seq) seq = p.m.n_seq - 1;
       rowbase[rt][r] = (seq / p.m.inner) * p.m.outer + (seq % p.m.inner);
     }
-  const char* whh = reinterpret_cast<const char*>(p.whh) + (long)dir * 4 * H * Hp * ES;
+  const int nslab = Hp * ES / 64;
+  // fragment-ordered weights: block(ut, ks, g) = 1 KiB, lane-linear
+  const char* whh = reinterpret_cast<const char*>(p.whh) + ((long)dir * nut * nslab * 4) * 1024 + lane * 16;
   T* gx = reinterpret_cast<T*>(p.gx);
   T* hout = reinterpret_cast<T*>(p.hout);
-  const int nslab = Hp * ES / 64;
   const long gcol0 = (long)dir * 4 * H;
   __syncthreads();
 
@@ -110,21 +136,33 @@ __global__ void __launch_bounds__(NTHR) lstm_fwd_kernel(LstmFwdArgs p) {
         const int u = ut * 16 + lc;
         const bool uvalid = u < H;
         const int uc = uvalid ? u : H - 1;
+        // gate pre-activations of this lane's (row, unit) pairs: independent of the recurrence, issued first
+        V4 gxv[RT][4];
+#ifndef ABL_NO_PW
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            gxv[rt][r] = *reinterpret_cast<const V4*>(gx + (rowbase[rt][r] + toff) * p.ldg + gcol0 + uc * 4);
+#endif
         f32x4_t acc[4][RT];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) acc[g][rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const char* wr = whh + ((long)uc * Hp) * ES + 16 * lr;
-        const long wg = (long)H * Hp * ES;  // gate stride
+        const char* wr = whh + ((long)ut * nslab * 4) * 1024;
         const char* ar = hc + lc * pitch + 16 * lr;
 #pragma unroll 4
         for (int ks = 0; ks < nslab; ++ks) {
           uint4 b[4], a[RT];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const uint4*>(wr + g * wg + ks * 64);
-#pragma unroll
           for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const uint4*>(ar + rt * 16 * pitch + ks * 64);
+#pragma unroll
+#ifdef ABL_NO_W
+          for (int g = 0; g < 4; ++g) b[g] = a[0];
+#else
+          for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const uint4*>(wr + (ks * 4 + g) * 1024);
+#endif
 #pragma unroll
           for (int g = 0; g < 4; ++g) mma_slab<T, RT>(a, b[g], acc[g]);
         }
@@ -133,24 +171,26 @@ __global__ void __launch_bounds__(NTHR) lstm_fwd_kernel(LstmFwdArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const long row = rowbase[rt][r] + toff;
-            T* gp = gx + row * p.ldg + gcol0 + uc;
-            const float gi = acc[0][rt][r] + to_f32<T>(gp[0]);
-            const float gf = acc[1][rt][r] + to_f32<T>(gp[H]);
-            const float gg = acc[2][rt][r] + to_f32<T>(gp[2 * H]);
-            const float go = acc[3][rt][r] + to_f32<T>(gp[3 * H]);
-            const float iv = sigmoidf_(gi), fv = sigmoidf_(gf), gv = tanhf_(gg), ov = sigmoidf_(go);
+            float pre[4] = {0.f, 0.f, 0.f, 0.f};
+#ifndef ABL_NO_PW
+            Vec4<T>::unpack(gxv[rt][r], pre);
+#endif
+            const float iv = sigmoidf_(acc[0][rt][r] + pre[0]), fv = sigmoidf_(acc[1][rt][r] + pre[1]);
+            const float gv = tanhf_(acc[2][rt][r] + pre[2]), ov = sigmoidf_(acc[3][rt][r] + pre[3]);
             const float cv = fv * cst[ui][rt][r] + iv * gv;
             cst[ui][rt][r] = cv;
             const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
             const T hT = from_f32<T>(hv);
             *reinterpret_cast<T*>(hn + (rt * 16 + lr * 4 + r) * pitch + u * ES) = hT;
+#ifdef ABL_NO_PW
+            if (rvalid[rt][r] && uvalid && step == p.m.seq_len - 1) {
+#else
             if (rvalid[rt][r] && uvalid) {
+#endif
               hout[row * p.ldh + (long)dir * H + u] = hT;
               if (p.save) {
-                gp[0] = from_f32<T>(iv);
-                gp[H] = from_f32<T>(fv);
-                gp[2 * H] = from_f32<T>(gv);
-                gp[3 * H] = from_f32<T>(ov);
+                const float act[4] = {iv, fv, gv, ov};
+                *reinterpret_cast<V4*>(gx + row * p.ldg + gcol0 + u * 4) = Vec4<T>::pack(act);
                 p.c[row * 2 * H + (long)dir * H + u] = cv;
               }
             }
@@ -161,10 +201,11 @@ __global__ void __launch_bounds__(NTHR) lstm_fwd_kernel(LstmFwdArgs p) {
   }
 }
 
-template <typename T, int RT, int MAXUT>
-__global__ void __launch_bounds__(NTHR) lstm_bwd_kernel(LstmBwdArgs p) {
+template <typename T, int RT, int MAXUT, int NW>
+__global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T), R = 16 * RT;
+  typedef typename Vec4<T>::raw V4;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   const int dir = blockIdx.y, s0 = blockIdx.x * R;
   const int H = p.H, nut = (H + 15) >> 4, G4 = 4 * H;
@@ -187,10 +228,10 @@ __global__ void __launch_bounds__(NTHR) lstm_bwd_kernel(LstmBwdArgs p) {
       if (seq >= p.m.n_seq) seq = p.m.n_seq - 1;
       rowbase[rt][r] = (seq / p.m.inner) * p.m.outer + (seq % p.m.inner);
     }
-  const char* whhT = reinterpret_cast<const char*>(p.whhT) + (long)dir * H * G4 * ES;
+  const int nslab = G4 * ES / 64;
+  const char* whhT = reinterpret_cast<const char*>(p.whhT) + ((long)dir * nut * nslab) * 1024 + lane * 16;
   const T* dh = reinterpret_cast<const T*>(p.dh);
   T* gates = reinterpret_cast<T*>(p.gates);
-  const int nslab = G4 * ES / 64;
   const long gcol0 = (long)dir * G4;
   const long prev_off = dir ? p.m.stride : -p.m.stride;
 
@@ -204,37 +245,39 @@ __global__ void __launch_bounds__(NTHR) lstm_bwd_kernel(LstmBwdArgs p) {
       if (ut < nut) {
         const int u = ut * 16 + lc;
         if (u < H) {
+          V4 gv4[RT][4];
+          float ctv[RT][4], cpv[RT][4], dhv[RT][4];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const long row = rowbase[rt][r] + toff;
-              T* gp = gates + row * p.ldg + gcol0 + u;
-              const float iv = to_f32<T>(gp[0]), fv = to_f32<T>(gp[H]), gv = to_f32<T>(gp[2 * H]),
-                          ov = to_f32<T>(gp[3 * H]);
+              gv4[rt][r] = *reinterpret_cast<const V4*>(gates + row * p.ldg + gcol0 + u * 4);
               const long ci = row * 2 * H + (long)dir * H + u;
-              const float ct = p.c[ci];
-              const float cp = first ? 0.f : p.c[ci + prev_off * 2 * H];
-              const float dhv = to_f32<T>(dh[row * p.ldd + (long)dir * H + u]) + dhr[ui][rt][r];
-              const float tc = tanhf_(ct);
-              const float dct = dcs[ui][rt][r] + dhv * ov * (1.f - tc * tc);
-              const float dgo = dhv * tc * ov * (1.f - ov);
-              const float dgi = dct * gv * iv * (1.f - iv);
-              const float dgf = dct * cp * fv * (1.f - fv);
-              const float dgg = dct * iv * (1.f - gv * gv);
+              ctv[rt][r] = p.c[ci];
+              cpv[rt][r] = first ? 0.f : p.c[ci + prev_off * 2 * H];
+              dhv[rt][r] = to_f32<T>(dh[row * p.ldd + (long)dir * H + u]);
+            }
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const long row = rowbase[rt][r] + toff;
+              float a[4];
+              Vec4<T>::unpack(gv4[rt][r], a);
+              const float iv = a[0], fv = a[1], gv = a[2], ov = a[3];
+              const float dht = dhv[rt][r] + dhr[ui][rt][r];
+              const float tc = tanhf_(ctv[rt][r]);
+              const float dct = dcs[ui][rt][r] + dht * ov * (1.f - tc * tc);
+              float dg[4];
+              dg[0] = dct * gv * iv * (1.f - iv);
+              dg[1] = dct * cpv[rt][r] * fv * (1.f - fv);
+              dg[2] = dct * iv * (1.f - gv * gv);
+              dg[3] = dht * tc * ov * (1.f - ov);
               dcs[ui][rt][r] = dct * fv;
-              const T ti = from_f32<T>(dgi), tf = from_f32<T>(dgf), tg = from_f32<T>(dgg), to = from_f32<T>(dgo);
-              char* lrow = smem + (rt * 16 + lr * 4 + r) * pitch;
-              *reinterpret_cast<T*>(lrow + (u)*ES) = ti;
-              *reinterpret_cast<T*>(lrow + (H + u) * ES) = tf;
-              *reinterpret_cast<T*>(lrow + (2 * H + u) * ES) = tg;
-              *reinterpret_cast<T*>(lrow + (3 * H + u) * ES) = to;
-              if (rvalid[rt][r]) {
-                gp[0] = ti;
-                gp[H] = tf;
-                gp[2 * H] = tg;
-                gp[3 * H] = to;
-              }
+              const V4 pk = Vec4<T>::pack(dg);
+              *reinterpret_cast<V4*>(smem + (rt * 16 + lr * 4 + r) * pitch + (u * 4) * ES) = pk;
+              if (rvalid[rt][r]) *reinterpret_cast<V4*>(gates + row * p.ldg + gcol0 + u * 4) = pk;
             }
         }
       }
@@ -245,17 +288,15 @@ __global__ void __launch_bounds__(NTHR) lstm_bwd_kernel(LstmBwdArgs p) {
       for (int ui = 0; ui < MAXUT; ++ui) {
         const int ut = w + NW * ui;
         if (ut < nut) {
-          const int u = ut * 16 + lc;
-          const int uc = u < H ? u : H - 1;
           f32x4_t acc[RT];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          const char* wr = whhT + ((long)uc * G4) * ES + 16 * lr;
+          const char* wr = whhT + ((long)ut * nslab) * 1024;
           const char* ar = smem + lc * pitch + 16 * lr;
-#pragma unroll 4
+#pragma unroll 8
           for (int ks = 0; ks < nslab; ++ks) {
             uint4 a[RT];
-            const uint4 b = *reinterpret_cast<const uint4*>(wr + ks * 64);
+            const uint4 b = *reinterpret_cast<const uint4*>(wr + ks * 1024);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const uint4*>(ar + rt * 16 * pitch + ks * 64);
             mma_slab<T, RT>(a, b, acc);
@@ -271,34 +312,111 @@ __global__ void __launch_bounds__(NTHR) lstm_bwd_kernel(LstmBwdArgs p) {
   }
 }
 
+// Packs one bidirectional LSTM's f32 master weights into the layouts the kernels read.
+//  out 0: wih_p  [8H][Np]   rows permuted to (dir, unit, gate), K zero padded
+//  out 1: wihT_p [N][8H]    same permutation on the columns
+//  out 2: bias   [8H] f32   b_ih + b_hh, permuted
+//  out 3: whh fragments     [2][nut][nslab][4][64 lanes][16 B]   (B operand of h * W_hh^T)
+//  out 4: whhT fragments    [2][nut][nslabT][64 lanes][16 B]     (B operand of dgates * W_hh, k = unit*4+gate)
+template <typename T>
+__global__ void __launch_bounds__(256) lstm_pack_kernel(const float* __restrict__ wih, const float* __restrict__ whh,
+                                                        const float* __restrict__ bih, const float* __restrict__ bhh,
+                                                        T* __restrict__ wih_p, T* __restrict__ wihT_p,
+                                                        float* __restrict__ bias, T* __restrict__ whh_f,
+                                                        T* __restrict__ whhT_f, int N, int Np, int H, int Hp) {
+  constexpr int ES = sizeof(T), EPL = 16 / ES, SK = 64 / ES;
+  const int nut = (H + 15) >> 4, G4 = 4 * H;
+  const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int which = blockIdx.y;
+  if (which == 0) {
+    for (long idx = i0; idx < (long)2 * G4 * Np; idx += stride) {
+      const int rp = (int)(idx / Np), n = (int)(idx - (long)rp * Np);
+      const int d = rp / G4, r = rp - d * G4, u = r >> 2, g = r & 3;
+      wih_p[idx] = from_f32<T>(n < N ? wih[((long)d * G4 + g * H + u) * N + n] : 0.f);
+    }
+  } else if (which == 1) {
+    for (long idx = i0; idx < (long)N * 2 * G4; idx += stride) {
+      const int n = (int)(idx / (2 * G4)), rp = (int)(idx - (long)n * 2 * G4);
+      const int d = rp / G4, r = rp - d * G4, u = r >> 2, g = r & 3;
+      wihT_p[idx] = from_f32<T>(wih[((long)d * G4 + g * H + u) * N + n]);
+    }
+  } else if (which == 2) {
+    for (long idx = i0; idx < 2 * G4; idx += stride) {
+      const int d = (int)idx / G4, r = (int)idx - d * G4, u = r >> 2, g = r & 3;
+      const int src = d * G4 + g * H + u;
+      bias[idx] = bih[src] + bhh[src];
+    }
+  } else if (which == 3) {
+    const int nslab = Hp / SK;
+    const long total = (long)2 * nut * nslab * 4 * 64 * EPL;
+    for (long idx = i0; idx < total; idx += stride) {
+      long q = idx;
+      const int j = (int)(q % EPL); q /= EPL;
+      const int lane = (int)(q % 64); q /= 64;
+      const int g = (int)(q % 4); q /= 4;
+      const int ks = (int)(q % nslab); q /= nslab;
+      const int ut = (int)(q % nut);
+      const int d = (int)(q / nut);
+      const int u = ut * 16 + (lane & 15), k = ks * SK + EPL * (lane >> 4) + j;
+      whh_f[idx] = from_f32<T>((u < H && k < H) ? whh[((long)d * G4 + g * H + u) * H + k] : 0.f);
+    }
+  } else {
+    const int nslab = G4 / SK;
+    const long total = (long)2 * nut * nslab * 64 * EPL;
+    for (long idx = i0; idx < total; idx += stride) {
+      long q = idx;
+      const int j = (int)(q % EPL); q /= EPL;
+      const int lane = (int)(q % 64); q /= 64;
+      const int ks = (int)(q % nslab); q /= nslab;
+      const int ut = (int)(q % nut);
+      const int d = (int)(q / nut);
+      const int n = ut * 16 + (lane & 15), kk = ks * SK + EPL * (lane >> 4) + j;
+      const int up = kk >> 2, gp = kk & 3;
+      whhT_f[idx] = from_f32<T>(n < H ? whh[((long)d * G4 + gp * H + up) * H + n] : 0.f);
+    }
+  }
+}
+
 template <typename K>
 static void allow_big_lds(K kernel) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
 }
 
-template <typename T, int RT, int MAXUT>
+template <typename T, int RT, int NW>
 static int launch_fwd(const LstmFwdArgs& p, hipStream_t st) {
-  static bool once = (allow_big_lds(lstm_fwd_kernel<T, RT, MAXUT>), true);
-  (void)once;
-  const int R = 16 * RT;
+  constexpr int R = 16 * RT;
   const size_t lds = (size_t)2 * R * (p.Hp * sizeof(T) + 16);
   URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_fwd: Hp %d with %d rows exceeds LDS", p.Hp, R);
   dim3 grid(ceil_div(p.m.n_seq, R), 2);
-  hipLaunchKernelGGL((lstm_fwd_kernel<T, RT, MAXUT>), grid, dim3(NTHR), lds, st, p);
+  const int upw = ((p.H + 15) / 16 + NW - 1) / NW;   // unit tiles per wave
+#define URSE_LF(MU)                                                                              \
+  {                                                                                              \
+    static bool once = (allow_big_lds(lstm_fwd_kernel<T, RT, MU, NW>), true);                    \
+    (void)once;                                                                                  \
+    hipLaunchKernelGGL((lstm_fwd_kernel<T, RT, MU, NW>), grid, dim3(NW * 64), lds, st, p);       \
+  }
+  if (upw <= 2) URSE_LF(2) else if (upw <= 4) URSE_LF(4) else URSE_LF(6)
+#undef URSE_LF
   URSE_CHECK_LAUNCH("urse_lstm_fwd");
   return URSE_OK;
 }
 
-template <typename T, int RT, int MAXUT>
+template <typename T, int RT, int NW>
 static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
-  static bool once = (allow_big_lds(lstm_bwd_kernel<T, RT, MAXUT>), true);
-  (void)once;
-  const int R = 16 * RT;
+  constexpr int R = 16 * RT;
   const size_t lds = (size_t)R * (4 * p.H * sizeof(T) + 16);
   URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_bwd: H %d with %d rows exceeds LDS", p.H, R);
   dim3 grid(ceil_div(p.m.n_seq, R), 2);
-  hipLaunchKernelGGL((lstm_bwd_kernel<T, RT, MAXUT>), grid, dim3(NTHR), lds, st, p);
+  const int upw = ((p.H + 15) / 16 + NW - 1) / NW;
+#define URSE_LB(MU)                                                                              \
+  {                                                                                              \
+    static bool once = (allow_big_lds(lstm_bwd_kernel<T, RT, MU, NW>), true);                    \
+    (void)once;                                                                                  \
+    hipLaunchKernelGGL((lstm_bwd_kernel<T, RT, MU, NW>), grid, dim3(NW * 64), lds, st, p);       \
+  }
+  if (upw <= 2) URSE_LB(2) else if (upw <= 4) URSE_LB(4) else URSE_LB(6)
+#undef URSE_LB
   URSE_CHECK_LAUNCH("urse_lstm_bwd");
   return URSE_OK;
 }
@@ -315,6 +433,24 @@ static int check_map(const SeqMap& m, int H, int es, const char* who) {
   return URSE_OK;
 }
 
+extern "C" int urse_lstm_pack(const float* wih, const float* whh, const float* bih, const float* bhh, void* wih_p,
+                              void* wihT_p, float* bias, void* whh_frag, void* whhT_frag, int N, int Np, int H, int Hp,
+                              int dtype, void* stream) {
+  URSE_CHECK_ARG(wih && whh && bih && bhh && wih_p && wihT_p && bias && whh_frag && whhT_frag, "urse_lstm_pack: null pointer");
+  const int es = dtype == URSE_BF16 ? 2 : 4;
+  URSE_CHECK_ARG(N > 0 && H > 0 && Np >= N && (Hp * es) % 64 == 0 && Hp >= ((H + 15) / 16) * 16 && (4 * H * es) % 64 == 0,
+                 "urse_lstm_pack: bad shape N%d Np%d H%d Hp%d", N, Np, H, Hp);
+  dim3 grid(256, 5), blk(256);
+  if (dtype == URSE_BF16)
+    hipLaunchKernelGGL(lstm_pack_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, wih, whh, bih, bhh, (bf16_t*)wih_p,
+                       (bf16_t*)wihT_p, bias, (bf16_t*)whh_frag, (bf16_t*)whhT_frag, N, Np, H, Hp);
+  else
+    hipLaunchKernelGGL(lstm_pack_kernel<float>, grid, blk, 0, (hipStream_t)stream, wih, whh, bih, bhh, (float*)wih_p,
+                       (float*)wihT_p, bias, (float*)whh_frag, (float*)whhT_frag, N, Np, H, Hp);
+  URSE_CHECK_LAUNCH("urse_lstm_pack");
+  return URSE_OK;
+}
+
 extern "C" int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int64_t ldh, float* c, int H,
                                    int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride,
                                    int save, int dtype, int rows16, void* stream) {
@@ -326,17 +462,22 @@ extern "C" int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void*
   int rc = check_map(p.m, H, es, "urse_lstm_bidir_fwd");
   if (rc) return rc;
   URSE_CHECK_ARG((Hp * es) % 64 == 0 && Hp >= ((H + 15) / 16) * 16, "urse_lstm_bidir_fwd: bad Hp %d for H %d", Hp, H);
-  URSE_CHECK_ARG(ldg >= 8L * H && ldh >= 2L * H, "urse_lstm_bidir_fwd: leading dimension too small");
-  const int ut_per_wave = ((H + 15) / 16 + NW - 1) / NW;
+  URSE_CHECK_ARG(ldg >= 8L * H && ldh >= 2L * H && ldg % 4 == 0, "urse_lstm_bidir_fwd: leading dimension too small");
   hipStream_t st = (hipStream_t)stream;
-  int rt = rows16;
-  if (rt <= 0) rt = n_seq >= 1024 ? 2 : 1;
+  // rows16: low 4 bits = row tiles per workgroup (0 auto), bit 4 = use 8 waves instead of 16 (tuning knob)
+  int rt = rows16 & 15;
+  bool nw8 = (rows16 >> 4) & 1;
+  if (rt == 0) { rt = 1; nw8 = false; }
   if (dtype == URSE_BF16) {
-    if (ut_per_wave <= 2) return rt >= 2 ? launch_fwd<bf16_t, 2, 2>(p, st) : launch_fwd<bf16_t, 1, 2>(p, st);
-    return rt >= 2 ? launch_fwd<bf16_t, 2, 3>(p, st) : launch_fwd<bf16_t, 1, 3>(p, st);
+    if (nw8) {
+      if (rt >= 4) return launch_fwd<bf16_t, 4, 8>(p, st);
+      if (rt == 2) return launch_fwd<bf16_t, 2, 8>(p, st);
+      return launch_fwd<bf16_t, 1, 8>(p, st);
+    }
+    if (rt >= 2 && H <= 256) return launch_fwd<bf16_t, 2, 16>(p, st);
+    return launch_fwd<bf16_t, 1, 16>(p, st);
   }
-  if (ut_per_wave <= 2) return launch_fwd<float, 1, 2>(p, st);
-  return launch_fwd<float, 1, 3>(p, st);
+  return launch_fwd<float, 1, 16>(p, st);
 }
 
 extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c,
@@ -349,16 +490,15 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
   const int es = dtype == URSE_BF16 ? 2 : 4;
   int rc = check_map(p.m, H, es, "urse_lstm_bidir_bwd");
   if (rc) return rc;
-  URSE_CHECK_ARG(ldg >= 8L * H && ldd >= 2L * H, "urse_lstm_bidir_bwd: leading dimension too small");
-  const int ut_per_wave = ((H + 15) / 16 + NW - 1) / NW;
+  URSE_CHECK_ARG(ldg >= 8L * H && ldd >= 2L * H && ldg % 4 == 0, "urse_lstm_bidir_bwd: leading dimension too small");
   hipStream_t st = (hipStream_t)stream;
-  int rt = rows16;
-  if (rt <= 0) rt = n_seq >= 1024 ? 2 : 1;
+  int rt = rows16 & 15;
+  bool nw8 = (rows16 >> 4) & 1;
+  if (rt == 0) { rt = 1; nw8 = false; }
   if (dtype == URSE_BF16) {
     const bool fits2 = (size_t)32 * (8 * H + 16) <= 160 * 1024;
-    if (ut_per_wave <= 2) return (rt >= 2 && fits2) ? launch_bwd<bf16_t, 2, 2>(p, st) : launch_bwd<bf16_t, 1, 2>(p, st);
-    return launch_bwd<bf16_t, 1, 3>(p, st);
+    if (nw8) return (rt >= 2 && fits2) ? launch_bwd<bf16_t, 2, 8>(p, st) : launch_bwd<bf16_t, 1, 8>(p, st);
+    return launch_bwd<bf16_t, 1, 16>(p, st);
   }
-  if (ut_per_wave <= 2) return launch_bwd<float, 1, 2>(p, st);
-  return launch_bwd<float, 1, 3>(p, st);
+  return launch_bwd<float, 1, 16>(p, st);
 }

@@ -105,7 +105,7 @@ def gemm_nt(A, W, bias=None, resid=None, act=0, out=None, out_dtype=None, N=None
     return out
 
 
-def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=0, invalid_step=0):
+def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=0, invalid_step=0, perm_h=0):
     """out[Mo, No] (f32) += A[R, Mo]^T @ B'[R, No]; optional colsum[Mo] += sum_r A[r]."""
     require_cuda(A, Bm, out)
     R = A.shape[0]
@@ -114,7 +114,7 @@ def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=
     assert Bm.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and A.dtype == Bm.dtype
     assert out.dtype == torch.float32 and out.stride(-1) == 1
     call("gemm_tn", A, A.stride(0), Bm, Bm.stride(0), out, out.stride(0), colsum, R, Mo, No, shift, inner, period,
-         invalid_step, _dt(A), stream_ptr())
+         invalid_step, perm_h, _dt(A), stream_ptr())
     return out
 
 
@@ -158,6 +158,22 @@ def groupnorm_bwd(x, dy, stats, gamma, dres, dgamma, dbeta, B, T, Kg, W, N, gstr
     call("groupnorm_bwd", x, dy, stats, gamma, dres, dx, dgamma, dbeta, sums, B, T, Kg, W, N, gstride, float(eps),
          stream_ptr())
     return dx
+
+
+def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
+    """f32 nn.LSTM weights (fwd+reverse concatenated) -> dict of kernel-layout operands (see urse_lstm_pack)."""
+    dev = wih.device
+    Np, Hp = kpad(N, dtype), kpad(pad_to(H, 16), dtype)
+    nu = pad_to(H, 16)
+    if out is None:
+            out = dict(wih=torch.empty(8 * H, Np, device=dev, dtype=dtype),
+                   wihT=torch.empty(N, 8 * H, device=dev, dtype=dtype),
+                   bias=torch.empty(8 * H, device=dev, dtype=torch.float32),
+                   whh=torch.empty(2 * nu * 4 * Hp, device=dev, dtype=dtype),
+                   whhT=torch.empty(2 * nu * 4 * H, device=dev, dtype=dtype), Np=Np, Hp=Hp)
+    call("lstm_pack", wih, whh, bih, bhh, out["wih"], out["wihT"], out["bias"], out["whh"], out["whhT"], N, Np, H, Hp,
+         _dt(out["wih"]), stream_ptr())
+    return out
 
 
 def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, rows16=0):
