@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol include/urse.h declares, and rejects
+bad arguments with an error code + message before touching the GPU."""
+import ctypes
+
+import pytest
+
+
+def test_exports_every_declared_symbol(lib):
+    from urgent2026_challenge_track1_amd import _lib
+    names = _lib.declared_symbols()
+    assert len(names) >= 25 and "urse_stft_fwd" in names and "urse_lstm_bidir_fwd" in names
+    for n in names:
+        assert hasattr(lib, n), n
+    protos = _lib.prototypes()
+    assert set(protos) == set(names)
+    assert lib.urse_version() >= 1
+
+
+def test_argument_errors_do_not_touch_the_gpu(lib):
+    rc = lib.urse_stft_fwd(None, None, None, 1, 100, 64, 32, 1, None)
+    assert rc == -1 and b"urse_stft_fwd" in lib.urse_last_error()
+    rc = lib.urse_gemm_nt(None, 0, None, 0, None, 0, None, None, 0, 4, 4, 32, 1, 1, 0, None)
+    assert rc == -1 and b"null" in lib.urse_last_error()
+    rc = lib.urse_lstm_bidir_fwd(ctypes.c_void_p(16), 8, ctypes.c_void_p(16), ctypes.c_void_p(16), 8, None, 7, 32, 1, 1, 1,
+                                 1, 1, 0, 1, 0, None)
+    assert rc == -1
+
+
+def test_product_path_has_no_cpu_fallback(lib):
+    import torch
+    from urgent2026_challenge_track1_amd import ops
+    from urgent2026_challenge_track1_amd._lib import UrseError
+    with pytest.raises(UrseError):
+        ops.stft_forward(torch.randn(1, 4000), 320, 160)
+    with pytest.raises(UrseError):
+        ops.mr_l1_loss(torch.randn(1, 4000), torch.randn(1, 4000))
+
+
+def test_product_package_never_imports_the_oracle():
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "urgent2026_challenge_track1_amd")
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f

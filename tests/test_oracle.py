@@ -1,0 +1,97 @@
+"""CPU: pins of the oracle itself (architecture counts from the reference yaml, independent numpy DFT,
+committed golden vectors)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import bsrnn_ref, losses_ref, stft_ref
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_parameter_counts_match_reference_yaml():
+    """conf/models/BSRNN_baseline.yaml:30-32: 32.0456657409668 Mi (16 kHz, 27 bands), 36.01795196533203 Mi (48 kHz),
+    '~38M' in total; counts exclude norm layers."""
+    m = bsrnn_ref.BSRNN_SE(196, 6)
+    total = sum(p.numel() for p in m.parameters())
+    assert total == 37800844
+    import re
+    is_norm = lambda n: ("norm" in n) or re.search(r"mlp_(mask|residual)\.\d+\.0\.", n) is not None
+    non_norm = sum(p.numel() for n, p in m.named_parameters() if not is_norm(n))
+    assert non_norm == 37767560 and abs(non_norm / 2 ** 20 - 36.01795196533203) < 1e-12
+
+    def used(n, K):   # parameters touched when only the first K bands run
+        for tag in ("band_split.norm.", "band_split.fc.", "mlp_mask.", "mlp_residual."):
+            if tag in n:
+                return int(n.split(tag)[1].split(".")[0]) < K
+        return True
+    K16 = bsrnn_ref.num_bands_for(161, bsrnn_ref.SUBBANDS_481)
+    assert K16 == 27
+    n16 = sum(p.numel() for n, p in m.named_parameters() if not is_norm(n) and used(n, K16))
+    assert n16 == 33602316 and abs(n16 / 2 ** 20 - 32.0456657409668) < 1e-12
+
+
+def test_band_rule():
+    exp = {41: 9 + 1, 81: 20, 161: 27, 221: 28, 241: 29, 321: 31, 442: 34, 481: 34}   # F -> K  
+    for F, K in exp.items():
+        got = bsrnn_ref.num_bands_for(F, bsrnn_ref.SUBBANDS_481)
+        if F in (81, 161, 221, 241, 321, 481):
+            assert got == K, (F, got)
+
+
+def test_stft_oracle_matches_numpy_dft():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3000, generator=g, dtype=torch.float64)
+    for n_fft, hop, win in ((320, 160, "hann"), (441, 220, "hann"), (256, 128, "rect")):
+        X, _ = stft_ref.stft(x, n_fft, hop, win)
+        Xn = stft_ref.stft_numpy(x.numpy(), n_fft, hop, win)
+        assert np.abs(X.numpy() - Xn).max() < 1e-9
+        y = stft_ref.istft(X, n_fft, hop, 3000, win).numpy()
+        yn = stft_ref.istft_numpy(Xn, n_fft, hop, 3000, win)
+        assert np.abs(y - yn).max() < 1e-9
+    X, _ = stft_ref.stft(x, 320, 160)
+    assert (stft_ref.istft(X, 320, 160, 3000) - x).abs().max() < 1e-9
+    # frames past olens are zeroed
+    X, ol = stft_ref.stft(x, 320, 160, "hann", torch.tensor([3000, 1000]))
+    assert ol.tolist() == [19, 7] and torch.all(X[1, 7:] == 0) and X[1, 6].abs().sum() > 0
+
+
+def test_golden_vectors_reproduce():
+    from tests.golden.make_golden import SMALL, small_inputs, small_model
+    g = np.load(os.path.join(GOLD, "oracle_small.npz"))
+    clean, noisy, lens = small_inputs()
+    assert np.array_equal(clean.numpy(), g["clean"]) and np.array_equal(noisy.numpy(), g["noisy"])
+    m = small_model()
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    assert abs(flat.double().sum().item() - g["param_checksum"][0]) < 1e-6
+    wav, spec = m(noisy, lens, SMALL["fs"])
+    assert np.abs(wav.detach().numpy() - g["wav"]).max() <= 1e-5 * np.abs(g["wav"]).max()
+    loss = losses_ref.mr_l1_loss(clean, wav)
+    assert np.allclose(loss.detach().numpy(), g["loss"], rtol=1e-5)
+    assert np.allclose(losses_ref.si_snr_loss(clean, wav.detach()).numpy(), g["sisnr"], atol=1e-4)
+
+
+def test_emulated_bf16_is_close_to_f32():
+    from tests.golden.make_golden import SMALL, small_inputs, small_model
+    clean, noisy, lens = small_inputs()
+    m = small_model()
+    with torch.no_grad():
+        a = m(noisy, lens, SMALL["fs"])[0]
+        b = m(noisy, lens, SMALL["fs"], True)[0]
+    assert (a - b).abs().max() < 2e-2 * a.abs().max()
+
+
+def test_mrl1_matches_manual_formula():
+    g = torch.Generator().manual_seed(3)
+    t = torch.randn(2, 2000, generator=g)
+    e = 0.5 * t + 0.1 * torch.randn(2, 2000, generator=g)
+    ref = losses_ref.mr_l1_loss(t, e)
+    tn, en = t / t.std(1, keepdim=True), e / e.std(1, keepdim=True)
+    a = (en * tn).sum(1, keepdim=True) / ((en ** 2).sum(1, keepdim=True) + 1e-6)
+    man = 0.5 * (a * en - tn).abs().sum(1)
+    for w in (256, 512, 768, 1024):
+        E = np.abs(stft_ref.stft_numpy((a * en).numpy(), w, w // 2, "rect"))
+        T = np.abs(stft_ref.stft_numpy(tn.numpy(), w, w // 2, "rect"))
+        man = man + 0.125 * torch.from_numpy(np.abs(E - T).sum((1, 2))).float()
+    assert torch.allclose(ref, man, rtol=1e-4)
