@@ -64,7 +64,9 @@ template <> struct Frag<float> {
 
 template <typename T, typename TO>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmDesc* __restrict__ descs, GemmDesc single, int act) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * ROWB];
+  // K is staged in 128-byte slabs (two 64-byte MFMA sub-slabs) per barrier; rows padded to 144 B
+  constexpr int SLAB2 = 2 * SLAB, PITCH = SLAB2 + 16;
+  __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * PITCH];
   const GemmDesc d = descs ? descs[blockIdx.z] : single;
   const int tn = (int)((d.N + BN - 1) / BN), tm = (int)((d.M + BM - 1) / BM);
   const int nblk = tm * tn;
@@ -74,31 +76,31 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmDesc* __restrict
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
   constexpr int ES = sizeof(T);
-  const long Kb = d.K * ES;  // bytes of K
-  const int nk = (int)(Kb / SLAB);
+  const long Kb = d.K * ES;  // bytes of K (multiple of 64)
+  const int nk = (int)((Kb + SLAB2 - 1) / SLAB2);
 
-  auto As = [&](int buf) -> char* { return lds + buf * (BM + BN) * ROWB; };
-  auto Bs = [&](int buf) -> char* { return lds + buf * (BM + BN) * ROWB + BM * ROWB; };
+  auto As = [&](int buf) -> char* { return lds + buf * (BM + BN) * PITCH; };
+  auto Bs = [&](int buf) -> char* { return lds + buf * (BM + BN) * PITCH + BM * PITCH; };
 
-  // staging map: 2 chunks of A and 2 of B per thread
-  const int srow = tid >> 2, skc = tid & 3;
-  uint4 ra[2], rb[2];
+  // staging map: 4 chunks (16 B) of A and 4 of B per thread; a row's 128 B are read by 8 consecutive lanes
+  const int srow = tid >> 3, skc = tid & 7;
+  uint4 ra[4], rb[4];
   auto gload = [&](int kt) {
+    const long kb = (long)kt * SLAB2 + skc * 16;
+    const bool kin = kb < Kb;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const long row = m0 + srow + 64 * i;
-      ra[i] = (row < d.M) ? *reinterpret_cast<const uint4*>(d.A + (row * d.lda) * ES + (long)kt * SLAB + skc * 16)
-                          : make_uint4(0, 0, 0, 0);
-      const long col = n0 + srow + 64 * i;
-      rb[i] = (col < d.N) ? *reinterpret_cast<const uint4*>(d.B + (col * d.ldb) * ES + (long)kt * SLAB + skc * 16)
-                          : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      const long row = m0 + srow + 32 * i;
+      ra[i] = (kin && row < d.M) ? *reinterpret_cast<const uint4*>(d.A + (row * d.lda) * ES + kb) : make_uint4(0, 0, 0, 0);
+      const long col = n0 + srow + 32 * i;
+      rb[i] = (kin && col < d.N) ? *reinterpret_cast<const uint4*>(d.B + (col * d.ldb) * ES + kb) : make_uint4(0, 0, 0, 0);
     }
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<uint4*>(As(buf) + (srow + 64 * i) * ROWB + skc * 16) = ra[i];
-      *reinterpret_cast<uint4*>(Bs(buf) + (srow + 64 * i) * ROWB + skc * 16) = rb[i];
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(As(buf) + (srow + 32 * i) * PITCH + skc * 16) = ra[i];
+      *reinterpret_cast<uint4*>(Bs(buf) + (srow + 32 * i) * PITCH + skc * 16) = rb[i];
     }
   };
 
@@ -114,46 +116,87 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmDesc* __restrict
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
-    const char* a_base = As(cur) + (wm * 64 + (lane & 15)) * ROWB;
-    const char* b_base = Bs(cur) + (wn * 64 + (lane & 15)) * ROWB;
+    const char* a_base = As(cur) + (wm * 64 + (lane & 15)) * PITCH;
+    const char* b_base = Bs(cur) + (wn * 64 + (lane & 15)) * PITCH;
 #pragma unroll
-    for (int s = 0; s < Frag<T>::KSUB; ++s) {
-      typename Frag<T>::type a[4], b[4];
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = Frag<T>::load(a_base + i * 16 * ROWB, lane, s);
-        b[i] = Frag<T>::load(b_base + i * 16 * ROWB, lane, s);
+      for (int s = 0; s < Frag<T>::KSUB; ++s) {
+        typename Frag<T>::type a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = Frag<T>::load(a_base + i * 16 * PITCH + h * SLAB, lane, s);
+          b[i] = Frag<T>::load(b_base + i * 16 * PITCH + h * SLAB, lane, s);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = Frag<T>::mma(a[i], b[j], acc[i][j]);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Frag<T>::mma(a[i], b[j], acc[i][j]);
     }
     if (kt + 1 < nk) sstore(cur ^ 1);
     __syncthreads();
   }
 
+  // ---- epilogue: stage the tile through LDS so that global stores (and the residual read) are full-row,
+  // 16-byte-per-lane coalesced instead of 2/4-byte scattered in the MFMA C layout ----
+  constexpr int OS = sizeof(TO);
+  constexpr int CP = BN * OS + 16;                 // staged row pitch
+  constexpr int RPP = (OS == 2) ? 128 : 64;        // rows per pass (fits the 72 KiB staging buffer)
+  constexpr int EPC = 16 / OS;                     // elements per 16-byte chunk
+  constexpr int CPR = BN / EPC;                    // chunks per row
   TO* C = reinterpret_cast<TO*>(d.C);
+  const bool vec_ok = ((d.ldc * OS) % 16 == 0) && ((reinterpret_cast<uintptr_t>(d.C) % 16) == 0) &&
+                      (!d.resid || act == 2 || (((d.ldr * 4) % 16 == 0) && (reinterpret_cast<uintptr_t>(d.resid) % 16) == 0));
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const long col = n0 + wn * 64 + j * 16 + (lane & 15);
-    if (col >= d.N) continue;
-    const float bv = d.bias ? d.bias[col] : 0.f;
+  for (int pass = 0; pass < BM / RPP; ++pass) {
+    if (pass > 0) __syncthreads();
+    if (OS == 2 || wm == pass) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 4; ++j) {
+        const int lcol = wn * 64 + j * 16 + (lane & 15);
+        const long col = n0 + lcol;
+        const float bv = (d.bias && col < d.N) ? d.bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (row >= d.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (act == 1) v = tanhf_(v);
-        if (act == 2) {  // tanh backward: aux (= resid slot, TO typed) holds h = tanh(.)
-          const float hv = to_f32<TO>(reinterpret_cast<const TO*>(d.resid)[row * d.ldr + col]);
-          v *= (1.f - hv * hv);
-        } else if (d.resid) {
-          v += d.resid[row * d.ldr + col];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int lrow = (OS == 2 ? wm * 64 : 0) + i * 16 + (lane >> 4) * 4 + r;
+            float v = acc[i][j][r] + bv;
+            if (act == 1) v = tanhf_(v);
+            if (act == 2) {  // tanh backward: aux (= resid slot, TO typed) holds h = tanh(.)
+              const long row = m0 + (OS == 2 ? 0 : pass * RPP) + lrow;
+              if (row < d.M && col < d.N) {
+                const float hv = to_f32<TO>(reinterpret_cast<const TO*>(d.resid)[row * d.ldr + col]);
+                v *= (1.f - hv * hv);
+              }
+            }
+            *reinterpret_cast<TO*>(lds + lrow * CP + lcol * OS) = from_f32<TO>(v);
+          }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RPP * CPR; idx += 256) {
+      const int lrow = idx / CPR, ch = idx - lrow * CPR;
+      const long row = m0 + pass * RPP + lrow, col = n0 + ch * EPC;
+      if (row >= d.M || col >= d.N) continue;
+      const char* src = lds + lrow * CP + ch * 16;
+      if (vec_ok && col + EPC <= d.N) {
+        uint4 v = *reinterpret_cast<const uint4*>(src);
+        if (OS == 4 && d.resid && act != 2) {
+          const float4 rr = *reinterpret_cast<const float4*>(d.resid + row * d.ldr + col);
+          float4 f = *reinterpret_cast<float4*>(&v);
+          f.x += rr.x; f.y += rr.y; f.z += rr.z; f.w += rr.w;
+          v = *reinterpret_cast<uint4*>(&f);
         }
-        C[row * d.ldc + col] = from_f32<TO>(v);
+        *reinterpret_cast<uint4*>(C + row * d.ldc + col) = v;
+      } else {
+        const TO* sv = reinterpret_cast<const TO*>(src);
+        for (int e = 0; e < EPC && col + e < d.N; ++e) {
+          float f = to_f32<TO>(sv[e]);
+          if (OS == 4 && d.resid && act != 2) f += d.resid[row * d.ldr + col + e];
+          C[row * d.ldc + col + e] = from_f32<TO>(f);
+        }
       }
     }
   }
