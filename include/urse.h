@@ -147,6 +147,8 @@ int urse_glu_mask_apply_fwd(const float* pre_m, const float* pre_r, const float*
 int urse_glu_mask_apply_bwd(const float* pre_m, const float* pre_r, const float* x, const float* dout, void* dpre_m,
                             void* dpre_r, const int32_t* bands, const int32_t* f2k, int64_t rows, int F, int ldp,
                             int out_dtype, void* stream);
+/* x <- x / max|x| * peak in place (baseline_code/inference.py:60); scratch = 4 device bytes. */
+int urse_peak_normalize(float* x, int64_t n, float peak, void* scratch, void* stream);
 /* y = a*x + b*y (f32). */
 int urse_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream);
 

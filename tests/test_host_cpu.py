@@ -108,3 +108,41 @@ def test_grad_bucket_reducer_gloo_world2():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get() for _ in range(2)) == [0, 1]
+
+
+def test_sampler_shard_rule_and_collate():
+    """GroupedBatchSampler: per-fs groups, length-sorted, indices[rank::world] (reference dataset.py:351-366);
+    collate_fn right-pads and returns (clean[B,1,T], noisy[B,1,T], fs int32 0-d, lengths int32[B])."""
+    from urgent2026_challenge_track1_amd.dataset import GroupedBatchSampler, SyntheticPairDataset, collate_fn
+    ds = SyntheticPairDataset(40, fs_list=(16000, 48000), seconds=0.05, vary_length=True)
+    lens, srs = ds.get_source_length(), ds.get_srs()
+    seen = []
+    for rank in range(2):
+        s = GroupedBatchSampler(ds, 4, rank, 2, drop_last=False)
+        exp = []
+        for sr in (16000, 48000):
+            idx = sorted([i for i in range(40) if srs[i] == sr], key=lambda i: lens[i])[rank::2]
+            exp += idx
+        got = [i for b in s for i in b]
+        assert sorted(got) == sorted(exp)
+        for b in s:
+            assert len({srs[i] for i in b}) == 1          # one sampling rate per batch
+        seen += got
+    assert sorted(seen) == list(range(40))               # ranks partition the data
+    batch = collate_fn([ds[0], ds[2]])
+    assert batch[0].shape == batch[1].shape and batch[0].shape[1] == 1
+    assert batch[0].shape[2] == max(lens[0], lens[2]) and batch[2].dtype == torch.int32 and batch[2].dim() == 0
+    assert batch[3].tolist() == [lens[0], lens[2]]
+    short = 0 if lens[0] < lens[2] else 1
+    assert torch.all(batch[0][short, 0, min(lens[0], lens[2]):] == 0)
+
+
+def test_wav_io_roundtrip(tmp_path):
+    from urgent2026_challenge_track1_amd.dataset import read_audio, write_audio
+    x = np.clip(np.random.default_rng(0).standard_normal(1000) * 0.3, -0.99, 0.99).astype(np.float32)
+    write_audio(str(tmp_path / "a.wav"), x, 16000, "FLOAT")
+    y, fs = read_audio(str(tmp_path / "a.wav"))
+    assert fs == 16000 and np.array_equal(y[0], x)
+    write_audio(str(tmp_path / "b.wav"), x, 48000)
+    y, fs = read_audio(str(tmp_path / "b.wav"))
+    assert fs == 48000 and np.abs(y[0] - x).max() <= 1.0 / 32768

@@ -1,0 +1,69 @@
+"""GPU: train-step parity vs the oracle (one full optimisation step incl. clip + AdamW), short training run,
+checkpoint -> inference round trip through the entry points."""
+import os
+
+import pytest
+import torch
+
+from oracle import bsrnn_ref, losses_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(**kw):
+    from urgent2026_challenge_track1_amd.config import Config
+    base = dict(model_configs={"num_channel": 16, "num_layer": 1}, compute_dtype="f32", seed=7, batch_size=2,
+                num_worker=0, train_set_path="synthetic:8", valid_set_path="synthetic", val_check_interval=3,
+                num_train_epochs=2, save_top_k=1, resume=False)
+    base.update(kw)
+    return Config(**base)
+
+
+def test_two_optimisation_steps_match_oracle(lib):
+    """SEModel.training_step + backward + clip 0.5 + AdamW for two steps == oracle train_step (f32)."""
+    from urgent2026_challenge_track1_amd.d_model import SEModel
+    torch.manual_seed(3)
+    ref = bsrnn_ref.BSRNN_SE(16, 1)
+    opt_r = losses_ref.make_optimizer(ref.parameters())
+    model = SEModel(_cfg())
+    model.se_model.load_state_dict(ref.state_dict())
+    model = model.cuda()
+    (opt,), _ = model.configure_optimizers()
+    g = torch.Generator().manual_seed(5)
+    for it in range(2):
+        clean = 0.3 * torch.randn(2, 1, 3200, generator=g)
+        noisy = clean + 0.1 * torch.randn(2, 1, 3200, generator=g)
+        lens = torch.tensor([3200, 3200], dtype=torch.int32)
+        fs = torch.tensor(16000, dtype=torch.int32)
+        loss_r, sisnr_r, gn_r = losses_ref.train_step(ref, opt_r, clean, noisy, 16000, lens)
+        loss = model.training_step((clean.cuda(), noisy.cuda(), fs, lens))
+        loss.backward()
+        model.optimizer_step(opt)
+        assert abs(float(loss) - float(loss_r)) <= 1e-3 * abs(float(loss_r)), it
+        assert abs(float(model.logged["train_sisnr"]) - float(sisnr_r)) <= 1e-2
+        assert abs(float(model.logged["Grad_norm"]) - float(gn_r)) <= 1e-3 * float(gn_r)
+    for (n, p), (_, q) in zip(model.se_model.named_parameters(), ref.named_parameters()):
+        assert (p.detach().cpu() - q.detach()).abs().max().item() <= 2e-5, n   # AdamW steps are ~lr=1e-3 each
+
+
+def test_fit_checkpoint_inference_roundtrip(lib, tmp_path):
+    from urgent2026_challenge_track1_amd import inference, train_se
+    from urgent2026_challenge_track1_amd.dataset import SyntheticPairDataset, read_audio, write_audio
+    os.chdir(tmp_path)
+    cfg = _cfg(train_tag="t", train_name="n")
+    model, steps = train_se.fit(cfg, max_steps=4, log_every=2)
+    assert steps == 4
+    ck = [f for f in os.listdir(train_se.ckpt_dir(cfg)) if "val_loss" in f]
+    assert len(ck) == 1
+    ds = SyntheticPairDataset(1, fs_list=(16000,), seconds=0.5)
+    clean, noisy, fs, L = ds[0]
+    write_audio(str(tmp_path / "in.wav"), noisy[0], fs, "FLOAT")
+    x, fs2 = read_audio(str(tmp_path / "in.wav"))
+    assert fs2 == fs and abs(x - noisy).max() == 0
+    (tmp_path / "in.scp").write_text("utt1 %s\n" % (tmp_path / "in.wav"))
+    args = inference.parser().parse_args(["--input_scp", str(tmp_path / "in.scp"), "--output_dir", str(tmp_path / "out"),
+                                          "--ckpt_path", os.path.join(train_se.ckpt_dir(cfg), ck[0])])
+    inference.main(args)
+    y, fs3 = read_audio(str(tmp_path / "out" / "wav" / "utt1.wav"))
+    assert fs3 == fs and y.shape[1] == L and abs(abs(y).max() - 0.9) < 1e-3
+    assert (tmp_path / "out" / "inf.scp").read_text().split()[0] == "utt1"

@@ -239,3 +239,31 @@ extern "C" int urse_axpby(const float* x, float* y, float a, float b, int64_t n,
   URSE_CHECK_LAUNCH("urse_axpby");
   return URSE_OK;
 }
+
+// ---- peak normalisation: x <- x / max|x| * peak   (inference.py:60) -------------------------------------
+namespace urse {
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, unsigned* __restrict__ out, long n) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like uints
+}
+__global__ void __launch_bounds__(256) scale_by_peak_kernel(float* __restrict__ x, const unsigned* __restrict__ mx,
+                                                            float peak, long n) {
+  const float s = peak / __uint_as_float(*mx);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= s;
+}
+}  // namespace urse
+
+extern "C" int urse_peak_normalize(float* x, int64_t n, float peak, void* scratch, void* stream) {
+  URSE_CHECK_ARG(x && scratch && n > 0, "urse_peak_normalize: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(scratch, 0, 4, st);
+  hipLaunchKernelGGL(urse::absmax_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, (unsigned*)scratch, (long)n);
+  hipLaunchKernelGGL(urse::scale_by_peak_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, (const unsigned*)scratch, peak,
+                     (long)n);
+  URSE_CHECK_LAUNCH("urse_peak_normalize");
+  return URSE_OK;
+}

@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""Training entry point: same CLI / yaml / checkpoint layout as ``baseline_code/train_se.py:37-84`` with an own
+loop instead of ``L.Trainer`` (one process per GPU, launched by ``python -m torch.distributed.run``; RANK /
+LOCAL_RANK / WORLD_SIZE from the environment).
+
+Kept from the reference: Config + yaml overlay (:41-43), seed (:45), ``init_from`` warm start accepting a raw or
+``{'state_dict': ...}`` file (:55-60), checkpoint directory ``exp/{tag}/{name}/version_{v}/checkpoints`` and file name
+``best_epoch=EE-step=SSSSSS-val_loss=X.XXX.ckpt`` with top-k by val_loss every ``val_check_interval`` steps (:17-35),
+resume from the newest ``*-val_loss*.ckpt`` (:67-72), clip ``gradient_clip`` (:78), StepLR per epoch.  Checkpoints are
+Lightning-shaped dicts (``state_dict`` with the ``se_model.`` prefix, ``hyper_parameters['cfg']``, ``epoch``,
+``global_step``) so the reference's ``inference.py`` conventions and ours interoperate.
+"""
+import glob
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from .config import Config, config_parser
+from .d_model import SEModel
+from .dataset import AudioDataModule
+from .ddp import GradBucketReducer
+
+
+def ckpt_dir(cfg):
+    return "./exp/%s/%s/version_%s/checkpoints" % (cfg.train_tag, cfg.train_name, cfg.train_version)
+
+
+def save_checkpoint(path, model, opt, sched, epoch, step, val_loss):
+    sd = {"se_model." + k: v.detach().cpu().clone() for k, v in model.se_model.state_dict().items()}
+    torch.save({"state_dict": sd, "hyper_parameters": {"cfg": model.cfg}, "epoch": epoch, "global_step": step,
+                "val_loss": val_loss, "optimizer_states": [{k: (v.cpu() if torch.is_tensor(v) else v)
+                                                            for k, v in opt.state_dict().items()}],
+                "lr_schedulers": [sched.state_dict()], "urse_version": 1}, path)
+
+
+def load_model_state(model, state_dict):
+    if "state_dict" in state_dict:
+        state_dict = state_dict["state_dict"]
+    sd = {k[len("se_model."):] if k.startswith("se_model.") else k: v for k, v in state_dict.items()}
+    model.se_model.load_state_dict(sd)
+
+
+def to_device(batch, dev):
+    clean, noisy, fs, lens = batch
+    return clean.to(dev, non_blocking=True), noisy.to(dev, non_blocking=True), fs, lens
+
+
+def validate(model, loader, dev):
+    tot, n = 0.0, 0
+    model.eval()
+    for batch in loader:
+        tot += float(model.validation_step(to_device(batch, dev))["loss"])
+        n += 1
+    model.train()
+    return tot / max(n, 1)
+
+
+def fit(cfg, max_steps=None, log_every=50):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(cfg.seed)
+
+    model = SEModel(cfg)
+    if cfg.init_from != "none":
+        load_model_state(model, torch.load(cfg.init_from, map_location="cpu", weights_only=False))
+        if rank == 0:
+            print("Init param loaded from %s" % cfg.init_from)
+    model = model.to(dev)
+    core = model.se_model.core
+    (opt,), (sched,) = model.configure_optimizers()
+    epoch0, step = 0, 0
+    os.makedirs(ckpt_dir(cfg), exist_ok=True)
+    ckpts = sorted(glob.glob(ckpt_dir(cfg) + "/*-val_loss*.ckpt"), key=os.path.getmtime, reverse=True)
+    if cfg.resume and ckpts:
+        ck = torch.load(ckpts[0], map_location="cpu", weights_only=False)
+        load_model_state(model, ck)
+        opt.load_state_dict({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in ck["optimizer_states"][0].items()})
+        sched.load_state_dict(ck["lr_schedulers"][0])
+        epoch0, step = ck["epoch"], ck["global_step"]
+        core.param_version += 1
+        if rank == 0:
+            print("Resume from %s" % ckpts[0])
+    if world > 1:
+        dist.broadcast(core.flat_params, 0)
+        core.param_version += 1
+    reducer = GradBucketReducer(core) if world > 1 else None
+
+    dm = AudioDataModule(cfg, rank, world)
+    train_loader, val_loader = dm.train_dataloader(), dm.val_dataloader()
+    best = []   # [(val_loss, path)]
+    t0 = time.time()
+    for epoch in range(epoch0, cfg.num_train_epochs):
+        # the reference never advances the sampler epoch (quirk C.3: on_train_epoch_start is not a DataModule hook)
+        for batch in train_loader:
+            loss = model.training_step(to_device(batch, dev))
+            loss.backward()
+            model.optimizer_step(opt, reducer)
+            step += 1
+            if rank == 0 and step % log_every == 0:
+                lg = {k: float(v) for k, v in model.logged.items()}
+                print("epoch %d step %d %s  (%.2f s/step)" % (epoch, step, lg, (time.time() - t0) / log_every), flush=True)
+                t0 = time.time()
+            if step % cfg.val_check_interval == 0:
+                vl = validate(model, val_loader, dev)
+                if rank == 0:
+                    path = "%s/best_epoch=%02d-step=%06d-val_loss=%.3f.ckpt" % (ckpt_dir(cfg), epoch, step, vl)
+                    save_checkpoint(path, model, opt, sched, epoch, step, vl)
+                    best = sorted(best + [(vl, path)])
+                    for _, p in best[cfg.save_top_k:]:
+                        os.remove(p)
+                    best = best[:cfg.save_top_k]
+                    print("val_loss %.3f -> %s" % (vl, path), flush=True)
+            if max_steps is not None and step >= max_steps:
+                return model, step
+        sched.step()
+    return model, step
+
+
+def main(argv=None):
+    args = config_parser(argv)
+    cfg = Config(**vars(args))
+    cfg.read_yaml()
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(vars(cfg))
+    if getattr(cfg, "model_type", "discriminative") == "flowse":
+        raise NotImplementedError("FlowSEModel training is driven through flow_model.py")
+    fit(cfg)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
