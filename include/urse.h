@@ -177,6 +177,22 @@ int urse_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp
                          const double* normsq, float max_norm, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
 
+/* ---- batched intrusive metrics ----------------------------------------------------------------------
+ * evaluation_metrics/calculate_intrusive_se_metrics.py: estoi_metric (:37-48) -> pystoi.stoi(extended=True),
+ * sdr_metric (:90-109) -> fast_bss_eval.bss_eval_sources(compute_permutation=False, clamp_db=50). */
+/* scipy.signal.resample_poly(x, up, down, window=h) (pystoi.utils.resample_oct): x f32 [P,L] -> y f32 [P,Lout];
+ * h_padded (f64, device) = zeros(n_pre_pad) ++ up*h as scipy builds it; n_pre_remove as scipy computes it. */
+int urse_resample_poly(const float* x, float* y, const double* h_padded, int hlen, int P, int L, int Lout, int up,
+                       int down, int n_pre_remove, void* stream);
+/* ESTOI of P pairs already at 10 kHz (f32 [P,L]); out f32 [P].  Scratch: ws_x/ws_y f32 [P,L], tob_x/tob_y f32
+ * [P,15,max(1,nfr)] with nfr = ceil((L-256)/128), lens int32 [P], tw512 = 512 complex twiddles e^{-2 pi i j/512}. */
+int urse_estoi_batch(const float* ref10k, const float* inf10k, float* out, float* ws_x, float* ws_y, float* tob_x,
+                     float* tob_y, int32_t* lens, const float* tw512, int P, int L, void* stream);
+/* SDR (dB) of P single-source pairs f32 [P,L] with a 512-tap distortion filter; scratch acf/xcorr f64 [P,512],
+ * norms f64 [P,2]. */
+int urse_sdr_batch(const float* ref, const float* est, float* out, double* acf, double* xcorr, double* norms, int P,
+                   int L, float clamp_db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,89 @@
+"""GPU parity: batched ESTOI / SDR vs the CPU oracle (oracle/metrics_ref.py); tolerance 1e-4 (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(P, L, fs, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(L) / fs
+    refs, infs = [], []
+    for p in range(P):
+        c = np.convolve(rng.standard_normal(L), [1, 0.9, 0.5, 0.2], "same") * (0.55 + 0.45 * np.sin(2 * np.pi * 4 * t + p))
+        c[: int(0.1 * L)] *= 1e-3
+        c[-int(0.08 * L):] *= 1e-3
+        c *= 0.9 / np.abs(c).max()
+        snr = rng.uniform(0, 25)
+        n = rng.standard_normal(L)
+        n *= np.sqrt((c ** 2).mean() / ((n ** 2).mean() * 10 ** (snr / 10)))
+        refs.append(c.astype(np.float32))
+        infs.append((c + n).astype(np.float32))
+    return np.stack(refs), np.stack(infs)
+
+
+@pytest.mark.parametrize("fs,L", [(16000, 32000), (48000, 60000), (10000, 20000), (8000, 12345)])
+def test_estoi_matches_oracle(lib, fs, L):
+    from urgent2026_challenge_track1_amd import metrics
+    ref, inf = _pairs(4, L, fs, fs + L)
+    got = metrics.estoi_batch(torch.from_numpy(ref).cuda(), torch.from_numpy(inf).cuda(), fs).cpu().numpy()
+    exp = np.array([metrics_ref.estoi(ref[p], inf[p], fs) for p in range(4)])
+    assert np.abs(got - exp).max() <= 1e-4, (got, exp)
+    assert abs(metrics.estoi_metric(ref[0], inf[0], fs) - exp[0]) <= 1e-4
+
+
+def test_estoi_edge_cases(lib):
+    from urgent2026_challenge_track1_amd import metrics
+    ref, inf = _pairs(2, 3000, 16000, 1)              # too short: < 30 frames -> 1e-5 (pystoi warning branch)
+    got = metrics.estoi_batch(torch.from_numpy(ref).cuda(), torch.from_numpy(inf).cuda(), 16000).cpu().numpy()
+    assert np.allclose(got, 1e-5)
+    ref, _ = _pairs(2, 32000, 16000, 2)               # identical signals -> 1
+    r = torch.from_numpy(ref).cuda()
+    assert np.abs(metrics.estoi_batch(r, r.clone(), 16000).cpu().numpy() - 1.0).max() <= 1e-5
+
+
+def test_resampler_matches_scipy(lib):
+    from urgent2026_challenge_track1_amd import metrics
+    ref, _ = _pairs(2, 48000, 48000, 3)
+    got = metrics.resample_to_10k(torch.from_numpy(ref).cuda(), 48000).cpu().numpy()
+    exp = np.stack([metrics_ref.resample_oct(ref[p].astype(np.float64), 10000, 48000) for p in range(2)])
+    assert got.shape == exp.shape and np.abs(got - exp).max() <= 2e-6
+
+
+@pytest.mark.parametrize("L", [16000, 64000, 5000])
+def test_sdr_matches_oracle(lib, L):
+    from urgent2026_challenge_track1_amd import metrics
+    ref, inf = _pairs(3, L, 16000, L)
+    got = metrics.sdr_batch(torch.from_numpy(ref).cuda(), torch.from_numpy(inf).cuda()).cpu().numpy()
+    exp = np.array([metrics_ref.sdr(ref[p], inf[p]) for p in range(3)])
+    assert np.abs(got - exp).max() <= 1e-4, (got, exp)
+    # a filtered + delayed copy is (almost) perfectly explained by the 512-tap filter -> clamp at 50 dB
+    d = np.zeros_like(ref)
+    d[:, 7:] = 0.5 * ref[:, :-7]
+    got = metrics.sdr_batch(torch.from_numpy(ref).cuda(), torch.from_numpy(d).cuda()).cpu().numpy()
+    exp = np.array([metrics_ref.sdr(ref[p], d[p]) for p in range(3)])
+    assert np.abs(got - exp).max() <= 1e-3 and np.all(got > 45)
+
+
+def test_metrics_driver_files(lib, tmp_path):
+    """scp in -> {METRIC}.scp + RESULTS.txt out, same formats as the reference script."""
+    from urgent2026_challenge_track1_amd import calculate_intrusive_se_metrics as drv
+    from urgent2026_challenge_track1_amd.dataset import write_audio
+    ref, inf = _pairs(3, 20000, 16000, 9)
+    with open(tmp_path / "ref.scp", "w") as fr, open(tmp_path / "inf.scp", "w") as fi:
+        for p in range(3):
+            write_audio(str(tmp_path / ("r%d.wav" % p)), ref[p], 16000, "FLOAT")
+            write_audio(str(tmp_path / ("i%d.wav" % p)), inf[p], 16000, "FLOAT")
+            fr.write("utt%d %s\n" % (p, tmp_path / ("r%d.wav" % p)))
+            fi.write("utt%d %s\n" % (p, tmp_path / ("i%d.wav" % p)))
+    drv.main(drv.parser().parse_args(["--ref_scp", str(tmp_path / "ref.scp"), "--inf_scp", str(tmp_path / "inf.scp"),
+                                      "--output_dir", str(tmp_path / "out")]))
+    lines = (tmp_path / "out" / "ESTOI.scp").read_text().strip().split("\n")
+    assert [l.split()[0] for l in lines] == ["utt0", "utt1", "utt2"]
+    exp = [metrics_ref.estoi(ref[p], inf[p], 16000) for p in range(3)]
+    assert max(abs(float(l.split()[1]) - e) for l, e in zip(lines, exp)) <= 1e-4
+    res = (tmp_path / "out" / "RESULTS.txt").read_text()
+    assert res.startswith("ESTOI: %.4f\n" % np.mean(exp)) and "SDR: " in res
