@@ -95,3 +95,39 @@ def test_mrl1_matches_manual_formula():
         T = np.abs(stft_ref.stft_numpy(tn.numpy(), w, w // 2, "rect"))
         man = man + 0.125 * torch.from_numpy(np.abs(E - T).sum((1, 2))).float()
     assert torch.allclose(ref, man, rtol=1e-4)
+
+
+def _load_flow_golden():
+    from oracle import flow_ref
+    g = np.load(os.path.join(GOLD, "ref_flow.npz"))
+    N = g["w:condition_fc.weight"].shape[0]
+    L = sum(1 for k in g["keys"].tolist() if k.startswith("norm_time.") and k.endswith(".weight"))
+    m = flow_ref.BSRNNFlow(769, N, L)
+    m.load_state_dict({k: torch.from_numpy(g["w:" + k]) for k in g["keys"].tolist()})
+    c = lambda a: torch.view_as_complex(torch.from_numpy(a))
+    return g, m, c
+
+
+def test_flow_oracle_matches_reference_goldens():
+    """oracle/flow_ref.py vs vectors produced by the REFERENCE's own bsrnn_flowse.py / odes.py / sampling
+    (tests/golden/make_golden_flow.py): DNN forward bitwise, ODE marginals, 4-step Euler trajectory."""
+    from oracle import flow_ref
+    g, m, c = _load_flow_golden()
+    x, y, t = c(g["x"]), c(g["y"]), torch.from_numpy(g["t"])
+    with torch.no_grad():
+        out = m(torch.cat([x, y], 1), t)
+    assert torch.equal(out, c(g["out"]))
+    ode = flow_ref.FlowMatching(0.05, 0.5)
+    mean, std = ode.marginal_prob(x, t, y)
+    assert torch.equal(mean, c(g["mean"])) and torch.equal(std, torch.from_numpy(g["std"]))
+    s = flow_ref.euler_sample(lambda xx, tt, yy: -m(torch.cat([xx, yy], 1), tt), ode, y, c(g["z"]), 1.0, 0.03, 4)
+    assert torch.allclose(s, c(g["sample"]), atol=1e-6)
+    full = flow_ref.BSRNNFlow(769, 384, 6)
+    assert sum(p.numel() for p in full.parameters()) == int(g["n_params_full"]) == 103245488
+
+
+def test_euler_schedule():
+    from oracle import flow_ref
+    ts, steps = flow_ref.euler_timesteps(1.0, 0.03, 15)
+    assert abs(float(ts[0]) - 1.0) < 1e-7 and abs(float(ts[-1]) - 0.03) < 1e-7
+    assert abs(steps[-1] - 0.03) < 1e-7 and abs(sum(steps) - 1.0) < 1e-6     # last step integrates down to t = 0
