@@ -85,9 +85,10 @@ int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
  * baseline_code/models/bsrnn_flowse.py:291,302 norm_time / norm_freq; :119-136 decoder norms).
  * x f32 [B, T, Kg, W]; a group = (b, kg) spans T rows of W values; channel = col % N;
  * gamma/beta index = kg * gstride + channel.  y rows are [B*T*Kg*(W/N)][Np] (zero padded), dtype
- * URSE_BF16 | URSE_F32.  stats / sums: f64 [B*Kg*2] scratch (sum, sum of squares). */
-int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, void* y, double* stats, int B, int T,
-                       int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* stream);
+ * URSE_BF16 | URSE_F32.  stats / sums: f64 [B*Kg*2] scratch (sum, sum of squares).  add (may be NULL): f32 [B, N]
+ * added after the affine (the flow model's time embedding, bsrnn_flowse.py:293-294). */
+int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* add, void* y, double* stats,
+                       int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* stream);
 /* dx = GN backward(dy) (+ dres); dgamma / dbeta are accumulated (+=). */
 int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, const float* gamma, const float* dres,
                        float* dx, float* dgamma, float* dbeta, double* sums, int B, int T, int Kg, int W, int N,
@@ -192,6 +193,37 @@ int urse_estoi_batch(const float* ref10k, const float* inf10k, float* out, float
  * norms f64 [P,2]. */
 int urse_sdr_batch(const float* ref, const float* est, float* out, double* acf, double* xcorr, double* norms, int P,
                    int L, float clamp_db, void* stream);
+
+/* ---- BSRNN-Flow (flow-matching generative model) ---------------------------------------------------------
+ * baseline_code/flow_model.py + models/bsrnn_flowse.py + models/odes.py + sampling/ (SURVEY rows a11-a14).
+ * Complex tensors are interleaved f32; feature maps are channel-last [B, T, F, C]. */
+/* STFTEncoder 'exponent' transform |X|^e e^{j angle X} * factor (inverse != 0: STFTDecoder.spec_back). */
+int urse_spec_transform(const float* x, float* y, int64_t n_complex, float exponent, float factor, int inverse,
+                        void* stream);
+/* xt = (1-t) x0 + t y + sigma(t) z and (cvf may be NULL) cvf = (sigma_max - sigma_min) z + (y - x0)
+ * (odes.py:74-98, flow_model.py:164-170); t f32 [B], per_b complex elements per utterance. */
+int urse_flow_prepare(const float* x0, const float* y, const float* z, const float* t, float* xt, float* cvf, int B,
+                      int64_t per_b, float sigma_min, float sigma_max, void* stream);
+/* y += a * x (f32): the Euler update x <- x - step * VF (sampling/odesolvers.py:76-81). */
+int urse_axpy(const float* x, float* y, float a, int64_t n, void* stream);
+/* GaussianFourierProjection (bsrnn_flowse.py:90-99): out [B, 2*half] = [sin(2 pi t W), cos(2 pi t W)]. */
+int urse_time_embedding(const float* t, const float* W, float* out, int B, int half, void* stream);
+/* GradDecoder tail (bsrnn_flowse.py:114-117): Conv2d(16 -> 4, 5x5, pad 2) over (F, T); U f32 [B,T,F,16],
+ * W [4][16][5][5] (oc, ic, k_F, k_T), pre f32 [B,T,F,4].  bwd: dU (=), dW / dbias (+=). */
+int urse_conv5x5_fwd(const float* U, const float* W, const float* bias, float* pre, int B, int T, int F, void* stream);
+int urse_conv5x5_bwd(const float* U, const float* W, const float* dpre, float* dU, float* dW, float* dbias, int B, int T,
+                     int F, void* stream);
+/* out[row, f<F] = sign * (GLU(pre_m) * x + GLU(pre_r)) with GLU over the 4 channels (c0 sig(c2), c1 sig(c3));
+ * pre maps are Fs >= F bins wide (bsrnn_flowse.py:311-315; sign = -1 gives FlowSEModel.forward :203-209). */
+int urse_glu4_apply_fwd(const float* pre_m, const float* pre_r, const float* x, float* out, int64_t rows, int F,
+                        int Fs, float sign, void* stream);
+int urse_glu4_apply_bwd(const float* pre_m, const float* pre_r, const float* x, const float* dout, float* dpre_m,
+                        float* dpre_r, int64_t rows, int F, int Fs, float sign, void* stream);
+/* loss[b] (f64) = 0.5 sum |vf - cvf|^2 (flow_model.py:122-132, 'mse'); grad (may be NULL) = (vf - cvf) * grad_scale. */
+int urse_flow_loss(const float* vf, const float* cvf, double* loss, float* grad, int B, int64_t per_b, float grad_scale,
+                   void* stream);
+/* torch_ema update: shadow -= one_minus_decay * (shadow - params). */
+int urse_ema_update(float* shadow, const float* params, float one_minus_decay, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,104 @@
+"""GPU parity: BSRNN-Flow DNN forward, flow-matching pieces and the Euler sampler vs vectors produced by the
+REFERENCE's own code (tests/golden/ref_flow.npz, see make_golden_flow.py) and vs oracle/flow_ref.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_ref, stft_ref
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_flow.npz")
+
+
+def _golden_model(dtype="f32"):
+    from urgent2026_challenge_track1_amd.config import Config
+    from urgent2026_challenge_track1_amd.flow_model import FlowSEModel
+    g = np.load(GOLD)
+    N = g["w:condition_fc.weight"].shape[0]
+    L = sum(1 for k in g["keys"].tolist() if k.startswith("norm_time.") and k.endswith(".weight"))
+    m = FlowSEModel(Config(bsrnn_hidden=N, num_layer=L, compute_dtype=dtype, sigma_min=0.05, sigma_max=0.5))
+    m.dnn.load_state_dict({k: torch.from_numpy(g["w:" + k]) for k in g["keys"].tolist()}, strict=True)
+    return g, m.cuda()
+
+
+def _ri(a):   # golden [B,1,F,T,2] -> [B,T,F,2]
+    return torch.from_numpy(a)[:, 0].permute(0, 2, 1, 3).contiguous().cuda()
+
+
+def test_dnn_forward_matches_reference_vectors(lib):
+    g, m = _golden_model()
+    with torch.no_grad():
+        out = m.dnn(_ri(g["x"]), _ri(g["y"]), torch.from_numpy(g["t"]).cuda(), sign=1.0)
+    ref = _ri(g["out"])
+    assert (out - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
+    print("flow dnn rel err %.2e" % ((out - ref).abs().max().item() / ref.abs().max().item()))
+    # reference-layout surface: forward(x, t, y) = -dnn(cat[x, y], t)
+    c = lambda a: torch.view_as_complex(torch.from_numpy(a)).cuda()
+    with torch.no_grad():
+        vf = m(c(g["x"]), torch.from_numpy(g["t"]).cuda(), c(g["y"]))
+    assert (vf + c(g["out"])).abs().max().item() <= 1e-3 * ref.abs().max().item()
+
+
+def test_euler_sampler_matches_reference_trajectory(lib):
+    g, m = _golden_model()
+    s = m.sample_ri(_ri(g["y"]), N=4, z_ri=_ri(g["z"]))
+    ref = _ri(g["sample"])
+    assert (s - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_bf16_forward_close(lib):
+    g, m = _golden_model("bf16")
+    with torch.no_grad():
+        out = m.dnn(_ri(g["x"]), _ri(g["y"]), torch.from_numpy(g["t"]).cuda(), sign=1.0)
+    ref = _ri(g["out"])
+    assert (out - ref).abs().max().item() <= 5e-2 * ref.abs().max().item()
+
+
+def test_features_loss_and_ema_vs_oracle(lib):
+    g, m = _golden_model()
+    N = g["w:condition_fc.weight"].shape[0]
+    ref = flow_ref.FlowSE(bsrnn_hidden=N, num_layer=2)
+    ref.dnn.load_state_dict({k: torch.from_numpy(g["w:" + k]) for k in g["keys"].tolist()})
+    gen = torch.Generator().manual_seed(4)
+    clean = 0.2 * torch.randn(2, 3456, generator=gen)
+    noisy = clean + 0.05 * torch.randn(2, 3456, generator=gen)
+    lens = torch.tensor([3456, 3456])
+    # exponent-compressed STFT features (n_fft 1536 / hop 384 @ 48 kHz) and the inverse path
+    x0_r = ref.speech_to_feature(clean, 48000, lens)
+    x0 = m.speech_to_feature(clean.cuda(), 48000, lens)
+    assert (x0.cpu() - x0_r).abs().max().item() <= 1e-4 * x0_r.abs().max().item() + 1e-6
+    back = m.feature_to_speech(x0, 48000, lens)
+    assert (back.cpu() - clean).abs().max().item() <= 1e-4
+    # flow-matching training loss for fixed t / noise
+    y_r = ref.speech_to_feature(noisy, 48000, lens)
+    t = torch.tensor([0.7, 0.2])
+    z = torch.randn(x0_r.shape, dtype=torch.complex64, generator=gen)
+    with torch.no_grad():
+        loss_r = ref.loss_from(x0_r, y_r, t, z)
+    to_ri = lambda c: torch.view_as_real(c.squeeze(1).permute(0, 2, 1).contiguous()).cuda()
+    loss = m.loss_from_ri(to_ri(x0_r), to_ri(y_r), t.cuda(), to_ri(z)).mean()
+    assert abs(float(loss) - float(loss_r)) <= 1e-3 * abs(float(loss_r))
+    # EMA
+    ema = m.init_ema()
+    shadow = [p.detach().clone() for p in ref.dnn.parameters() if p.requires_grad]
+    nu = 0
+    with torch.no_grad():
+        for p in ref.dnn.parameters():
+            if p.requires_grad:
+                p.add_(0.01)
+        m.dnn.flat_params.add_(0.01)
+    nu = flow_ref.ema_update(shadow, [p for p in ref.dnn.parameters() if p.requires_grad], 0.999, nu)
+    ema.update()
+    ema.store(); ema.copy_to()
+    mine = dict(m.dnn.named_parameters())
+    for (n, p), s in zip([(n, p) for n, p in ref.dnn.named_parameters() if p.requires_grad], shadow):
+        assert (mine[n].detach().cpu() - s).abs().max().item() <= 1e-6, n
+    ema.restore()
+    assert (mine["condition_fc.bias"].detach().cpu() - dict(ref.dnn.named_parameters())["condition_fc.bias"]).abs().max() <= 1e-6
+
+
+def test_full_size_parameter_count(lib):
+    from urgent2026_challenge_track1_amd.flow_model import FlowBSRNNCore
+    assert sum(p.numel() for p in FlowBSRNNCore(769, 384, 6).parameters()) == 103245488   # SURVEY 4 / golden

@@ -22,6 +22,7 @@ from . import ops
 from ._lib import call, stream_ptr
 
 SUBBANDS_481 = tuple([5] + [4] * 19 + [10] * 6 + [40] * 7 + [60])   # reference bsrnn_flowse.py:29
+SUBBANDS_769 = tuple([5] + [4] * 26 + [10] * 10 + [50] * 10 + [60])  # reference bsrnn_flowse.py:36
 GN_EPS = 1e-5
 
 
@@ -44,6 +45,15 @@ class _PackPlan:
         self.segs.append([in_off, in_rows, in_cols, in_cols, off, out_rows, out_cols, out_cols])
         self.size += (out_rows * out_cols + 31) // 32 * 32
         return (off, out_rows, out_cols)
+
+    def reserve(self, n):
+        off = self.size
+        self.size += (n + 31) // 32 * 32
+        return off
+
+    def add_at(self, in_off, in_rows, in_cols, out_off, out_rows, out_cols, out_ld):
+        """copy a block to an explicit place of the output buffer (row pitch out_ld)."""
+        self.segs.append([in_off, in_rows, in_cols, in_cols, out_off, out_rows, out_cols, out_ld])
 
     def run(self, flat, dtype):
         if not self.segs:
@@ -81,31 +91,21 @@ class BSRNNCore(nn.Module):
         super().__init__()
         if causal or num_spk != 1:
             raise NotImplementedError("the reference uses causal=False, num_spk=1 (models/bsrnn.py:27-34)")
-        if not (input_dim == 481 and target_fs == 48000):
-            raise NotImplementedError("band table defined for input_dim=481 @ 48 kHz (bsrnn_flowse.py:23-40)")
+        if target_fs != 48000 or input_dim not in (481, 769):
+            raise NotImplementedError("band tables defined for input_dim 481 / 769 @ 48 kHz (bsrnn_flowse.py:23-40)")
         if num_channel % 4:
             raise ValueError("num_channel must be a multiple of 4")
-        self.subbands = SUBBANDS_481
+        self.subbands = SUBBANDS_481 if input_dim == 481 else SUBBANDS_769
         self.input_dim, self.N, self.H, self.num_layer = input_dim, num_channel, 2 * num_channel, num_layer
         self.compute_dtype = compute_dtype
         N, H = self.N, self.H
-        # ---- parameter containers with the espnet names -----------------------------------------
-        bs = nn.Module()
-        bs.norm = nn.ModuleList([nn.GroupNorm(1, 2 * sb) for sb in self.subbands])
-        bs.fc = nn.ModuleList([nn.Conv1d(2 * sb, N, 1) for sb in self.subbands])
-        self.band_split = bs
+        self._make_front_back()
         self.norm_time = nn.ModuleList([nn.GroupNorm(1, N) for _ in range(num_layer)])
         self.rnn_time = nn.ModuleList([nn.LSTM(N, H, batch_first=True, bidirectional=True) for _ in range(num_layer)])
         self.fc_time = nn.ModuleList([nn.Linear(2 * H, N) for _ in range(num_layer)])
         self.norm_freq = nn.ModuleList([nn.GroupNorm(1, N) for _ in range(num_layer)])
         self.rnn_freq = nn.ModuleList([nn.LSTM(N, H, batch_first=True, bidirectional=True) for _ in range(num_layer)])
         self.fc_freq = nn.ModuleList([nn.Linear(2 * H, N) for _ in range(num_layer)])
-        md = nn.Module()
-        mk = lambda sb: nn.Sequential(nn.GroupNorm(1, N), nn.Conv1d(N, 4 * N, 1), nn.Tanh(),
-                                      nn.Conv1d(4 * N, 4 * sb, 1), nn.GLU(dim=1))
-        md.mlp_mask = nn.ModuleList([mk(sb) for sb in self.subbands])
-        md.mlp_residual = nn.ModuleList([mk(sb) for sb in self.subbands])
-        self.mask_decoder = md
         self._flat = None
         self._flat_grad = None
         self._off = {}
@@ -117,14 +117,50 @@ class BSRNNCore(nn.Module):
         self.grad_ready_hook = None     # callable(tag) fired when a parameter group's grads are final
 
     # ------------------------------------------------------------------------------------------
+    # parameter containers (espnet names) of the parts that differ between the discriminative and the flow DNN
+    # ------------------------------------------------------------------------------------------
+    def _make_band_split(self):
+        bs = nn.Module()
+        bs.norm = nn.ModuleList([nn.GroupNorm(1, 2 * sb) for sb in self.subbands])
+        bs.fc = nn.ModuleList([nn.Conv1d(2 * sb, self.N, 1) for sb in self.subbands])
+        return bs
+
+    def _make_front_back(self):
+        N = self.N
+        self.band_split = self._make_band_split()
+        md = nn.Module()
+        mk = lambda sb: nn.Sequential(nn.GroupNorm(1, N), nn.Conv1d(N, 4 * N, 1), nn.Tanh(),
+                                      nn.Conv1d(4 * N, 4 * sb, 1), nn.GLU(dim=1))
+        md.mlp_mask = nn.ModuleList([mk(sb) for sb in self.subbands])
+        md.mlp_residual = nn.ModuleList([mk(sb) for sb in self.subbands])
+        self.mask_decoder = md
+
+    @staticmethod
+    def _bs_params(prefix, bs):
+        return [(prefix + ".gamma", [m.weight for m in bs.norm]), (prefix + ".beta", [m.bias for m in bs.norm]),
+                (prefix + ".w", [m.weight for m in bs.fc]), (prefix + ".b", [m.bias for m in bs.fc])]
+
+    def _front_params(self):
+        return self._bs_params("bs", self.band_split)
+
+    def _back_params(self):
+        order = []
+        for tag, mlps in (("m", self.mask_decoder.mlp_mask), ("r", self.mask_decoder.mlp_residual)):
+            p = "md%s." % tag
+            order += [(p + "gamma", [s[0].weight for s in mlps]), (p + "beta", [s[0].bias for s in mlps]),
+                      (p + "w1", [s[1].weight for s in mlps]), (p + "b1", [s[1].bias for s in mlps]),
+                      (p + "w2", [s[3].weight for s in mlps]), (p + "b2", [s[3].bias for s in mlps])]
+        return order
+
+    back_tag = "md"
+
+    # ------------------------------------------------------------------------------------------
     # flat parameter / gradient buffers
     # ------------------------------------------------------------------------------------------
     def _ordered_params(self):
         """Flat layout: groups that the kernels read as one matrix are made contiguous."""
-        bs, md, L = self.band_split, self.mask_decoder, self.num_layer
-        order = []
-        order += [("bs.gamma", [m.weight for m in bs.norm]), ("bs.beta", [m.bias for m in bs.norm]),
-                  ("bs.w", [m.weight for m in bs.fc]), ("bs.b", [m.bias for m in bs.fc])]
+        L = self.num_layer
+        order = list(self._front_params())
         for l in range(L):
             for path, norm, rnn, fc in (("t", self.norm_time[l], self.rnn_time[l], self.fc_time[l]),
                                         ("f", self.norm_freq[l], self.rnn_freq[l], self.fc_freq[l])):
@@ -135,12 +171,7 @@ class BSRNNCore(nn.Module):
                           (p + "bhh", [rnn.bias_hh_l0, rnn.bias_hh_l0_reverse]),
                           (p + "whh", [rnn.weight_hh_l0, rnn.weight_hh_l0_reverse]),
                           (p + "wfc", [fc.weight]), (p + "bfc", [fc.bias])]
-        for tag, mlps in (("m", md.mlp_mask), ("r", md.mlp_residual)):
-            p = "md%s." % tag
-            order += [(p + "gamma", [s[0].weight for s in mlps]), (p + "beta", [s[0].bias for s in mlps]),
-                      (p + "w1", [s[1].weight for s in mlps]), (p + "b1", [s[1].bias for s in mlps]),
-                      (p + "w2", [s[3].weight for s in mlps]), (p + "b2", [s[3].bias for s in mlps])]
-        return order
+        return order + list(self._back_params())
 
     def _ensure_flat(self):
         first = next(self.parameters())
@@ -157,7 +188,7 @@ class BSRNNCore(nn.Module):
             for p in ps:
                 plist.append((p, total))
                 total += p.numel()
-        assert len(plist) == len(list(self.parameters()))
+        assert len(plist) == len([q for q in self.parameters() if q.requires_grad])
         flat = torch.zeros(total, dtype=torch.float32, device=first.device)
         grad = torch.zeros(total, dtype=torch.float32, device=first.device)
         with torch.no_grad():
@@ -189,16 +220,18 @@ class BSRNNCore(nn.Module):
         spans = {n: (self._off[n], e - self._off[n]) for n, e in zip(names, ends)}
         groups = []
 
-        def span(prefix):
-            ns = [n for n in names if n.startswith(prefix)]
+        def span(ns):
             lo = min(spans[n][0] for n in ns)
             hi = max(spans[n][0] + spans[n][1] for n in ns)
             return lo, hi - lo
-        groups.append(("md",) + span("md"))
+        is_layer = lambda n: n[0] == "l" and n[1].isdigit()
+        first = min(i for i, n in enumerate(names) if is_layer(n))
+        last = max(i for i, n in enumerate(names) if is_layer(n))
+        groups.append((self.back_tag,) + span(names[last + 1:]))
         for l in reversed(range(self.num_layer)):
-            groups.append(("l%df" % l,) + span("l%df." % l))
-            groups.append(("l%dt" % l,) + span("l%dt." % l))
-        groups.append(("bs",) + span("bs."))
+            groups.append(("l%df" % l,) + span([n for n in names if n.startswith("l%df." % l)]))
+            groups.append(("l%dt" % l,) + span([n for n in names if n.startswith("l%dt." % l)]))
+        groups.append(("bs",) + span(names[:first]))
         return groups
 
     def _g(self, name, numel=None, off=0):
@@ -224,19 +257,30 @@ class BSRNNCore(nn.Module):
         pn, pt = _PackPlan(False), _PackPlan(True)
         h = {}
         o = self._off
-        f0 = 0
-        w_off = 0
-        for k, sb in enumerate(self.subbands):
-            xpad = ops.kpad(2 * sb, dtype)
-            h["bs.w", k] = pn.add(o["bs.w"] + w_off, N, 2 * sb, N, xpad)
-            h["bs.wT", k] = pt.add(o["bs.w"] + w_off, N, 2 * sb, 2 * sb, Np)
-            w_off += N * 2 * sb
-            f0 += sb
+        self._dims = dict(Np=Np, Hp=Hp, ld2H=ld2H, ld4N=ld4N)
+        self._plan_front(pn, pt, h, dtype)
         for l in range(self.num_layer):
             for path in "tf":
                 p = "l%d%s." % (l, path)
                 h[p + "wfc"] = pn.add(o[p + "wfc"], N, 2 * H, N, ld2H)
                 h[p + "wfcT"] = pt.add(o[p + "wfc"], N, 2 * H, 2 * H, Np)
+        self._plan_back(pn, pt, h, dtype)
+        self._plans = (dtype, pn, pt, h)
+
+    def _plan_band_split(self, prefix, pn, pt, h, dtype):
+        N, Np, o = self.N, self._dims["Np"], self._off
+        w_off = 0
+        for k, sb in enumerate(self.subbands):
+            xpad = ops.kpad(2 * sb, dtype)
+            h[prefix + ".w", k] = pn.add(o[prefix + ".w"] + w_off, N, 2 * sb, N, xpad)
+            h[prefix + ".wT", k] = pt.add(o[prefix + ".w"] + w_off, N, 2 * sb, 2 * sb, Np)
+            w_off += N * 2 * sb
+
+    def _plan_front(self, pn, pt, h, dtype):
+        self._plan_band_split("bs", pn, pt, h, dtype)
+
+    def _plan_back(self, pn, pt, h, dtype):
+        N, Np, ld4N, o = self.N, self._dims["Np"], self._dims["ld4N"], self._off
         for tag in "mr":
             p = "md%s." % tag
             w2_off = 0
@@ -247,8 +291,6 @@ class BSRNNCore(nn.Module):
                 h[p + "w2", k] = pn.add(o[p + "w2"] + w2_off, 4 * sb, 4 * N, 4 * sb, ld4N)
                 h[p + "w2T", k] = pt.add(o[p + "w2"] + w2_off, 4 * sb, 4 * N, 4 * N, ppad)
                 w2_off += 4 * sb * 4 * N
-        self._plans = (dtype, pn, pt, h)
-        self._dims = dict(Np=Np, Hp=Hp, ld2H=ld2H, ld4N=ld4N)
 
     def _prepare(self):
         """(re)pack the GEMM operands from the f32 master weights; once per parameter version."""
@@ -308,7 +350,9 @@ class BSRNNCore(nn.Module):
     # ------------------------------------------------------------------------------------------
     # band split
     # ------------------------------------------------------------------------------------------
-    def bandsplit_fwd(self, spec):
+    def bandsplit_fwd(self, spec, prefix="bs", out=None, width=None, col0=0):
+        """band split of spec [B,T,F,2]; default -> z f32 [B,T,K,N]; with `out` (a [B,T,K,width] tensor of the compute
+        dtype) the N channels are written at column offset col0 (flow: x / y halves of the condition_fc input)."""
         B, T, F, _ = spec.shape
         dt, dev, N = self.compute_dtype, spec.device, self.N
         tb = self._band_tables(F, dt, dev)
@@ -316,43 +360,50 @@ class BSRNNCore(nn.Module):
         n_gb = 2 * sum(self.subbands)
         xnb = torch.empty(B * T, tb["ldx"], dtype=dt, device=dev)
         stats = torch.empty(B * K * 2, dtype=torch.float64, device=dev)
-        call("bandsplit_norm_fwd", spec, tb["bands"], self._p("bs.gamma", n_gb), self._p("bs.beta", n_gb), xnb, stats,
-             B, T, F, K, tb["ldx"], GN_EPS, ops._dt(xnb), stream_ptr())
-        z = torch.empty(B, T, K, N, dtype=torch.float32, device=dev)
+        call("bandsplit_norm_fwd", spec, tb["bands"], self._p(prefix + ".gamma", n_gb), self._p(prefix + ".beta", n_gb),
+             xnb, stats, B, T, F, K, tb["ldx"], GN_EPS, ops._dt(xnb), stream_ptr())
+        if out is None:
+            out, width = torch.empty(B, T, K, N, dtype=torch.float32, device=dev), N
         M = B * T
         rows = []
         for k in range(K):
             r = tb["rows"][k]
-            w = pk["bs.w", k]
-            rows.append([_ptr(xnb, r[2]), _ptr(w), _ptr(z, k * N), _ptr(self._flat, self._off["bs.b"] + k * N), 0,
-                         tb["ldx"], w.shape[1], K * N, M, N, r[3], 0])
-        call("gemm_nt_grouped", _descs(rows, dev), K, _tiles(M, N), ops._dt(xnb), ops.F32, 0, stream_ptr())
-        return z, (xnb, stats, tb)
+            w = pk[prefix + ".w", k]
+            rows.append([_ptr(xnb, r[2]), _ptr(w), _ptr(out, k * width + col0),
+                         _ptr(self._flat, self._off[prefix + ".b"] + k * N), 0,
+                         tb["ldx"], w.shape[1], K * width, M, N, r[3], 0])
+        call("gemm_nt_grouped", _descs(rows, dev), K, _tiles(M, N), ops._dt(xnb), ops._dt(out), 0, stream_ptr())
+        return out, (xnb, stats, tb)
 
-    def bandsplit_bwd(self, spec, saved, dz):
+    def bandsplit_bwd(self, spec, saved, dz, prefix="bs", dzT=None, width=None, col0=0, ready=True):
+        """dz f32 [B,T,K,N], or (flow) dzT = [B*T*K, width] of the compute dtype holding the N gradient channels at
+        column offset col0 (width-col0 >= kpad(N), zero padded)."""
         xnb, stats, tb = saved
         B, T, F, _ = spec.shape
         dt, dev, N = self.compute_dtype, spec.device, self.N
         K, pk, Np = tb["K"], self._packed, self._dims["Np"]
         M = B * T
-        dzT = ops.pack2d(dz.reshape(M * K, N), M * K, Np, dt)
+        if dzT is None:
+            dzT, width = ops.pack2d(dz.reshape(M * K, N), M * K, Np, dt), Np
         dxnb = torch.empty(M, tb["ldx"], dtype=torch.float32, device=dev)
         rows = []
         w_off = 0
         for k in range(K):
             r = tb["rows"][k]
             sb = r[1]
-            a = dzT.view(M, K * Np)[:, k * Np:(k + 1) * Np]
-            gw = self._g("bs.w", N * 2 * sb, w_off).view(N, 2 * sb)
-            ops.gemm_tn(a, xnb[:, r[2]:r[2] + r[3]], gw, colsum=self._g("bs.b", N, k * N), Mo=N, No=2 * sb)
-            wT = pk["bs.wT", k]
-            rows.append([_ptr(dzT, k * Np), _ptr(wT), _ptr(dxnb, r[2]), 0, 0, K * Np, Np, tb["ldx"], M, 2 * sb, Np, 0])
+            a = dzT.view(M, K * width)[:, k * width + col0:k * width + col0 + Np]
+            gw = self._g(prefix + ".w", N * 2 * sb, w_off).view(N, 2 * sb)
+            ops.gemm_tn(a, xnb[:, r[2]:r[2] + r[3]], gw, colsum=self._g(prefix + ".b", N, k * N), Mo=N, No=2 * sb)
+            wT = pk[prefix + ".wT", k]
+            rows.append([_ptr(dzT, k * width + col0), _ptr(wT), _ptr(dxnb, r[2]), 0, 0, K * width, Np, tb["ldx"], M,
+                         2 * sb, Np, 0])
             w_off += N * 2 * sb
         call("gemm_nt_grouped", _descs(rows, dev), K, _tiles(M, 128), ops._dt(dzT), ops.F32, 0, stream_ptr())
         n_gb = 2 * sum(self.subbands)
-        call("bandsplit_norm_bwd", spec, dxnb, tb["bands"], stats, self._g("bs.gamma", n_gb), self._g("bs.beta", n_gb),
-             B, T, F, K, tb["ldx"], GN_EPS, stream_ptr())
-        self._ready("bs")
+        call("bandsplit_norm_bwd", spec, dxnb, tb["bands"], stats, self._g(prefix + ".gamma", n_gb),
+             self._g(prefix + ".beta", n_gb), B, T, F, K, tb["ldx"], GN_EPS, stream_ptr())
+        if ready:
+            self._ready("bs")
 
     # ------------------------------------------------------------------------------------------
     # dual-path half layer: GN -> BLSTM -> Linear -> +skip   (time: sequences along T, band: along K)
@@ -362,13 +413,13 @@ class BSRNNCore(nn.Module):
             return dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
         return dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
 
-    def dualpath_fwd(self, skip, l, path, save):
+    def dualpath_fwd(self, skip, l, path, save, temb=None):
         B, T, K, N = skip.shape
         H, dt, pk, d = self.H, self.compute_dtype, self._packed, self._dims
         p = "l%d%s." % (l, path)
         M = B * T * K
         xn, stats = ops.groupnorm_fwd(skip, self._p(p + "gamma", N), self._p(p + "beta", N), B, T, 1, K * N, N,
-                                      d["Np"], 0, dt, GN_EPS)
+                                      d["Np"], 0, dt, GN_EPS, add=temb)
         gx = ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
         sm = self._seqmap(path, B, T, K)
         hout, c = ops.lstm_fwd(gx, pk[p + "whh"], H, d["Hp"], save=save, **sm)
@@ -525,8 +576,8 @@ class _BandSplitFn(torch.autograd.Function):
 
 class _DualPathFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, skip, core, l, path):
-        out, saved = core.dualpath_fwd(skip, l, path, True)
+    def forward(ctx, skip, core, l, path, temb=None):
+        out, saved = core.dualpath_fwd(skip, l, path, True, temb)
         ctx.core, ctx.saved, ctx.skip, ctx.l, ctx.path = core, saved, skip, l, path
         return out
 
@@ -534,7 +585,7 @@ class _DualPathFn(torch.autograd.Function):
     def backward(ctx, dout):
         d = ctx.core.dualpath_bwd(ctx.skip, ctx.saved, ctx.l, ctx.path, dout.contiguous())
         ctx.saved = None
-        return d, None, None, None
+        return d, None, None, None, None
 
 
 class _MaskDecFn(torch.autograd.Function):

@@ -64,7 +64,8 @@ __device__ __forceinline__ void gn_mean_rstd(const double* stats, long g, double
 template <typename TO>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       TO* __restrict__ y, GnShape s, float eps) {
+                                                       const float* __restrict__ add, TO* __restrict__ y, GnShape s,
+                                                       float eps) {
   const int n4 = s.Np >> 2;
   const long total = (long)s.B * s.T * s.Kg * (s.W / s.N) * n4;
   const double cnt = (double)s.T * s.W;
@@ -84,10 +85,12 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
       const float4 v = *reinterpret_cast<const float4*>(x + vec * s.N + c);
       const float* g = gamma + (long)kg * s.gstride + c;
       const float* be = beta + (long)kg * s.gstride + c;
-      o[0] = from_f32<TO>((v.x - mean) * rstd * g[0] + be[0]);
-      o[1] = from_f32<TO>((v.y - mean) * rstd * g[1] + be[1]);
-      o[2] = from_f32<TO>((v.z - mean) * rstd * g[2] + be[2]);
-      o[3] = from_f32<TO>((v.w - mean) * rstd * g[3] + be[3]);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // per-(utterance, channel) additive term (flow time embedding)
+      if (add) { const float* ap = add + (long)b * s.N + c; a0 = ap[0]; a1 = ap[1]; a2 = ap[2]; a3 = ap[3]; }
+      o[0] = from_f32<TO>((v.x - mean) * rstd * g[0] + be[0] + a0);
+      o[1] = from_f32<TO>((v.y - mean) * rstd * g[1] + be[1] + a1);
+      o[2] = from_f32<TO>((v.z - mean) * rstd * g[2] + be[2] + a2);
+      o[3] = from_f32<TO>((v.w - mean) * rstd * g[3] + be[3] + a3);
     } else {
       o[0] = o[1] = o[2] = o[3] = from_f32<TO>(0.f);
     }
@@ -216,7 +219,8 @@ static int make_shape(GnShape* s, int B, int T, int Kg, int W, int N, int Np, in
   return URSE_OK;
 }
 
-extern "C" int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, void* y, double* stats,
+extern "C" int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* add, void* y,
+                                  double* stats,
                                   int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype,
                                   void* stream) {
   GnShape s;
@@ -232,10 +236,10 @@ extern "C" int urse_groupnorm_fwd(const float* x, const float* gamma, const floa
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, stats, s, rpb);
   const long total = (long)B * T * Kg * (W / N) * (Np / 4);
   if (out_dtype == URSE_BF16)
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta,
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, add,
                        (bf16_t*)y, s, eps);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta,
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, add,
                        (float*)y, s, eps);
   URSE_CHECK_LAUNCH("urse_groupnorm_fwd");
   return URSE_OK;

@@ -1,0 +1,306 @@
+"""BSRNN-Flow on MI355X: the generative (flow-matching) model of the reference behind its own surface.
+
+Mirrors ``baseline_code/models/bsrnn_flowse.py::BSRNN`` (two band splits + ``condition_fc``, 6 x dual-path BLSTM with
+a Gaussian-Fourier time embedding added after ``norm_time``, ``GradDecoder`` = per-band GN + 1x1 conv + tanh ->
+Conv2d(16->4, 5x5) + GLU, complex ``m * x_t + r``; :171-318), ``models/odes.py::FLOWMATCHING`` (:52-98), the white-box
+Euler sampler (``sampling/__init__.py:30-65``, ``odesolvers.py:72-81``) and ``flow_model.py::FlowSEModel``
+(``speech_to_feature`` :134-139, ``forward`` :203-209, ``forward_step`` :149-187, ``enhance`` :189-200, EMA :53,84,
+98-112).  Parameter names follow the reference (``dnn.band_split_x...``, ``dnn.grad_decoder.conv_after_mask.0...``) so
+``flow_bsrnn.ckpt`` loads by name.  Internally features are ``[B, T, F, 2]`` f32 (the reference's ``[B,1,F,T]`` complex
+is converted at the surface only).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import call, require_cuda, stream_ptr
+from .bsrnn import BSRNNCore, GN_EPS, _PackPlan, _descs, _ptr, _tiles, _view, _DualPathFn
+from .d_model import _DTYPES, StepLR
+
+SUB_CH = 16
+
+
+class _TCond(nn.Module):
+    """GaussianFourierProjection(embedding_size=N/2, scale=1): fixed random frequencies (not trained)."""
+
+    def __init__(self, half):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(half), requires_grad=False)
+
+
+class FlowBSRNNCore(BSRNNCore):
+    back_tag = "gd"
+
+    def __init__(self, input_dim=769, num_channel=384, num_layer=6, compute_dtype=torch.bfloat16):
+        super().__init__(input_dim, num_channel, num_layer, 48000, False, 1, compute_dtype)
+        self._pf = None
+
+    # ---- containers / flat layout -----------------------------------------------------------------------
+    def _make_front_back(self):
+        N = self.N
+        self.band_split_y = self._make_band_split()
+        self.band_split_x = self._make_band_split()
+        self.condition_fc = nn.Linear(2 * N, N)
+        self.t_cond = nn.ModuleList([_TCond(N // 2) for _ in range(self.num_layer)])
+        gd = nn.Module()
+        gd.conv_after_mask = nn.Sequential(nn.Conv2d(SUB_CH, 4, 5, 1, 2), nn.GLU(dim=1))
+        gd.conv_after_residual = nn.Sequential(nn.Conv2d(SUB_CH, 4, 5, 1, 2), nn.GLU(dim=1))
+        mk = lambda sb: nn.Sequential(nn.GroupNorm(1, N), nn.Conv1d(N, sb * SUB_CH, 1), nn.Tanh())
+        gd.mlp_mask = nn.ModuleList([mk(sb) for sb in self.subbands])
+        gd.mlp_residual = nn.ModuleList([mk(sb) for sb in self.subbands])
+        self.grad_decoder = gd
+
+    def _front_params(self):
+        return (self._bs_params("bsx", self.band_split_x) + self._bs_params("bsy", self.band_split_y) +
+                [("cfc.w", [self.condition_fc.weight]), ("cfc.b", [self.condition_fc.bias])])
+
+    def _back_params(self):
+        gd, order = self.grad_decoder, []
+        for tag, mlps, conv in (("m", gd.mlp_mask, gd.conv_after_mask), ("r", gd.mlp_residual, gd.conv_after_residual)):
+            p = "gd%s." % tag
+            order += [(p + "gamma", [s[0].weight for s in mlps]), (p + "beta", [s[0].bias for s in mlps]),
+                      (p + "w1", [s[1].weight for s in mlps]), (p + "b1", [s[1].bias for s in mlps]),
+                      (p + "cw", [conv[0].weight]), (p + "cb", [conv[0].bias])]
+        return order
+
+    def _plan_front(self, pn, pt, h, dtype):
+        N, Np, o = self.N, self._dims["Np"], self._off
+        self._plan_band_split("bsx", pn, pt, h, dtype)
+        self._plan_band_split("bsy", pn, pt, h, dtype)
+        h["cfc.w"] = pn.add(o["cfc.w"], N, 2 * N, N, ops.kpad(2 * N, dtype))
+        h["cfc.wT"] = pt.add(o["cfc.w"], N, 2 * N, 2 * N, Np)
+
+    def _plan_back(self, pn, pt, h, dtype):
+        """decoder 1x1 convs with output rows permuted (ch, f) -> (f, ch) so that the GEMM writes the channel-last
+        [B,T,F,16] feature map the 5x5 convolution reads; biases permuted the same way (f32 plan)."""
+        N, Np, o = self.N, self._dims["Np"], self._off
+        self._pf, self._pf_h = _PackPlan(False), {}
+        for tag in "mr":
+            p = "gd%s." % tag
+            w_off = b_off = 0
+            for k, sb in enumerate(self.subbands):
+                blk = pn.reserve(SUB_CH * sb * Np)
+                bblk = self._pf.reserve(SUB_CH * sb)
+                for ch in range(SUB_CH):
+                    pn.add_at(o[p + "w1"] + w_off + ch * sb * N, sb, N, blk + ch * Np, sb, Np, SUB_CH * Np)
+                    self._pf.add_at(o[p + "b1"] + b_off + ch * sb, sb, 1, bblk + ch, sb, 1, SUB_CH)
+                h[p + "w1", k] = (blk, SUB_CH * sb, Np)
+                self._pf_h[p + "b1", k] = (bblk, SUB_CH * sb, 1)
+                w_off += SUB_CH * sb * N
+                b_off += SUB_CH * sb
+
+    def _prepare(self):
+        stale = self._packed_version != self.param_version or self._plans is None or self._plans[0] != self.compute_dtype
+        super()._prepare()
+        if stale:
+            bf = self._pf.run(self._flat, torch.float32)
+            for key, hd in self._pf_h.items():
+                self._packed[key] = _view(bf, hd).view(-1)
+
+    # ---- forward pieces ---------------------------------------------------------------------------------------
+    def front_fwd(self, x, y):
+        """two band splits -> concat on channels -> condition_fc  (bsrnn_flowse.py:283-287)."""
+        B, T, F, _ = x.shape
+        dt, dev, N, pk = self.compute_dtype, x.device, self.N, self._packed
+        K = self._band_tables(F, dt, dev)["K"]
+        W2 = ops.kpad(2 * N, dt)
+        cat = torch.zeros(B, T, K, W2, dtype=dt, device=dev) if W2 != 2 * N else \
+            torch.empty(B, T, K, W2, dtype=dt, device=dev)
+        _, sx = self.bandsplit_fwd(x, "bsx", cat, W2, 0)
+        _, sy = self.bandsplit_fwd(y, "bsy", cat, W2, N)
+        z = torch.empty(B, T, K, N, dtype=torch.float32, device=dev)
+        ops.gemm_nt(cat.view(B * T * K, W2), pk["cfc.w"], self._p("cfc.b", N), out=z.view(B * T * K, N))
+        return z, (cat, sx, sy)
+
+    def time_embeddings(self, t):
+        B, N = t.shape[0], self.N
+        out = []
+        for l in range(self.num_layer):
+            e = torch.empty(B, N, dtype=torch.float32, device=t.device)
+            call("time_embedding", t, self.t_cond[l].W, e, B, N // 2, stream_ptr())
+            out.append(e)
+        return out
+
+    def graddec_fwd(self, skip, xt, sign, save):
+        B, T, K, N = skip.shape
+        F = xt.shape[2]
+        dt, dev, pk, Np = self.compute_dtype, skip.device, self._packed, self._dims["Np"]
+        tb = self._band_tables(F, dt, dev)
+        Fs = sum(self.subbands[:K])
+        M, Kf = B * T, len(self.subbands)
+        xns, sts, Us, pres = [], [], [], []
+        rows = []
+        for tag in "mr":
+            p = "gd%s." % tag
+            xn, st = ops.groupnorm_fwd(skip, self._p(p + "gamma", Kf * N), self._p(p + "beta", Kf * N), B, T, K, N, N,
+                                       Np, N, dt, GN_EPS)
+            U = torch.empty(B, T, Fs, SUB_CH, dtype=torch.float32, device=dev)
+            for k in range(K):
+                sb, f0 = self.subbands[k], tb["rows"][k][0]
+                rows.append([_ptr(xn, k * Np), _ptr(pk[p + "w1", k]), _ptr(U, f0 * SUB_CH), _ptr(pk[p + "b1", k]), 0,
+                             K * Np, Np, Fs * SUB_CH, M, SUB_CH * sb, Np, 0])
+            xns.append(xn); sts.append(st); Us.append(U)
+        call("gemm_nt_grouped", _descs(rows, dev), 2 * K, _tiles(M, SUB_CH * max(self.subbands[:K])), ops._dt(xns[0]),
+             ops.F32, 1, stream_ptr())
+        for i, tag in enumerate("mr"):
+            p = "gd%s." % tag
+            pre = torch.empty(B, T, Fs, 4, dtype=torch.float32, device=dev)
+            call("conv5x5_fwd", Us[i], self._p(p + "cw", 4 * SUB_CH * 25), self._p(p + "cb", 4), pre, B, T, Fs,
+                 stream_ptr())
+            pres.append(pre)
+        out = torch.empty(B, T, F, 2, dtype=torch.float32, device=dev)
+        call("glu4_apply_fwd", pres[0], pres[1], xt, out, M, F, Fs, float(sign), stream_ptr())
+        return out, ((xns, sts, Us, pres, Fs) if save else None)
+
+    def forward(self, x_ri, y_ri, t, sign=1.0):
+        """x_ri (= x_t), y_ri: f32 [B,T,F,2]; t f32 [B] -> sign * (m * x_t + r) as f32 [B,T,F,2]."""
+        require_cuda(x_ri, y_ri, t)
+        self._prepare()
+        x_ri, y_ri, t = x_ri.contiguous().float(), y_ri.contiguous().float(), t.contiguous().float()
+        tembs = self.time_embeddings(t)
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if train:
+            raise NotImplementedError("flow DNN backward is the next row to be built (forward / sampling only)")
+        z, _ = self.front_fwd(x_ri, y_ri)
+        for l in range(self.num_layer):
+            z, _ = self.dualpath_fwd(z, l, "t", False, tembs[l])
+            z, _ = self.dualpath_fwd(z, l, "f", False)
+        return self.graddec_fwd(z, x_ri, sign, False)[0]
+
+
+class FlowEMA:
+    """torch_ema.ExponentialMovingAverage(parameters, decay, use_num_updates=True) on the flat buffer."""
+
+    def __init__(self, core, decay):
+        self.core, self.decay, self.num_updates = core, decay, 0
+        self.shadow = core.flat_params.clone()
+        self.collected = None
+
+    def update(self):
+        self.num_updates += 1
+        d = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+        call("ema_update", self.shadow, self.core.flat_params, float(1.0 - d), self.shadow.numel(), stream_ptr())
+
+    def store(self):
+        self.collected = self.core.flat_params.clone()
+
+    def copy_to(self):
+        self.core.flat_params.copy_(self.shadow)
+        self.core.param_version += 1
+
+    def restore(self):
+        if self.collected is not None:
+            self.core.flat_params.copy_(self.collected)
+            self.core.param_version += 1
+            self.collected = None
+
+    def state_dict(self):
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_flat": self.shadow}
+
+    def load_state_dict(self, sd):
+        self.decay, self.num_updates = sd["decay"], sd["num_updates"]
+        self.shadow.copy_(sd["shadow_flat"])
+
+
+class FlowSEModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        g = lambda k, d: getattr(cfg, k, d)
+        self.n_fft, self.hop = g("n_fft", 1536), g("hop_length", 384)
+        self.spec_e, self.spec_factor = g("spec_abs_exponent", 0.667), g("spec_factor", 0.065)
+        self.sigma_min, self.sigma_max = g("sigma_min", 0.05), g("sigma_max", 0.5)
+        self.t_eps, self.T_rev = g("t_eps", 0.03), g("T_rev", 1.0)
+        self.loss_type = g("loss_type", "mse")
+        dtype = _DTYPES[str(g("compute_dtype", "bf16"))]
+        self.dnn = FlowBSRNNCore(self.n_fft // 2 + 1, g("bsrnn_hidden", 384), g("num_layer", 6), dtype)
+        self.ema_decay = g("ema_decay", 0.999)
+        self.ema = None
+        self.logged = {}
+
+    # ---- features ----------------------------------------------------------------------------------------------
+    def _stft_cfg(self, fs):
+        if fs is None:
+            return self.n_fft, self.hop
+        fs = int(fs)
+        return self.n_fft * fs // 48000, self.hop * fs // 48000
+
+    def speech_to_feature_ri(self, speech, fs, speech_length):
+        n_fft, hop = self._stft_cfg(fs)
+        spec = ops.stft_forward(speech.float(), n_fft, hop, ops.WIN_HANN, torch.as_tensor(speech_length))
+        ri = torch.view_as_real(spec).contiguous()
+        out = torch.empty_like(ri)
+        call("spec_transform", ri, out, ri.numel() // 2, float(self.spec_e), float(self.spec_factor), 0, stream_ptr())
+        return out                                                   # [B,T,F,2]
+
+    def feature_ri_to_speech(self, feat_ri, fs, speech_length):
+        n_fft, hop = self._stft_cfg(fs)
+        back = torch.empty_like(feat_ri)
+        call("spec_transform", feat_ri.contiguous(), back, feat_ri.numel() // 2, float(self.spec_e),
+             float(self.spec_factor), 1, stream_ptr())
+        return ops.istft_forward(back, n_fft, hop, int(torch.as_tensor(speech_length).max()))
+
+    def speech_to_feature(self, speech, fs, speech_length):
+        """reference layout: complex [B,1,F,T] (flow_model.py:134-139)."""
+        return torch.view_as_complex(self.speech_to_feature_ri(speech, fs, speech_length)).permute(0, 2, 1).unsqueeze(1)
+
+    def feature_to_speech(self, feature, fs, speech_length):
+        ri = torch.view_as_real(feature.squeeze(1).permute(0, 2, 1).contiguous())
+        return self.feature_ri_to_speech(ri, fs, speech_length)
+
+    # ---- vector field ----------------------------------------------------------------------------------------------
+    def vector_field_ri(self, xt_ri, t, y_ri):
+        """FlowSEModel.forward (:203-209): -dnn(cat[x, y], t), on [B,T,F,2] tensors."""
+        return self.dnn(xt_ri, y_ri, t, sign=-1.0)
+
+    def forward(self, x, t, y):
+        to_ri = lambda c: torch.view_as_real(c.squeeze(1).permute(0, 2, 1).contiguous())
+        out = self.vector_field_ri(to_ri(x), t, to_ri(y))
+        return torch.view_as_complex(out).permute(0, 2, 1).unsqueeze(1)
+
+    def prior_sample_ri(self, Y_ri, z_ri=None):
+        """ode.prior_sampling (odes.py:84-91): x_T = Y + sigma(1) z, z ~ CN(0, 1)."""
+        if z_ri is None:
+            z_ri = torch.view_as_real(torch.randn(Y_ri.shape[:-1], dtype=torch.complex64, device=Y_ri.device))
+        B = Y_ri.shape[0]
+        xt = torch.empty_like(Y_ri)
+        ones = torch.ones(B, device=Y_ri.device)
+        call("flow_prepare", Y_ri, Y_ri, z_ri.contiguous(), ones, xt, None, B, Y_ri[0].numel() // 2,
+             float(self.sigma_min), float(self.sigma_max), stream_ptr())
+        return xt
+
+    def sample_ri(self, Y_ri, N=15, z_ri=None):
+        """white-box Euler solver (sampling/__init__.py:30-65): x <- x - step_i * VF(x, t_i, Y)."""
+        with torch.no_grad():
+            xt = self.prior_sample_ri(Y_ri, z_ri)
+            ts = torch.linspace(self.T_rev, self.t_eps, N)
+            B = Y_ri.shape[0]
+            for i in range(N):
+                step = float(ts[i] - ts[i + 1]) if i != N - 1 else float(ts[-1])
+                vec_t = torch.full((B,), float(ts[i]), device=Y_ri.device)
+                vf = self.vector_field_ri(xt, vec_t, Y_ri)
+                call("axpy", vf, xt, -step, xt.numel(), stream_ptr())
+            return xt
+
+    def enhance(self, y, fs, speech_length, N=15):
+        """flow_model.py:189-200."""
+        Y = self.speech_to_feature_ri(y, fs, speech_length)
+        return self.feature_ri_to_speech(self.sample_ri(Y, N), fs, speech_length)
+
+    # ---- training-side pieces that exist so far ---------------------------------------------------------------------
+    def loss_from_ri(self, x0_ri, y_ri, t, z_ri):
+        """forward_step :164-172 / _loss :122-132 ('mse') for given t and noise (forward value, no gradient yet)."""
+        B = x0_ri.shape[0]
+        per_b = x0_ri[0].numel() // 2
+        xt, cvf = torch.empty_like(x0_ri), torch.empty_like(x0_ri)
+        call("flow_prepare", x0_ri.contiguous(), y_ri.contiguous(), z_ri.contiguous(), t.contiguous().float(), xt, cvf, B,
+             per_b, float(self.sigma_min), float(self.sigma_max), stream_ptr())
+        with torch.no_grad():
+            vf = self.vector_field_ri(xt, t, y_ri)
+        loss = torch.empty(B, dtype=torch.float64, device=x0_ri.device)
+        call("flow_loss", vf, cvf, loss, None, B, per_b, 1.0, stream_ptr())
+        return loss
+
+    def init_ema(self):
+        self.ema = FlowEMA(self.dnn, self.ema_decay)
+        return self.ema

@@ -142,12 +142,12 @@ def pack2d(inp, out_rows, out_cols, dtype, transpose=False, out=None):
     return out
 
 
-def groupnorm_fwd(x, gamma, beta, B, T, Kg, W, N, Np, gstride, dtype, eps=1e-5):
+def groupnorm_fwd(x, gamma, beta, B, T, Kg, W, N, Np, gstride, dtype, eps=1e-5, add=None):
     """x f32 [B,T,Kg,W] -> (y [B*T*Kg*(W/N), Np] dtype, stats f64 [B*Kg*2])."""
     require_cuda(x)
     y = torch.empty(B * T * Kg * (W // N), Np, device=x.device, dtype=dtype)
     stats = torch.empty(B * Kg * 2, device=x.device, dtype=torch.float64)
-    call("groupnorm_fwd", x, gamma, beta, y, stats, B, T, Kg, W, N, Np, gstride, float(eps), _dt(y), stream_ptr())
+    call("groupnorm_fwd", x, gamma, beta, add, y, stats, B, T, Kg, W, N, Np, gstride, float(eps), _dt(y), stream_ptr())
     return y, stats
 
 
