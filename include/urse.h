@@ -75,7 +75,8 @@ int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_d
  * B'[r] = B[r+shift], zero when period > 0 and ((r / inner) % period) == invalid_step
  * (the h_{t-1} operand of the recurrent weight gradient).  perm_h > 0: the columns of A are in the LSTM
  * kernels' gate-interleaved order (dir, unit, gate) and C rows / colsum are written back in nn.LSTM's
- * (dir, gate, unit) order with H = perm_h. */
+ * (dir, gate, unit) order with H = perm_h.  perm_h < 0: flow grad decoder, A columns (bin, 16 sub-channels) ->
+ * weight rows (sub-channel, bin) with sb = -perm_h. */
 int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
                  int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner, int64_t period,
                  int64_t invalid_step, int64_t perm_h, int dtype, void* stream);
@@ -219,6 +220,9 @@ int urse_glu4_apply_fwd(const float* pre_m, const float* pre_r, const float* x, 
                         int Fs, float sign, void* stream);
 int urse_glu4_apply_bwd(const float* pre_m, const float* pre_r, const float* x, const float* dout, float* dpre_m,
                         float* dpre_r, int64_t rows, int F, int Fs, float sign, void* stream);
+/* dst [rows, n] (pitch ldd, bf16|f32) = dU * (1 - U^2): tanh backward of the decoder map, cast for the GEMMs. */
+int urse_tanh_bwd_pack(const float* dU, const float* U, void* dst, int64_t rows, int n, int64_t ldd, int out_dtype,
+                       void* stream);
 /* loss[b] (f64) = 0.5 sum |vf - cvf|^2 (flow_model.py:122-132, 'mse'); grad (may be NULL) = (vf - cvf) * grad_scale. */
 int urse_flow_loss(const float* vf, const float* cvf, double* loss, float* grad, int B, int64_t per_b, float grad_scale,
                    void* stream);

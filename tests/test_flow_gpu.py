@@ -102,3 +102,50 @@ def test_features_loss_and_ema_vs_oracle(lib):
 def test_full_size_parameter_count(lib):
     from urgent2026_challenge_track1_amd.flow_model import FlowBSRNNCore
     assert sum(p.numel() for p in FlowBSRNNCore(769, 384, 6).parameters()) == 103245488   # SURVEY 4 / golden
+
+
+def test_flow_training_gradients_match_oracle(lib):
+    """flow-matching loss backward through GradDecoder / dual-path / condition_fc / both band splits vs autograd of
+    the oracle (itself bitwise-equal to the reference DNN), f32 mode."""
+    g, m = _golden_model()
+    N = g["w:condition_fc.weight"].shape[0]
+    ref = flow_ref.FlowSE(bsrnn_hidden=N, num_layer=2)
+    ref.dnn.load_state_dict({k: torch.from_numpy(g["w:" + k]) for k in g["keys"].tolist()})
+    c = lambda a: torch.view_as_complex(torch.from_numpy(a))
+    x0, y, z, t = c(g["x"]), c(g["y"]), c(g["z"]), torch.from_numpy(g["t"])
+    loss_r = ref.loss_from(x0, y, t, z)
+    loss_r.backward()
+    B = x0.shape[0]
+    from urgent2026_challenge_track1_amd._lib import call, stream_ptr
+    xt, cvf = torch.empty_like(_ri(g["x"])), torch.empty_like(_ri(g["x"]))
+    call("flow_prepare", _ri(g["x"]), _ri(g["y"]), _ri(g["z"]), t.cuda(), xt, cvf, B, xt[0].numel() // 2, 0.05, 0.5,
+         stream_ptr())
+    from urgent2026_challenge_track1_amd.flow_model import _FlowLossFn
+    vf = m.vector_field_ri(xt, t.cuda(), _ri(g["y"]))
+    loss = _FlowLossFn.apply(vf, cvf)
+    loss.backward()
+    assert abs(float(loss) - float(loss_r)) <= 1e-3 * abs(float(loss_r))
+    mine = dict(m.dnn.named_parameters())
+    worst = 0.0
+    for n, p in ref.dnn.named_parameters():
+        if not p.requires_grad:
+            continue
+        gr = p.grad
+        err = (mine[n].grad.cpu() - gr).abs().max().item()
+        worst = max(worst, err / (gr.abs().max().item() + 1e-12))
+        assert err <= 2e-3 * gr.abs().max().item() + 1e-6, (n, err, gr.abs().max().item())
+    print("flow worst relative grad error %.2e" % worst)
+
+
+def test_flow_train_step_runs_and_updates_ema(lib):
+    g, m = _golden_model()
+    (opt,), _ = m.configure_optimizers()
+    gen = torch.Generator().manual_seed(9)
+    clean = 0.2 * torch.randn(2, 1, 3456, generator=gen).cuda()
+    noisy = clean + 0.05 * torch.randn(2, 1, 3456, generator=gen).cuda()
+    before = m.dnn.flat_params.clone()
+    loss = m.training_step((clean, noisy, torch.tensor(48000, dtype=torch.int32), torch.tensor([3456, 3456])))
+    loss.backward()
+    m.optimizer_step(opt)
+    assert torch.isfinite(loss) and not torch.equal(before, m.dnn.flat_params)
+    assert m.ema.num_updates == 1 and torch.all(m.dnn.flat_grads == 0)

@@ -207,6 +207,19 @@ __global__ void __launch_bounds__(256) glu4_apply_bwd_kernel(const float4* __res
   }
 }
 
+// dst (TO, pitch ldd) = dU * (1 - U^2): tanh backward of the decoder feature map, cast to the GEMM operand type
+template <typename TO>
+__global__ void __launch_bounds__(256) tanh_bwd_pack_kernel(const float* __restrict__ dU, const float* __restrict__ U,
+                                                            TO* __restrict__ dst, long rows, int n, long ldd) {
+  const long total = rows * n;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / n;
+    const int c = (int)(idx - r * n);
+    const float u = U[idx];
+    dst[r * ldd + c] = from_f32<TO>(dU[idx] * (1.f - u * u));
+  }
+}
+
 // loss_b = 0.5 * sum |vf - cvf|^2 ; grad = (vf - cvf) * scale
 __global__ void __launch_bounds__(256) flow_loss_kernel(const float2* __restrict__ vf, const float2* __restrict__ cvf,
                                                         double* __restrict__ loss, float2* __restrict__ grad,
@@ -309,6 +322,20 @@ extern "C" int urse_glu4_apply_bwd(const float* pre_m, const float* pre_r, const
                      (const float4*)pre_m, (const float4*)pre_r, (const float2*)x, (const float2*)dout, (float4*)dpre_m,
                      (float4*)dpre_r, (long)rows, F, Fs, sign);
   URSE_CHECK_LAUNCH("urse_glu4_apply_bwd");
+  return URSE_OK;
+}
+
+extern "C" int urse_tanh_bwd_pack(const float* dU, const float* U, void* dst, int64_t rows, int n, int64_t ldd,
+                                  int out_dtype, void* stream) {
+  URSE_CHECK_ARG(dU && U && dst && rows > 0 && n > 0 && ldd >= n, "urse_tanh_bwd_pack: bad argument");
+  dim3 g(fgrid(rows * n)), b(256);
+  if (out_dtype == URSE_BF16)
+    hipLaunchKernelGGL(tanh_bwd_pack_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, dU, U, (bf16_t*)dst, (long)rows, n,
+                       (long)ldd);
+  else
+    hipLaunchKernelGGL(tanh_bwd_pack_kernel<float>, g, b, 0, (hipStream_t)stream, dU, U, (float*)dst, (long)rows, n,
+                       (long)ldd);
+  URSE_CHECK_LAUNCH("urse_tanh_bwd_pack");
   return URSE_OK;
 }
 

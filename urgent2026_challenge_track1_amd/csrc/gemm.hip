@@ -218,7 +218,11 @@ struct TnArgs {
 };
 
 __device__ __forceinline__ long tn_perm(long m, long h) {
-  if (h <= 0) return m;
+  if (h == 0) return m;
+  if (h < 0) {           // flow grad decoder: A columns ordered (bin, 16 sub-channels) -> weight rows (sub-channel, bin)
+    const long sb = -h;
+    return (m & 15) * sb + (m >> 4);
+  }
   const long g4 = 4 * h, d = m / g4, r = m - d * g4;
   return d * g4 + (r & 3) * h + (r >> 2);
 }

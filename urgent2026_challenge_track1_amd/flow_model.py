@@ -152,6 +152,65 @@ class FlowBSRNNCore(BSRNNCore):
         call("glu4_apply_fwd", pres[0], pres[1], xt, out, M, F, Fs, float(sign), stream_ptr())
         return out, ((xns, sts, Us, pres, Fs) if save else None)
 
+    # ---- backward pieces ------------------------------------------------------------------------------------------
+    def front_bwd(self, x, y, saved, dz):
+        cat, sx, sy = saved
+        B, T, K, W2 = cat.shape
+        dt, dev, N, pk, Np = self.compute_dtype, x.device, self.N, self._packed, self._dims["Np"]
+        R = B * T * K
+        dzT = ops.pack2d(dz.reshape(R, N), R, Np, dt)
+        ops.gemm_tn(dzT, cat.view(R, W2), self._g("cfc.w", N * 2 * N).view(N, 2 * N), colsum=self._g("cfc.b", N), Mo=N,
+                    No=2 * N)
+        dcat = torch.zeros(R * W2 + 64, dtype=dt, device=dev)[:R * W2].view(R, W2)   # slack: band slices read kpad(N) wide
+        ops.gemm_nt(dzT, pk["cfc.wT"], out=dcat, N=2 * N)
+        self.bandsplit_bwd(x, sx, None, "bsx", dcat, W2, 0, ready=False)
+        self.bandsplit_bwd(y, sy, None, "bsy", dcat, W2, N, ready=True)
+
+    def graddec_bwd(self, skip, xt, saved, dout, sign):
+        xns, sts, Us, pres, Fs = saved
+        B, T, K, N = skip.shape
+        F = xt.shape[2]
+        dt, dev, pk, Np = self.compute_dtype, skip.device, self._packed, self._dims["Np"]
+        tb = self._band_tables(F, dt, dev)
+        M, Kf = B * T, len(self.subbands)
+        dpre = [torch.empty(B, T, Fs, 4, dtype=torch.float32, device=dev) for _ in range(2)]
+        call("glu4_apply_bwd", pres[0], pres[1], xt, dout, dpre[0], dpre[1], M, F, Fs, float(sign), stream_ptr())
+        ldu = ops.kpad(Fs * SUB_CH, dt)
+        dxn = [torch.empty(M * K, N, dtype=torch.float32, device=dev) for _ in range(2)]
+        rows = []
+        keep = []
+        for i, tag in enumerate("mr"):
+            p = "gd%s." % tag
+            dU = torch.empty(B, T, Fs, SUB_CH, dtype=torch.float32, device=dev)
+            call("conv5x5_bwd", Us[i], self._p(p + "cw", 4 * SUB_CH * 25), dpre[i], dU, self._g(p + "cw", 4 * SUB_CH * 25),
+                 self._g(p + "cb", 4), B, T, Fs, stream_ptr())
+            dUp = torch.zeros(M, ldu, dtype=dt, device=dev)
+            call("tanh_bwd_pack", dU, Us[i], dUp, M, Fs * SUB_CH, ldu, ops._dt(dUp), stream_ptr())
+            keep.append(dUp)
+            w_off = b_off = 0
+            for k in range(K):
+                sb, f0 = self.subbands[k], tb["rows"][k][0]
+                n_out = SUB_CH * sb
+                a = dUp[:, f0 * SUB_CH:f0 * SUB_CH + n_out]
+                xk = xns[i].view(M, K * Np)[:, k * Np:(k + 1) * Np]
+                ops.gemm_tn(a, xk, self._g(p + "w1", n_out * N, w_off).view(n_out, N),
+                            colsum=self._g(p + "b1", n_out, b_off), Mo=n_out, No=N, perm_h=-sb)
+                kp = ops.kpad(n_out, dt)
+                w1T = ops.pack2d(pk[p + "w1", k], N, kp, dt, transpose=True)       # [N, kpad(16 sb)]
+                keep.append(w1T)
+                rows.append([_ptr(dUp, f0 * SUB_CH), _ptr(w1T), _ptr(dxn[i], k * N), 0, 0, ldu, kp, K * N, M, N, kp, 0])
+                w_off += n_out * N
+                b_off += n_out
+        call("gemm_nt_grouped", _descs(rows, dev), 2 * K, _tiles(M, N), ops._dt(keep[0]), ops.F32, 0, stream_ptr())
+        dskip = None
+        for i, tag in enumerate("mr"):
+            p = "gd%s." % tag
+            dskip = ops.groupnorm_bwd(skip, dxn[i].view(B, T, K, N), sts[i], self._p(p + "gamma", Kf * N), dskip,
+                                      self._g(p + "gamma", Kf * N), self._g(p + "beta", Kf * N), B, T, K, N, N, N,
+                                      GN_EPS)
+        self._ready("gd")
+        return dskip
+
     def forward(self, x_ri, y_ri, t, sign=1.0):
         """x_ri (= x_t), y_ri: f32 [B,T,F,2]; t f32 [B] -> sign * (m * x_t + r) as f32 [B,T,F,2]."""
         require_cuda(x_ri, y_ri, t)
@@ -160,12 +219,67 @@ class FlowBSRNNCore(BSRNNCore):
         tembs = self.time_embeddings(t)
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if train:
-            raise NotImplementedError("flow DNN backward is the next row to be built (forward / sampling only)")
+            anchor = self._flat.new_zeros((), requires_grad=True)
+            z = _FlowFrontFn.apply(anchor, x_ri, y_ri, self)
+            for l in range(self.num_layer):
+                z = _DualPathFn.apply(z, self, l, "t", tembs[l])
+                z = _DualPathFn.apply(z, self, l, "f")
+            return _GradDecFn.apply(z, x_ri, self, float(sign))
         z, _ = self.front_fwd(x_ri, y_ri)
         for l in range(self.num_layer):
             z, _ = self.dualpath_fwd(z, l, "t", False, tembs[l])
             z, _ = self.dualpath_fwd(z, l, "f", False)
         return self.graddec_fwd(z, x_ri, sign, False)[0]
+
+
+class _FlowFrontFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x, y, core):
+        z, saved = core.front_fwd(x, y)
+        ctx.core, ctx.saved, ctx.x, ctx.y = core, saved, x, y
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        ctx.core.front_bwd(ctx.x, ctx.y, ctx.saved, dz.contiguous())
+        ctx.saved = None
+        return None, None, None, None
+
+
+class _GradDecFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, xt, core, sign):
+        out, saved = core.graddec_fwd(skip, xt, sign, True)
+        ctx.core, ctx.saved, ctx.skip, ctx.xt, ctx.sign = core, saved, skip, xt, sign
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d = ctx.core.graddec_bwd(ctx.skip, ctx.xt, ctx.saved, dout.contiguous(), ctx.sign)
+        ctx.saved = None
+        return d, None, None, None
+
+
+class _FlowLossFn(torch.autograd.Function):
+    """mean_B( 0.5 * sum |vf - cvf|^2 )  (flow_model.py:122-132, loss_type 'mse')."""
+
+    @staticmethod
+    def forward(ctx, vf, cvf):
+        B = vf.shape[0]
+        per_b = vf[0].numel() // 2
+        loss = torch.empty(B, dtype=torch.float64, device=vf.device)
+        grad = torch.empty_like(vf)
+        call("flow_loss", vf, cvf, loss, grad, B, per_b, 1.0 / B, stream_ptr())
+        ctx.grad = grad
+        return loss.mean().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        out = ctx.grad
+        ctx.grad = None
+        if float(g) != 1.0:      # upstream scale other than 1 (not used by the training loop): scale in place
+            call("axpby", out.view(-1), out.view(-1), float(g), 0.0, out.numel(), stream_ptr())
+        return out, None
 
 
 class FlowEMA:
@@ -304,3 +418,43 @@ class FlowSEModel(nn.Module):
     def init_ema(self):
         self.ema = FlowEMA(self.dnn, self.ema_decay)
         return self.ema
+
+    def forward_step(self, batch, t=None, z_ri=None):
+        """flow_model.py:149-187.  t ~ min((1-U)(T_rev - t_eps) + t_eps, T_rev) and z ~ CN(0,1) unless given."""
+        clean_speech, noisy_speech, fs, speech_length = batch
+        B, C, T = clean_speech.shape
+        assert C == 1
+        x0 = self.speech_to_feature_ri(clean_speech.view(B, T), fs, speech_length)
+        y = self.speech_to_feature_ri(noisy_speech.view(B, T), fs, speech_length)
+        dev = x0.device
+        if t is None:
+            t = torch.clamp((1 - torch.rand(B, device=dev)) * (self.T_rev - self.t_eps) + self.t_eps, max=self.T_rev)
+        if z_ri is None:
+            z_ri = torch.view_as_real(torch.randn(x0.shape[:-1], dtype=torch.complex64, device=dev))
+        xt, cvf = torch.empty_like(x0), torch.empty_like(x0)
+        call("flow_prepare", x0, y, z_ri.contiguous(), t.contiguous().float(), xt, cvf, B, x0[0].numel() // 2,
+             float(self.sigma_min), float(self.sigma_max), stream_ptr())
+        vf = self.vector_field_ri(xt, t, y)
+        loss = _FlowLossFn.apply(vf, cvf)
+        self.logged["train_loss"] = loss.detach()
+        return loss
+
+    def training_step(self, batch):
+        return self.forward_step(batch)
+
+    def configure_optimizers(self):
+        core = self.dnn
+        opt = ops.FusedClipAdamW(core.flat_params, core.flat_grads, lr=getattr(self.cfg, "learning_rate", 1e-4),
+                                 eps=getattr(self.cfg, "adam_epsilon", 1e-8),
+                                 weight_decay=getattr(self.cfg, "weight_decay", 1e-6),
+                                 max_norm=getattr(self.cfg, "gradient_clip", 0.5))
+        return [opt], [StepLR(opt, getattr(self.cfg, "lr_step_size", 1), getattr(self.cfg, "lr_gamma", 0.85))]
+
+    def optimizer_step(self, optimizer, reducer=None):
+        """clip + AdamW, then ema.update (flow_model.py:69-84)."""
+        scale = reducer.finish() if reducer is not None else 1.0
+        optimizer.step(grad_scale=scale, zero_grad=True)
+        self.dnn.param_version += 1
+        if self.ema is None:
+            self.init_ema()
+        self.ema.update()
