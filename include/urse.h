@@ -123,6 +123,16 @@ int urse_lstm_pack(const float* wih, const float* whh, const float* bih, const f
 int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int64_t ldh, float* c, int H, int Hp,
                         int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save, int dtype,
                         int rows16, void* stream);
+/* Persistent cluster variant of urse_lstm_bidir_fwd (bf16): recurrent weights stay in registers, C workgroups share a
+ * set of sequences and exchange h_t through `hx` with an agent-scope release/acquire barrier per step.
+ *  whhq: quad-ordered fragments from urse_lstm_pack_quads; plan (urse_lstm_cluster_plan) = {C, clusters per direction,
+ *  rows per cluster, padded rows, hx elements (bf16, must be zero-initialised once), counters (uint32)};
+ *  err_flag: uint32 set to 1 if a barrier timed out (results are then invalid). */
+int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, void* stream);
+int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan);
+int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
+                          void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
+                          int64_t outer, int64_t stride, int save, void* stream);
 /* Backward through time.  dh [M, ldd>=2H] = gradient w.r.t. hout; gates: in = saved activations,
  * out = gradient w.r.t. the gate pre-activations (same interleaved layout); whhT = fragment-ordered
  * transposed recurrent weights from urse_lstm_pack. */

@@ -75,3 +75,33 @@ def _case(B, T, K, N, path, dtype, seed=0):
 @pytest.mark.parametrize("B,T,K,N", [(2, 9, 20, 16), (1, 33, 5, 24), (3, 7, 34, 196)])
 def test_lstm_fwd_bwd(lib, dtype, path, B, T, K, N):
     _case(B, T, K, N, path, dtype)
+
+
+@pytest.mark.parametrize("path", ["time", "band"])
+@pytest.mark.parametrize("B,T,K,N", [(2, 9, 20, 16), (3, 7, 34, 196), (2, 40, 34, 196)])
+def test_cluster_kernel_matches_streaming_kernel(lib, path, B, T, K, N):
+    """persistent cluster LSTM (weights in registers, cross-CU h exchange) == streaming kernel, bit for bit on h/c
+    (same bf16 MFMA products, same f32 cell math)."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(1)
+    H, dtype, dev = 2 * N, torch.bfloat16, "cuda"
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    M = B * T * K
+    if path == "time":
+        sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+    else:
+        sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    assert ops.lstm_cluster_plan(H, pk["Hp"], sm["n_seq"]) is not None
+    xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dtype)
+    gx1 = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    gx2 = gx1.clone()
+    h1, c1 = ops.lstm_fwd(gx1, pk["whh"], H, pk["Hp"], **sm)
+    h2, c2, err = ops.lstm_fwd_cluster(gx2, pk["whhq"], H, pk["Hp"], **sm)
+    assert int(err.item()) == 0
+    assert (h1.float() - h2.float()).abs().max().item() <= 1e-2      # a bf16 ulp where accumulation order differs
+    assert (c1 - c2).abs().max().item() <= 2e-2
+    assert (gx1.float() - gx2.float()).abs().max().item() <= 2e-2   # saved gate activations
+    assert (h1.float() - h2.float()).abs().mean().item() <= 1e-4

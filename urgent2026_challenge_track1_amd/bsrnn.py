@@ -320,6 +320,7 @@ class BSRNNCore(nn.Module):
                 self._lstm_bufs[p] = lp
                 pk[p + "wih"], pk[p + "wihT"], pk[p + "bias"] = lp["wih"], lp["wihT"], lp["bias"]
                 pk[p + "whh"], pk[p + "whhT"] = lp["whh"], lp["whhT"]
+                pk[p + "whhq"] = lp.get("whhq")
         self._packed = pk
         self._packed_version = self.param_version
 
@@ -422,7 +423,12 @@ class BSRNNCore(nn.Module):
                                       d["Np"], 0, dt, GN_EPS, add=temb)
         gx = ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
         sm = self._seqmap(path, B, T, K)
-        hout, c = ops.lstm_fwd(gx, pk[p + "whh"], H, d["Hp"], save=save, **sm)
+        if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and \
+                ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
+            hout, c, err = ops.lstm_fwd_cluster(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
+            self._cluster_err = err
+        else:
+            hout, c = ops.lstm_fwd(gx, pk[p + "whh"], H, d["Hp"], save=save, **sm)
         out = torch.empty_like(skip)
         ops.gemm_nt(hout, pk[p + "wfc"], self._p(p + "bfc", N), resid=skip.view(M, N), out=out.view(M, N))
         return out, ((stats, xn, gx, c, hout) if save else None)

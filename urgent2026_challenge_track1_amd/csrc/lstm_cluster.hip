@@ -1,0 +1,356 @@
+// Persistent "cluster" LSTM forward recurrence: recurrent weights RESIDENT IN REGISTERS for the whole sequence.
+//
+// lstm.hip streams W_hh (1.2 MB bf16 per direction) from L2 on every time step and is bound by the per-CU L1/L2
+// bandwidth (~8.5 us per step).  Here a cluster of C workgroups (one per CU) shares a set of sequences: workgroup j
+// owns 14 "quads" of hidden units (4 units x 4 gates = one 16-column MFMA B tile per quad, one quad per wave), keeps
+// those B fragments in VGPRs (13 x 16 B per lane for Hp = 416), and per step
+//   1. loads the cluster's h_{t-1} rows [64, Hp] from the exchange buffer into LDS (MFMA A operand),
+//   2. every wave computes its quad's 16 gate columns for the 64 rows, transposes the accumulator inside each lane
+//      quad with DPP so that one lane holds i,f,g,o of one (row, unit), applies the LSTM cell (c_t stays in registers),
+//   3. stages h_t through LDS and writes it with 16-byte stores to the exchange buffer and to hout,
+//   4. cluster barrier: release fence + one device-scope atomic per workgroup; acquire on the consumers.
+// Placement-independent (MI355X_MICROARCH "visibility"): agent-scope release/acquire only, bounded spins, counters
+// zeroed by a memset node before every launch, grid <= 256 workgroups so all are co-resident.
+// Same math / layouts as lstm.hip (gate-interleaved gx, bf16 h, f32 c); bf16 only (the f32 parity mode keeps lstm.hip).
+#include "urse_common.h"
+
+namespace urse {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int CW = 14;            // working waves per workgroup (one unit quad each)
+constexpr int CTHR = CW * 64;     // 896 threads
+constexpr int CROWS = 64;         // rows (sequences) per chunk = 4 MFMA row tiles
+constexpr int UW = CW * 4;        // hidden units per workgroup (56)
+
+struct ClusterArgs {
+  void* gx; long ldg;
+  const void* whhq;               // [2][nq][NSLAB][64][16 B] quad-ordered fragments
+  void* hout; long ldh;
+  float* c;
+  bf16_t* hx;                     // exchange [2 parity][2 dir][ncl][rows_pad][Hp]
+  unsigned* cnt;                  // [2 dir][ncl] arrival counters (zeroed per launch)
+  unsigned* err;                  // timeout flag
+  int H, Hp, save;
+  long inner, outer, stride;
+  int n_seq, seq_len;
+  int C, ncl, rows_per_cluster, rows_pad;
+};
+
+__device__ __forceinline__ float quad_bcast(float v, int k) {
+  // value of quad-lane k, broadcast inside each group of 4 lanes (DPP quad_perm)
+  int r;
+  const int iv = __float_as_int(v);
+  switch (k) {
+    case 0: r = __builtin_amdgcn_mov_dpp(iv, 0x00, 0xf, 0xf, true); break;
+    case 1: r = __builtin_amdgcn_mov_dpp(iv, 0x55, 0xf, 0xf, true); break;
+    case 2: r = __builtin_amdgcn_mov_dpp(iv, 0xAA, 0xf, 0xf, true); break;
+    default: r = __builtin_amdgcn_mov_dpp(iv, 0xFF, 0xf, 0xf, true); break;
+  }
+  return __int_as_float(r);
+}
+
+// write-through (sc1) 16-byte accesses to the exchange buffer: bypass this CU's L1 on loads, leave L2 on stores, so the
+// hand-off needs no release / acquire fence (MI355X_MICROARCH "Valid forms": every payload store and load sc1, every
+// storing wave drains vmcnt, one lane per workgroup signals with an agent-scope atomic, the poller is an sc1 load).
+__device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off, uint4 v) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs, (int)off, 0, 16);
+}
+__device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
+  return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+template <int NSLAB, int MAXCH>
+__global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
+  const int dir = blockIdx.y;
+  const int cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
+  const int H = p.H, Hp = p.Hp;
+  const int pitch = Hp * 2 + 16;
+  char* htile = smem;                                    // [CROWS][pitch]
+  bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + CROWS * pitch);   // [CROWS][UW]
+  const int nq = (H + 3) >> 2;
+  const int qd = j * CW + w;                             // this wave's unit quad
+  const bool qvalid = qd < nq;
+  const int ul = lc >> 2, q = lc & 3;                    // unit within quad / quad lane
+  const int u = qd * 4 + ul;
+  const bool uvalid = qvalid && u < H;
+  const int uc = uvalid ? u : H - 1;
+
+  uint4 breg[NSLAB];                                     // resident B fragments
+  {
+    const char* src = reinterpret_cast<const char*>(p.whhq) + (((long)dir * nq + (qvalid ? qd : 0)) * NSLAB) * 1024 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < NSLAB; ++ks) breg[ks] = *reinterpret_cast<const uint4*>(src + ks * 1024);
+  }
+  for (int i = tid; i < CROWS * UW / 2; i += CTHR) reinterpret_cast<unsigned*>(hstage)[i] = 0u;   // pad units stay 0
+  float cst[MAXCH][4];
+#pragma unroll
+  for (int a = 0; a < MAXCH; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cst[a][b] = 0.f;
+
+  const int seq0 = cl * p.rows_per_cluster;
+  int seq1 = seq0 + p.rows_per_cluster;
+  if (seq1 > p.n_seq) seq1 = p.n_seq;
+  const int nrows = seq1 - seq0;
+  const int nch = (nrows + CROWS - 1) / CROWS;
+  bf16_t* gx = reinterpret_cast<bf16_t*>(p.gx);
+  bf16_t* hout = reinterpret_cast<bf16_t*>(p.hout);
+  const long gcol0 = (long)dir * 4 * H;
+  const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * p.rows_pad * Hp * 2);
+  const unsigned cl_bytes = (unsigned)(((long)dir * p.ncl + cl) * p.rows_pad * Hp * 2);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2u * plane_bytes), 0x00020000);
+  unsigned* cnt = p.cnt + dir * p.ncl + cl;
+  const int cpr = Hp * 2 / 16;                           // 16-B chunks per h row
+  constexpr int HL = (CROWS * 52 + CTHR - 1) / CTHR;     // h-tile chunks per thread (Hp <= 416)
+  bool dead = false;
+
+  // row bookkeeping of this lane for chunk ch, row tile rt
+  auto row_of = [&](int ch, int rt, long toff, bool* valid) -> long {
+    const int lrow = ch * CROWS + rt * 16 + lr * 4 + q;
+    *valid = lrow < nrows;
+    int seq = seq0 + lrow;
+    if (seq >= p.n_seq) seq = p.n_seq - 1;
+    return (seq / p.inner) * p.outer + (seq % p.inner) + toff;
+  };
+  auto load_gx = [&](int ch, long toff, uint2 (&dst)[4]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      bool v;
+      const long row = row_of(ch, rt, toff, &v);
+      dst[rt] = *reinterpret_cast<const uint2*>(gx + row * p.ldg + gcol0 + uc * 4);
+    }
+  };
+  auto load_h = [&](int ch, unsigned plane, uint4 (&dst)[HL]) {
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+      const int idx = tid + i * CTHR;
+      const int row = idx / cpr, cc = idx - row * cpr;
+      dst[i] = make_uint4(0, 0, 0, 0);
+      if (idx < CROWS * cpr && ch * CROWS + row < nrows)
+        dst[i] = load_sc1(rs, plane * plane_bytes + cl_bytes + (unsigned)((ch * CROWS + row) * Hp * 2 + cc * 16));
+    }
+  };
+
+  uint2 gxn[4];                                          // gate pre-activations, prefetched one step ahead
+  load_gx(0, (long)(dir ? p.seq_len - 1 : 0) * p.stride, gxn);
+
+  for (int step = 0; step < p.seq_len; ++step) {
+    const int t = dir ? (p.seq_len - 1 - step) : step;
+    const long toff = (long)t * p.stride;
+    const unsigned pprev = (unsigned)((step + 1) & 1), pcur = (unsigned)(step & 1);
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      if (ch < nch) {
+        const int r0 = ch * CROWS;
+        // 1. h_{t-1} rows (complete only now, after the cluster barrier) -> LDS
+        {
+          uint4 hn[HL];
+          if (step > 0) {
+            load_h(ch, pprev, hn);
+          } else {
+#pragma unroll
+            for (int i = 0; i < HL; ++i) hn[i] = make_uint4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < HL; ++i) {
+            const int idx = tid + i * CTHR;
+            const int row = idx / cpr, cc = idx - row * cpr;
+            if (idx < CROWS * cpr) *reinterpret_cast<uint4*>(htile + row * pitch + cc * 16) = hn[i];
+          }
+        }
+        uint2 gxc[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) gxc[rt] = gxn[rt];
+        __syncthreads();
+        // prefetch the gate pre-activations of the next step (independent of the recurrence)
+        if (step + 1 < p.seq_len) load_gx(0, (long)(dir ? t - 1 : t + 1) * p.stride, gxn);
+        // 2. gates for (64 rows) x (this wave's quad)
+        uint2 gsave[4];
+        float csave[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          const char* ar = htile + (rt * 16 + lc) * pitch + 16 * lr;
+#pragma unroll
+          for (int ks = 0; ks < NSLAB; ++ks) {
+            const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                          __builtin_bit_cast(bf16x8_t, breg[ks]), acc, 0, 0, 0);
+          }
+          // acc[r] = gate (lc & 3) of unit (lc >> 2), row rt*16 + lr*4 + r.  4x4 transpose inside the lane quad
+          float pre[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float v0 = quad_bcast(acc[0], g), v1 = quad_bcast(acc[1], g), v2 = quad_bcast(acc[2], g),
+                        v3 = quad_bcast(acc[3], g);
+            pre[g] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
+          }
+          const uint2 gxv = gxc[rt];
+          const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
+          const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
+          const float iv = sigmoidf_(gi), fv = sigmoidf_(gf), gv = tanhf_(gg), ov = sigmoidf_(go);
+          const float cv = fv * cst[ch][rt] + iv * gv;
+          cst[ch][rt] = cv;
+          const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
+          if (qvalid) hstage[(rt * 16 + lr * 4 + q) * UW + w * 4 + ul] = f32_to_bf16(hv);
+          gsave[rt].x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
+          gsave[rt].y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
+          csave[rt] = cv;
+        }
+        __syncthreads();
+        // 3. h_t of this workgroup's units -> exchange buffer FIRST (write-through), then the plain stores
+        constexpr int SC = UW * 2 / 16;   // 7 chunks per row
+        for (int idx = tid; idx < CROWS * SC; idx += CTHR) {
+          const int row = idx / SC, cc = idx - row * SC;
+          const int ucol = j * UW + cc * 8;
+          if (r0 + row >= nrows || ucol >= Hp) continue;
+          const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
+          store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)((r0 + row) * Hp * 2 + ucol * 2), v);
+        }
+        if (ch + 1 == nch && step + 1 < p.seq_len) {
+          // last chunk: drain the exchange stores and arrive at the cluster barrier before the (slow) plain stores
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int idx = tid; idx < CROWS * SC; idx += CTHR) {
+          const int row = idx / SC, cc = idx - row * SC;
+          const int ucol = j * UW + cc * 8;
+          if (r0 + row >= nrows || ucol >= H) continue;
+          const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
+          const int seq = seq0 + r0 + row;
+          const long grow = (seq / p.inner) * p.outer + (seq % p.inner) + toff;
+          if (ucol + 8 <= H) {
+            *reinterpret_cast<uint4*>(hout + grow * p.ldh + (long)dir * H + ucol) = v;
+          } else {
+            const bf16_t* sv = reinterpret_cast<const bf16_t*>(&v);
+            for (int e = 0; e < 8 && ucol + e < H; ++e) hout[grow * p.ldh + (long)dir * H + ucol + e] = sv[e];
+          }
+        }
+        if (p.save && uvalid) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            bool v;
+            const long row = row_of(ch, rt, toff, &v);
+            if (v) {
+              *reinterpret_cast<uint2*>(gx + row * p.ldg + gcol0 + u * 4) = gsave[rt];
+              p.c[row * 2 * H + (long)dir * H + u] = csave[rt];
+            }
+          }
+        }
+        __syncthreads();   // hstage / htile are rewritten by the next stage
+      }
+    }
+    // 4. wait for the other workgroups of the cluster
+    if (step + 1 < p.seq_len) {
+      if (tid == 0) {
+        const unsigned target = (unsigned)(step + 1) * (unsigned)p.C;
+        unsigned spins = 0;
+        while (!dead && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 24)) { dead = true; atomicExch(p.err, 1u); }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// quad-ordered recurrent weights: block (dir, quad, slab) = 64 lanes x 16 B; lane (lr, lc): unit quad*4 + (lc>>2),
+// gate lc & 3, k = slab*32 + 8*lr + j
+__global__ void __launch_bounds__(256) lstm_pack_quads_kernel(const float* __restrict__ whh, bf16_t* __restrict__ out,
+                                                              int H, int Hp) {
+  const int nq = (H + 3) >> 2, nslab = Hp / 32, G4 = 4 * H;
+  const long total = (long)2 * nq * nslab * 64 * 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int jj = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int ks = (int)(r % nslab); r /= nslab;
+    const int qd = (int)(r % nq);
+    const int d = (int)(r / nq);
+    const int lc = lane & 15, lr = lane >> 4;
+    const int u = qd * 4 + (lc >> 2), g = lc & 3, k = ks * 32 + 8 * lr + jj;
+    out[idx] = f32_to_bf16((u < H && k < H) ? whh[((long)d * G4 + g * H + u) * H + k] : 0.f);
+  }
+}
+
+template <int NSLAB, int MAXCH>
+static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  const size_t lds = (size_t)CROWS * (p.Hp * 2 + 16) + (size_t)CROWS * UW * 2;
+  dim3 grid(p.C * p.ncl, 2);
+  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH>), grid, dim3(CTHR), lds, st, p);
+  URSE_CHECK_LAUNCH("urse_lstm_cluster_fwd");
+  return URSE_OK;
+}
+
+}  // namespace urse
+
+using namespace urse;
+
+extern "C" int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, void* stream) {
+  URSE_CHECK_ARG(whh && out && H > 0 && Hp % 32 == 0 && Hp >= H, "urse_lstm_pack_quads: bad argument");
+  hipLaunchKernelGGL(lstm_pack_quads_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, whh, (bf16_t*)out, H, Hp);
+  URSE_CHECK_LAUNCH("urse_lstm_pack_quads");
+  return URSE_OK;
+}
+
+// workspace query: {C, ncl, rows_per_cluster, rows_pad, hx_elems, n_counters}; returns < 0 if the shape is unsupported
+extern "C" int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan) {
+  URSE_CHECK_ARG(plan && H > 0 && n_seq > 0, "urse_lstm_cluster_plan: bad argument");
+  const int nslab = Hp / 32;
+  if (Hp % 32 != 0 || !(nslab == 1 || nslab == 2 || nslab == 13) || H % 8 != 0) {
+    set_error("urse_lstm_cluster_plan: unsupported H=%d Hp=%d", H, Hp);
+    return URSE_ERR_UNSUPPORTED;
+  }
+  const int nq = (H + 3) / 4;
+  const int C = (nq + CW - 1) / CW;
+  int ncl = 126 / C;                       // 2 directions * ncl * C <= 252 workgroups: all co-resident
+  if (ncl < 1) ncl = 1;
+  int rpc = (n_seq + ncl - 1) / ncl;
+  if (rpc < 1) rpc = 1;
+  const int max_rows = CROWS;              // one 64-row chunk per cluster (long-sequence / few-sequence regime)
+  if (rpc > max_rows) {
+    set_error("urse_lstm_cluster_plan: %d sequences exceed the cluster capacity", n_seq);
+    return URSE_ERR_UNSUPPORTED;
+  }
+  ncl = (n_seq + rpc - 1) / rpc;
+  const int rows_pad = (rpc + CROWS - 1) / CROWS * CROWS;
+  plan[0] = C; plan[1] = ncl; plan[2] = rpc; plan[3] = rows_pad;
+  plan[4] = (int64_t)2 * 2 * ncl * rows_pad * Hp;
+  plan[5] = 2 * ncl;
+  return URSE_OK;
+}
+
+extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
+                                     void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len,
+                                     int64_t inner, int64_t outer, int64_t stride, int save, void* stream) {
+  URSE_CHECK_ARG(gx && whhq && hout && hx && counters && err_flag && (c || !save), "urse_lstm_cluster_fwd: null pointer");
+  int64_t plan[6];
+  int rc = urse_lstm_cluster_plan(H, Hp, n_seq, plan);
+  if (rc) return rc;
+  URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldh >= 2L * H && (ldh * 2) % 16 == 0 &&
+                     ((uintptr_t)hout % 16) == 0 && ((uintptr_t)hx % 16) == 0,
+                 "urse_lstm_cluster_fwd: bad leading dimension / alignment");
+  ClusterArgs p;
+  p.gx = gx; p.ldg = ldg; p.whhq = whhq; p.hout = hout; p.ldh = ldh; p.c = c; p.hx = (bf16_t*)hx;
+  p.cnt = (unsigned*)counters; p.err = (unsigned*)err_flag; p.H = H; p.Hp = Hp; p.save = save;
+  p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
+  p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2]; p.rows_pad = (int)plan[3];
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(counters, 0, sizeof(unsigned) * plan[5], st);
+  const int nslab = Hp / 32;
+  if (nslab == 13) return launch_cluster<13, 1>(p, st);
+  if (nslab == 2) return launch_cluster<2, 1>(p, st);
+  return launch_cluster<1, 1>(p, st);
+}

@@ -3,6 +3,8 @@
 PyTorch supplies device memory, streams and autograd bookkeeping only; every
 arithmetic step runs in a hand-written gfx950 kernel of liburse_hip.so.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -173,7 +175,43 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
                    whhT=torch.empty(2 * nu * 4 * H, device=dev, dtype=dtype), Np=Np, Hp=Hp)
     call("lstm_pack", wih, whh, bih, bhh, out["wih"], out["wihT"], out["bias"], out["whh"], out["whhT"], N, Np, H, Hp,
          _dt(out["wih"]), stream_ptr())
+    if dtype == torch.bfloat16 and Hp % 32 == 0:
+        if "whhq" not in out:
+            out["whhq"] = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=dtype)
+        call("lstm_pack_quads", whh, out["whhq"], H, Hp, stream_ptr())
     return out
+
+
+_cluster_ws = {}
+USE_CLUSTER_LSTM = os.environ.get("URSE_LSTM_CLUSTER", "1") != "0"
+
+
+def lstm_cluster_plan(H, Hp, n_seq):
+    """None if the persistent cluster kernel does not support this shape."""
+    import ctypes
+    plan = (ctypes.c_int64 * 6)()
+    lib = _lib.load()
+    if lib.urse_lstm_cluster_plan(H, Hp, n_seq, plan) != 0:
+        return None
+    return list(plan)
+
+
+def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save=True):
+    """persistent cluster LSTM forward (bf16): see csrc/lstm_cluster.hip."""
+    plan = lstm_cluster_plan(H, Hp, n_seq)
+    M, dev = gx.shape[0], gx.device
+    key = (dev, H, Hp, n_seq)
+    if key not in _cluster_ws:
+        _cluster_ws[key] = (torch.zeros(plan[4], device=dev, dtype=torch.bfloat16),
+                            torch.zeros(plan[5], device=dev, dtype=torch.int32),
+                            torch.zeros(1, device=dev, dtype=torch.int32))
+    hx, cnt, err = _cluster_ws[key]
+    ldh = kpad(2 * H, gx.dtype)
+    hout = torch.zeros(M, ldh, device=dev, dtype=gx.dtype)
+    c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
+    timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster_fwd", gx, gx.stride(0), whhq, hout, ldh,
+               c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
+    return hout, c, err
 
 
 def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, rows16=0):
