@@ -133,6 +133,12 @@ int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan);
 int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                           void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
                           int64_t outer, int64_t stride, int save, void* stream);
+/* Cluster BPTT (bf16), same protocol: whhTq from urse_lstm_pack_bwd_quads(whh, out [2*C*4*(H/8)*512 bf16], H, C);
+ * dgx = exchange buffer of 2*2*ncl*64*4H bf16 elements. */
+int urse_lstm_pack_bwd_quads(const float* whh, void* out, int H, int C, void* stream);
+int urse_lstm_cluster_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhTq,
+                          void* dgx, void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
+                          int64_t outer, int64_t stride, void* stream);
 /* Backward through time.  dh [M, ldd>=2H] = gradient w.r.t. hout; gates: in = saved activations,
  * out = gradient w.r.t. the gate pre-activations (same interleaved layout); whhT = fragment-ordered
  * transposed recurrent weights from urse_lstm_pack. */

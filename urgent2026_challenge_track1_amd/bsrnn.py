@@ -320,7 +320,7 @@ class BSRNNCore(nn.Module):
                 self._lstm_bufs[p] = lp
                 pk[p + "wih"], pk[p + "wihT"], pk[p + "bias"] = lp["wih"], lp["wihT"], lp["bias"]
                 pk[p + "whh"], pk[p + "whhT"] = lp["whh"], lp["whhT"]
-                pk[p + "whhq"] = lp.get("whhq")
+                pk[p + "whhq"], pk[p + "whhTq"] = lp.get("whhq"), lp.get("whhTq")
         self._packed = pk
         self._packed_version = self.param_version
 
@@ -446,7 +446,11 @@ class BSRNNCore(nn.Module):
         ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N,
                     No=2 * H)
         sm = self._seqmap(path, B, T, K)
-        dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, **sm)   # dgates, gate-interleaved columns
+        if ops.USE_CLUSTER_LSTM_BWD and pk.get(p + "whhTq") is not None and \
+                ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
+            dg, self._cluster_err = ops.lstm_bwd_cluster(dh, gates, c, pk[p + "whhTq"], H, d["Hp"], **sm)
+        else:
+            dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, **sm)   # dgates, gate-interleaved columns
         gb = self._g(p + "bih", 8 * H)
         ops.gemm_tn(dg, xn, self._g(p + "wih", 8 * H * N).view(8 * H, N), colsum=gb, Mo=8 * H, No=N, perm_h=H)
         call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())

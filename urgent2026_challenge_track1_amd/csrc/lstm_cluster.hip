@@ -282,6 +282,221 @@ __global__ void __launch_bounds__(256) lstm_pack_quads_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward through time, cluster form.  Per step (reverse order):
+//   A. every lane (row, unit) of the workgroup's 56 units turns dh_out + dh_rec into the four gate gradients, stages them
+//      in LDS and publishes its 224 gate columns of the cluster's [64, 4H] dgates tile (sc1 stores); cluster barrier;
+//   B. dh_rec[64, 56] = dgates_tile[64, 4H] x W_hh[4H, 56 units]: W_hh^T fragments are register resident, 12 waves =
+//      4 unit tiles x 3 K-thirds, the tile is streamed through LDS in two 32-row halves, K-partials are summed via LDS.
+// Gate gradients are also written to `gates` (for the weight-gradient GEMMs) after the barrier arrival.
+struct ClusterBwdArgs {
+  const void* dh; long ldd;
+  void* gates; long ldg;
+  const float* c;
+  const void* whhTq;              // [2][C][4][nslabT][64][16 B]
+  bf16_t* dgx;                    // exchange [2 parity][2 dir][ncl][CROWS][4H]
+  unsigned* cnt;
+  unsigned* err;
+  int H;
+  long inner, outer, stride;
+  int n_seq, seq_len;
+  int C, ncl, rows_per_cluster;
+};
+
+template <int KPW>
+__global__ void __launch_bounds__(CTHR) lstm_bwd_cluster_kernel(ClusterBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
+  const int dir = blockIdx.y;
+  const int cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
+  const int H = p.H, G4 = 4 * H;
+  const int pitch = G4 * 2 + 16;
+  char* atile = smem;                                               // [32][pitch]  (phase B)  /  stage [64][224] (phase A)
+  float* part = reinterpret_cast<float*>(smem + 32 * pitch);        // [3][4][64][16]
+  const int nq = (H + 3) >> 2;
+  const int qd = j * CW + w;
+  const int ul = lc >> 2, q = lc & 3;
+  const int lu = w * 4 + ul;                                        // local unit 0..55
+  const int u = j * UW + lu;
+  const bool uvalid = qd < nq && u < H;
+  const int uc = uvalid ? u : H - 1;
+  const int nslab = G4 * 2 / 64;
+  // phase-B role: unit tile tau, K-third kth
+  const int tau = w / 3, kth = w - tau * 3;
+  const bool gemm_wave = w < 12;
+  const int ks0 = kth * KPW;
+  uint4 breg[KPW];
+  {
+    const char* src = reinterpret_cast<const char*>(p.whhTq) +
+                      ((((long)dir * p.C + j) * 4 + (gemm_wave ? tau : 0)) * nslab) * 1024 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+      breg[i] = (gemm_wave && ks0 + i < nslab) ? *reinterpret_cast<const uint4*>(src + (long)(ks0 + i) * 1024)
+                                               : make_uint4(0, 0, 0, 0);
+  }
+  const int seq0 = cl * p.rows_per_cluster;
+  int seq1 = seq0 + p.rows_per_cluster;
+  if (seq1 > p.n_seq) seq1 = p.n_seq;
+  const int nrows = seq1 - seq0;
+  const bf16_t* dh = reinterpret_cast<const bf16_t*>(p.dh);
+  bf16_t* gates = reinterpret_cast<bf16_t*>(p.gates);
+  const long gcol0 = (long)dir * G4;
+  const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * CROWS * G4 * 2);
+  const unsigned cl_bytes = (unsigned)(((long)dir * p.ncl + cl) * CROWS * G4 * 2);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dgx, 0, (int)(2u * plane_bytes), 0x00020000);
+  unsigned* cnt = p.cnt + dir * p.ncl + cl;
+  const long prev_off = dir ? p.stride : -p.stride;
+  bool dead = false;
+
+  int rowb[4];       // row of (sequence, t = 0); negative = row beyond the cluster (clamped, never stored)
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int lrow = rt * 16 + lr * 4 + q;
+    int seq = seq0 + lrow;
+    if (seq >= p.n_seq) seq = p.n_seq - 1;
+    const int rb = (int)((seq / p.inner) * p.outer + (seq % p.inner));
+    rowb[rt] = lrow < nrows ? rb : -rb - 1;
+  }
+  auto rowbase = [&](int rt) -> long { return rowb[rt] >= 0 ? rowb[rt] : -(rowb[rt] + 1); };
+  float dcs[4] = {0.f, 0.f, 0.f, 0.f}, dhr[4] = {0.f, 0.f, 0.f, 0.f}, ccur[4];
+  uint2 gpre[4];
+  float cpre[4], dhpre[4];
+  auto prefetch = [&](int step) {     // operands of the pointwise phase of `step` (independent of the recurrence)
+    const int t = dir ? step : (p.seq_len - 1 - step);
+    const bool first = dir ? (t == p.seq_len - 1) : (t == 0);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const long row = rowbase(rt) + (long)t * p.stride;
+      gpre[rt] = *reinterpret_cast<const uint2*>(gates + row * p.ldg + gcol0 + uc * 4);
+      const long ci = row * 2 * H + (long)dir * H + uc;
+      cpre[rt] = first ? 0.f : p.c[ci + prev_off * 2 * H];
+      dhpre[rt] = bf16_to_f32(dh[row * p.ldd + (long)dir * H + uc]);
+    }
+  };
+  {
+    const int t0 = dir ? 0 : (p.seq_len - 1);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) ccur[rt] = p.c[(rowbase(rt) + (long)t0 * p.stride) * 2 * H + (long)dir * H + uc];
+  }
+  prefetch(0);
+
+  for (int step = 0; step < p.seq_len; ++step) {
+    const int t = dir ? step : (p.seq_len - 1 - step);
+    const long toff = (long)t * p.stride;
+    const unsigned plane = (unsigned)(step & 1);
+    const bool last = step + 1 == p.seq_len;
+    // ---- phase A ----
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const float iv = __uint_as_float(gpre[rt].x << 16), fv = __uint_as_float(gpre[rt].x & 0xffff0000u);
+      const float gv = __uint_as_float(gpre[rt].y << 16), ov = __uint_as_float(gpre[rt].y & 0xffff0000u);
+      const float dht = dhpre[rt] + dhr[rt];
+      const float tc = tanhf_(ccur[rt]);
+      const float dct = dcs[rt] + dht * ov * (1.f - tc * tc);
+      const float dgi = dct * gv * iv * (1.f - iv), dgf = dct * cpre[rt] * fv * (1.f - fv);
+      const float dgg = dct * iv * (1.f - gv * gv), dgo = dht * tc * ov * (1.f - ov);
+      dcs[rt] = dct * fv;
+      ccur[rt] = cpre[rt];               // c_{t-1} is the next processed step's c_t
+      uint2 pk = make_uint2(0u, 0u);
+      if (uvalid) {
+        pk.x = (unsigned)f32_to_bf16(dgi) | ((unsigned)f32_to_bf16(dgf) << 16);
+        pk.y = (unsigned)f32_to_bf16(dgg) | ((unsigned)f32_to_bf16(dgo) << 16);
+      }
+      *reinterpret_cast<uint2*>(atile + (rt * 16 + lr * 4 + q) * (UW * 8) + lu * 8) = pk;   // stage [64][56 units x 4]
+      // gate gradients for the weight-gradient GEMMs
+      if (uvalid && rowb[rt] >= 0) *reinterpret_cast<uint2*>(gates + (rowbase(rt) + toff) * p.ldg + gcol0 + u * 4) = pk;
+    }
+    if (!last) prefetch(step + 1);
+    __syncthreads();
+    if (!last) {
+      constexpr int SC = UW * 8 / 16;   // 28 chunks of 16 B per staged row
+      for (int idx = tid; idx < CROWS * SC; idx += CTHR) {
+        const int row = idx / SC, cc = idx - row * SC;
+        const int colb = j * UW * 8 + cc * 16;
+        if (colb >= G4 * 2) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(atile + row * (UW * 8) + cc * 16);
+        store_sc1(rs, plane * plane_bytes + cl_bytes + (unsigned)(row * G4 * 2 + colb), v);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (last) break;
+    if (tid == 0) {
+      const unsigned target = (unsigned)(step + 1) * (unsigned)p.C;
+      unsigned spins = 0;
+      while (!dead && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 24)) { dead = true; atomicExch(p.err, 1u); }
+      }
+    }
+    __syncthreads();
+    // ---- phase B: dh_rec = dgates_tile x W_hh (this workgroup's units) ----
+    const int cpr = G4 * 2 / 16;
+#pragma unroll 1
+    for (int hf = 0; hf < 2; ++hf) {
+      f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+      for (int idx = tid; idx < 32 * cpr; idx += CTHR) {
+        const int row = idx / cpr, cc = idx - row * cpr;
+        const uint4 v = load_sc1(rs, plane * plane_bytes + cl_bytes + (unsigned)((hf * 32 + row) * G4 * 2 + cc * 16));
+        *reinterpret_cast<uint4*>(atile + row * pitch + cc * 16) = v;
+      }
+      __syncthreads();
+      if (gemm_wave) {
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const char* ar = atile + (r2 * 16 + lc) * pitch + 16 * lr;
+#pragma unroll
+          for (int i = 0; i < KPW; ++i) {
+            // slabs past the end have zero B fragments: clamp the A address instead of branching
+            const int ks = (ks0 + i < nslab) ? ks0 + i : nslab - 1;
+            const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
+            acc[r2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, breg[i]), acc[r2], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            part[((kth * 4 + tau) * CROWS + (hf * 2 + r2) * 16 + lr * 4 + r) * 16 + lc] = acc[r2][r];
+      }
+      __syncthreads();
+    }
+    {
+      const int tt = lu >> 4, col = lu & 15;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int row = rt * 16 + lr * 4 + q;
+        dhr[rt] = part[((0 * 4 + tt) * CROWS + row) * 16 + col] + part[((1 * 4 + tt) * CROWS + row) * 16 + col] +
+                  part[((2 * 4 + tt) * CROWS + row) * 16 + col];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// W_hh^T fragments for the cluster BPTT: block (dir, wg j, unit tile tau, slab ks): lane (lr, lc): unit j*56 + tau*16 + lc,
+// kk = ks*32 + 8*lr + jj in the gate-interleaved order (u' = kk >> 2, g' = kk & 3)
+__global__ void __launch_bounds__(256) lstm_pack_bwd_quads_kernel(const float* __restrict__ whh, bf16_t* __restrict__ out,
+                                                                  int H, int C) {
+  const int G4 = 4 * H, nslab = G4 / 32;
+  const long total = (long)2 * C * 4 * nslab * 64 * 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int jj = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int ks = (int)(r % nslab); r /= nslab;
+    const int tau = (int)(r % 4); r /= 4;
+    const int j = (int)(r % C);
+    const int d = (int)(r / C);
+    const int lc = lane & 15, lr = lane >> 4;
+    const int lu = tau * 16 + lc, unit = j * UW + lu, kk = ks * 32 + 8 * lr + jj;
+    const int up = kk >> 2, gp = kk & 3;
+    out[idx] = f32_to_bf16((lu < UW && unit < H && kk < G4) ? whh[((long)d * G4 + gp * H + up) * H + unit] : 0.f);
+  }
+}
+
 template <int NSLAB, int MAXCH>
 static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH>),
@@ -303,6 +518,52 @@ extern "C" int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, 
   hipLaunchKernelGGL(lstm_pack_quads_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, whh, (bf16_t*)out, H, Hp);
   URSE_CHECK_LAUNCH("urse_lstm_pack_quads");
   return URSE_OK;
+}
+
+extern "C" int urse_lstm_pack_bwd_quads(const float* whh, void* out, int H, int C, void* stream) {
+  URSE_CHECK_ARG(whh && out && H > 0 && H % 8 == 0 && C > 0, "urse_lstm_pack_bwd_quads: bad argument");
+  hipLaunchKernelGGL(lstm_pack_bwd_quads_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, whh, (bf16_t*)out, H, C);
+  URSE_CHECK_LAUNCH("urse_lstm_pack_bwd_quads");
+  return URSE_OK;
+}
+
+template <int KPW>
+static int launch_cluster_bwd(const ClusterBwdArgs& p, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_cluster_kernel<KPW>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  size_t lds = (size_t)32 * (4 * p.H * 2 + 16) + (size_t)3 * 4 * CROWS * 16 * 4;
+  const size_t stage = (size_t)CROWS * UW * 8;
+  if (lds < stage + 3 * 4 * CROWS * 16 * 4) lds = stage + 3 * 4 * CROWS * 16 * 4;
+  URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_cluster_bwd: H %d exceeds LDS", p.H);
+  dim3 grid(p.C * p.ncl, 2);
+  hipLaunchKernelGGL((lstm_bwd_cluster_kernel<KPW>), grid, dim3(CTHR), lds, st, p);
+  URSE_CHECK_LAUNCH("urse_lstm_cluster_bwd");
+  return URSE_OK;
+}
+
+extern "C" int urse_lstm_cluster_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c,
+                                     const void* whhTq, void* dgx, void* counters, void* err_flag, int H, int Hp,
+                                     int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, void* stream) {
+  URSE_CHECK_ARG(dh && gates && c && whhTq && dgx && counters && err_flag, "urse_lstm_cluster_bwd: null pointer");
+  int64_t plan[6];
+  int rc = urse_lstm_cluster_plan(H, Hp, n_seq, plan);
+  if (rc) return rc;
+  URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldd >= 2L * H && ((uintptr_t)dgx % 16) == 0,
+                 "urse_lstm_cluster_bwd: bad leading dimension / alignment");
+  ClusterBwdArgs p;
+  p.dh = dh; p.ldd = ldd; p.gates = gates; p.ldg = ldg; p.c = c; p.whhTq = whhTq; p.dgx = (bf16_t*)dgx;
+  p.cnt = (unsigned*)counters; p.err = (unsigned*)err_flag; p.H = H;
+  p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
+  p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2];
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(counters, 0, sizeof(unsigned) * plan[5], st);
+  const int nslab = 4 * H * 2 / 64;
+  const int kpw = (nslab + 2) / 3;
+  if (kpw <= 2) return launch_cluster_bwd<2>(p, st);
+  if (kpw <= 17) return launch_cluster_bwd<17>(p, st);
+  set_error("urse_lstm_cluster_bwd: H=%d not supported", H);
+  return URSE_ERR_UNSUPPORTED;
 }
 
 // workspace query: {C, ncl, rows_per_cluster, rows_pad, hx_elems, n_counters}; returns < 0 if the shape is unsupported

@@ -179,11 +179,19 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
         if "whhq" not in out:
             out["whhq"] = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=dtype)
         call("lstm_pack_quads", whh, out["whhq"], H, Hp, stream_ptr())
+        if H % 8 == 0:
+            C = ((H + 3) // 4 + 13) // 14
+            if "whhTq" not in out:
+                out["whhTq"] = torch.empty(2 * C * 4 * (H // 8) * 512, device=dev, dtype=dtype)
+            call("lstm_pack_bwd_quads", whh, out["whhTq"], H, C, stream_ptr())
     return out
 
 
 _cluster_ws = {}
 USE_CLUSTER_LSTM = os.environ.get("URSE_LSTM_CLUSTER", "1") != "0"
+# the cluster BPTT kernel is correct (tests/test_lstm_gpu.py) but, at 16 us + 200 KB of tile traffic per step and with
+# register spills at 14 waves, still slower than the streaming BPTT (95 vs 76 ms/step at C2): opt-in until it wins
+USE_CLUSTER_LSTM_BWD = os.environ.get("URSE_LSTM_CLUSTER_BWD", "0") == "1"
 
 
 def lstm_cluster_plan(H, Hp, n_seq):
@@ -223,6 +231,21 @@ def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, ro
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_bidir_fwd", gx, gx.stride(0), whh, hout, ldh,
                c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), _dt(gx), rows16, stream_ptr())
     return hout, c
+
+
+def lstm_bwd_cluster(dh, gates, c, whhTq, H, Hp, n_seq, seq_len, inner, outer, stride):
+    """persistent cluster BPTT (bf16): gates (saved activations) is overwritten with d(pre-activations)."""
+    plan = lstm_cluster_plan(H, Hp, n_seq)
+    dev = gates.device
+    key = ("bwd", dev, H, Hp, n_seq)
+    if key not in _cluster_ws:
+        _cluster_ws[key] = (torch.zeros(2 * 2 * plan[1] * 64 * 4 * H, device=dev, dtype=torch.bfloat16),
+                            torch.zeros(plan[5], device=dev, dtype=torch.int32),
+                            torch.zeros(1, device=dev, dtype=torch.int32))
+    dgx, cnt, err = _cluster_ws[key]
+    timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_cluster_bwd", dh, dh.stride(0), gates,
+               gates.stride(0), c, whhTq, dgx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, stream_ptr())
+    return gates, err
 
 
 def lstm_bwd(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride, rows16=0):
