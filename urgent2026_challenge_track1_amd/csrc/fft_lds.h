@@ -15,7 +15,14 @@ struct FftPlan {
   int n;
   int nrad;
   int radix[12];
+  // magic multipliers: floor(x / d) == __umulhi(x, m) for x, d < 2^16 (m = floor(2^32 / d) + 1); integer division
+  // has no hardware instruction on CDNA and dominated the index arithmetic of these kernels
+  unsigned m_n, m_f;            // d = n, d = n/2 + 1
+  unsigned m_nb[12], m_ns[12];  // d = n / radix[s], d = product of the previous radices
 };
+
+static inline unsigned fastdiv_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d) + 1u; }
+__device__ __forceinline__ int fastdiv(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }
 
 static inline bool make_fft_plan(int n, FftPlan* p) {
   p->n = n;
@@ -27,7 +34,16 @@ static inline bool make_fft_plan(int n, FftPlan* p) {
   while (m % 5 == 0) { p->radix[p->nrad++] = 5; m /= 5; }
   for (int f = 7; f <= 61 && m > 1; f += 2)
     while (m % f == 0) { if (p->nrad >= 12) return false; p->radix[p->nrad++] = f; m /= f; }
-  return m == 1 && p->nrad <= 12;
+  if (!(m == 1 && p->nrad <= 12) || n >= 65536) return false;
+  p->m_n = fastdiv_magic((unsigned)n);
+  p->m_f = fastdiv_magic((unsigned)(n / 2 + 1));
+  int Ns = 1;
+  for (int s = 0; s < p->nrad; ++s) {
+    p->m_nb[s] = fastdiv_magic((unsigned)(n / p->radix[s]));
+    p->m_ns[s] = fastdiv_magic((unsigned)Ns);
+    Ns *= p->radix[s];
+  }
+  return true;
 }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -49,10 +65,11 @@ __device__ inline float2* fft_lds_forward(float2* a, float2* b, int nf, const Ff
     const int nb = n / R;
     const int total = nf * nb;
     const int tstride = n / (Ns * R);
+    const unsigned mnb = plan.m_nb[s], mns = plan.m_ns[s];
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-      const int f = idx / nb;
+      const int f = fastdiv(idx, mnb);
       const int j = idx - f * nb;
-      const int k = j % Ns;
+      const int k = j - fastdiv(j, mns) * Ns;
       const float2* in = a + f * n + j;
       float2* out = b + f * n + (j - k) * R + k;
       const int tk = k * tstride;

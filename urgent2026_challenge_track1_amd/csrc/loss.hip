@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) mrl1_spec_kernel(const float* __restrict_
   const float* eb = e + (long)b * L;
   for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
   for (int idx = threadIdx.x; idx < NF * n; idx += blockDim.x) {
-    const int f = idx / n, i = idx - f * n;
+    const int f = fastdiv(idx, plan.m_n), i = idx - f * n;
     const int fr = t0 + f;
     float2 v = make_float2(0.f, 0.f);
     if (fr < T) {
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) mrl1_spec_kernel(const float* __restrict_
   float2* Y = (Z == bufA) ? bufB : bufA;
   double s = 0;
   for (int idx = threadIdx.x; idx < NF * (half + 1); idx += blockDim.x) {
-    const int f = idx / (half + 1), k = idx - f * (half + 1);
+    const int f = fastdiv(idx, plan.m_f), k = idx - f * (half + 1);
     const float2 zk = Z[f * n + k];
     const float2 zc = Z[f * n + (k == 0 ? 0 : n - k)];
     const float2 U = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
@@ -176,14 +176,14 @@ __global__ void __launch_bounds__(256) mrl1_spec_kernel(const float* __restrict_
     // pair frames (2p, 2p+1): in = conj(Ya + i Yb)
     const int NP = NF / 2;
     for (int idx = threadIdx.x; idx < NP * n; idx += blockDim.x) {
-      const int pidx = idx / n, k = idx - pidx * n;
+      const int pidx = fastdiv(idx, plan.m_n), k = idx - pidx * n;
       const float2 ya = Y[(2 * pidx) * n + k], yb = Y[(2 * pidx + 1) * n + k];
       Z[idx] = make_float2(ya.x - yb.y, -(ya.y + yb.x));
     }
     __syncthreads();
     const float2* R = fft_lds_forward(Z, Y, NP, plan, tw);
     for (int idx = threadIdx.x; idx < NP * n; idx += blockDim.x) {
-      const int pidx = idx / n, i = idx - pidx * n;
+      const int pidx = fastdiv(idx, plan.m_n), i = idx - pidx * n;
       const float2 r = R[idx];
       const int fa = t0 + 2 * pidx;
       if (fa < T) atomicAdd(G + (long)b * L + reflect_idx(fa * hop + i - half, L), r.x);

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <vector>
 #include <math.h>
+#include <stdlib.h>
 
 #include "fft_lds.h"
 
@@ -56,11 +57,18 @@ static int get_tables(int n, StftTables* out) {
 
 // number of complex FFTs (frame pairs) a workgroup carries so that two workgroups fit a CU's LDS
 static int pick_nf(int n, int min_nf) {
-  int nf = 4;
+  // measured (scripts/time_stft.py, B32 x 4 s @ 48 kHz): the kernels are VALU-issue bound, one frame pair per 256-thread
+  // workgroup is fastest (NF 1/2/4/8 -> 53/64/74/129 us for the 960-point STFT)
+  int nf = 1;
+  if (const char* e = getenv("URSE_STFT_NF")) { nf = atoi(e); return nf < min_nf ? min_nf : nf; }   // tuning knob
   while (nf > min_nf && (size_t)(2 * nf * n) * sizeof(float2) + n * 12 > 76 * 1024) --nf;
   return nf < min_nf ? min_nf : nf;
 }
 static size_t lds_bytes(int n, int nf) { return (size_t)n * 8 + (size_t)n * 4 + (size_t)2 * nf * n * 8; }
+static int stft_threads() {
+  if (const char* e = getenv("URSE_STFT_THREADS")) return atoi(e);
+  return 256;
+}
 
 // dynamic LDS above 64 KiB must be opted into once per kernel
 template <typename K>
@@ -108,7 +116,7 @@ __global__ void __launch_bounds__(256) stft_kernel(const float* __restrict__ x, 
   if (MODE == 1) __syncthreads();  // envelope needs the window
   const float* xb = x + (size_t)b * L;
   for (int idx = threadIdx.x; idx < NF * n; idx += blockDim.x) {
-    const int f = idx / n, i = idx - f * n;
+    const int f = fastdiv(idx, plan.m_n), i = idx - f * n;
     float v[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -137,7 +145,7 @@ __global__ void __launch_bounds__(256) stft_kernel(const float* __restrict__ x, 
   const bool even = (n & 1) == 0;
   const float inv_n = 1.0f / (float)n;
   for (int idx = threadIdx.x; idx < NF * F; idx += blockDim.x) {
-    const int f = idx / F, k = idx - f * F;
+    const int f = fastdiv(idx, plan.m_f), k = idx - f * F;
     const float2 zk = Z[f * n + k];
     const float2 zc = Z[f * n + (k == 0 ? 0 : n - k)];
     // Xa = (zk + conj(zc))/2 ; Xb = -i (zk - conj(zc))/2
@@ -179,7 +187,7 @@ __global__ void __launch_bounds__(256) istft_kernel(const float2* __restrict__ s
   }
   // load conj(Xa_full + i*Xb_full)
   for (int idx = threadIdx.x; idx < NF * n; idx += blockDim.x) {
-    const int f = idx / n, k = idx - f * n;
+    const int f = fastdiv(idx, plan.m_n), k = idx - f * n;
     const int kk = (k <= half) ? k : n - k;
     const bool edge = (kk == 0) || (even && kk == half);
     float2 X[2];
@@ -201,7 +209,7 @@ __global__ void __launch_bounds__(256) istft_kernel(const float2* __restrict__ s
   float* frames = reinterpret_cast<float*>(Y == bufA ? bufB : bufA);  // [2*NF][n]
   const float inv_n = 1.0f / (float)n;
   for (int idx = threadIdx.x; idx < NF * n; idx += blockDim.x) {
-    const int f = idx / n, i = idx - f * n;
+    const int f = fastdiv(idx, plan.m_n), i = idx - f * n;
     const float2 y = Y[idx];
     const float w = win[i] * inv_n;
     frames[(2 * f) * n + i] = y.x * w;
@@ -251,7 +259,7 @@ extern "C" int urse_stft_fwd(const float* wav, const int32_t* lens, float* spec,
   const int T = L / hop + 1;
   const int NF = pick_nf(n_fft, 1);
   dim3 grid(ceil_div(T, 2 * NF), B);
-  hipLaunchKernelGGL(stft_kernel<0>, grid, dim3(256), lds_bytes(n_fft, NF), (hipStream_t)stream, wav, lens,
+  hipLaunchKernelGGL(stft_kernel<0>, grid, dim3(stft_threads()), lds_bytes(n_fft, NF), (hipStream_t)stream, wav, lens,
                      reinterpret_cast<float2*>(spec), L, T, tb.plan, hop, tb.win[window], tb.tw, NF);
   URSE_CHECK_LAUNCH("urse_stft_fwd");
   return URSE_OK;
@@ -267,7 +275,7 @@ extern "C" int urse_istft_bwd(const float* grad_wav, float* grad_spec, int B, in
   if (rc) return rc;
   const int NF = pick_nf(n_fft, 1);
   dim3 grid(ceil_div(T, 2 * NF), B);
-  hipLaunchKernelGGL(stft_kernel<1>, grid, dim3(256), lds_bytes(n_fft, NF), (hipStream_t)stream, grad_wav,
+  hipLaunchKernelGGL(stft_kernel<1>, grid, dim3(stft_threads()), lds_bytes(n_fft, NF), (hipStream_t)stream, grad_wav,
                      (const int32_t*)nullptr, reinterpret_cast<float2*>(grad_spec), L_out, T, tb.plan, hop,
                      tb.win[window], tb.tw, NF);
   URSE_CHECK_LAUNCH("urse_istft_bwd");
@@ -289,7 +297,7 @@ extern "C" int urse_istft_fwd(const float* spec, float* wav, int B, int T, int n
   // padded axis covers positions [0, n + hop*(T-1)); only [half, half + L_out) is written
   const long need = (long)n_fft / 2 + L_out;
   dim3 grid(ceil_div(need, (long)C * hop), B);
-  hipLaunchKernelGGL(istft_kernel, grid, dim3(256), lds_bytes(n_fft, NF), (hipStream_t)stream,
+  hipLaunchKernelGGL(istft_kernel, grid, dim3(stft_threads()), lds_bytes(n_fft, NF), (hipStream_t)stream,
                      reinterpret_cast<const float2*>(spec), wav, T, L_out, tb.plan, hop, tb.win[window], tb.tw, NF, C,
                      ov);
   URSE_CHECK_LAUNCH("urse_istft_fwd");
