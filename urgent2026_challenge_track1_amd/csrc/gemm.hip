@@ -9,6 +9,8 @@
 // launches (one descriptor per band) serve the band-split / mask-decoder 1x1 convolutions.
 // They replace the cuBLAS calls under nn.Linear / nn.Conv1d(k=1) / nn.LSTM input projections of
 // espnet2's BSRNN (reference twin: baseline_code/models/bsrnn_flowse.py:66-81,296-307).
+#include <stdlib.h>
+
 #include "urse_common.h"
 
 namespace urse {
@@ -425,7 +427,11 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   p.perm_h = perm_h;
   const long tiles = ((Mo + BM - 1) / BM) * ((No + BN - 1) / BN);
   const int bkr = dtype == URSE_BF16 ? 32 : 16;
-  long slices = (1024 + tiles - 1) / tiles;
+  // one full round of resident workgroups (3 per CU at this kernel's register budget): a partial second round costs
+  // up to 25 % on the big weight-gradient shapes
+  long target = 768;
+  if (const char* e = getenv("URSE_TN_TARGET")) target = atol(e);
+  long slices = target / tiles;
   const long max_slices = (R + 4 * bkr - 1) / (4 * bkr);
   if (slices > max_slices) slices = max_slices;
   if (slices < 1) slices = 1;

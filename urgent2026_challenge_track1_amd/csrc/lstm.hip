@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
     for (int b = 0; b < RT; ++b)
 #pragma unroll
       for (int c = 0; c < 4; ++c) cst[a][b][c] = 0.f;
-  long rowbase[RT][4];
+  int rowbase[RT][4];
   bool rvalid[RT][4];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
       int seq = s0 + rt * 16 + lr * 4 + r;
       rvalid[rt][r] = seq < p.m.n_seq;
       if (seq >= p.m.n_seq) seq = p.m.n_seq - 1;
-      rowbase[rt][r] = (seq / p.m.inner) * p.m.outer + (seq % p.m.inner);
+      rowbase[rt][r] = (int)((seq / p.m.inner) * p.m.outer + (seq % p.m.inner));
     }
   const int nslab = Hp * ES / 64;
   // fragment-ordered weights: block(ut, ks, g) = 1 KiB, lane-linear
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            gxv[rt][r] = *reinterpret_cast<const V4*>(gx + (rowbase[rt][r] + toff) * p.ldg + gcol0 + uc * 4);
+            gxv[rt][r] = *reinterpret_cast<const V4*>(gx + ((long)rowbase[rt][r] + toff) * p.ldg + gcol0 + uc * 4);
 #endif
         f32x4_t acc[4][RT];
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const long row = rowbase[rt][r] + toff;
+            const long row = (long)rowbase[rt][r] + toff;
             float pre[4] = {0.f, 0.f, 0.f, 0.f};
 #ifndef ABL_NO_PW
             Vec4<T>::unpack(gxv[rt][r], pre);
