@@ -43,6 +43,7 @@ struct LstmBwdArgs {
   const float* c;            // [M, 2H]
   const void* whhT;          // fragment-ordered [2][nut][nslabT][64][16 B]
   int H;
+  int dbuf;                  // two LDS tiles (set by the launcher when they fit)
   SeqMap m;
 };
 
@@ -152,19 +153,30 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
           for (int rt = 0; rt < RT; ++rt) acc[g][rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const char* wr = whh + ((long)ut * nslab * 4) * 1024;
         const char* ar = hc + lc * pitch + 16 * lr;
-#pragma unroll 4
-        for (int ks = 0; ks < nslab; ++ks) {
-          uint4 b[4], a[RT];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const uint4*>(ar + rt * 16 * pitch + ks * 64);
-#pragma unroll
-#ifdef ABL_NO_W
-          for (int g = 0; g < 4; ++g) b[g] = a[0];
-#else
-          for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const uint4*>(wr + (ks * 4 + g) * 1024);
+        // the weight stream (L2 -> registers) is the bottleneck: keep KB slabs x 4 gates of fragment loads in flight
+#ifndef URSE_FWD_KB
+#define URSE_FWD_KB 3
 #endif
+        constexpr int KB = (RT == 1 && sizeof(T) == 2) ? URSE_FWD_KB : 3;
+        for (int k0 = 0; k0 < nslab; k0 += KB) {
+          uint4 b[KB][4];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) mma_slab<T, RT>(a, b[g], acc[g]);
+          for (int i = 0; i < KB; ++i) {
+            const int ks = (k0 + i < nslab) ? k0 + i : nslab - 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b[i][g] = *reinterpret_cast<const uint4*>(wr + (ks * 4 + g) * 1024);
+          }
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            if (k0 + i < nslab) {
+              uint4 a[RT];
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt)
+                a[rt] = *reinterpret_cast<const uint4*>(ar + rt * 16 * pitch + (k0 + i) * 64);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) mma_slab<T, RT>(a, b[i][g], acc[g]);
+            }
+          }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -210,24 +222,20 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   const int dir = blockIdx.y, s0 = blockIdx.x * R;
   const int H = p.H, nut = (H + 15) >> 4, G4 = 4 * H;
   const int pitch = G4 * ES + 16;
-  float dcs[MAXUT][RT][4], dhr[MAXUT][RT][4];
-#pragma unroll
-  for (int a = 0; a < MAXUT; ++a)
-#pragma unroll
-    for (int b = 0; b < RT; ++b)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { dcs[a][b][c] = 0.f; dhr[a][b][c] = 0.f; }
-  long rowbase[RT][4];
-  bool rvalid[RT][4];
+  const int nbuf = p.dbuf ? 2 : 1;         // double-buffered dgates tile: one barrier per step
+  float dcs[MAXUT][RT][4], dhr[MAXUT][RT][4], ccur[MAXUT][RT][4];
+  int rowbase[RT][4];                      // negative: sequence beyond n_seq (clamped, never stored)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int seq = s0 + rt * 16 + lr * 4 + r;
-      rvalid[rt][r] = seq < p.m.n_seq;
-      if (seq >= p.m.n_seq) seq = p.m.n_seq - 1;
-      rowbase[rt][r] = (seq / p.m.inner) * p.m.outer + (seq % p.m.inner);
+      const bool ok = seq < p.m.n_seq;
+      if (!ok) seq = p.m.n_seq - 1;
+      const int rb = (int)((seq / p.m.inner) * p.m.outer + (seq % p.m.inner));
+      rowbase[rt][r] = ok ? rb : -rb - 1;
     }
+  auto rowb = [&](int rt, int r) -> long { return rowbase[rt][r] >= 0 ? rowbase[rt][r] : -(rowbase[rt][r] + 1); };
   const int nslab = G4 * ES / 64;
   const char* whhT = reinterpret_cast<const char*>(p.whhT) + ((long)dir * nut * nslab) * 1024 + lane * 16;
   const T* dh = reinterpret_cast<const T*>(p.dh);
@@ -235,80 +243,110 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   const long gcol0 = (long)dir * G4;
   const long prev_off = dir ? p.m.stride : -p.m.stride;
 
+  {
+    const long toff0 = (long)(dir ? 0 : p.m.seq_len - 1) * p.m.stride;
+#pragma unroll
+    for (int ui = 0; ui < MAXUT; ++ui) {
+      const int u = (w + NW * ui) * 16 + lc;
+      const int uc = u < H ? u : H - 1;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dcs[ui][rt][r] = 0.f;
+          dhr[ui][rt][r] = 0.f;
+          ccur[ui][rt][r] = p.c[(rowb(rt, r) + toff0) * 2 * H + (long)dir * H + uc];
+        }
+    }
+  }
   for (int step = 0; step < p.m.seq_len; ++step) {
     const int t = dir ? step : (p.m.seq_len - 1 - step);
-    const bool first = dir ? (t == p.m.seq_len - 1) : (t == 0);  // first step of the forward recurrence
+    const bool first = dir ? (t == p.m.seq_len - 1) : (t == 0);   // first step of the forward recurrence: c_{-1} = 0
     const long toff = (long)t * p.m.stride;
+    char* tile = smem + (step % nbuf) * R * pitch;
 #pragma unroll
     for (int ui = 0; ui < MAXUT; ++ui) {
       const int ut = w + NW * ui;
       if (ut < nut) {
         const int u = ut * 16 + lc;
         if (u < H) {
-          V4 gv4[RT][4];
-          float ctv[RT][4], cpv[RT][4], dhv[RT][4];
+          V4 gpre[RT][4];
+          float cpre[RT][4];
+          T dhpre[RT][4];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const long row = rowbase[rt][r] + toff;
-              gv4[rt][r] = *reinterpret_cast<const V4*>(gates + row * p.ldg + gcol0 + u * 4);
-              const long ci = row * 2 * H + (long)dir * H + u;
-              ctv[rt][r] = p.c[ci];
-              cpv[rt][r] = first ? 0.f : p.c[ci + prev_off * 2 * H];
-              dhv[rt][r] = to_f32<T>(dh[row * p.ldd + (long)dir * H + u]);
+              const long row = rowb(rt, r) + toff;
+              gpre[rt][r] = *reinterpret_cast<const V4*>(gates + row * p.ldg + gcol0 + u * 4);
+              cpre[rt][r] = first ? 0.f : p.c[row * 2 * H + (long)dir * H + u + prev_off * 2 * H];
+              dhpre[rt][r] = dh[row * p.ldd + (long)dir * H + u];
             }
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const long row = rowbase[rt][r] + toff;
               float a[4];
-              Vec4<T>::unpack(gv4[rt][r], a);
+              Vec4<T>::unpack(gpre[rt][r], a);
               const float iv = a[0], fv = a[1], gv = a[2], ov = a[3];
-              const float dht = dhv[rt][r] + dhr[ui][rt][r];
-              const float tc = tanhf_(ctv[rt][r]);
+              const float dht = to_f32<T>(dhpre[rt][r]) + dhr[ui][rt][r];
+              const float tc = tanhf_(ccur[ui][rt][r]);
               const float dct = dcs[ui][rt][r] + dht * ov * (1.f - tc * tc);
               float dg[4];
               dg[0] = dct * gv * iv * (1.f - iv);
-              dg[1] = dct * cpv[rt][r] * fv * (1.f - fv);
+              dg[1] = dct * cpre[rt][r] * fv * (1.f - fv);
               dg[2] = dct * iv * (1.f - gv * gv);
               dg[3] = dht * tc * ov * (1.f - ov);
               dcs[ui][rt][r] = dct * fv;
+              ccur[ui][rt][r] = cpre[rt][r];          // c_{t-1} is the next processed step's c_t
               const V4 pk = Vec4<T>::pack(dg);
-              *reinterpret_cast<V4*>(smem + (rt * 16 + lr * 4 + r) * pitch + (u * 4) * ES) = pk;
-              if (rvalid[rt][r]) *reinterpret_cast<V4*>(gates + row * p.ldg + gcol0 + u * 4) = pk;
+              *reinterpret_cast<V4*>(tile + (rt * 16 + lr * 4 + r) * pitch + (u * 4) * ES) = pk;
+              if (rowbase[rt][r] >= 0) *reinterpret_cast<V4*>(gates + (rowb(rt, r) + toff) * p.ldg + gcol0 + u * 4) = pk;
             }
         }
       }
     }
+    if (step + 1 == p.m.seq_len) break;
     __syncthreads();
-    if (step + 1 < p.m.seq_len) {
 #pragma unroll
-      for (int ui = 0; ui < MAXUT; ++ui) {
-        const int ut = w + NW * ui;
-        if (ut < nut) {
-          f32x4_t acc[RT];
+    for (int ui = 0; ui < MAXUT; ++ui) {
+      const int ut = w + NW * ui;
+      if (ut < nut) {
+        f32x4_t acc[RT];
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          const char* wr = whhT + ((long)ut * nslab) * 1024;
-          const char* ar = smem + lc * pitch + 16 * lr;
-#pragma unroll 8
-          for (int ks = 0; ks < nslab; ++ks) {
-            uint4 a[RT];
-            const uint4 b = *reinterpret_cast<const uint4*>(wr + ks * 1024);
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const char* wr = whhT + ((long)ut * nslab) * 1024;
+        const char* ar = tile + lc * pitch + 16 * lr;
+        // the weight stream (L2 -> registers) is the bottleneck: keep KB fragment loads in flight per wave
+#ifndef URSE_BWD_KB
+#define URSE_BWD_KB 13
+#endif
+        constexpr int KB = (sizeof(T) == 2) ? URSE_BWD_KB : 8;
+        for (int k0 = 0; k0 < nslab; k0 += KB) {
+          uint4 b[KB];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const uint4*>(ar + rt * 16 * pitch + ks * 64);
-            mma_slab<T, RT>(a, b, acc);
+          for (int i = 0; i < KB; ++i) {
+            const int ks = (k0 + i < nslab) ? k0 + i : nslab - 1;
+            b[i] = *reinterpret_cast<const uint4*>(wr + ks * 1024);
           }
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
+          for (int i = 0; i < KB; ++i) {
+            if (k0 + i < nslab) {
+              uint4 a[RT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dhr[ui][rt][r] = acc[rt][r];
+              for (int rt = 0; rt < RT; ++rt)
+                a[rt] = *reinterpret_cast<const uint4*>(ar + rt * 16 * pitch + (k0 + i) * 64);
+              mma_slab<T, RT>(a, b[i], acc);
+            }
+          }
         }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dhr[ui][rt][r] = acc[rt][r];
       }
     }
-    __syncthreads();
+    if (nbuf == 1) __syncthreads();
   }
 }
 
@@ -405,15 +443,18 @@ static int launch_fwd(const LstmFwdArgs& p, hipStream_t st) {
 template <typename T, int RT, int NW>
 static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
   constexpr int R = 16 * RT;
-  const size_t lds = (size_t)R * (4 * p.H * sizeof(T) + 16);
+  size_t lds = (size_t)R * (4 * p.H * sizeof(T) + 16);
   URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_bwd: H %d with %d rows exceeds LDS", p.H, R);
+  LstmBwdArgs pa = p;
+  pa.dbuf = (2 * lds <= 150 * 1024) ? 1 : 0;
+  if (pa.dbuf) lds *= 2;
   dim3 grid(ceil_div(p.m.n_seq, R), 2);
   const int upw = ((p.H + 15) / 16 + NW - 1) / NW;
 #define URSE_LB(MU)                                                                              \
   {                                                                                              \
     static bool once = (allow_big_lds(lstm_bwd_kernel<T, RT, MU, NW>), true);                    \
     (void)once;                                                                                  \
-    hipLaunchKernelGGL((lstm_bwd_kernel<T, RT, MU, NW>), grid, dim3(NW * 64), lds, st, p);       \
+    hipLaunchKernelGGL((lstm_bwd_kernel<T, RT, MU, NW>), grid, dim3(NW * 64), lds, st, pa);      \
   }
   if (upw <= 2) URSE_LB(2) else if (upw <= 4) URSE_LB(4) else URSE_LB(6)
 #undef URSE_LB
