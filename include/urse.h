@@ -139,6 +139,14 @@ int urse_lstm_pack_bwd_quads(const float* whh, void* out, int H, int C, void* st
 int urse_lstm_cluster_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhTq,
                           void* dgx, void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
                           int64_t outer, int64_t stride, void* stream);
+/* "Wide" streaming variant of urse_lstm_bidir_fwd (bf16): 64 sequences per workgroup so every streamed weight byte
+ * feeds four MFMA row tiles (the band path's 12,832 short sequences).  whhb = block-ordered fragments from
+ * urse_lstm_pack_blocks (2*ceil(H/16)*(Hp/32)*4*512 bf16).  `c` [M, 2H] f32 is REQUIRED (it carries c_{t-1} between
+ * steps, also when save == 0).  urse_lstm_wide_supported(H, Hp) != 0 tells whether the shape has a kernel. */
+int urse_lstm_wide_supported(int H, int Hp);
+int urse_lstm_pack_blocks(const float* whh, void* out, int H, int Hp, void* stream);
+int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_t ldh, float* c, int H, int Hp,
+                       int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save, void* stream);
 /* Backward through time.  dh [M, ldd>=2H] = gradient w.r.t. hout; gates: in = saved activations,
  * out = gradient w.r.t. the gate pre-activations (same interleaved layout); whhT = fragment-ordered
  * transposed recurrent weights from urse_lstm_pack. */

@@ -4,12 +4,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
-variants = {"f4b17": [], "f3b13": ["-DURSE_FWD_KB=3", "-DURSE_BWD_KB=13"], "f4b25": ["-DURSE_FWD_KB=4", "-DURSE_BWD_KB=25"], "f2b21": ["-DURSE_FWD_KB=2", "-DURSE_BWD_KB=21"]}
+variants = {"base": [], "nost": ["-DABL_NO_ST"], "nold": ["-DABL_NO_LD"]}
 libs = {}
 for name, fl in variants.items():
     so = "/tmp/abl_%s.so" % name
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", *fl,
-                           os.path.join(CS, "lstm.hip"), os.path.join(CS, "api.hip"), "-o", so])
+                           os.path.join(CS, "lstm.hip"), os.path.join(CS, "lstm_wide.hip"), os.path.join(CS, "api.hip"), "-o", so])
     libs[name] = ctypes.CDLL(so)
 B, T, K, N = 32, 401, 34, 196
 H, Hp = 2 * N, 416
@@ -33,9 +33,15 @@ def bwd(lib, path, rt):
     else: a = (B * T, K, 1, K, 1)
     return lib.urse_lstm_bidir_bwd(P(dh.data_ptr()), ctypes.c_int64(800), P(gx.data_ptr()), ctypes.c_int64(8 * H), P(c.data_ptr()),
         P(whhT.data_ptr()), H, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 1, rt, P(st))
-for fn, fname in ((fwd, "fwd"), (bwd, "bwd")):
+whhb = (torch.randn(2 * 25 * 13 * 4 * 512, device=dev) * 0.05).to(torch.bfloat16)
+def fwd_wide(lib, path, rt):
+    if path == "time": a = (B * K, T, K, T * K, K)
+    else: a = (B * T, K, 1, K, 1)
+    return lib.urse_lstm_wide_fwd(P(gx.data_ptr()), ctypes.c_int64(8 * H), P(whhb.data_ptr()), P(hout.data_ptr()), ctypes.c_int64(800),
+        P(c.data_ptr()), H, Hp, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 1, P(st))
+for fn, fname in ((fwd_wide, "fwd_wide"),):
     for path in ("time", "band"):
-        for rt in (1,):
+        for rt in ((1,) if fname != 'bwd' else (1, 18)):
             res = []
             for name, lib in libs.items():
                 assert fn(lib, path, rt) == 0

@@ -26,3 +26,16 @@ t("nt dgrad fc (N784 K224)", lambda: ops.gemm_nt(doT, wfcT, out=dh, N=2 * H), 2.
 t("tn wih (3136x196)", lambda: ops.gemm_tn(dg, xn, gwih, colsum=cs, Mo=8 * H, No=N, perm_h=H), 2.0 * M * 8 * H * 196)
 t("tn whh (1568x392 shifted)", lambda: ops.gemm_tn(dg[:, :4 * H], hout[:, :H], gwhh, Mo=4 * H, No=H, shift=-34, inner=34, period=401, invalid_step=0, perm_h=H), 2.0 * M * 4 * H * H)
 t("tn wfc (196x784)", lambda: ops.gemm_tn(doT, hout, gwfc, colsum=cs[:N], Mo=N, No=2 * H), 2.0 * M * N * 2 * H)
+# library yardstick (hipBLASLt / rocBLAS through torch) for the same contractions; not used by the product path
+gxo = torch.empty(M, 8 * H, device=dev, dtype=bf)
+t("torch ih fwd", lambda: torch.mm(xn, wih.t(), out=gxo), 2.0 * M * 8 * H * 196)
+o2 = torch.empty(M, N, device=dev, dtype=bf)
+t("torch fc fwd", lambda: torch.mm(hout, wfc.t(), out=o2), 2.0 * M * N * 784)
+t("torch dgrad ih", lambda: torch.mm(dg, wihT.t(), out=o2), 2.0 * M * N * 8 * H)
+o3 = torch.empty(M, 2 * H, device=dev, dtype=bf)
+t("torch dgrad fc", lambda: torch.mm(doT, wfcT.t(), out=o3), 2.0 * M * 2 * H * 196)
+o4 = torch.empty(8 * H, 224, device=dev, dtype=bf)
+t("torch tn wih", lambda: torch.mm(dg.t(), xn, out=o4), 2.0 * M * 8 * H * 196)
+o5 = torch.empty(4 * H, H, device=dev, dtype=bf)
+hh = hout[:, :H].contiguous()
+t("torch tn whh", lambda: torch.mm(dg[:, :4 * H].t(), hh, out=o5), 2.0 * M * 4 * H * H)

@@ -133,3 +133,61 @@ def test_cluster_bptt_matches_streaming_kernel(lib, path, B, T, K, N):
     d = (g1.float() - g2.float()).abs()
     scale = g1.float().abs().max().item()
     assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, (d.max().item(), d.mean().item(), scale)
+
+
+@pytest.mark.parametrize("path", ["time", "band"])
+@pytest.mark.parametrize("B,T,K,N", [(2, 9, 20, 16), (1, 33, 5, 24), (3, 7, 34, 196), (5, 40, 34, 196)])
+def test_wide_kernel_matches_streaming_kernel(lib, path, B, T, K, N):
+    """wide LSTM forward (64 sequences per workgroup, block-ordered weights) == streaming kernel up to the f32
+    accumulation order (the pre-activation enters the accumulator first instead of last)."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(3)
+    H, dtype, dev = 2 * N, torch.bfloat16, "cuda"
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    M = B * T * K
+    if path == "time":
+        sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+    else:
+        sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    assert "whhb" in pk
+    xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dtype)
+    gx1 = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    gx2 = gx1.clone()
+    h1, c1 = ops.lstm_fwd(gx1, pk["whh"], H, pk["Hp"], **sm)
+    h2, c2 = ops.lstm_fwd_wide(gx2, pk["whhb"], H, pk["Hp"], **sm)
+    assert torch.all(h2[:, 2 * H:] == 0)
+    assert (h1.float() - h2.float()).abs().max().item() <= 1e-2
+    assert (c1 - c2).abs().max().item() <= 2e-2
+    assert (gx1.float() - gx2.float()).abs().max().item() <= 2e-2
+    assert (h1.float() - h2.float()).abs().mean().item() <= 1e-4
+
+
+@pytest.mark.parametrize("path", ["time", "band"])
+def test_bptt_32_row_variant_matches_16_row_variant(lib, path):
+    """rows16 = 18 (32 sequences / 8 waves per workgroup, picked automatically for the C2 band path) vs rows16 = 1."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(4)
+    B, T, K, N = 3, 7, 34, 196
+    H, dtype, dev = 2 * N, torch.bfloat16, "cuda"
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    M = B * T * K
+    if path == "time":
+        sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+    else:
+        sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dtype)
+    gx = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    hout, c = ops.lstm_fwd(gx, pk["whh"], H, pk["Hp"], **sm)
+    dh = ops.pack2d(torch.randn(M, 2 * H, device=dev), M, hout.shape[1], dtype)
+    g1, g2 = gx.clone(), gx.clone()
+    ops.lstm_bwd(dh, g1, c, pk["whhT"], H, rows16=1, **sm)
+    ops.lstm_bwd(dh, g2, c, pk["whhT"], H, rows16=18, **sm)
+    d = (g1.float() - g2.float()).abs()
+    scale = g1.float().abs().max().item()
+    assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, (d.max().item(), d.mean().item(), scale)

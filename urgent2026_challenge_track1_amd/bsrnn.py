@@ -321,6 +321,7 @@ class BSRNNCore(nn.Module):
                 pk[p + "wih"], pk[p + "wihT"], pk[p + "bias"] = lp["wih"], lp["wihT"], lp["bias"]
                 pk[p + "whh"], pk[p + "whhT"] = lp["whh"], lp["whhT"]
                 pk[p + "whhq"], pk[p + "whhTq"] = lp.get("whhq"), lp.get("whhTq")
+                pk[p + "whhb"] = lp.get("whhb")
         self._packed = pk
         self._packed_version = self.param_version
 
@@ -427,6 +428,8 @@ class BSRNNCore(nn.Module):
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
             hout, c, err = ops.lstm_fwd_cluster(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
             self._cluster_err = err
+        elif ops.USE_WIDE_LSTM and pk.get(p + "whhb") is not None and sm["n_seq"] >= ops.WIDE_MIN_SEQ:
+            hout, c = ops.lstm_fwd_wide(gx, pk[p + "whhb"], H, d["Hp"], save=save, **sm)
         else:
             hout, c = ops.lstm_fwd(gx, pk[p + "whh"], H, d["Hp"], save=save, **sm)
         out = torch.empty_like(skip)

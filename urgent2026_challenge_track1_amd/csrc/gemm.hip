@@ -236,9 +236,15 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs p) {
   constexpr int PITCH = (ES == 2) ? TROW_BF16 : TROW_F32;
   __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 32 * TROW_BF16];
   const int tn = (int)((p.No + BN - 1) / BN);
-  const int tile_m = blockIdx.x / tn, tile_n = blockIdx.x - tile_m * tn;
+  // XCD-aware order: the workgroups that land on one XCD (blockIdx % 8) take consecutive (slice, tile) ids, so all
+  // output tiles of one row slice stream the same A / B rows through the same L2 at the same time (the operands are
+  // re-read once per tile column / row; spread over the eight L2s those re-reads were served at Infinity-Cache rate)
+  const int tiles = tn * (int)((p.Mo + BM - 1) / BM);
+  const int lid = xcd_remap(blockIdx.x, (int)gridDim.x);
+  const int slice = lid / tiles, tile = lid - slice * tiles;
+  const int tile_m = tile / tn, tile_n = tile - tile_m * tn;
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
-  const long r_begin = (long)blockIdx.y * p.rows_per_slice;
+  const long r_begin = (long)slice * p.rows_per_slice;
   long r_end = r_begin + p.rows_per_slice;
   if (r_end > p.R) r_end = p.R;
   if (r_begin >= r_end) return;
@@ -439,7 +445,8 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   rps = (rps + bkr - 1) / bkr * bkr;
   slices = (R + rps - 1) / rps;
   p.rows_per_slice = rps;
-  dim3 grid((unsigned)tiles, (unsigned)slices);
+  URSE_CHECK_ARG(tiles * slices < (1L << 31), "urse_gemm_tn: too many tiles");
+  dim3 grid((unsigned)(tiles * slices));
   if (dtype == URSE_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
   URSE_CHECK_LAUNCH("urse_gemm_tn");

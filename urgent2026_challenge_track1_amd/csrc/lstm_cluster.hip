@@ -152,9 +152,12 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
         // 1. h_{t-1} rows (complete only now, after the cluster barrier) -> LDS
         {
           uint4 hn[HL];
+#ifndef CABL_NO_XLOAD
           if (step > 0) {
             load_h(ch, pprev, hn);
-          } else {
+          } else
+#endif
+          {
 #pragma unroll
             for (int i = 0; i < HL; ++i) hn[i] = make_uint4(0, 0, 0, 0);
           }
@@ -212,7 +215,9 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
           const int ucol = j * UW + cc * 8;
           if (r0 + row >= nrows || ucol >= Hp) continue;
           const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
+#ifndef CABL_NO_XSTORE
           store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)((r0 + row) * Hp * 2 + ucol * 2), v);
+#endif
         }
         if (ch + 1 == nch && step + 1 < p.seq_len) {
           // last chunk: drain the exchange stores and arrive at the cluster barrier before the (slow) plain stores
@@ -220,6 +225,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
           __syncthreads();
           if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#ifndef CABL_NO_PLAIN
         for (int idx = tid; idx < CROWS * SC; idx += CTHR) {
           const int row = idx / SC, cc = idx - row * SC;
           const int ucol = j * UW + cc * 8;
@@ -245,6 +251,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
             }
           }
         }
+#endif
         __syncthreads();   // hstage / htile are rewritten by the next stage
       }
     }
@@ -253,10 +260,12 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
       if (tid == 0) {
         const unsigned target = (unsigned)(step + 1) * (unsigned)p.C;
         unsigned spins = 0;
+#ifndef CABL_NO_WAIT
         while (!dead && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > (1u << 24)) { dead = true; atomicExch(p.err, 1u); }
         }
+#endif
       }
       __syncthreads();
     }

@@ -179,6 +179,10 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
         if "whhq" not in out:
             out["whhq"] = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=dtype)
         call("lstm_pack_quads", whh, out["whhq"], H, Hp, stream_ptr())
+        if _lib.load().urse_lstm_wide_supported(H, Hp):
+            if "whhb" not in out:
+                out["whhb"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32) * 4 * 512, device=dev, dtype=dtype)
+            call("lstm_pack_blocks", whh, out["whhb"], H, Hp, stream_ptr())
         if H % 8 == 0:
             C = ((H + 3) // 4 + 13) // 14
             if "whhTq" not in out:
@@ -231,6 +235,22 @@ def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, ro
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_bidir_fwd", gx, gx.stride(0), whh, hout, ldh,
                c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), _dt(gx), rows16, stream_ptr())
     return hout, c
+
+
+USE_WIDE_LSTM = os.environ.get("URSE_LSTM_WIDE", "1") != "0"
+# the wide kernel wins once there are enough 64-sequence workgroups to fill the chip in both directions
+WIDE_MIN_SEQ = int(os.environ.get("URSE_LSTM_WIDE_MIN_SEQ", str(64 * 128)))
+
+
+def lstm_fwd_wide(gx, whhb, H, Hp, n_seq, seq_len, inner, outer, stride, save=True):
+    """wide streaming LSTM forward (bf16, 64 sequences per workgroup): see csrc/lstm_wide.hip."""
+    M = gx.shape[0]
+    ldh = kpad(2 * H, gx.dtype)
+    hout = torch.zeros(M, ldh, device=gx.device, dtype=gx.dtype)
+    c = torch.empty(M, 2 * H, device=gx.device, dtype=torch.float32)
+    timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_wide_fwd", gx, gx.stride(0), whhb, hout, ldh,
+               c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
+    return hout, (c if save else None)
 
 
 def lstm_bwd_cluster(dh, gates, c, whhTq, H, Hp, n_seq, seq_len, inner, outer, stride):
