@@ -78,3 +78,40 @@ def test_gemm_tn_shifted_operand(lib, inner, period, rev):
     ops.gemm_tn(A.cuda(), Bm.cuda(), out, shift=(inner if rev else -inner), inner=inner, period=period,
                 invalid_step=(period - 1 if rev else 0))
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("R,Mo,No,inner,period,rev,perm", [(20000, 608, 200, 1, 0, False, 0), (17 * 34 * 40, 1568, 392, 34, 40, False, 392),
+                                                           (17 * 34 * 40, 1568, 392, 34, 40, True, 392), (16500, 3136, 196, 1, 0, False, 392)])
+def test_gemm_tn_large_dma_path(lib, R, Mo, No, inner, period, rev, perm):
+    """shapes that take the 256-wide LDS-DMA kernel: ragged tile edges, shifted / masked B rows, gate un-permute,
+    column sums, split-R atomics."""
+    from urgent2026_challenge_track1_amd import ops
+    lda, ldb = (Mo + 7) // 8 * 8 + 8, (No + 31) // 32 * 32
+    A, Bm = _mk((R, lda), torch.bfloat16, 11), _mk((R, ldb), torch.bfloat16, 12)
+    Bs = Bm.clone()
+    kw = {}
+    if period:
+        step = (torch.arange(R) // inner) % period
+        Bs = torch.zeros_like(Bm)
+        if not rev:
+            Bs[inner:] = Bm[:-inner]
+            Bs[step == 0] = 0
+        else:
+            Bs[:-inner] = Bm[inner:]
+            Bs[step == period - 1] = 0
+        kw = dict(shift=(inner if rev else -inner), inner=inner, period=period, invalid_step=(period - 1 if rev else 0))
+    ref = A.double()[:, :Mo].T @ Bs.double()[:, :No]
+    csr = A.double()[:, :Mo].sum(0)
+    if perm:   # rows (dir, unit, gate) -> (dir, gate, unit)
+        m = torch.arange(Mo)
+        d, r = m // (4 * perm), m % (4 * perm)
+        dst = d * 4 * perm + (r % 4) * perm + r // 4
+        ref2, cs2 = torch.zeros_like(ref), torch.zeros_like(csr)
+        ref2[dst], cs2[dst] = ref, csr
+        ref, csr = ref2, cs2
+    out = torch.zeros(Mo, No, device="cuda")
+    cs = torch.zeros(Mo, device="cuda")
+    ops.gemm_tn(A.cuda(), Bm.cuda(), out, colsum=cs, Mo=Mo, No=No, perm_h=perm, **kw)
+    tol = 1e-4 * (R ** 0.5)
+    assert (out.cpu().double() - ref).abs().max().item() <= tol
+    assert (cs.cpu().double() - csr).abs().max().item() <= tol

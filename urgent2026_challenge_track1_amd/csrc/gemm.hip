@@ -366,6 +366,155 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs p) {
 
 using namespace urse;
 
+// ---------------------------------------------------------------------------------------------
+// TN, large shapes (bf16): 256 x (32*NTW) output tile per workgroup of 8 waves, 32-row K steps streamed by LDS-DMA
+// (global_load_lds_dwordx4, no staging registers) through a 4-stage ring with three stages in flight across the
+// barrier (counted vmcnt, raw s_barrier).  Versus the 128x128 kernel above: half the operand bytes per FLOP and
+// ~2x the bytes in flight per CU -- that kernel sat at the rate its re-read operands arrive from the Infinity Cache.
+// LDS-DMA writes lane-linear (1 KiB per wave-instruction = two 512-byte image rows), so the bank swizzle the
+// transposed ds_read_b64_tr_b16 fragment reads need is applied to the per-lane SOURCE column: image segment s (32 B)
+// of row r holds global segment s ^ (r & 7); masked rows / columns read a zero page instead (DMA cannot zero-fill).
+__device__ uint4 g_tn_zero_page[64];
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to lds_dst + lane*16.  Issued as inline
+// asm on purpose: hipcc (ROCm 7.2) drains every outstanding DMA (vmcnt(0)) in front of the next LDS read it can see,
+// which serialises the ring; the kernel orders DMA -> read itself with a counted vmcnt and a raw barrier.
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+template <int NTW>
+__global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
+  constexpr int BMX = 256, BNX = 32 * NTW, NST = 4, STAGE = 32768;
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
+  const int tn = (int)((p.No + BNX - 1) / BNX);
+  const int tiles = tn * (int)((p.Mo + BMX - 1) / BMX);
+  const int lid = xcd_remap(blockIdx.x, (int)gridDim.x);
+  const int slice = lid / tiles, tile = lid - slice * tiles;
+  const int tile_m = tile / tn, tile_n = tile - tile_m * tn;
+  const long m0 = (long)tile_m * BMX, n0 = (long)tile_n * BNX;
+  const long r_begin = (long)slice * p.rows_per_slice;
+  long r_end = r_begin + p.rows_per_slice;
+  if (r_end > p.R) r_end = p.R;
+  if (r_begin >= r_end) return;
+  const int nk = (int)((r_end - r_begin + 31) / 32);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+
+  // ---- DMA source mapping: wave w fills image rows 4w .. 4w+3 of A and of B (two wave-instructions each) ----
+  const char* zsrc = reinterpret_cast<const char*>(g_tn_zero_page) + lane * 16;
+  const int half = lane >> 5, chunk = lane & 31;
+  long acol[2], bcol[2];
+  bool aok[2], bok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rowl = 4 * w + 2 * j + half;
+    const int seg = (chunk >> 1) ^ (rowl & 7);
+    const int cel = seg * 16 + (chunk & 1) * 8;          // element column inside the tile
+    acol[j] = m0 + cel;
+    bcol[j] = n0 + cel;
+    aok[j] = acol[j] < p.lda;
+    bok[j] = cel < BNX && bcol[j] < p.ldb;
+  }
+  auto issue = [&](int kt, int slot) {
+    char* sbase = lds + slot * STAGE + 4 * w * 512;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long r = r_begin + (long)kt * 32 + 4 * w + 2 * j + half;
+      const bool rin = kt < nk && r < r_end;
+      const char* sa = (rin && aok[j]) ? p.A + (r * p.lda + acol[j]) * 2 : zsrc;
+      bool ok = rin && bok[j];
+      const long rs = r + p.shift;
+      if (p.period) ok = ok && ((((unsigned)r / (unsigned)p.inner) % (unsigned)p.period) != (unsigned)p.invalid_step);
+      ok = ok && rs >= 0 && rs < p.R;
+      const char* sb = ok ? p.B + (rs * p.ldb + bcol[j]) * 2 : zsrc;
+      glds16(sa, sbase + j * 1024);
+      glds16(sb, sbase + 16384 + j * 1024);
+    }
+  };
+
+  f32x4_t acc[4][NTW];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t accs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = (p.colsum != nullptr) && tile_n == 0 && wn == 0;
+  const short8_t ones = short8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int row0 = 8 * g + q;                           // fragment rows row0 (k 0..3 of the lane) and row0 + 4
+  const int off0 = row0 * 512 + pp * 8, off1 = (row0 + 4) * 512 + pp * 8;
+  const int sw0 = q, sw1 = q + 4;                       // (row & 7) of the two rows
+
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, 2);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed for this wave once at most the 8 younger DMAs (stages kt+1, kt+2) are outstanding; the
+    // barrier then makes every wave's part visible and retires the slot that stage kt+3 is about to overwrite
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(kt + 3, (kt + 3) & 3);
+    const char* As = lds + (kt & 3) * STAGE;
+    const char* Bs = As + 16384;
+    short8_t a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int S = wm * 4 + i;
+      short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(As + off0 + ((S ^ sw0) << 5)));
+      short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(As + off1 + ((S ^ sw1) << 5)));
+      a[i] = short8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int S = wn * NTW + j;
+      short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(Bs + off0 + ((S ^ sw0) << 5)));
+      short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(Bs + off1 + ((S ^ sw1) << 5)));
+      const short8_t b = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b, acc[i][j]);
+    }
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accs[i] = Frag<bf16_t>::mma(a[i], ones, accs[i]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (zero page) DMAs must not outlive the workgroup
+
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const long col = n0 + (wn * NTW + j) * 16 + (lane & 15);
+    if (col >= p.No) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (row < p.Mo) atomicAdd(p.C + tn_perm(row, p.perm_h) * p.ldc + col, acc[i][j][r]);
+      }
+  }
+  if (do_colsum && (lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (row < p.Mo) atomicAdd(p.colsum + tn_perm(row, p.perm_h), accs[i][r]);
+      }
+  }
+}
+
 static int check_desc_host(const GemmDesc& d, int es, const char* who) {
   URSE_CHECK_ARG(d.A && d.B && d.C, "%s: null operand", who);
   URSE_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "%s: empty problem", who);
@@ -431,6 +580,25 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.R = R; p.Mo = Mo; p.No = No;
   p.shift = shift; p.inner = inner > 0 ? inner : 1; p.period = period; p.invalid_step = invalid_step;
   p.perm_h = perm_h;
+  static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr;
+  if (dtype == URSE_BF16 && !no_dma && Mo >= 512 && No >= 160 && R >= 16384 && inner < (1L << 31) && R < (1L << 31)) {
+    // big weight gradients: 256-wide tiles on the LDS-DMA ring, one workgroup per CU
+    const long pad7 = (No + 223) / 224 * 224, pad8 = (No + 255) / 256 * 256;
+    const int ntw = pad7 < pad8 ? 7 : 8;
+    const long bnx = 32L * ntw;
+    const long tl = ((Mo + 255) / 256) * ((No + bnx - 1) / bnx);
+    long slices = 256 / tl;
+    if (slices < 1) slices = 1;
+    long rps = (R + slices - 1) / slices;
+    rps = (rps + 31) / 32 * 32;
+    slices = (R + rps - 1) / rps;
+    p.rows_per_slice = rps;
+    dim3 grid((unsigned)(tl * slices));
+    if (ntw == 7) hipLaunchKernelGGL(gemm_tn_dma_kernel<7>, grid, dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_tn_dma_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, p);
+    URSE_CHECK_LAUNCH("urse_gemm_tn");
+    return URSE_OK;
+  }
   const long tiles = ((Mo + BM - 1) / BM) * ((No + BN - 1) / BN);
   const int bkr = dtype == URSE_BF16 ? 32 : 16;
   // one full round of resident workgroups (3 per CU at this kernel's register budget): a partial second round costs
