@@ -11,7 +11,8 @@ def _mk(shape, dtype, seed):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("M,N,K", [(300, 200, 224), (128, 128, 32), (1000, 3136, 224), (77, 196, 800), (513, 1568, 416)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 224), (128, 128, 32), (1000, 3136, 224), (77, 196, 800), (513, 1568, 416),
+                                   (2500, 196, 800), (2309, 790, 224), (4100, 1000, 96), (2048, 260, 3136)])
 def test_gemm_nt(lib, dtype, M, N, K):
     from urgent2026_challenge_track1_amd import ops
     A, W = _mk((M, K), dtype, 1), _mk((N, K), dtype, 2)
@@ -30,6 +31,12 @@ def test_gemm_nt(lib, dtype, M, N, K):
     r = res.clone().cuda()
     ops.gemm_nt(Ap.cuda()[:, :K], W.cuda(), bias.cuda(), resid=r, out=r)
     assert (r.cpu().double() - (ref + res.double())).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / 10)
+    if dtype == torch.bfloat16:
+        # tanh-backward epilogue: out = (A W^T) * (1 - h^2), h given in the output dtype
+        h = torch.tanh(_mk((M, N), torch.float32, 9)).to(torch.bfloat16)
+        got3 = ops.gemm_nt(A.cuda(), W.cuda(), None, act=2, resid=h.cuda(), out_dtype=torch.bfloat16).cpu()
+        ref3 = (ref - bias.double()) * (1 - h.double() ** 2)
+        assert (got3.double() - ref3).abs().max().item() <= 1e-2 * max(1.0, ref3.abs().max().item())
 
 
 def test_gemm_nt_identity_asymmetric(lib):

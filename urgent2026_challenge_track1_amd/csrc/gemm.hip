@@ -515,6 +515,193 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// NT, large shapes (bf16 operands): 256 x (32*NTW) tile per workgroup of 8 waves (4 x 2, 64 x 16*NTW each), K in
+// 32-element steps on the same 4-stage LDS-DMA ring as gemm_tn_dma_kernel.  Image rows are 64 bytes (4 chunks of
+// 16 B); physical chunk = k-chunk ^ ((row >> 2) & 3), applied on the DMA source address and on the ds_read_b128
+// fragment reads, so the 16 rows of a fragment hit 16 different 16-byte bank groups.  Epilogue as gemm_nt_kernel
+// (bias / tanh / tanh-backward / residual, output staged through LDS for 16-byte coalesced stores).
+template <typename TO, int NTW, int ACT, int BMX>
+__global__ void __launch_bounds__(BMX * 2) gemm_nt_dma_kernel(GemmDesc d) {
+  // BMX = 256: 8 waves, 4 stages of 32 KB, one workgroup per CU (long K: least operand traffic per FLOP)
+  // BMX = 128: 4 waves, 3 stages of 24 KB, two workgroups per CU (short K: one's epilogue overlaps the other's loop)
+  constexpr int BNX = 32 * NTW, NWV = BMX / 32, NTHR = NWV * 64;
+  constexpr int NST = BMX == 256 ? 4 : 3, STAGE = (BMX + 256) * 64, BOFF = BMX * 64;
+  constexpr int BI = 16 / NWV;                   // B wave-instructions per wave per stage (A: always 2)
+  constexpr int DPW = 2 + BI;                    // DMAs per wave per stage
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
+  const int tn = (int)((d.N + BNX - 1) / BNX), tm = (int)((d.M + BMX - 1) / BMX);
+  const int bid = xcd_remap(blockIdx.x, tm * tn);
+  const int tile_m = bid / tn, tile_n = bid - tile_m * tn;
+  const long m0 = (long)tile_m * BMX, n0 = (long)tile_n * BNX;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+  const int nk = (int)(d.K / 32);
+  const char* zsrc = reinterpret_cast<const char*>(g_tn_zero_page) + lane * 16;
+  const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 4) & 3);     // source k-chunk of this lane's slot
+  const int lc = lane & 15, lr = lane >> 4;
+  const int foff = lc * 64 + ((lr ^ ((lc >> 2) & 3)) << 4);    // fragment byte offset inside a 16-row block
+
+  // DMA: wave w fills image rows 32w .. 32w+31 of A (two 16-row wave-instructions) and 16*BI*w .. of B
+  const char* pa[2];
+  const char* pb[BI];
+  bool aok[2], bok[BI];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rowl = 32 * w + 16 * j + srow;
+    aok[j] = m0 + rowl < d.M;
+    pa[j] = d.A + ((m0 + rowl) * d.lda) * 2 + schunk * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int rowl = 16 * BI * w + 16 * j + srow;
+    bok[j] = rowl < BNX && n0 + rowl < d.N;
+    pb[j] = d.B + ((n0 + rowl) * d.ldb) * 2 + schunk * 16;
+  }
+  auto issue = [&](int kt, int slot) {
+    char* sbase = lds + slot * STAGE;
+    const bool kin = kt < nk;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16((kin && aok[j]) ? pa[j] + (long)kt * 64 : zsrc, sbase + w * 2048 + j * 1024);
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      glds16((kin && bok[j]) ? pb[j] + (long)kt * 64 : zsrc, sbase + BOFF + (w * BI + j) * 1024);
+  };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) issue(s, s);
+
+  constexpr int OS = sizeof(TO);
+  // The weight fragment is passed as the MFMA "A" operand, so the accumulator tile is D[n][m]: lane (lr, lc) holds
+  // output row m = lc and the FOUR CONSECUTIVE columns n = 4*lr .. 4*lr+3 -> 8-byte (bf16) / 16-byte (f32) pieces of an
+  // output row per lane, staged with one LDS write per tile instead of four 2-byte ones.
+  f32x4_t bv[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const long col = n0 + (wn * NTW + j) * 16 + lr * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = (d.bias && col + r < d.N) ? d.bias[col + r] : 0.f;
+  }
+  f32x4_t acc[4][NTW];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed for this wave once only the (NST-2) younger stages are outstanding; the barrier makes every
+    // wave's part visible and retires the slot that stage kt+NST-1 is about to overwrite
+    if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    static_assert((NST - 2) * DPW == (NST == 4 ? 8 : 6), "wait count");
+    __builtin_amdgcn_s_barrier();
+    int nslot = slot + NST - 1;
+    if (nslot >= NST) nslot -= NST;
+    issue(kt + NST - 1, nslot);
+    const char* As = lds + slot * STAGE + wm * 4096 + foff;
+    const char* Bs = lds + slot * STAGE + BOFF + wn * NTW * 1024 + foff;
+    short8_t a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const short8_t*>(As + i * 1024);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const short8_t b = *reinterpret_cast<const short8_t*>(Bs + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(b, a[i], acc[i][j]);   // D[n][m]: see the epilogue
+    }
+    if (++slot == NST) slot = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#ifdef NABL_NO_EPI
+  if (acc[0][0][0] == 123.456f) d.C[0] = 1;
+  return;
+#endif
+
+  // ---- epilogue: the tile goes through LDS (the ring is idle) RPP rows at a time, all waves of those rows writing
+  // at once, so that global stores / residual reads are 16-byte coalesced ----
+  constexpr int CP = BNX * OS + 16;
+  constexpr int RPP = (BMX * CP <= NST * STAGE) ? BMX : ((BMX / 2 * CP <= NST * STAGE) ? BMX / 2 : BMX / 4);
+  static_assert(RPP * CP <= NST * STAGE && RPP >= 64, "staging does not fit");
+  constexpr int EPC = 16 / OS;
+  constexpr int CPR = BNX / EPC;
+  TO* C = reinterpret_cast<TO*>(d.C);
+  const bool vec_ok = ((d.ldc * OS) % 16 == 0) && ((reinterpret_cast<uintptr_t>(d.C) % 16) == 0) &&
+                      (!d.resid || ACT == 2 || (((d.ldr * 4) % 16 == 0) && (reinterpret_cast<uintptr_t>(d.resid) % 16) == 0));
+#pragma unroll 1
+  for (int pass = 0; pass < BMX / RPP; ++pass) {
+    if (pass > 0) __syncthreads();
+    if ((wm * 64) / RPP == pass) {
+      const int rbase = (wm * 64) % RPP;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int lcol = (wn * NTW + j) * 16 + lr * 4;
+        const long col = n0 + lcol;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int lrow = rbase + i * 16 + lc;
+          f32x4_t v = acc[i][j] + bv[j];
+          if (ACT == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
+          }
+          if (ACT == 2) {   // tanh backward: aux (= resid slot, TO typed) holds h = tanh(.)
+            const long row = m0 + wm * 64 + i * 16 + lc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float hv = 0.f;
+              if (row < d.M && col + r < d.N) hv = to_f32<TO>(reinterpret_cast<const TO*>(d.resid)[row * d.ldr + col + r]);
+              v[r] *= (1.f - hv * hv);
+            }
+          }
+          char* dst = lds + lrow * CP + lcol * OS;
+          if (OS == 2) {
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(dst) = pk;
+          } else {
+            *reinterpret_cast<f32x4_t*>(dst) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // the threads sweep RPP rows x CPR 16-byte chunks; (lrow, ch) advance incrementally (no division in the loop)
+    int lrow = tid / CPR, ch = tid - lrow * CPR;
+    constexpr int DROW = NTHR / CPR, DCH = NTHR - DROW * CPR;
+    for (; lrow < RPP; lrow += DROW) {
+      const long row = m0 + pass * RPP + lrow, col = n0 + ch * EPC;
+      if (row < d.M && col < d.N) {
+        const char* src = lds + lrow * CP + ch * 16;
+        if (vec_ok && col + EPC <= d.N) {
+          uint4 v = *reinterpret_cast<const uint4*>(src);
+          if (OS == 4 && d.resid && ACT != 2) {
+            const float4 rr = *reinterpret_cast<const float4*>(d.resid + row * d.ldr + col);
+            float4 f = *reinterpret_cast<float4*>(&v);
+            f.x += rr.x; f.y += rr.y; f.z += rr.z; f.w += rr.w;
+            v = *reinterpret_cast<uint4*>(&f);
+          }
+#ifdef NABL_NO_GST
+          if (v.x == 0x12345678u)
+#endif
+          // streaming output (read next by a different kernel): non-temporal store, measured -16 % on the [M, 8H] gates
+          __builtin_nontemporal_store(*reinterpret_cast<const f32x4_t*>(&v), reinterpret_cast<f32x4_t*>(C + row * d.ldc + col));
+        } else {
+          const TO* sv = reinterpret_cast<const TO*>(src);
+          for (int e = 0; e < EPC && col + e < d.N; ++e) {
+            float f = to_f32<TO>(sv[e]);
+            if (OS == 4 && d.resid && ACT != 2) f += d.resid[row * d.ldr + col + e];
+            C[row * d.ldc + col + e] = from_f32<TO>(f);
+          }
+        }
+      }
+      ch += DCH;
+      if (ch >= CPR) { ch -= CPR; ++lrow; }
+    }
+  }
+}
+
 static int check_desc_host(const GemmDesc& d, int es, const char* who) {
   URSE_CHECK_ARG(d.A && d.B && d.C, "%s: null operand", who);
   URSE_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "%s: empty problem", who);
@@ -553,6 +740,30 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
   if (rc) return rc;
   URSE_CHECK_ARG(!resid || act == 2 || out_dtype == URSE_F32, "urse_gemm_nt: residual epilogue writes f32");
   URSE_CHECK_ARG(act != 2 || resid, "urse_gemm_nt: act 2 (tanh backward) needs the aux operand");
+  static const bool no_dma = getenv("URSE_NT_NO_DMA") != nullptr;
+  if (in_dtype == URSE_BF16 && !no_dma && M >= 2048 && N >= 160 && K % 32 == 0 && K >= 96) {
+    const long pad7 = (N + 223) / 224 * 224, pad8 = (N + 255) / 256 * 256;
+    int ntw = pad7 <= pad8 ? 7 : 8;
+    if (const char* e = getenv("URSE_NT_NTW")) ntw = atoi(e) == 8 ? 8 : 7;
+    int bmx = 256;                        // (the 128-row, two-workgroups-per-CU variant measured no faster at any K)
+    if (const char* e = getenv("URSE_NT_BMX")) bmx = atoi(e) == 128 ? 128 : 256;
+    const long tl = ((M + bmx - 1) / bmx) * ((N + 32L * ntw - 1) / (32L * ntw));
+    URSE_CHECK_ARG(tl < (1L << 31), "urse_gemm_nt: too many tiles");
+    dim3 grid((unsigned)tl);
+    hipStream_t st = (hipStream_t)stream;
+#define URSE_NT_DMA(TO_, NTW_, ACT_, BMX_) \
+  hipLaunchKernelGGL((gemm_nt_dma_kernel<TO_, NTW_, ACT_, BMX_>), grid, dim3(BMX_ * 2), 0, st, d)
+#define URSE_NT_DMA_B(TO_, NTW_, ACT_) do { if (bmx == 128) URSE_NT_DMA(TO_, NTW_, ACT_, 128); else URSE_NT_DMA(TO_, NTW_, ACT_, 256); } while (0)
+#define URSE_NT_DMA_ACT(TO_, NTW_) \
+  do { if (act == 0) URSE_NT_DMA_B(TO_, NTW_, 0); else if (act == 1) URSE_NT_DMA_B(TO_, NTW_, 1); else URSE_NT_DMA_B(TO_, NTW_, 2); } while (0)
+    if (out_dtype == URSE_BF16) {
+      if (ntw == 7) URSE_NT_DMA_ACT(bf16_t, 7); else URSE_NT_DMA_ACT(bf16_t, 8);
+    } else {
+      if (ntw == 7) URSE_NT_DMA_ACT(float, 7); else URSE_NT_DMA_ACT(float, 8);
+    }
+    URSE_CHECK_LAUNCH("urse_gemm_nt");
+    return URSE_OK;
+  }
   const long blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   URSE_CHECK_ARG(blocks < (1L << 31), "urse_gemm_nt: too many tiles");
   return dispatch_nt(nullptr, d, 1, (int)blocks, in_dtype, out_dtype, act, (hipStream_t)stream);
