@@ -124,10 +124,12 @@ int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int6
                         int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save, int dtype,
                         int rows16, void* stream);
 /* Persistent cluster variant of urse_lstm_bidir_fwd (bf16): recurrent weights stay in registers, C workgroups share a
- * set of sequences and exchange h_t through `hx` with an agent-scope release/acquire barrier per step.
+ * set of sequences and exchange h_t through `hx` (zeroed by the call).  Hand-off = "tag in data": every published bf16
+ * h carries a step-parity bit in its unused exponent MSB and consumers re-load a chunk until its tags are current (no
+ * counters, placement-independent, bounded spins).
  *  whhq: quad-ordered fragments from urse_lstm_pack_quads; plan (urse_lstm_cluster_plan) = {C, clusters per direction,
- *  rows per cluster, padded rows, hx elements (bf16, must be zero-initialised once), counters (uint32)};
- *  err_flag: uint32 set to 1 if a barrier timed out (results are then invalid). */
+ *  rows per cluster, padded rows, hx elements (bf16), counters (uint32, used by the BPTT variant only)};
+ *  err_flag: uint32 set to 1 if a hand-off timed out (results are then invalid). */
 int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, void* stream);
 int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan);
 int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,

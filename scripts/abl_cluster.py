@@ -3,9 +3,7 @@ import ctypes, os, subprocess, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
-variants = {"base": [], "noplain": ["-DCABL_NO_PLAIN"], "nowait": ["-DCABL_NO_WAIT"], "noxload": ["-DCABL_NO_XLOAD", "-DCABL_NO_WAIT"],
-            "noxall": ["-DCABL_NO_XLOAD", "-DCABL_NO_WAIT", "-DCABL_NO_XSTORE"],
-            "nothing": ["-DCABL_NO_XLOAD", "-DCABL_NO_WAIT", "-DCABL_NO_XSTORE", "-DCABL_NO_PLAIN"]}
+variants = {"base": [], "noxstore": ["-DCABL_NO_XSTORE"]}
 libs = {}
 for name, fl in variants.items():
     so = "/tmp/ablc_%s.so" % name

@@ -1,16 +1,16 @@
 // Persistent "cluster" LSTM forward recurrence: recurrent weights RESIDENT IN REGISTERS for the whole sequence.
 //
-// lstm.hip streams W_hh (1.2 MB bf16 per direction) from L2 on every time step and is bound by the per-CU L1/L2
-// bandwidth (~8.5 us per step).  Here a cluster of C workgroups (one per CU) shares a set of sequences: workgroup j
-// owns 14 "quads" of hidden units (4 units x 4 gates = one 16-column MFMA B tile per quad, one quad per wave), keeps
-// those B fragments in VGPRs (13 x 16 B per lane for Hp = 416), and per step
-//   1. loads the cluster's h_{t-1} rows [64, Hp] from the exchange buffer into LDS (MFMA A operand),
+// lstm.hip streams W_hh (1.2 MB bf16 per direction) from L2 on every time step and is bound by the ~70 GB/s at which
+// one CU can read its L2 (18 us per step).  Here a cluster of C workgroups (one per CU) shares a set of sequences:
+// workgroup j owns 14 "quads" of hidden units (4 units x 4 gates = one 16-column MFMA B tile per quad, one quad per
+// wave), keeps those B fragments in VGPRs (13 x 16 B per lane for Hp = 416), and per step
+//   1. loads the cluster's h_{t-1} rows [64, Hp] from the exchange buffer into LDS (MFMA A operand), polling every
+//      16-byte chunk until the step tag embedded in its elements is current (see the protocol note in the kernel),
 //   2. every wave computes its quad's 16 gate columns for the 64 rows, transposes the accumulator inside each lane
 //      quad with DPP so that one lane holds i,f,g,o of one (row, unit), applies the LSTM cell (c_t stays in registers),
-//   3. stages h_t through LDS and writes it with 16-byte stores to the exchange buffer and to hout,
-//   4. cluster barrier: release fence + one device-scope atomic per workgroup; acquire on the consumers.
-// Placement-independent (MI355X_MICROARCH "visibility"): agent-scope release/acquire only, bounded spins, counters
-// zeroed by a memset node before every launch, grid <= 256 workgroups so all are co-resident.
+//   3. stages h_t through LDS and writes it with 16-byte stores to the exchange buffer (sc1, tagged) and to hout.
+// Placement-independent: visibility comes from sc1 (write-through) stores and sc1 (L1-bypassing) loads of data that
+// validates itself; spins are bounded (error flag); grid <= 256 workgroups so all are co-resident.
 // Same math / layouts as lstm.hip (gate-interleaved gx, bf16 h, f32 c); bf16 only (the f32 parity mode keeps lstm.hip).
 #include "urse_common.h"
 
@@ -140,135 +140,139 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
 
   uint2 gxn[4];                                          // gate pre-activations, prefetched one step ahead
   load_gx(0, (long)(dir ? p.seq_len - 1 : 0) * p.stride, gxn);
+  unsigned* deadflag = reinterpret_cast<unsigned*>(smem + CROWS * pitch + CROWS * UW * 2);
+  if (tid == 0) *deadflag = 0u;
+  const int hchunks = H / 8;                             // 16-byte chunks of a row that carry data (H % 8 == 0)
+  constexpr unsigned TAGM = 0x40004000u;                 // bit 14 of both bf16 halves: always 0 in |h| <= 1
 
+  // Hand-off protocol ("tag in data"): every bf16 h element published through the exchange buffer carries, in its
+  // never-used exponent MSB, one bit that toggles each time its parity plane is rewritten (the host zeroes the planes
+  // before the launch, the first write carries 1).  A consumer simply re-loads (sc1, L1-bypassing) a 16-byte chunk
+  // until all eight tags show the value expected for that step: no arrival counter, no store drain + barrier + atomic +
+  // poll round trips on the critical path, and correct at any placement / at 2-byte store granularity.  A plane is
+  // overwritten only by a producer that has already consumed every workgroup's h of the step in between, which those
+  // workgroups published only after consuming the data being overwritten.
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? (p.seq_len - 1 - step) : step;
     const long toff = (long)t * p.stride;
     const unsigned pprev = (unsigned)((step + 1) & 1), pcur = (unsigned)(step & 1);
+    const unsigned tag_cur = (((unsigned)step >> 1) & 1u) ^ 1u;
+    const unsigned tag_prev = (((unsigned)(step - 1) >> 1) & 1u) ^ 1u;
+    constexpr int ch = 0;
+    const int r0 = 0;
+    // 1. h_{t-1} rows -> LDS, each chunk polled until its tags are current
+    {
+      uint4 hn[HL];
+      unsigned pend = 0u;
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
-      if (ch < nch) {
-        const int r0 = ch * CROWS;
-        // 1. h_{t-1} rows (complete only now, after the cluster barrier) -> LDS
-        {
-          uint4 hn[HL];
-#ifndef CABL_NO_XLOAD
-          if (step > 0) {
-            load_h(ch, pprev, hn);
-          } else
-#endif
-          {
+      for (int i = 0; i < HL; ++i) {
+        hn[i] = make_uint4(0, 0, 0, 0);
+        const int idx = tid + i * CTHR;
+        const int row = idx / cpr, cc = idx - row * cpr;
+        if (step > 0 && idx < CROWS * cpr && row < nrows && cc < hchunks) pend |= 1u << i;
+      }
+      if (pend && *reinterpret_cast<volatile unsigned*>(deadflag)) pend = 0u;
+      const unsigned want = tag_prev ? TAGM : 0u;
+      unsigned spins = 0;
+      while (pend) {
 #pragma unroll
-            for (int i = 0; i < HL; ++i) hn[i] = make_uint4(0, 0, 0, 0);
-          }
-#pragma unroll
-          for (int i = 0; i < HL; ++i) {
+        for (int i = 0; i < HL; ++i) {
+          if (pend & (1u << i)) {
             const int idx = tid + i * CTHR;
             const int row = idx / cpr, cc = idx - row * cpr;
-            if (idx < CROWS * cpr) *reinterpret_cast<uint4*>(htile + row * pitch + cc * 16) = hn[i];
+            hn[i] = load_sc1(rs, pprev * plane_bytes + cl_bytes + (unsigned)(row * Hp * 2 + cc * 16));
           }
         }
-        uint2 gxc[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) gxc[rt] = gxn[rt];
-        __syncthreads();
-        // prefetch the gate pre-activations of the next step (independent of the recurrence)
-        if (step + 1 < p.seq_len) load_gx(0, (long)(dir ? t - 1 : t + 1) * p.stride, gxn);
-        // 2. gates for (64 rows) x (this wave's quad)
-        uint2 gsave[4];
-        float csave[4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          const char* ar = htile + (rt * 16 + lc) * pitch + 16 * lr;
-#pragma unroll
-          for (int ks = 0; ks < NSLAB; ++ks) {
-            const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                          __builtin_bit_cast(bf16x8_t, breg[ks]), acc, 0, 0, 0);
+        for (int i = 0; i < HL; ++i) {
+          if (pend & (1u << i)) {
+            const uint4 v = hn[i];
+            if ((v.x & TAGM) == want && (v.y & TAGM) == want && (v.z & TAGM) == want && (v.w & TAGM) == want)
+              pend &= ~(1u << i);
           }
-          // acc[r] = gate (lc & 3) of unit (lc >> 2), row rt*16 + lr*4 + r.  4x4 transpose inside the lane quad
-          float pre[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float v0 = quad_bcast(acc[0], g), v1 = quad_bcast(acc[1], g), v2 = quad_bcast(acc[2], g),
-                        v3 = quad_bcast(acc[3], g);
-            pre[g] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
-          }
-          const uint2 gxv = gxc[rt];
-          const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
-          const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
-          const float iv = sigmoidf_(gi), fv = sigmoidf_(gf), gv = tanhf_(gg), ov = sigmoidf_(go);
-          const float cv = fv * cst[ch][rt] + iv * gv;
-          cst[ch][rt] = cv;
-          const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
-          if (qvalid) hstage[(rt * 16 + lr * 4 + q) * UW + w * 4 + ul] = f32_to_bf16(hv);
-          gsave[rt].x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
-          gsave[rt].y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
-          csave[rt] = cv;
         }
-        __syncthreads();
-        // 3. h_t of this workgroup's units -> exchange buffer FIRST (write-through), then the plain stores
-        constexpr int SC = UW * 2 / 16;   // 7 chunks per row
-        for (int idx = tid; idx < CROWS * SC; idx += CTHR) {
-          const int row = idx / SC, cc = idx - row * SC;
-          const int ucol = j * UW + cc * 8;
-          if (r0 + row >= nrows || ucol >= Hp) continue;
-          const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
+        if (pend) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 20)) { atomicExch(p.err, 1u); *reinterpret_cast<volatile unsigned*>(deadflag) = 1u; pend = 0u; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < HL; ++i) {
+        const int idx = tid + i * CTHR;
+        const int row = idx / cpr, cc = idx - row * cpr;
+        uint4 v = hn[i];
+        v.x &= ~TAGM; v.y &= ~TAGM; v.z &= ~TAGM; v.w &= ~TAGM;
+        if (idx < CROWS * cpr) *reinterpret_cast<uint4*>(htile + row * pitch + cc * 16) = v;
+      }
+    }
+    uint2 gxc[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) gxc[rt] = gxn[rt];
+    __syncthreads();
+    // prefetch the gate pre-activations of the next step (independent of the recurrence)
+    if (step + 1 < p.seq_len) load_gx(0, (long)(dir ? t - 1 : t + 1) * p.stride, gxn);
+    // 2. gates for (64 rows) x (this wave's quad)
+    uint2 gsave[4];
+    float csave[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const char* ar = htile + (rt * 16 + lc) * pitch + 16 * lr;
+#pragma unroll
+      for (int ks = 0; ks < NSLAB; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, breg[ks]), acc, 0, 0, 0);
+      }
+      // acc[r] = gate (lc & 3) of unit (lc >> 2), row rt*16 + lr*4 + r.  4x4 transpose inside the lane quad
+      float pre[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = quad_bcast(acc[0], g), v1 = quad_bcast(acc[1], g), v2 = quad_bcast(acc[2], g),
+                    v3 = quad_bcast(acc[3], g);
+        pre[g] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
+      }
+      const uint2 gxv = gxc[rt];
+      const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
+      const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
+      const float iv = sigmoidf_(gi), fv = sigmoidf_(gf), gv = tanhf_(gg), ov = sigmoidf_(go);
+      const float cv = fv * cst[ch][rt] + iv * gv;
+      cst[ch][rt] = cv;
+      const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
+      if (qvalid) hstage[(rt * 16 + lr * 4 + q) * UW + w * 4 + ul] = f32_to_bf16(hv);
+      gsave[rt].x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
+      gsave[rt].y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
+      csave[rt] = cv;
+    }
+    __syncthreads();
+    // 3. h_t of this workgroup's units -> exchange buffer FIRST (write-through, tagged), then the plain stores
+    constexpr int SC = UW * 2 / 16;   // 7 chunks per row
+    const unsigned tagv = tag_cur ? TAGM : 0u;
+    for (int idx = tid; idx < CROWS * SC; idx += CTHR) {
+      const int row = idx / SC, cc = idx - row * SC;
+      const int ucol = j * UW + cc * 8;
+      if (r0 + row >= nrows || ucol >= H) continue;
+      uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
+      const uint4 vt = make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv);
 #ifndef CABL_NO_XSTORE
-          store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)((r0 + row) * Hp * 2 + ucol * 2), v);
+      if (step + 1 < p.seq_len) store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)((r0 + row) * Hp * 2 + ucol * 2), vt);
 #endif
-        }
-        if (ch + 1 == nch && step + 1 < p.seq_len) {
-          // last chunk: drain the exchange stores and arrive at the cluster barrier before the (slow) plain stores
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#ifndef CABL_NO_PLAIN
-        for (int idx = tid; idx < CROWS * SC; idx += CTHR) {
-          const int row = idx / SC, cc = idx - row * SC;
-          const int ucol = j * UW + cc * 8;
-          if (r0 + row >= nrows || ucol >= H) continue;
-          const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
-          const int seq = seq0 + r0 + row;
-          const long grow = (seq / p.inner) * p.outer + (seq % p.inner) + toff;
-          if (ucol + 8 <= H) {
-            *reinterpret_cast<uint4*>(hout + grow * p.ldh + (long)dir * H + ucol) = v;
-          } else {
-            const bf16_t* sv = reinterpret_cast<const bf16_t*>(&v);
-            for (int e = 0; e < 8 && ucol + e < H; ++e) hout[grow * p.ldh + (long)dir * H + ucol + e] = sv[e];
-          }
-        }
-        if (p.save && uvalid) {
+      const int seq = seq0 + r0 + row;
+      const long grow = (seq / p.inner) * p.outer + (seq % p.inner) + toff;
+      *reinterpret_cast<uint4*>(hout + grow * p.ldh + (long)dir * H + ucol) = v;    // H % 8 == 0: whole chunks
+    }
+    if (p.save && uvalid) {
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) {
-            bool v;
-            const long row = row_of(ch, rt, toff, &v);
-            if (v) {
-              *reinterpret_cast<uint2*>(gx + row * p.ldg + gcol0 + u * 4) = gsave[rt];
-              p.c[row * 2 * H + (long)dir * H + u] = csave[rt];
-            }
-          }
+      for (int rt = 0; rt < 4; ++rt) {
+        bool v;
+        const long row = row_of(ch, rt, toff, &v);
+        if (v) {
+          *reinterpret_cast<uint2*>(gx + row * p.ldg + gcol0 + u * 4) = gsave[rt];
+          p.c[row * 2 * H + (long)dir * H + u] = csave[rt];
         }
-#endif
-        __syncthreads();   // hstage / htile are rewritten by the next stage
       }
     }
-    // 4. wait for the other workgroups of the cluster
-    if (step + 1 < p.seq_len) {
-      if (tid == 0) {
-        const unsigned target = (unsigned)(step + 1) * (unsigned)p.C;
-        unsigned spins = 0;
-#ifndef CABL_NO_WAIT
-        while (!dead && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 24)) { dead = true; atomicExch(p.err, 1u); }
-        }
-#endif
-      }
-      __syncthreads();
-    }
+    __syncthreads();   // hstage / htile are rewritten by the next step
   }
 }
 
@@ -511,7 +515,7 @@ static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  const size_t lds = (size_t)CROWS * (p.Hp * 2 + 16) + (size_t)CROWS * UW * 2;
+  const size_t lds = (size_t)CROWS * (p.Hp * 2 + 16) + (size_t)CROWS * UW * 2 + 16;
   dim3 grid(p.C * p.ncl, 2);
   hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH>), grid, dim3(CTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_cluster_fwd");
@@ -618,7 +622,8 @@ extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, vo
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
   p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2]; p.rows_pad = (int)plan[3];
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(counters, 0, sizeof(unsigned) * plan[5], st);
+  // the exchange planes start with every tag bit clear (see the hand-off protocol in the kernel)
+  (void)hipMemsetAsync(hx, 0, sizeof(bf16_t) * plan[4], st);
   const int nslab = Hp / 32;
   if (nslab == 13) return launch_cluster<13, 1>(p, st);
   if (nslab == 2) return launch_cluster<2, 1>(p, st);
