@@ -122,3 +122,23 @@ def test_gemm_tn_large_dma_path(lib, R, Mo, No, inner, period, rev, perm):
     tol = 1e-4 * (R ** 0.5)
     assert (out.cpu().double() - ref).abs().max().item() <= tol
     assert (cs.cpu().double() - csr).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_tn_grouped_matches_single_calls(lib, dtype):
+    from urgent2026_challenge_track1_amd import ops
+    shapes = [(900, 64, 40), (900, 12, 784), (1300, 784, 200), (77, 200, 8)]
+    rows, outs, refs, css, keep = [], [], [], [], []
+    for i, (R, Mo, No) in enumerate(shapes):
+        A, Bm = _mk((R, (Mo + 15) // 8 * 8), dtype, 20 + i).cuda(), _mk((R, (No + 15) // 8 * 8), dtype, 40 + i).cuda()
+        keep += [A, Bm]                                   # descriptors hold raw pointers
+        out, cs = torch.zeros(Mo, No, device="cuda"), torch.zeros(Mo, device="cuda")
+        rows.append(ops.tn_desc(A, Bm, out, colsum=cs, Mo=Mo, No=No))
+        ref, rcs = torch.zeros(Mo, No, device="cuda"), torch.zeros(Mo, device="cuda")
+        ops.gemm_tn(A, Bm, ref, colsum=rcs, Mo=Mo, No=No)
+        outs.append(out); refs.append(ref); css.append((cs, rcs))
+    ops.gemm_tn_grouped(rows, dtype, "cuda")
+    for out, ref, (cs, rcs) in zip(outs, refs, css):
+        tol = 1e-5 * max(1.0, ref.abs().max().item())        # same products, different split-R summation order
+        assert (out - ref).abs().max().item() <= tol
+        assert (cs - rcs).abs().max().item() <= 1e-5 * max(1.0, rcs.abs().max().item())

@@ -388,18 +388,20 @@ class BSRNNCore(nn.Module):
         if dzT is None:
             dzT, width = ops.pack2d(dz.reshape(M * K, N), M * K, Np, dt), Np
         dxnb = torch.empty(M, tb["ldx"], dtype=torch.float32, device=dev)
-        rows = []
+        rows, tn_rows = [], []
         w_off = 0
         for k in range(K):
             r = tb["rows"][k]
             sb = r[1]
             a = dzT.view(M, K * width)[:, k * width + col0:k * width + col0 + Np]
             gw = self._g(prefix + ".w", N * 2 * sb, w_off).view(N, 2 * sb)
-            ops.gemm_tn(a, xnb[:, r[2]:r[2] + r[3]], gw, colsum=self._g(prefix + ".b", N, k * N), Mo=N, No=2 * sb)
+            tn_rows.append(ops.tn_desc(a, xnb[:, r[2]:r[2] + r[3]], gw, colsum=self._g(prefix + ".b", N, k * N), Mo=N,
+                                       No=2 * sb))
             wT = pk[prefix + ".wT", k]
             rows.append([_ptr(dzT, k * width + col0), _ptr(wT), _ptr(dxnb, r[2]), 0, 0, K * width, Np, tb["ldx"], M,
                          2 * sb, Np, 0])
             w_off += N * 2 * sb
+        ops.gemm_tn_grouped(tn_rows, dt, dev)     # all per-band weight / bias gradients in one launch
         call("gemm_nt_grouped", _descs(rows, dev), K, _tiles(M, 128), ops._dt(dzT), ops.F32, 0, stream_ptr())
         n_gb = 2 * sum(self.subbands)
         call("bandsplit_norm_bwd", spec, dxnb, tb["bands"], stats, self._g(prefix + ".gamma", n_gb),
@@ -529,19 +531,22 @@ class BSRNNCore(nn.Module):
                                ld4N, K * N, M, N, ld4N, 0])
         call("gemm_nt_grouped", _descs(rows_a, dev), 2 * K, _tiles(M, 4 * N), ops._dt(dpre[0]), ops._dt(dhp[0]), 2,
              stream_ptr())
+        tn_rows = []
         for i, tag in enumerate("mr"):
             p = "md%s." % tag
             w2_off = b2_off = 0
             for k in range(K):
                 sb = self.subbands[k]
                 r = tb["rows"][k]
-                ops.gemm_tn(dpre[i][:, r[5]:r[5] + r[6]], hids[i][k], self._g(p + "w2", 16 * sb * N, w2_off).view(4 * sb, 4 * N),
-                            colsum=self._g(p + "b2", 4 * sb, b2_off), Mo=4 * sb, No=4 * N)
+                tn_rows.append(ops.tn_desc(dpre[i][:, r[5]:r[5] + r[6]], hids[i][k],
+                                           self._g(p + "w2", 16 * sb * N, w2_off).view(4 * sb, 4 * N),
+                                           colsum=self._g(p + "b2", 4 * sb, b2_off), Mo=4 * sb, No=4 * N))
                 xk = xns[i].view(M, K * Np)[:, k * Np:(k + 1) * Np]
-                ops.gemm_tn(dhp[i][k], xk, self._g(p + "w1", 4 * N * N, k * 4 * N * N).view(4 * N, N),
-                            colsum=self._g(p + "b1", 4 * N, k * 4 * N), Mo=4 * N, No=N)
+                tn_rows.append(ops.tn_desc(dhp[i][k], xk, self._g(p + "w1", 4 * N * N, k * 4 * N * N).view(4 * N, N),
+                                           colsum=self._g(p + "b1", 4 * N, k * 4 * N), Mo=4 * N, No=N))
                 w2_off += 16 * sb * N
                 b2_off += 4 * sb
+        ops.gemm_tn_grouped(tn_rows, dt, dev)     # 4 x K weight / bias gradients in one launch
         call("gemm_nt_grouped", _descs(rows_b, dev), 2 * K, _tiles(M, N), ops._dt(dhp[0]), ops.F32, 0, stream_ptr())
         dskip = None
         for i, tag in enumerate("mr"):

@@ -230,17 +230,16 @@ __device__ __forceinline__ long tn_perm(long m, long h) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs p) {
+__device__ __forceinline__ void gemm_tn_body(const TnArgs& p, const int bx, const int nblk, char* lds) {
   constexpr int ES = sizeof(T);
   constexpr int BKR = (ES == 2) ? 32 : 16;  // rows per step
   constexpr int PITCH = (ES == 2) ? TROW_BF16 : TROW_F32;
-  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 32 * TROW_BF16];
   const int tn = (int)((p.No + BN - 1) / BN);
   // XCD-aware order: the workgroups that land on one XCD (blockIdx % 8) take consecutive (slice, tile) ids, so all
   // output tiles of one row slice stream the same A / B rows through the same L2 at the same time (the operands are
   // re-read once per tile column / row; spread over the eight L2s those re-reads were served at Infinity-Cache rate)
   const int tiles = tn * (int)((p.Mo + BM - 1) / BM);
-  const int lid = xcd_remap(blockIdx.x, (int)gridDim.x);
+  const int lid = xcd_remap(bx, nblk);
   const int slice = lid / tiles, tile = lid - slice * tiles;
   const int tile_m = tile / tn, tile_n = tile - tile_m * tn;
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
@@ -361,6 +360,25 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs p) {
   }
   if (do_colsum && m0 + tid < p.Mo) atomicAdd(p.colsum + tn_perm(m0 + tid, p.perm_h), csum);
 }
+
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 32 * TROW_BF16];
+  gemm_tn_body<T>(p, (int)blockIdx.x, (int)gridDim.x, lds);
+}
+
+// grouped launch: one TnArgs descriptor per group (blockIdx.y), e.g. the per-band weight gradients of the band-split
+// and mask-decoder 1x1 convolutions (espnet2 BandSplit / MaskDecoder; twin bsrnn_flowse.py:66-81,137-168)
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_tn_grouped_kernel(const TnArgs* __restrict__ descs) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 32 * TROW_BF16];
+  const TnArgs p = descs[blockIdx.y];
+  const int tiles = (int)((p.No + BN - 1) / BN) * (int)((p.Mo + BM - 1) / BM);
+  const int nblk = tiles * (int)((p.R + p.rows_per_slice - 1) / p.rows_per_slice);
+  if ((int)blockIdx.x >= nblk) return;
+  gemm_tn_body<T>(p, (int)blockIdx.x, nblk, lds);
+}
+
 
 }  // namespace urse
 
@@ -829,5 +847,16 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   if (dtype == URSE_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
   URSE_CHECK_LAUNCH("urse_gemm_tn");
+  return URSE_OK;
+}
+
+extern "C" int urse_gemm_tn_grouped(const void* descs, int groups, int max_blocks, int dtype, void* stream) {
+  URSE_CHECK_ARG(descs && groups > 0 && max_blocks > 0 && groups < 65536, "urse_gemm_tn_grouped: bad argument");
+  dim3 grid((unsigned)max_blocks, (unsigned)groups);
+  if (dtype == URSE_BF16)
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const TnArgs*)descs);
+  else
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const TnArgs*)descs);
+  URSE_CHECK_LAUNCH("urse_gemm_tn_grouped");
   return URSE_OK;
 }

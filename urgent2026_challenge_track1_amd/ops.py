@@ -120,6 +120,34 @@ def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=
     return out
 
 
+def tn_desc(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=0, invalid_step=0, perm_h=0):
+    """one row of a urse_gemm_tn_grouped descriptor table (rows_per_slice is filled in by gemm_tn_grouped)."""
+    R = A.shape[0]
+    Mo = A.shape[1] if Mo is None else Mo
+    No = Bm.shape[1] if No is None else No
+    assert Bm.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and A.dtype == Bm.dtype
+    assert out.dtype == torch.float32 and out.stride(-1) == 1 and out.stride(0) >= No
+    return [A.data_ptr(), Bm.data_ptr(), out.data_ptr(), 0 if colsum is None else colsum.data_ptr(), A.stride(0),
+            Bm.stride(0), out.stride(0), R, Mo, No, shift, max(1, inner), period, invalid_step, 0, perm_h]
+
+
+def gemm_tn_grouped(rows, dtype, device, target_blocks=1024):
+    """out_g[Mo, No] += A_g^T @ B_g for every descriptor row (see tn_desc) in ONE launch."""
+    bkr = 32 if dtype == torch.bfloat16 else 16
+    tiles = [((r[8] + 127) // 128) * ((r[9] + 127) // 128) for r in rows]
+    per_group = max(1, target_blocks // max(1, sum(tiles)))
+    max_blocks = 0
+    for r, tl in zip(rows, tiles):
+        R = r[7]
+        slices = max(1, min(per_group, (R + 4 * bkr - 1) // (4 * bkr)))
+        rps = (R + slices - 1) // slices
+        rps = (rps + bkr - 1) // bkr * bkr
+        r[14] = rps
+        max_blocks = max(max_blocks, tl * ((R + rps - 1) // rps))
+    descs = torch.tensor(rows, dtype=torch.int64, device=device)
+    call("gemm_tn_grouped", descs, len(rows), max_blocks, BF16 if dtype == torch.bfloat16 else F32, stream_ptr())
+
+
 # ---------------------------------------------------------------------------------------------
 # GroupNorm / packing / LSTM recurrence (raw, non-autograd wrappers; bsrnn.py composes them)
 # ---------------------------------------------------------------------------------------------
