@@ -181,6 +181,18 @@ def main():
     peak = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
     ach = dom_flops / (kt[dom][0] * 1e-3) / 1e12
     stft_bytes = B * (L * 4 + T * Fb * 8)
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
+    # comes from the committed rocprofv3 passes of this same command (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+    # FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes); null if no summary matches this configuration
+    traffic, traffic_src = None, None
+    pmc_names = {"lstm_bwd_time": "lstm_bwd_kernel<unsigned short, 1, 2, 16>", "lstm_bwd_band": "lstm_bwd_kernel<unsigned short, 2, 4, 8>",
+                 "lstm_fwd_time": "lstm_fwd_cluster_kernel", "lstm_fwd_band": "lstm_fwd_wide_kernel"}
+    if (B, args.seconds, args.channels, args.layers, args.dtype) == (32, 4.0, 196, 6, "bf16"):
+        import glob
+        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic_*.json")))[-1:]:
+            for k, v in json.load(open(f)).items():
+                if pmc_names[dom] in k:
+                    traffic, traffic_src = (v["fetch_GB"] + v["write_GB"]) * 1e9, os.path.basename(f)
     out = {
         "metric": "utterances/sec (4 s @ 48 kHz) train step", "value": world * B * args.steps / dt, "unit": "utt/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -189,7 +201,8 @@ def main():
                                "MR-L1 loss, clip 0.5 + AdamW" % (B, args.seconds, args.channels, args.layers),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                     "frac": ach / peak, "traffic": None, "algorithmic_flops_per_launch": dom_flops,
+                     "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
+                     "traffic_source": traffic_src, "algorithmic_flops_per_launch": dom_flops,
                      "kernel_ms": kt[dom][0], "launches_per_step": kt[dom][1] / args.steps},
         "kernels_ms_per_step": {n: tot_ms[n] / args.steps for n in tot_ms},
         "stft_roofline": {"bound": "hbm", "achieved": stft_bytes / (kt["stft_fwd"][0] * 1e-3) / 1e9,

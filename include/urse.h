@@ -182,6 +182,36 @@ int urse_glu_mask_apply_bwd(const float* pre_m, const float* pre_r, const float*
                             int out_dtype, void* stream);
 /* x <- x / max|x| * peak in place (baseline_code/inference.py:60); scratch = 4 device bytes. */
 int urse_peak_normalize(float* x, int64_t n, float peak, void* scratch, void* stream);
+/* ---- on-device dynamic mixing (simulation/simulate_data_from_param.py) -------------------------
+ * Batched [B, ld] f32 signals with per-utterance lengths (int32 device arrays); samples >= len are written as 0.
+ * urse_nonsilence_power: mean power over the samples espnet2 detect_non_silence(x, 0.01, 1024, 512, boxcar) keeps
+ *   (:121-122); hop_scratch = f64 [B * ceil(ld/512)], power = f64 [B].
+ * urse_mix_noise (mix_noise :95-126): noise_raw [B, ldn] is wrap-padded (front offset) or cropped (start offset) to the
+ *   speech length, scaled to snr_db against the speech, noise_out = scaled noise, noisy_out = speech + noise_out;
+ *   scratch = f64 [B * ceil(ld/512) + 2B].
+ * urse_fir_full: y = scipy.signal.convolve(x, taps, "full")[:, :len] (add_reverberation :220-230); taps [B or 1, ldt]
+ *   with ntaps (device int32 [B or 1]); taps_per_utt != 0 selects one filter per utterance.  x != y.
+ * urse_filtfilt_fir: scipy.signal.filtfilt(taps, 1.0, x) (high-pass :461, taps from filter_designs :29-56), ntaps_dev =
+ *   device int32 [1] = ntaps; scratch = f32 [2 * B * lds], lds >= ld + 7 * ntaps - 1.
+ * urse_quantile_clip (clipping :255-276): np.quantile(x, [qmin, qmax]) with linear interpolation, exact (radix
+ *   select), then np.clip in place; bounds = f32 [B, 2] receives the two thresholds.
+ * urse_zero_segments (packet_loss :333-341): segments = device int32 [nseg, 3] {utterance, start, end}.
+ * urse_joint_peak_scale (:576-584): all three signals *= target / max(|noisy|, |speech|, |noise|, 1e-6) per utterance;
+ *   peak_scratch = 4 * B device bytes. */
+int urse_nonsilence_power(const float* x, const int32_t* lens, int B, int64_t ld, double threshold, double* hop_scratch,
+                          double* power, void* stream);
+int urse_mix_noise(const float* speech, const float* noise_raw, const int32_t* noise_lens, int64_t ldn, const int32_t* lens,
+                   const int32_t* offsets, const float* snr_db, int B, int64_t ld, float* noise_out, float* noisy_out,
+                   double* scratch, void* stream);
+int urse_fir_full(const float* x, const int32_t* lens, int B, int64_t ld, const float* taps, const int32_t* ntaps, int64_t ldt,
+                  int taps_per_utt, float* y, void* stream);
+int urse_filtfilt_fir(const float* x, const int32_t* lens, int B, int64_t ld, const float* taps, const int32_t* ntaps_dev,
+                      int ntaps, float* y, float* scratch, int64_t lds, void* stream);
+int urse_quantile_clip(float* x, const int32_t* lens, int B, int64_t ld, const float* qmin, const float* qmax, float* bounds,
+                       void* stream);
+int urse_zero_segments(float* x, int64_t ld, const int32_t* segments, int nseg, void* stream);
+int urse_joint_peak_scale(float* speech, float* noisy, float* noise, int B, int64_t ld, float target, void* peak_scratch,
+                          void* stream);
 /* y = a*x + b*y (f32). */
 int urse_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream);
 

@@ -1,0 +1,96 @@
+"""Oracle: the numpy / scipy DSP subset of the reference's on-the-fly simulator, float64.
+
+TEST INFRASTRUCTURE - never imported by the product path.
+
+Restates ``simulation/simulate_data_from_param.py``: ``filter_designs`` :25-54, ``mix_noise`` :95-126,
+``add_reverberation`` :220-230, ``clipping`` :255-276, ``packet_loss`` :333-341, the high-pass ``filtfilt`` call :461 and
+the final joint peak normalisation :576-584.  The reference module itself cannot be imported here (espnet2, soundfile,
+librosa are absent), but everything it calls for these functions except ``espnet2.train.preprocessor
+.detect_non_silence`` is numpy / scipy, which ARE present, so this file calls the same library routines
+(``scipy.signal.convolve`` / ``filtfilt`` / ``firwin2``, ``np.quantile`` / ``np.clip`` / ``np.pad(mode="wrap")``).
+``detect_non_silence`` / ``framing`` are restated from espnet 202412: PARITY UNPINNED for that one function.
+"""
+import numpy as np
+import scipy.signal
+
+
+def framing(x, frame_length=512, frame_shift=256, centered=True, padded=True):
+    if centered:
+        pad = [(0, 0)] * (x.ndim - 1) + [(frame_length // 2, frame_length // 2)]
+        x = np.pad(x, pad, mode="constant", constant_values=0)
+    if padded:
+        nadd = (-(x.shape[-1] - frame_length) % frame_shift) % frame_length
+        x = np.pad(x, [(0, 0)] * (x.ndim - 1) + [(0, nadd)], mode="constant", constant_values=0)
+    n = (x.shape[-1] - frame_length) // frame_shift + 1
+    idx = np.arange(frame_length)[None, :] + frame_shift * np.arange(n)[:, None]
+    return x[..., idx]
+
+
+def detect_non_silence(x, threshold=0.01, frame_length=1024, frame_shift=512, window="boxcar"):
+    if x.shape[-1] < frame_length:
+        return np.full(x.shape, True, dtype=bool)
+    framed = framing(x.astype(np.float64), frame_length, frame_shift, centered=False, padded=True)
+    framed = framed * scipy.signal.get_window(window, frame_length)
+    power = (framed ** 2).mean(axis=-1)
+    mean_power = np.mean(power, axis=-1, keepdims=True)
+    if np.all(mean_power == 0):
+        return np.full(x.shape, True, dtype=bool)
+    det = power / mean_power > threshold
+    det = np.broadcast_to(det[..., None], det.shape + (frame_shift,)).reshape(*det.shape[:-1], -1)
+    return np.pad(det, [(0, 0)] * (x.ndim - 1) + [(0, x.shape[-1] - det.shape[-1])], mode="edge")
+
+
+def align_noise(noise, len_speech, offset):
+    """the wrap / crop branch of mix_noise (:108-119) with the offset the host drew."""
+    len_noise = noise.shape[-1]
+    if len_noise < len_speech:
+        return np.pad(noise, [(0, 0), (offset, len_speech - len_noise - offset)], mode="wrap")
+    if len_noise > len_speech:
+        return noise[:, offset:offset + len_speech]
+    return noise
+
+
+def mix_noise(speech, noise, snr, offset=0):
+    noise = align_noise(noise, speech.shape[-1], offset)
+    ps = (speech[detect_non_silence(speech)] ** 2).mean()
+    pn = (noise[detect_non_silence(noise)] ** 2).mean()
+    scale = 10 ** (-snr / 20) * np.sqrt(ps) / np.sqrt(max(pn, 1e-10))
+    noise = scale * noise
+    return speech + noise, noise
+
+
+def add_reverberation(speech, rir):
+    return scipy.signal.convolve(speech, rir, mode="full")[:, :speech.shape[1]]
+
+
+def filter_designs(fs, cutoff=70, transition_width=15, attenuation=10):
+    nyq = 0.5 * fs
+    stop = cutoff - transition_width
+    if stop < 0:
+        stop, transition_width = 0, cutoff
+    norm_stop, norm_pass = stop / nyq, min(cutoff, nyq) / nyq
+    numtaps = max(int((attenuation * fs) / (22 * transition_width)), 101)
+    if numtaps % 2 == 0:
+        numtaps += 1
+    return scipy.signal.firwin2(numtaps, freq=[0, norm_stop, norm_pass, 1.0], gain=[0, 0, 1, 1])
+
+
+def high_pass(speech, fs):
+    return scipy.signal.filtfilt(filter_designs(fs), 1.0, speech.flatten()).reshape(speech.shape)
+
+
+def clipping(speech, min_quantile=0.0, max_quantile=0.9):
+    mn, mx = np.quantile(speech, np.array([min_quantile, max_quantile]), axis=-1, keepdims=False)
+    return np.stack([np.clip(speech[i], mn[i], mx[i]) for i in range(speech.shape[0])], axis=0)
+
+
+def packet_loss(speech, fs, indices, packet_duration_ms=20):
+    speech = speech.copy()
+    for idx in indices:
+        speech[:, idx * packet_duration_ms * fs // 1000:(idx + 1) * packet_duration_ms * fs // 1000] = 0
+    return speech
+
+
+def joint_peak_normalise(speech, noisy, noise, target=0.9):
+    scale = target / max(np.max(np.abs(noisy)), np.max(np.abs(speech)), np.max(np.abs(noise)), 1e-6)
+    return speech * scale, noisy * scale, noise * scale

@@ -1,0 +1,134 @@
+"""GPU parity: on-device dynamic mixing kernels (csrc/mix.hip) vs the float64 numpy / scipy oracle (oracle/mix_ref.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _signals(B, L, seed, silent=True):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, L))
+    for b in range(B):                      # one-pole low-pass + envelope with near-silent stretches
+        for i in range(1, L):
+            x[b, i] = 0.9 * x[b, i - 1] + x[b, i]
+    if silent:
+        env = 0.55 + 0.45 * np.sin(2 * np.pi * 3 * np.arange(L) / L + rng.uniform(0, 6, (B, 1)))
+        env[:, :L // 7] *= 1e-3
+        x = x * env
+    return (x / np.abs(x).max(-1, keepdims=True) * 0.8).astype(np.float32)
+
+
+def test_nonsilence_power_and_mix_noise(lib):
+    from urgent2026_challenge_track1_amd import mixing
+    from oracle import mix_ref
+    B, L = 5, 20000
+    sp = _signals(B, L, 1)
+    lens = [20000, 19999, 1536, 1000, 17000]                       # < frame_length, exact frame multiples, ragged
+    nlens = [9000, 30000, 1536, 400, 17000]
+    offs = [3000, 1234, 0, 77, 0]
+    snr = [5.0, -3.5, 20.0, 0.0, 12.25]
+    nz = _signals(B, 30000, 2, silent=False)
+    for b in range(B):
+        sp[b, lens[b]:] = 0
+    noisy, noise = mixing.mix_noise(torch.tensor(sp).cuda(), torch.tensor(nz).cuda(), nlens, lens, snr, torch.tensor(offs))
+    pw = mixing.nonsilence_power(torch.tensor(sp).cuda(), lens).cpu().numpy()
+    for b in range(B):
+        s64 = sp[b:b + 1, :lens[b]].astype(np.float64)
+        ref_p = (s64[mix_ref.detect_non_silence(s64)] ** 2).mean()
+        assert abs(pw[b] - ref_p) <= 1e-12 * max(1.0, ref_p), (b, pw[b], ref_p)
+        rn, rz = mix_ref.mix_noise(s64, nz[b:b + 1, :nlens[b]].astype(np.float64), snr[b], offs[b])
+        assert np.abs(noisy[b, :lens[b]].cpu().numpy() - rn[0]).max() <= 2e-6 * max(1.0, np.abs(rn).max())
+        assert np.abs(noise[b, :lens[b]].cpu().numpy() - rz[0]).max() <= 2e-6 * max(1.0, np.abs(rz).max())
+        assert torch.all(noisy[b, lens[b]:] == 0)
+
+
+def test_reverberation_and_high_pass(lib):
+    from urgent2026_challenge_track1_amd import mixing
+    from oracle import mix_ref
+    B, L = 3, 24000
+    sp = _signals(B, L, 3)
+    lens = [24000, 18001, 9000]
+    rng = np.random.default_rng(4)
+    rl = [3000, 700, 12000]                                         # one RIR longer than the 1024-tap LDS chunk x several
+    rir = np.zeros((B, 12000), np.float32)
+    for b in range(B):
+        rir[b, :rl[b]] = (rng.standard_normal(rl[b]) * np.exp(-np.arange(rl[b]) / (rl[b] / 6))).astype(np.float32)
+        sp[b, lens[b]:] = 0
+    out = mixing.add_reverberation(torch.tensor(sp).cuda(), lens, torch.tensor(rir).cuda(), rl).cpu().numpy()
+    for b in range(B):
+        ref = mix_ref.add_reverberation(sp[b:b + 1, :lens[b]].astype(np.float64), rir[b:b + 1, :rl[b]].astype(np.float64))
+        assert np.abs(out[b, :lens[b]] - ref[0]).max() <= 2e-6 * np.abs(ref).max(), b
+    for fs in (8000, 16000):
+        hp = mixing.high_pass(torch.tensor(sp).cuda(), lens, fs).cpu().numpy()
+        for b in range(B):
+            ref = mix_ref.high_pass(sp[b:b + 1, :lens[b]].astype(np.float64), fs)
+            assert np.abs(hp[b, :lens[b]] - ref[0]).max() <= 5e-6 * max(1.0, np.abs(ref).max()), (fs, b)
+            assert np.all(hp[b, lens[b]:] == 0)
+    np.testing.assert_allclose(mixing.filter_designs(16000), mix_ref.filter_designs(16000), rtol=0, atol=0)
+
+
+def test_clipping_packet_loss_peak_norm(lib):
+    from urgent2026_challenge_track1_amd import mixing
+    from oracle import mix_ref
+    B, L, fs = 4, 48000, 16000
+    sp = _signals(B, L, 5)
+    lens = [48000, 31111, 5, 20000]
+    qmin, qmax = [0.0, 0.05, 0.1, 0.02], [0.9, 0.95, 0.75, 1.0]
+    for b in range(B):
+        sp[b, lens[b]:] = 0
+    x = torch.tensor(sp).cuda()
+    bounds = mixing.clipping(x, lens, qmin, qmax).cpu().numpy()
+    for b in range(B):
+        s64 = sp[b:b + 1, :lens[b]].astype(np.float64)
+        ref = mix_ref.clipping(s64, qmin[b], qmax[b])
+        mn, mx = np.quantile(s64, [qmin[b], qmax[b]], axis=-1)
+        assert abs(bounds[b, 0] - mn[0]) <= 1e-6 and abs(bounds[b, 1] - mx[0]) <= 1e-6, (b, bounds[b], mn, mx)
+        assert np.abs(x[b, :lens[b]].cpu().numpy() - ref[0]).max() <= 1e-6
+    idx = [[0, 3, 7], [], [1], [149]]
+    y = torch.tensor(sp).cuda()
+    mixing.packet_loss(y, fs, idx)
+    for b in range(B):
+        assert np.array_equal(y[b].cpu().numpy(), mix_ref.packet_loss(sp[b:b + 1], fs, idx[b])[0])
+    a, n_, z = torch.tensor(sp).cuda(), torch.tensor(sp * 1.7).cuda(), torch.tensor(sp * 0.3).cuda()
+    mixing.joint_peak_normalise(a, n_, z)
+    for b in range(B):
+        ra, rn, rz = mix_ref.joint_peak_normalise(sp[b].astype(np.float64), sp[b].astype(np.float64) * 1.7, sp[b].astype(np.float64) * 0.3)
+        assert np.abs(n_[b].cpu().numpy() - rn).max() <= 1e-6 and np.abs(a[b].cpu().numpy() - ra).max() <= 1e-6
+        assert abs(float(n_[b].abs().max()) - 0.9) <= 1e-6
+
+
+def test_simulate_batch_matches_oracle_chain(lib):
+    """the reference's per-utterance order (high-pass, reverberation + early-RIR target, additive noise, clipping,
+    packet loss, joint peak normalisation) on a ragged batch."""
+    from urgent2026_challenge_track1_amd import mixing
+    from oracle import mix_ref
+    B, L, fs = 3, 20000, 8000
+    sp, nz = _signals(B, L, 7), _signals(B, 26000, 8, silent=False)
+    lens, nlens, offs, snr = [20000, 15000, 12001], [26000, 4000, 12001], [1500, 321, 0], [3.0, 10.0, -2.0]
+    rng = np.random.default_rng(9)
+    rl = [900, 2500, 400]
+    rir = np.zeros((B, 2500), np.float32)
+    for b in range(B):
+        sp[b, lens[b]:] = 0
+        h = rng.standard_normal(rl[b]) * np.exp(-np.arange(rl[b]) / (rl[b] / 5))
+        h[:20] *= 0.01
+        rir[b, :rl[b]] = h
+    stops = [mixing.early_rir_stop(rir[b, :rl[b]], fs) for b in range(B)]
+    qmin, qmax = [0.02, 0.0, 0.1], [0.95, 0.9, 0.99]
+    pidx = [[1, 5], [], [0, 2, 30]]
+    s, n, fs_out, z = mixing.simulate_batch(torch.tensor(sp).cuda(), lens, torch.tensor(nz).cuda(), nlens, fs, snr, torch.tensor(offs),
+                                            rir=torch.tensor(rir).cuda(), rir_lens=rl, rir_early_stops=stops,
+                                            clip_quantiles=(qmin, qmax), packet_loss_indices=pidx)
+    assert fs_out == fs
+    for b in range(B):
+        x = mix_ref.high_pass(sp[b:b + 1, :lens[b]].astype(np.float64), fs)
+        h = rir[b:b + 1, :rl[b]].astype(np.float64)
+        he = h.copy()
+        he[:, stops[b]:] = 0
+        noisy, clean = mix_ref.add_reverberation(x, h), mix_ref.add_reverberation(x, he)
+        noisy, noise = mix_ref.mix_noise(noisy, nz[b:b + 1, :nlens[b]].astype(np.float64), snr[b], offs[b])
+        noisy = mix_ref.packet_loss(mix_ref.clipping(noisy, qmin[b], qmax[b]), fs, pidx[b])
+        clean, noisy, noise = mix_ref.joint_peak_normalise(clean, noisy, noise)
+        for got, ref in ((s, clean), (n, noisy), (z, noise)):
+            assert np.abs(got[b, :lens[b]].cpu().numpy() - ref[0]).max() <= 2e-5, b

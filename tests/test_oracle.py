@@ -131,3 +131,25 @@ def test_euler_schedule():
     ts, steps = flow_ref.euler_timesteps(1.0, 0.03, 15)
     assert abs(float(ts[0]) - 1.0) < 1e-7 and abs(float(ts[-1]) - 0.03) < 1e-7
     assert abs(steps[-1] - 0.03) < 1e-7 and abs(sum(steps) - 1.0) < 1e-6     # last step integrates down to t = 0
+
+
+def test_mix_oracle_detect_non_silence_and_scipy_calls():
+    """a20 oracle: the espnet detect_non_silence restatement behaves as SURVEY A.5 states; the rest is scipy / numpy."""
+    import numpy as np
+    from oracle import mix_ref
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 5000))
+    x[:, :2048] *= 1e-3                                     # two silent frames' worth
+    m = mix_ref.detect_non_silence(x)
+    assert m.shape == x.shape and m.dtype == bool
+    assert not m[0, :1024].any() and m[0, 3000:].all()
+    assert mix_ref.detect_non_silence(x[:, :1000]).all()   # shorter than one frame: everything counts
+    assert mix_ref.detect_non_silence(np.zeros((1, 4096))).all()
+    # SNR of the mix equals the request when measured with the same power rule
+    sp, nz = rng.standard_normal((1, 8000)), rng.standard_normal((1, 3000))
+    noisy, noise = mix_ref.mix_noise(sp, nz, 7.0, offset=100)
+    ps = (sp[mix_ref.detect_non_silence(sp)] ** 2).mean()
+    pn = (noise[mix_ref.detect_non_silence(noise)] ** 2).mean()
+    assert abs(10 * np.log10(ps / pn) - 7.0) < 1e-9 and np.allclose(noisy, sp + noise)
+    assert noise.shape == sp.shape and np.allclose(noise[0, 100:3100] / noise[0, 100], nz[0] / nz[0, 0])
+    assert len(mix_ref.filter_designs(48000)) == 1455 and len(mix_ref.filter_designs(8000)) == 243

@@ -1,0 +1,150 @@
+"""On-device dynamic mixing: the batched counterpart of the reference's per-utterance simulator functions
+(``simulation/simulate_data_from_param.py``: ``mix_noise`` :95-126, ``add_reverberation`` :220-230, high-pass :29-56,461,
+``clipping`` :255-276, ``packet_loss`` :333-341, final peak normalisation :576-584) on the HIP kernels of csrc/mix.hip.
+
+Signals are f32 ``[B, L]`` CUDA tensors with per-utterance ``lens`` (int32 CUDA); the random draws of the recipe (SNR,
+noise offset, packet indices, quantiles: ``dataset.py:232-278``) stay on the host and come in as small tensors.  The
+FIR taps of the high-pass are designed on the host with the same ``scipy.signal.firwin2`` call as the reference.
+"""
+import functools
+
+import torch
+
+from . import ops
+from ._lib import call
+from .ops import stream_ptr
+
+
+def _i32(v, dev):
+    return torch.as_tensor(v, dtype=torch.int32).to(dev).contiguous()
+
+
+def _f32(v, dev):
+    return torch.as_tensor(v, dtype=torch.float32).to(dev).contiguous()
+
+
+def nonsilence_power(x, lens):
+    ops.require_cuda(x)
+    B, L = x.shape
+    hop = torch.empty(B * ((L + 511) // 512), dtype=torch.float64, device=x.device)
+    power = torch.empty(B, dtype=torch.float64, device=x.device)
+    call("nonsilence_power", x, _i32(lens, x.device), B, x.stride(0), 0.01, hop, power, stream_ptr())
+    return power
+
+
+def mix_noise(speech, noise_raw, noise_lens, lens, snr_db, offsets=None):
+    """-> (noisy, scaled noise); ``offsets`` = the ``rng.integers`` draw of :109/:117 per utterance (0 if equal lengths)."""
+    ops.require_cuda(speech, noise_raw)
+    B, L = speech.shape
+    dev = speech.device
+    offsets = torch.zeros(B, dtype=torch.int32) if offsets is None else offsets
+    noise, noisy = torch.empty_like(speech), torch.empty_like(speech)
+    scratch = torch.empty(B * ((L + 511) // 512) + 2 * B, dtype=torch.float64, device=dev)
+    call("mix_noise", speech, noise_raw, _i32(noise_lens, dev), noise_raw.stride(0), _i32(lens, dev), _i32(offsets, dev),
+         _f32(snr_db, dev), B, speech.stride(0), noise, noisy, scratch, stream_ptr())
+    return noisy, noise
+
+
+def add_reverberation(speech, lens, rir, rir_lens):
+    """one RIR per utterance, ``scipy.signal.convolve(..., "full")[:, :L]``."""
+    ops.require_cuda(speech, rir)
+    out = torch.empty_like(speech)
+    call("fir_full", speech, _i32(lens, speech.device), speech.shape[0], speech.stride(0), rir, _i32(rir_lens, rir.device),
+         rir.stride(0), 1, out, stream_ptr())
+    return out
+
+
+@functools.lru_cache(maxsize=None)
+def filter_designs(fs, cutoff=70, transition_width=15, attenuation=10):
+    """high-pass FIR taps exactly as ``filter_designs`` (:25-54): same firwin2 call, host side."""
+    from scipy.signal import firwin2
+    nyq = 0.5 * fs
+    stop = cutoff - transition_width
+    if stop < 0:
+        stop, transition_width = 0, cutoff
+    numtaps = max(int((attenuation * fs) / (22 * transition_width)), 101)
+    if numtaps % 2 == 0:
+        numtaps += 1
+    return firwin2(numtaps, freq=[0, stop / nyq, min(cutoff, nyq) / nyq, 1.0], gain=[0, 0, 1, 1])
+
+
+def high_pass(speech, lens, fs):
+    """``filtfilt(high_pass_taps[fs], 1.0, x)`` (:461)."""
+    ops.require_cuda(speech)
+    B, L = speech.shape
+    dev = speech.device
+    taps = filter_designs(int(fs))
+    nt = len(taps)
+    lds = L + 7 * nt
+    scratch = torch.empty(2 * B * lds, dtype=torch.float32, device=dev)
+    out = torch.empty_like(speech)
+    call("filtfilt_fir", speech, _i32(lens, dev), B, speech.stride(0), _f32(taps, dev), _i32([nt], dev), nt, out, scratch, lds,
+         stream_ptr())
+    return out
+
+
+def clipping(speech, lens, min_quantile, max_quantile):
+    """in place; returns the per-utterance (min, max) thresholds."""
+    ops.require_cuda(speech)
+    B = speech.shape[0]
+    dev = speech.device
+    bounds = torch.empty(B, 2, dtype=torch.float32, device=dev)
+    call("quantile_clip", speech, _i32(lens, dev), B, speech.stride(0), _f32(min_quantile, dev), _f32(max_quantile, dev), bounds,
+         stream_ptr())
+    return bounds
+
+
+def packet_loss(speech, fs, packet_loss_indices, packet_duration_ms=20):
+    """in place; ``packet_loss_indices`` = one list of packet numbers per utterance (:337-339)."""
+    ops.require_cuda(speech)
+    segs = [[b, idx * packet_duration_ms * fs // 1000, (idx + 1) * packet_duration_ms * fs // 1000]
+            for b, lst in enumerate(packet_loss_indices) for idx in lst]
+    if segs:
+        call("zero_segments", speech, speech.stride(0), _i32(segs, speech.device), len(segs), stream_ptr())
+    return speech
+
+
+def joint_peak_normalise(speech, noisy, noise, target=0.9):
+    """in place on all three (:576-584)."""
+    ops.require_cuda(speech, noisy, noise)
+    B = speech.shape[0]
+    scratch = torch.empty(B, dtype=torch.int32, device=speech.device)
+    call("joint_peak_scale", speech, noisy, noise, B, speech.stride(0), float(target), scratch, stream_ptr())
+    return speech, noisy, noise
+
+
+def early_rir_stop(rir, fs, early_rir_sec=0.05, level_ratio=1e-1):
+    """index after which ``estimate_early_rir`` (simulation/rir_utils.py:4-20,24-61) zeroes a single-channel RIR: first
+    sample above ``level_ratio * max|h|`` (searched up to the maximum) + ``early_rir_sec * fs``.  Host side: RIRs are
+    read on the host and this is one argmax per file."""
+    import numpy as np
+    h = np.abs(np.asarray(rir).reshape(-1))
+    mi = int(np.argmax(h))
+    start = int(np.argmax(h[:mi + 1] > level_ratio * h[mi]))
+    return start + int(early_rir_sec * fs)
+
+
+def simulate_batch(speech, lens, noise_raw, noise_lens, fs, snr_db, noise_offsets=None, rir=None, rir_lens=None,
+                   rir_early_stops=None, highpass=True, clip_quantiles=None, packet_loss_indices=None):
+    """The supported subset of ``process_one_sample`` (simulate_data_from_param.py:440-590) for a batch that shares
+    ``fs``: high-pass(speech) -> [reverberate: noisy = speech * rir, speech = speech * early rir] -> additive noise at
+    ``snr_db`` -> clipping / packet loss on the noisy signal -> joint peak normalisation to 0.9.
+    ``clip_quantiles`` = (min [B], max [B]) with NaN rows meaning "no clipping" is not supported: pass None to skip;
+    codec / bandwidth-limitation / wind-noise augmentations need ffmpeg / librosa and stay out of scope.
+    -> (speech, noisy, fs) like the reference's on-the-fly return (:586-587), plus the scaled noise."""
+    if highpass:
+        speech = high_pass(speech, lens, fs)
+    noisy = speech
+    if rir is not None:
+        noisy = add_reverberation(speech, lens, rir, rir_lens)
+        early = rir_lens if rir_early_stops is None else [min(int(a), int(b)) for a, b in zip(rir_lens, rir_early_stops)]
+        speech = add_reverberation(speech, lens, rir, early)
+    noisy, noise = mix_noise(noisy, noise_raw, noise_lens, lens, snr_db, noise_offsets)
+    if clip_quantiles is not None:
+        clipping(noisy, lens, clip_quantiles[0], clip_quantiles[1])
+    if packet_loss_indices is not None:
+        packet_loss(noisy, fs, packet_loss_indices)
+    if speech.data_ptr() == noisy.data_ptr():
+        speech = speech.clone()
+    joint_peak_normalise(speech, noisy, noise)
+    return speech, noisy, fs, noise
