@@ -154,6 +154,15 @@ int urse_lstm_wide_supported(int H, int Hp);
 int urse_lstm_pack_blocks(const float* whh, void* out, int H, int Hp, void* stream);
 int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_t ldh, float* c, int H, int Hp,
                        int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save, void* stream);
+/* Split BPTT (bf16) for few, long sequences (time path): 2-3 workgroups share 32 sequences and split the reduction of
+ * the recurrent product; f32 partial sums are exchanged through `xbuf` (zeroed by the call) with the tag-in-data
+ * hand-off (step parity in the mantissa LSB).  Arguments as urse_lstm_bidir_bwd (whhT from urse_lstm_pack).
+ * urse_lstm_split_plan -> {nsplit, clusters per direction, xbuf f32 elements}, < 0 if unsupported (too many sequences
+ * for all workgroups to be co-resident, H % 8 != 0, ...).  err_flag: uint32 set to 1 if a hand-off timed out. */
+int urse_lstm_split_plan(int H, int n_seq, int64_t* plan);
+int urse_lstm_split_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT, void* xbuf,
+                        void* err_flag, int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride,
+                        void* stream);
 /* Backward through time.  dh [M, ldd>=2H] = gradient w.r.t. hout; gates: in = saved activations,
  * out = gradient w.r.t. the gate pre-activations (same interleaved layout); whhT = fragment-ordered
  * transposed recurrent weights from urse_lstm_pack. */

@@ -4,12 +4,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
-variants = {"base": [], "nost": ["-DABL_NO_ST"], "nold": ["-DABL_NO_LD"]}
+variants = {"base": [], "nowait": ["-DSABL_NO_WAIT"], "nowait_nopub": ["-DSABL_NO_WAIT", "-DSABL_NO_PUB"], "nowait_now": ["-DSABL_NO_WAIT", "-DSABL_NO_W"], "nowait_nost": ["-DSABL_NO_WAIT", "-DSABL_NO_ST"], "all": ["-DSABL_NO_WAIT", "-DSABL_NO_W", "-DSABL_NO_PUB", "-DSABL_NO_ST"]}
 libs = {}
 for name, fl in variants.items():
     so = "/tmp/abl_%s.so" % name
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", *fl,
-                           os.path.join(CS, "lstm.hip"), os.path.join(CS, "lstm_wide.hip"), os.path.join(CS, "api.hip"), "-o", so])
+                           os.path.join(CS, "lstm.hip"), os.path.join(CS, "lstm_wide.hip"), os.path.join(CS, "lstm_split.hip"), os.path.join(CS, "api.hip"), "-o", so])
     libs[name] = ctypes.CDLL(so)
 B, T, K, N = 32, 401, 34, 196
 H, Hp = 2 * N, 416
@@ -39,9 +39,18 @@ def fwd_wide(lib, path, rt):
     else: a = (B * T, K, 1, K, 1)
     return lib.urse_lstm_wide_fwd(P(gx.data_ptr()), ctypes.c_int64(8 * H), P(whhb.data_ptr()), P(hout.data_ptr()), ctypes.c_int64(800),
         P(c.data_ptr()), H, Hp, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 1, P(st))
-for fn, fname in ((fwd_wide, "fwd_wide"),):
-    for path in ("time", "band"):
-        for rt in ((1,) if fname != 'bwd' else (1, 18)):
+plan = (ctypes.c_int64 * 3)()
+assert libs["base"].urse_lstm_split_plan(H, B * K, plan) == 0
+print("split plan", list(plan))
+xbuf = torch.empty(plan[2], device=dev, dtype=torch.float32)
+errf = torch.zeros(1, device=dev, dtype=torch.int32)
+def bwd_split(lib, path, rt):
+    a = (B * K, T, K, T * K, K)
+    return lib.urse_lstm_split_bwd(P(dh.data_ptr()), ctypes.c_int64(800), P(gx.data_ptr()), ctypes.c_int64(8 * H), P(c.data_ptr()),
+        P(whhT.data_ptr()), P(xbuf.data_ptr()), P(errf.data_ptr()), H, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), P(st))
+for fn, fname in ((bwd_split, "bwd_split"),):
+    for path in (("time",) if fname == "bwd_split" else ("time", "band")):
+        for rt in (1,):
             res = []
             for name, lib in libs.items():
                 assert fn(lib, path, rt) == 0

@@ -191,3 +191,30 @@ def test_bptt_32_row_variant_matches_16_row_variant(lib, path):
     d = (g1.float() - g2.float()).abs()
     scale = g1.float().abs().max().item()
     assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, (d.max().item(), d.mean().item(), scale)
+
+
+@pytest.mark.parametrize("B,T,K,N", [(2, 9, 20, 48), (3, 7, 34, 196), (2, 40, 34, 196), (5, 25, 33, 196)])
+def test_split_bptt_matches_streaming_kernel(lib, B, T, K, N):
+    """time-path BPTT split over 2-3 workgroups per 32 sequences (f32 partial sums exchanged with tagged data) vs the
+    one-workgroup streaming kernel: same bf16 products, partial sums lose their LSB and are added in a different order."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(5)
+    H, dtype, dev = 2 * N, torch.bfloat16, "cuda"
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    M = B * T * K
+    sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+    assert ops.lstm_split_plan(H, sm["n_seq"]) is not None
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dtype)
+    gx = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    hout, c = ops.lstm_fwd(gx, pk["whh"], H, pk["Hp"], **sm)
+    dh = ops.pack2d(torch.randn(M, 2 * H, device=dev), M, hout.shape[1], dtype)
+    g1, g2 = gx.clone(), gx.clone()
+    ops.lstm_bwd(dh, g1, c, pk["whhT"], H, **sm)
+    _, err = ops.lstm_bwd_split(dh, g2, c, pk["whhT"], H, **sm)
+    assert int(err.item()) == 0
+    d = (g1.float() - g2.float()).abs()
+    scale = g1.float().abs().max().item()
+    assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, (d.max().item(), d.mean().item(), scale)

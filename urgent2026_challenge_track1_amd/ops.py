@@ -296,6 +296,34 @@ def lstm_bwd_cluster(dh, gates, c, whhTq, H, Hp, n_seq, seq_len, inner, outer, s
     return gates, err
 
 
+# split BPTT (csrc/lstm_split.hip): correct (tests/test_lstm_gpu.py) but not faster than the streaming kernel yet (7.0-8.9 vs
+# 7.2 ms per time-path launch): the serial phases of a step (hand-off wait, dgates, barrier chain, publish) cost 8 us with
+# the weight stream switched off (scripts/abl_lstm.py).  Opt-in until it wins.
+USE_SPLIT_LSTM_BWD = os.environ.get("URSE_LSTM_SPLIT_BWD", "0") == "1"
+
+
+def lstm_split_plan(H, n_seq):
+    """None if the split BPTT kernel does not support this shape."""
+    import ctypes
+    plan = (ctypes.c_int64 * 3)()
+    if _lib.load().urse_lstm_split_plan(H, n_seq, plan) != 0:
+        return None
+    return list(plan)
+
+
+def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
+    """split BPTT (bf16, time path): gates (saved activations) is overwritten with d(pre-activations)."""
+    plan = lstm_split_plan(H, n_seq)
+    dev = gates.device
+    key = ("split", dev, H, n_seq)
+    if key not in _cluster_ws:
+        _cluster_ws[key] = (torch.empty(plan[2], device=dev, dtype=torch.float32), torch.zeros(1, device=dev, dtype=torch.int32))
+    xbuf, err = _cluster_ws[key]
+    timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_split_bwd", dh, dh.stride(0), gates, gates.stride(0), c,
+               whhT, xbuf, err, H, n_seq, seq_len, inner, outer, stride, stream_ptr())
+    return gates, err
+
+
 def lstm_bwd(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride, rows16=0):
     """gates (saved activations) is overwritten with d(pre-activations)."""
     timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_bidir_bwd", dh, dh.stride(0), gates,
