@@ -115,6 +115,7 @@ class BSRNNCore(nn.Module):
         self._packed_version = -1
         self.param_version = 0          # bumped by the optimizer after every update
         self.grad_ready_hook = None     # callable(tag) fired when a parameter group's grads are final
+        self._deferred, self._inflight, self._side = [], None, None     # weight-gradient GEMMs parked for the side stream
 
     # ------------------------------------------------------------------------------------------
     # parameter containers (espnet names) of the parts that differ between the discriminative and the flow DNN
@@ -385,6 +386,7 @@ class BSRNNCore(nn.Module):
         dt, dev, N = self.compute_dtype, spec.device, self.N
         K, pk, Np = tb["K"], self._packed, self._dims["Np"]
         M = B * T
+        self._flush_deferred_wgrads()            # the dual-path layers are behind us: nothing left to hide them under
         if dzT is None:
             dzT, width = ops.pack2d(dz.reshape(M * K, N), M * K, Np, dt), Np
         dxnb = torch.empty(M, tb["ldx"], dtype=torch.float32, device=dev)
@@ -448,9 +450,12 @@ class BSRNNCore(nn.Module):
         doT = ops.pack2d(dout2, M, d["Np"], dt)
         dh = torch.empty(M, d["ld2H"], dtype=dt, device=skip.device)
         ops.gemm_nt(doT, pk[p + "wfcT"], out=dh, N=2 * H)
-        ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N,
-                    No=2 * H)
         sm = self._seqmap(path, B, T, K)
+        overlap = ops.TN_OVERLAP and skip.is_cuda
+        if overlap and path == "t":
+            # the time path's BPTT occupies 136 of the 256 CUs for ~7 ms: the weight-gradient GEMMs deferred by the
+            # previous half layers run beside it on a second stream (they only feed the optimizer / all-reduce)
+            self._run_deferred_wgrads(skip.device)
         if ops.USE_CLUSTER_LSTM_BWD and pk.get(p + "whhTq") is not None and \
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
             dg, self._cluster_err = ops.lstm_bwd_cluster(dh, gates, c, pk[p + "whhTq"], H, d["Hp"], **sm)
@@ -458,19 +463,66 @@ class BSRNNCore(nn.Module):
             dg, self._cluster_err = ops.lstm_bwd_split(dh, gates, c, pk[p + "whhT"], H, **sm)
         else:
             dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, **sm)   # dgates, gate-interleaved columns
-        gb = self._g(p + "bih", 8 * H)
-        ops.gemm_tn(dg, xn, self._g(p + "wih", 8 * H * N).view(8 * H, N), colsum=gb, Mo=8 * H, No=N, perm_h=H)
-        call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())
+        if overlap and path == "t":
+            self._join_deferred_wgrads()
         st, L = sm["stride"], sm["seq_len"]
-        for dr, (sh, inv) in enumerate(((-st, 0), (st, L - 1))):
-            ops.gemm_tn(dg[:, dr * 4 * H:(dr + 1) * 4 * H], hout[:, dr * H:(dr + 1) * H],
-                        self._g(p + "whh", 4 * H * H, dr * 4 * H * H).view(4 * H, H), Mo=4 * H, No=H, shift=sh,
-                        inner=st, period=L, invalid_step=inv, perm_h=H)
+        tag = "l%d%s" % (l, path)
+
+        def wgrads():
+            ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N, No=2 * H)
+            gb = self._g(p + "bih", 8 * H)
+            ops.gemm_tn(dg, xn, self._g(p + "wih", 8 * H * N).view(8 * H, N), colsum=gb, Mo=8 * H, No=N, perm_h=H)
+            call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())
+            for dr, (sh, inv) in enumerate(((-st, 0), (st, L - 1))):
+                ops.gemm_tn(dg[:, dr * 4 * H:(dr + 1) * 4 * H], hout[:, dr * H:(dr + 1) * H],
+                            self._g(p + "whh", 4 * H * H, dr * 4 * H * H).view(4 * H, H), Mo=4 * H, No=H, shift=sh,
+                            inner=st, period=L, invalid_step=inv, perm_h=H)
+
+        if overlap:
+            self._deferred.append((wgrads, tag))       # the closure keeps doT / hout / dg / xn alive until it has run
+        else:
+            wgrads()
         dxn = ops.gemm_nt(dg, pk[p + "wihT"], out_dtype=torch.float32, N=N)
         dskip = ops.groupnorm_bwd(skip, dxn, stats, self._p(p + "gamma", N), dout, self._g(p + "gamma", N),
                                   self._g(p + "beta", N), B, T, 1, K * N, N, 0, GN_EPS)
-        self._ready("l%d%s" % (l, path))
+        if not overlap:
+            self._ready(tag)
         return dskip
+
+    # deferred weight-gradient GEMMs (see dualpath_bwd) --------------------------------------------------------------
+    def _run_deferred_wgrads(self, device):
+        """launch everything deferred so far on the side stream, gated on the compute stream's current position."""
+        if not self._deferred:
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=device)
+        start = torch.cuda.Event()
+        start.record(torch.cuda.current_stream())
+        self._side.wait_event(start)
+        with torch.cuda.stream(self._side):
+            for fn, _ in self._deferred:
+                fn()
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._inflight = (done, self._deferred)
+        self._deferred = []
+
+    def _join_deferred_wgrads(self):
+        if self._inflight is None:
+            return
+        done, items = self._inflight
+        torch.cuda.current_stream().wait_event(done)
+        self._inflight = None
+        for _, tag in items:                             # gradients final: tell the reducer (and drop the closures)
+            self._ready(tag)
+
+    def _flush_deferred_wgrads(self):
+        """end of backward: whatever is still deferred runs on the compute stream."""
+        self._join_deferred_wgrads()
+        items, self._deferred = self._deferred, []
+        for fn, tag in items:
+            fn()
+            self._ready(tag)
 
     # ------------------------------------------------------------------------------------------
     # mask decoder + complex mask apply
@@ -564,6 +616,7 @@ class BSRNNCore(nn.Module):
         """spec_ri f32 [B, T, F, 2] -> masked spectrum f32 [B, T, F, 2] (num_spk = 1 squeezed)."""
         ops.require_cuda(spec_ri)
         self._prepare()
+        self._deferred, self._inflight = [], None     # nothing survives an aborted backward
         spec_ri = spec_ri.contiguous().float()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not train:
