@@ -3,7 +3,7 @@ import ctypes, os, subprocess, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
-variants = {"base": [], "noepi": ["-DNABL_NO_EPI"], "nogst": ["-DNABL_NO_GST"], "ntstore": ["-DNABL_NT_STORE"]}
+variants = {"base": [], "direct": ["-DURSE_NT_DIRECT_EPILOGUE"]}
 libs = {}
 for name, fl in variants.items():
     so = "/tmp/ablg_%s.so" % name

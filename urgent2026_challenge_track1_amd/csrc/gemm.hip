@@ -646,6 +646,7 @@ __global__ void __launch_bounds__(BMX * 2) gemm_nt_dma_kernel(GemmDesc d) {
   TO* C = reinterpret_cast<TO*>(d.C);
   const bool vec_ok = ((d.ldc * OS) % 16 == 0) && ((reinterpret_cast<uintptr_t>(d.C) % 16) == 0) &&
                       (!d.resid || ACT == 2 || (((d.ldr * 4) % 16 == 0) && (reinterpret_cast<uintptr_t>(d.resid) % 16) == 0));
+  // (storing straight from the accumulators, 8/16 B per lane, measured 2.3x slower than this staged epilogue)
 #pragma unroll 1
   for (int pass = 0; pass < BMX / RPP; ++pass) {
     if (pass > 0) __syncthreads();
