@@ -393,6 +393,9 @@ using namespace urse;
 // transposed ds_read_b64_tr_b16 fragment reads need is applied to the per-lane SOURCE column: image segment s (32 B)
 // of row r holds global segment s ^ (r & 7); masked rows / columns read a zero page instead (DMA cannot zero-fill).
 __device__ uint4 g_tn_zero_page[64];
+// perm_h value that selects the TRANSPOSED-output mode of the big TN kernel: C[No, Mo] += (A^T B)^T and `colsum` sums
+// the columns of B.  Lets a wide-and-short gradient (fc weight: 196 x 784) be computed as its tall transpose.
+constexpr long TN_TRANSPOSED = -(1L << 40);
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to lds_dst + lane*16.  Issued as inline
 // asm on purpose: hipcc (ROCm 7.2) drains every outstanding DMA (vmcnt(0)) in front of the next LDS read it can see,
@@ -463,7 +466,12 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   f32x4_t accs[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) accs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = (p.colsum != nullptr) && tile_n == 0 && wn == 0;
+  const bool trans = p.perm_h == TN_TRANSPOSED;
+  const bool do_colsum = (p.colsum != nullptr) && !trans && tile_n == 0 && wn == 0;
+  const bool do_colsum_b = (p.colsum != nullptr) && trans && tile_m == 0 && wm == 0;
+  f32x4_t accb[NTW];
+#pragma unroll
+  for (int jj = 0; jj < NTW; ++jj) accb[jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const short8_t ones = short8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
@@ -502,6 +510,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
       const short8_t b = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b, acc[i][j]);
+      if (do_colsum_b) accb[j] = Frag<bf16_t>::mma(ones, b, accb[j]);
     }
     if (do_colsum) {
 #pragma unroll
@@ -519,8 +528,18 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (row < p.Mo) atomicAdd(p.C + tn_perm(row, p.perm_h) * p.ldc + col, acc[i][j][r]);
+        if (row < p.Mo) {
+          if (trans) atomicAdd(p.C + col * p.ldc + row, acc[i][j][r]);
+          else atomicAdd(p.C + tn_perm(row, p.perm_h) * p.ldc + col, acc[i][j][r]);
+        }
       }
+  }
+  if (do_colsum_b && (lane >> 4) == 0) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const long col = n0 + (wn * NTW + j) * 16 + (lane & 15);
+      if (col < p.No) atomicAdd(p.colsum + col, accb[j][0]);
+    }
   }
   if (do_colsum && (lane & 15) == 0) {
 #pragma unroll
@@ -811,6 +830,29 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   p.shift = shift; p.inner = inner > 0 ? inner : 1; p.period = period; p.invalid_step = invalid_step;
   p.perm_h = perm_h;
   static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr;
+  if (dtype == URSE_BF16 && !no_dma && perm_h == 0 && shift == 0 && period == 0 && Mo < 512 && Mo >= 160 && No >= 512 &&
+      R >= 16384 && R < (1L << 31)) {
+    // wide-and-short gradient (fc weight [196, 784]): run the big kernel on the transposed problem
+    TnArgs q = p;
+    q.A = (const char*)B; q.lda = ldb; q.Mo = No;
+    q.B = (const char*)A; q.ldb = lda; q.No = Mo;
+    q.perm_h = TN_TRANSPOSED;
+    const long pad7 = (q.No + 223) / 224 * 224, pad8 = (q.No + 255) / 256 * 256;
+    const int ntw = pad7 < pad8 ? 7 : 8;
+    const long bnx = 32L * ntw;
+    const long tl = ((q.Mo + 255) / 256) * ((q.No + bnx - 1) / bnx);
+    long slices = 256 / tl;
+    if (slices < 1) slices = 1;
+    long rps = (R + slices - 1) / slices;
+    rps = (rps + 31) / 32 * 32;
+    slices = (R + rps - 1) / rps;
+    q.rows_per_slice = rps;
+    dim3 grid((unsigned)(tl * slices));
+    if (ntw == 7) hipLaunchKernelGGL(gemm_tn_dma_kernel<7>, grid, dim3(512), 0, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL(gemm_tn_dma_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, q);
+    URSE_CHECK_LAUNCH("urse_gemm_tn");
+    return URSE_OK;
+  }
   if (dtype == URSE_BF16 && !no_dma && Mo >= 512 && No >= 160 && R >= 16384 && inner < (1L << 31) && R < (1L << 31)) {
     // big weight gradients: 256-wide tiles on the LDS-DMA ring, one workgroup per CU
     const long pad7 = (No + 223) / 224 * 224, pad8 = (No + 255) / 256 * 256;
