@@ -95,10 +95,11 @@ int urse_gemm_tn_grouped(const void* descs, int groups, int max_blocks, int dtyp
  * added after the affine (the flow model's time embedding, bsrnn_flowse.py:293-294). */
 int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* add, void* y, double* stats,
                        int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* stream);
-/* dx = GN backward(dy) (+ dres); dgamma / dbeta are accumulated (+=). */
+/* dx = GN backward(dy) (+ dres); dgamma / dbeta are accumulated (+=).  dx_packed (may be NULL): bf16 copy of dx as
+ * rows [B*T*Kg*(W/N)][ldp] with columns N..ldp-1 zeroed (the A operand of the next dgrad GEMM, saves a pack pass). */
 int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, const float* gamma, const float* dres,
                        float* dx, float* dgamma, float* dbeta, double* sums, int B, int T, int Kg, int W, int N,
-                       int gstride, float eps, void* stream);
+                       int gstride, float eps, void* dx_packed, int ldp, void* stream);
 /* out[out_rows, out_cols] (pitch ldo) = zero-padded copy of in[rows, cols] (or its transpose), with cast. */
 int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int rows, int cols,
                 int out_rows, int out_cols, int transpose, void* stream);

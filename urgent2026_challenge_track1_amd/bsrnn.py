@@ -116,6 +116,7 @@ class BSRNNCore(nn.Module):
         self.param_version = 0          # bumped by the optimizer after every update
         self.grad_ready_hook = None     # callable(tag) fired when a parameter group's grads are final
         self._deferred, self._inflight, self._side = [], None, None     # weight-gradient GEMMs parked for the side stream
+        self._grad_pack = None          # (data_ptr of a gradient stream tensor, its bf16 K-padded copy)
 
     # ------------------------------------------------------------------------------------------
     # parameter containers (espnet names) of the parts that differ between the discriminative and the flow DNN
@@ -447,7 +448,11 @@ class BSRNNCore(nn.Module):
         p = "l%d%s." % (l, path)
         M = B * T * K
         dout2 = dout.reshape(M, N)
-        doT = ops.pack2d(dout2, M, d["Np"], dt)
+        if self._grad_pack is not None and self._grad_pack[0] == dout.data_ptr() and self._grad_pack[1].shape == (M, d["Np"]):
+            doT = self._grad_pack[1]              # written by the GroupNorm backward that produced `dout`
+        else:
+            doT = ops.pack2d(dout2, M, d["Np"], dt)
+        self._grad_pack = None
         dh = torch.empty(M, d["ld2H"], dtype=dt, device=skip.device)
         ops.gemm_nt(doT, pk[p + "wfcT"], out=dh, N=2 * H)
         sm = self._seqmap(path, B, T, K)
@@ -483,8 +488,13 @@ class BSRNNCore(nn.Module):
         else:
             wgrads()
         dxn = ops.gemm_nt(dg, pk[p + "wihT"], out_dtype=torch.float32, N=N)
-        dskip = ops.groupnorm_bwd(skip, dxn, stats, self._p(p + "gamma", N), dout, self._g(p + "gamma", N),
-                                  self._g(p + "beta", N), B, T, 1, K * N, N, 0, GN_EPS)
+        if dt == torch.bfloat16 and N % 4 == 0:
+            dskip, packed = ops.groupnorm_bwd(skip, dxn, stats, self._p(p + "gamma", N), dout, self._g(p + "gamma", N),
+                                              self._g(p + "beta", N), B, T, 1, K * N, N, 0, GN_EPS, pack_ld=d["Np"])
+            self._grad_pack = (dskip.data_ptr(), packed)
+        else:
+            dskip = ops.groupnorm_bwd(skip, dxn, stats, self._p(p + "gamma", N), dout, self._g(p + "gamma", N),
+                                      self._g(p + "beta", N), B, T, 1, K * N, N, 0, GN_EPS)
         if not overlap:
             self._ready(tag)
         return dskip
@@ -605,9 +615,13 @@ class BSRNNCore(nn.Module):
         dskip = None
         for i, tag in enumerate("mr"):
             p = "md%s." % tag
+            last = i == 1 and dt == torch.bfloat16 and N % 4 == 0
             dskip = ops.groupnorm_bwd(skip, dxn[i].view(B, T, K, N), sts[i], self._p(p + "gamma", Kf * N), dskip,
                                       self._g(p + "gamma", Kf * N), self._g(p + "beta", Kf * N), B, T, K, N, N, N,
-                                      GN_EPS)
+                                      GN_EPS, pack_ld=Np if last else 0)
+            if last:                              # the last dual-path half layer consumes this gradient next
+                dskip, packed = dskip
+                self._grad_pack = (dskip.data_ptr(), packed)
         self._ready("md")
         return dskip
 
@@ -616,7 +630,7 @@ class BSRNNCore(nn.Module):
         """spec_ri f32 [B, T, F, 2] -> masked spectrum f32 [B, T, F, 2] (num_spk = 1 squeezed)."""
         ops.require_cuda(spec_ri)
         self._prepare()
-        self._deferred, self._inflight = [], None     # nothing survives an aborted backward
+        self._deferred, self._inflight, self._grad_pack = [], None, None     # nothing survives an aborted backward
         spec_ri = spec_ri.contiguous().float()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not train:

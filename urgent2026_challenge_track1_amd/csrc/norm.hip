@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
                                                            const double* __restrict__ sums,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ dres, float* __restrict__ dx,
-                                                           GnShape s, float eps) {
+                                                           GnShape s, float eps, bf16_t* __restrict__ dxp, int ldp) {
   const int n4 = s.N >> 2;
   const long total = (long)s.B * s.T * s.Kg * (s.W / s.N) * n4;
   const double cnt = (double)s.T * s.W;
@@ -184,6 +184,16 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     *reinterpret_cast<float4*>(dx + off) = o;
+    if (dxp) {
+      // bf16, K-padded copy of the gradient stream: the A operand of the next half layer's first dgrad GEMM
+      bf16_t* pr = dxp + vec * ldp;
+      uint2 pk;
+      pk.x = (unsigned)f32_to_bf16(o.x) | ((unsigned)f32_to_bf16(o.y) << 16);
+      pk.y = (unsigned)f32_to_bf16(o.z) | ((unsigned)f32_to_bf16(o.w) << 16);
+      *reinterpret_cast<uint2*>(pr + c) = pk;
+      if (c + 4 >= s.N)
+        for (int z = s.N; z < ldp; z += 4) *reinterpret_cast<uint2*>(pr + z) = make_uint2(0u, 0u);
+    }
   }
 }
 
@@ -247,7 +257,10 @@ extern "C" int urse_groupnorm_fwd(const float* x, const float* gamma, const floa
 
 extern "C" int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, const float* gamma,
                                   const float* dres, float* dx, float* dgamma, float* dbeta, double* sums, int B,
-                                  int T, int Kg, int W, int N, int gstride, float eps, void* stream) {
+                                  int T, int Kg, int W, int N, int gstride, float eps, void* dx_packed, int ldp,
+                                  void* stream) {
+  URSE_CHECK_ARG(!dx_packed || (ldp >= N && ldp % 4 == 0 && N % 4 == 0 && ((uintptr_t)dx_packed % 8) == 0),
+                 "urse_groupnorm_bwd: packed copy needs N, ldp multiples of 4 and an 8-byte aligned buffer");
   GnShape s;
   int rc = make_shape(&s, B, T, Kg, W, N, N, gstride, "urse_groupnorm_bwd");
   if (rc) return rc;
@@ -262,7 +275,7 @@ extern "C" int urse_groupnorm_bwd(const float* x, const float* dy, const double*
                      rpb);
   const long total = (long)B * T * Kg * (W / N) * (N / 4);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, dy, stats, sums, gamma, dres,
-                     dx, s, eps);
+                     dx, s, eps, (bf16_t*)dx_packed, ldp);
   URSE_CHECK_LAUNCH("urse_groupnorm_bwd");
   return URSE_OK;
 }

@@ -181,13 +181,15 @@ def groupnorm_fwd(x, gamma, beta, B, T, Kg, W, N, Np, gstride, dtype, eps=1e-5, 
     return y, stats
 
 
-def groupnorm_bwd(x, dy, stats, gamma, dres, dgamma, dbeta, B, T, Kg, W, N, gstride, eps=1e-5):
-    """returns dx f32 (same layout as x); dgamma/dbeta accumulated in place."""
+def groupnorm_bwd(x, dy, stats, gamma, dres, dgamma, dbeta, B, T, Kg, W, N, gstride, eps=1e-5, pack_ld=0):
+    """returns dx f32 (same layout as x); dgamma/dbeta accumulated in place.  pack_ld > 0: also returns the bf16 copy of dx
+    as rows of pack_ld columns (zero padded) -> (dx, dx_packed)."""
     dx = torch.empty_like(x)
     sums = torch.empty(B * Kg * 2, device=x.device, dtype=torch.float64)
-    call("groupnorm_bwd", x, dy, stats, gamma, dres, dx, dgamma, dbeta, sums, B, T, Kg, W, N, gstride, float(eps),
-         stream_ptr())
-    return dx
+    dxp = torch.empty(x.numel() // N, pack_ld, device=x.device, dtype=torch.bfloat16) if pack_ld else None
+    call("groupnorm_bwd", x, dy, stats, gamma, dres, dx, dgamma, dbeta, sums, B, T, Kg, W, N, gstride, float(eps), dxp,
+         pack_ld, stream_ptr())
+    return (dx, dxp) if pack_ld else dx
 
 
 def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
@@ -219,6 +221,14 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
     return out
 
 
+def _hout_buffer(M, ldh, H, like):
+    """hidden-state matrix [M, ldh]: the kernels write every row's 2H columns, only the K padding needs zeros."""
+    hout = torch.empty(M, ldh, device=like.device, dtype=like.dtype)
+    if ldh > 2 * H:
+        hout[:, 2 * H:].zero_()
+    return hout
+
+
 _cluster_ws = {}
 USE_CLUSTER_LSTM = os.environ.get("URSE_LSTM_CLUSTER", "1") != "0"
 # the cluster BPTT kernel is correct (tests/test_lstm_gpu.py) but, at 16 us + 200 KB of tile traffic per step and with
@@ -247,7 +257,7 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
                             torch.zeros(1, device=dev, dtype=torch.int32))
     hx, cnt, err = _cluster_ws[key]
     ldh = kpad(2 * H, gx.dtype)
-    hout = torch.zeros(M, ldh, device=dev, dtype=gx.dtype)
+    hout = _hout_buffer(M, ldh, H, gx)
     c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster_fwd", gx, gx.stride(0), whhq, hout, ldh,
                c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
@@ -258,7 +268,7 @@ def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, ro
     """gx [M, 8H] (overwritten by gate activations if save) -> (hout [M, kpad(2H)], c [M, 2H] f32)."""
     M = gx.shape[0]
     ldh = kpad(2 * H, gx.dtype)
-    hout = torch.zeros(M, ldh, device=gx.device, dtype=gx.dtype)
+    hout = _hout_buffer(M, ldh, H, gx)
     c = torch.empty(M, 2 * H, device=gx.device, dtype=torch.float32) if save else None
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_bidir_fwd", gx, gx.stride(0), whh, hout, ldh,
                c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), _dt(gx), rows16, stream_ptr())
@@ -276,7 +286,7 @@ def lstm_fwd_wide(gx, whhb, H, Hp, n_seq, seq_len, inner, outer, stride, save=Tr
     """wide streaming LSTM forward (bf16, 64 sequences per workgroup): see csrc/lstm_wide.hip."""
     M = gx.shape[0]
     ldh = kpad(2 * H, gx.dtype)
-    hout = torch.zeros(M, ldh, device=gx.device, dtype=gx.dtype)
+    hout = _hout_buffer(M, ldh, H, gx)
     c = torch.empty(M, 2 * H, device=gx.device, dtype=torch.float32)
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_wide_fwd", gx, gx.stride(0), whhb, hout, ldh,
                c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
