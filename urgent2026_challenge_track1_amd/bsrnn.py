@@ -457,9 +457,10 @@ class BSRNNCore(nn.Module):
         ops.gemm_nt(doT, pk[p + "wfcT"], out=dh, N=2 * H)
         sm = self._seqmap(path, B, T, K)
         overlap = ops.TN_OVERLAP and skip.is_cuda
-        if overlap and path == "t":
-            # the time path's BPTT occupies 136 of the 256 CUs for ~7 ms: the weight-gradient GEMMs deferred by the
-            # previous half layers run beside it on a second stream (they only feed the optimizer / all-reduce)
+        if overlap and (path == "t" or ops.TN_OVERLAP_BAND):
+            # the time path's BPTT occupies 136 of the 256 CUs for ~7 ms (and the band path's last round of workgroups
+            # leaves most CUs idle): the weight-gradient GEMMs deferred by the previous half layers run beside it on a
+            # second stream (they only feed the optimizer / all-reduce)
             self._run_deferred_wgrads(skip.device)
         if ops.USE_CLUSTER_LSTM_BWD and pk.get(p + "whhTq") is not None and \
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
@@ -514,17 +515,17 @@ class BSRNNCore(nn.Module):
                 fn()
             done = torch.cuda.Event()
             done.record(self._side)
-        self._inflight = (done, self._deferred)
+        self._inflight = (self._inflight or []) + [(done, self._deferred)]
         self._deferred = []
 
     def _join_deferred_wgrads(self):
         if self._inflight is None:
             return
-        done, items = self._inflight
-        torch.cuda.current_stream().wait_event(done)
-        self._inflight = None
-        for _, tag in items:                             # gradients final: tell the reducer (and drop the closures)
-            self._ready(tag)
+        batches, self._inflight = self._inflight, None
+        for done, items in batches:
+            torch.cuda.current_stream().wait_event(done)
+            for _, tag in items:                         # gradients final: tell the reducer (and drop the closures)
+                self._ready(tag)
 
     def _flush_deferred_wgrads(self):
         """end of backward: whatever is still deferred runs on the compute stream."""
