@@ -511,8 +511,10 @@ class BSRNNCore(nn.Module):
         start.record(torch.cuda.current_stream())
         self._side.wait_event(start)
         with torch.cuda.stream(self._side):
+            call("gemm_tn_set_target", ops.TN_SHADOW_WGS)      # they share the chip with a BPTT kernel on 136 CUs
             for fn, _ in self._deferred:
                 fn()
+            call("gemm_tn_set_target", 256)
             done = torch.cuda.Event()
             done.record(self._side)
         self._inflight = (self._inflight or []) + [(done, self._deferred)]

@@ -816,6 +816,15 @@ extern "C" int urse_gemm_nt_grouped(const void* descs, int groups, int max_block
                      (hipStream_t)stream);
 }
 
+// workgroups the big TN kernels aim for (one per CU).  A caller that runs them beside another kernel on part of the
+// chip (bsrnn.py: deferred wgrads next to the time path's BPTT) lowers it to the CUs that are actually free, so the
+// launch is one round of long workgroups instead of two-and-a-bit rounds.
+static int g_tn_target_wgs = 256;
+extern "C" int urse_gemm_tn_set_target(int workgroups) {
+  g_tn_target_wgs = workgroups > 0 ? workgroups : 256;
+  return URSE_OK;
+}
+
 extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                             float* colsum, int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner,
                             int64_t period, int64_t invalid_step, int64_t perm_h, int dtype, void* stream) {
@@ -841,7 +850,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     const int ntw = pad7 < pad8 ? 7 : 8;
     const long bnx = 32L * ntw;
     const long tl = ((q.Mo + 255) / 256) * ((q.No + bnx - 1) / bnx);
-    long slices = 256 / tl;
+    long slices = g_tn_target_wgs / tl;
     if (slices < 1) slices = 1;
     long rps = (R + slices - 1) / slices;
     rps = (rps + 31) / 32 * 32;
@@ -859,7 +868,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     const int ntw = pad7 < pad8 ? 7 : 8;
     const long bnx = 32L * ntw;
     const long tl = ((Mo + 255) / 256) * ((No + bnx - 1) / bnx);
-    long slices = 256 / tl;
+    long slices = g_tn_target_wgs / tl;
     if (slices < 1) slices = 1;
     long rps = (R + slices - 1) / slices;
     rps = (rps + 31) / 32 * 32;

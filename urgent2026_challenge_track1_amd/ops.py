@@ -278,6 +278,7 @@ def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, ro
 USE_WIDE_LSTM = os.environ.get("URSE_LSTM_WIDE", "1") != "0"
 # run the dual-path weight-gradient GEMMs on a second stream beside the time path's BPTT kernel (which fills 136 CUs)
 TN_OVERLAP = os.environ.get("URSE_TN_OVERLAP", "1") != "0"
+TN_SHADOW_WGS = int(os.environ.get("URSE_TN_SHADOW_WGS", "120"))
 TN_OVERLAP_BAND = os.environ.get("URSE_TN_OVERLAP_BAND", "1") != "0"   # also start deferred wgrads beside the band path's BPTT
 # the wide kernel wins once there are enough 64-sequence workgroups to fill the chip in both directions
 WIDE_MIN_SEQ = int(os.environ.get("URSE_LSTM_WIDE_MIN_SEQ", str(64 * 128)))
