@@ -10,6 +10,11 @@ to un-vendored third-party packages (espnet==202412, pesq, pystoi,
 fast_bss_eval) that are absent here and holds no tests / golden vectors, so
 every module states its own pin:
 
+* ``mix_ref``    -- the numpy / scipy DSP subset of ``simulation/simulate_data_from_param.py`` (mix_noise,
+  add_reverberation, filtfilt high-pass, clipping, packet_loss, peak normalisation): calls the same scipy / numpy routines
+  as the reference; espnet2's ``detect_non_silence`` restated -> that function UNPINNED.
+* ``metrics_ref`` -- pystoi 0.4.1 ESTOI and fast_bss_eval SDR restated from the published algorithms; cross-checked against
+  scipy (``resample_poly``, ``solve_toeplitz``); UNPINNED (packages absent).
 * ``flow_ref``  - pinned against the reference's own ``bsrnn_flowse.py``,
   ``odes.py`` and ``sampling/`` imported in the build container
   (``tests/golden/make_golden.py`` generated the committed vectors).
