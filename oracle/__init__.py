@@ -22,6 +22,7 @@ every module states its own pin:
   ``conf/models/BSRNN_baseline.yaml:30-31`` and, structurally, by the in-tree
   twin ``bsrnn_flowse.py`` (same dual-path loop / BandSplit); numerics are
   stock ``torch`` CPU ops.  espnet numerics themselves: parity unpinned.
-* ``stft_ref``, ``losses_ref``, ``metrics_ref``, ``pesq_ref`` - restated from
-  the published algorithms; parity unpinned by the reference.
+* ``stft_ref``, ``losses_ref`` - restated from the published algorithms
+  (cross-checked against an independent float64 numpy DFT / manual formulas);
+  parity unpinned by the reference.  There is no PESQ oracle (not built).
 """
