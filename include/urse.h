@@ -80,11 +80,17 @@ int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_d
 int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
                  int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner, int64_t period,
                  int64_t invalid_step, int64_t perm_h, int dtype, void* stream);
+/* Two weight gradients that share their A operand in one pass over A (the two wgrads of one LSTM direction):
+ * C[Mo,No] += A^T B (+ colsum) and C2[Mo,No2] += A^T B2', B2' = B2 shifted / masked as in urse_gemm_tn. */
+int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
+                      const void* B2, int64_t ldb2, float* C2, int64_t ldc2, int64_t R, int64_t Mo, int64_t No, int64_t No2,
+                      int64_t shift, int64_t inner, int64_t period, int64_t invalid_step, int64_t perm_h, int dtype,
+                      void* stream);
 /* Number of workgroups the large-shape urse_gemm_tn kernels aim for (default 256 = one per CU; process-wide). */
 int urse_gemm_tn_set_target(int workgroups);
 /* `groups` independent urse_gemm_tn problems in one launch (per-band weight gradients).  descs = device int64
- * [groups, 16]: {A, B, C, colsum, lda, ldb, ldc, R, Mo, No, shift, inner (>= 1), period, invalid_step,
- * rows_per_slice (multiple of 32; the row range is cut into ceil(R / rows_per_slice) split-R slices), perm_h};
+ * [groups, 24]: {A, B, C, colsum, lda, ldb, ldc, R, Mo, No, shift, inner (>= 1), period, invalid_step,
+ * rows_per_slice (multiple of 32; the row range is cut into ceil(R / rows_per_slice) split-R slices), perm_h, 8 x 0};
  * max_blocks >= max over groups of ceil(Mo/128)*ceil(No/128)*slices.  Operand alignment as urse_gemm_tn. */
 int urse_gemm_tn_grouped(const void* descs, int groups, int max_blocks, int dtype, void* stream);
 

@@ -39,3 +39,6 @@ t("torch tn wih", lambda: torch.mm(dg.t(), xn, out=o4), 2.0 * M * 8 * H * 196)
 o5 = torch.empty(4 * H, H, device=dev, dtype=bf)
 hh = hout[:, :H].contiguous()
 t("torch tn whh", lambda: torch.mm(dg[:, :4 * H].t(), hh, out=o5), 2.0 * M * 4 * H * H)
+gw1, gw2 = torch.zeros(4 * H, N, device=dev), torch.zeros(4 * H, H, device=dev)
+t("tn dual (wih_d + whh_d)", lambda: ops.gemm_tn_dual(dg[:, :4 * H], xn, gw1, cs[:4 * H], hout[:, :H], gw2, 4 * H, N, H, -34, 34, 401, 0, perm_h=H),
+  2.0 * M * 4 * H * (196 + H))

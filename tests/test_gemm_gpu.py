@@ -143,3 +143,23 @@ def test_gemm_tn_grouped_matches_single_calls(lib, dtype):
         tol = 1e-5 * max(1.0, ref.abs().max().item())        # same products, different split-R summation order
         assert (out - ref).abs().max().item() <= tol
         assert (cs - rcs).abs().max().item() <= 1e-5 * max(1.0, rcs.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,R,H,N,inner,period,rev", [(torch.bfloat16, 34 * 20 * 25, 392, 196, 34, 25, False),
+                                                          (torch.bfloat16, 34 * 20 * 25, 392, 196, 34, 25, True),
+                                                          (torch.float32, 600, 24, 16, 5, 12, False)])
+def test_gemm_tn_dual_matches_two_calls(lib, dtype, R, H, N, inner, period, rev):
+    """both weight gradients of one LSTM direction in one pass over the dgates == the two separate contractions
+    (large bf16 shapes take the dual-operand ring kernel, everything else falls back to two calls)."""
+    from urgent2026_challenge_track1_amd import ops
+    A = _mk((R, 4 * H), dtype, 30).cuda()
+    X = _mk((R, (N + 31) // 32 * 32), dtype, 31).cuda()
+    Hh = _mk((R, (H + 31) // 32 * 32), dtype, 32).cuda()
+    sh, inv = (inner, period - 1) if rev else (-inner, 0)
+    c1, c2, cs = torch.zeros(4 * H, N, device="cuda"), torch.zeros(4 * H, H, device="cuda"), torch.zeros(4 * H, device="cuda")
+    r1, r2, rs = torch.zeros_like(c1), torch.zeros_like(c2), torch.zeros_like(cs)
+    ops.gemm_tn_dual(A, X, c1, cs, Hh, c2, 4 * H, N, H, sh, inner, period, inv, perm_h=H)
+    ops.gemm_tn(A, X, r1, colsum=rs, Mo=4 * H, No=N, perm_h=H)
+    ops.gemm_tn(A, Hh, r2, Mo=4 * H, No=H, shift=sh, inner=inner, period=period, invalid_step=inv, perm_h=H)
+    for got, ref in ((c1, r1), (c2, r2), (cs, rs)):
+        assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())

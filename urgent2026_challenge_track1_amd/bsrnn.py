@@ -477,12 +477,14 @@ class BSRNNCore(nn.Module):
         def wgrads():
             ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N, No=2 * H)
             gb = self._g(p + "bih", 8 * H)
-            ops.gemm_tn(dg, xn, self._g(p + "wih", 8 * H * N).view(8 * H, N), colsum=gb, Mo=8 * H, No=N, perm_h=H)
-            call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())
+            gwih = self._g(p + "wih", 8 * H * N).view(8 * H, N)
+            # per direction ONE pass over the [M, 4H] dgates yields dW_ih (+ bias gradient) and dW_hh
             for dr, (sh, inv) in enumerate(((-st, 0), (st, L - 1))):
-                ops.gemm_tn(dg[:, dr * 4 * H:(dr + 1) * 4 * H], hout[:, dr * H:(dr + 1) * H],
-                            self._g(p + "whh", 4 * H * H, dr * 4 * H * H).view(4 * H, H), Mo=4 * H, No=H, shift=sh,
-                            inner=st, period=L, invalid_step=inv, perm_h=H)
+                ops.gemm_tn_dual(dg[:, dr * 4 * H:(dr + 1) * 4 * H], xn, gwih[dr * 4 * H:(dr + 1) * 4 * H],
+                                 gb[dr * 4 * H:(dr + 1) * 4 * H], hout[:, dr * H:(dr + 1) * H],
+                                 self._g(p + "whh", 4 * H * H, dr * 4 * H * H).view(4 * H, H), 4 * H, N, H, sh, st, L, inv,
+                                 perm_h=H)
+            call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())
 
         if overlap:
             self._deferred.append((wgrads, tag))       # the closure keeps doT / hout / dg / xn alive until it has run

@@ -217,6 +217,12 @@ struct TnArgs {
   long shift, inner, period, invalid_step;
   long rows_per_slice;
   long perm_h;   // > 0: A columns are gate-interleaved (dir, unit, gate); C rows / colsum are written as (dir, gate, unit)
+  // dual-operand mode of the big kernel (B2 != nullptr): the first nt1 column tiles multiply A^T with B (plain rows,
+  // colsum) into C, the others with B2 (row shift / step mask) into C2 -- one pass over A (the [M, 4H] dgates of one
+  // direction) yields both dW_ih and dW_hh
+  const char* B2; float* C2;
+  long ldb2, ldc2, No2, nt1;
+  long pad_[2];
 };
 
 __device__ __forceinline__ long tn_perm(long m, long h) {
@@ -412,12 +418,18 @@ template <int NTW>
 __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   constexpr int BMX = 256, BNX = 32 * NTW, NST = 4, STAGE = 32768;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
-  const int tn = (int)((p.No + BNX - 1) / BNX);
+  const bool dual = p.B2 != nullptr;
+  const int tn = dual ? (int)(p.nt1 + (p.No2 + BNX - 1) / BNX) : (int)((p.No + BNX - 1) / BNX);
   const int tiles = tn * (int)((p.Mo + BMX - 1) / BMX);
   const int lid = xcd_remap(blockIdx.x, (int)gridDim.x);
   const int slice = lid / tiles, tile = lid - slice * tiles;
   const int tile_m = tile / tn, tile_n = tile - tile_m * tn;
-  const long m0 = (long)tile_m * BMX, n0 = (long)tile_n * BNX;
+  const bool second = dual && tile_n >= p.nt1;                 // this tile works on (B2, C2)
+  const char* Bop = second ? p.B2 : p.B;
+  float* Cop = second ? p.C2 : p.C;
+  const long ldb_ = second ? p.ldb2 : p.ldb, ldc_ = second ? p.ldc2 : p.ldc, No_ = second ? p.No2 : p.No;
+  const long shift_ = (dual && !second) ? 0 : p.shift, period_ = (dual && !second) ? 0 : p.period;
+  const long m0 = (long)tile_m * BMX, n0 = (long)(second ? tile_n - p.nt1 : tile_n) * BNX;
   const long r_begin = (long)slice * p.rows_per_slice;
   long r_end = r_begin + p.rows_per_slice;
   if (r_end > p.R) r_end = p.R;
@@ -439,7 +451,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
     acol[j] = m0 + cel;
     bcol[j] = n0 + cel;
     aok[j] = acol[j] < p.lda;
-    bok[j] = cel < BNX && bcol[j] < p.ldb;
+    bok[j] = cel < BNX && bcol[j] < ldb_;
   }
   auto issue = [&](int kt, int slot) {
     char* sbase = lds + slot * STAGE + 4 * w * 512;
@@ -449,10 +461,10 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
       const bool rin = kt < nk && r < r_end;
       const char* sa = (rin && aok[j]) ? p.A + (r * p.lda + acol[j]) * 2 : zsrc;
       bool ok = rin && bok[j];
-      const long rs = r + p.shift;
-      if (p.period) ok = ok && ((((unsigned)r / (unsigned)p.inner) % (unsigned)p.period) != (unsigned)p.invalid_step);
+      const long rs = r + shift_;
+      if (period_) ok = ok && ((((unsigned)r / (unsigned)p.inner) % (unsigned)period_) != (unsigned)p.invalid_step);
       ok = ok && rs >= 0 && rs < p.R;
-      const char* sb = ok ? p.B + (rs * p.ldb + bcol[j]) * 2 : zsrc;
+      const char* sb = ok ? Bop + (rs * ldb_ + bcol[j]) * 2 : zsrc;
       glds16(sa, sbase + j * 1024);
       glds16(sb, sbase + 16384 + j * 1024);
     }
@@ -467,7 +479,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) accs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const bool trans = p.perm_h == TN_TRANSPOSED;
-  const bool do_colsum = (p.colsum != nullptr) && !trans && tile_n == 0 && wn == 0;
+  const bool do_colsum = (p.colsum != nullptr) && !trans && tile_n == 0 && wn == 0;   // (dual: tile 0 belongs to B)
   const bool do_colsum_b = (p.colsum != nullptr) && trans && tile_m == 0 && wm == 0;
   f32x4_t accb[NTW];
 #pragma unroll
@@ -522,15 +534,15 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const long col = n0 + (wn * NTW + j) * 16 + (lane & 15);
-    if (col >= p.No) continue;
+    if (col >= No_) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
         if (row < p.Mo) {
-          if (trans) atomicAdd(p.C + col * p.ldc + row, acc[i][j][r]);
-          else atomicAdd(p.C + tn_perm(row, p.perm_h) * p.ldc + col, acc[i][j][r]);
+          if (trans) atomicAdd(Cop + col * ldc_ + row, acc[i][j][r]);
+          else atomicAdd(Cop + tn_perm(row, p.perm_h) * ldc_ + col, acc[i][j][r]);
         }
       }
   }
@@ -838,6 +850,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.R = R; p.Mo = Mo; p.No = No;
   p.shift = shift; p.inner = inner > 0 ? inner : 1; p.period = period; p.invalid_step = invalid_step;
   p.perm_h = perm_h;
+  p.B2 = nullptr; p.C2 = nullptr; p.ldb2 = p.ldc2 = p.No2 = p.nt1 = 0; p.pad_[0] = p.pad_[1] = 0;
   static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr;
   if (dtype == URSE_BF16 && !no_dma && perm_h == 0 && shift == 0 && period == 0 && Mo < 512 && Mo >= 160 && No >= 512 &&
       R >= 16384 && R < (1L << 31)) {
@@ -910,5 +923,42 @@ extern "C" int urse_gemm_tn_grouped(const void* descs, int groups, int max_block
   else
     hipLaunchKernelGGL(gemm_tn_grouped_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const TnArgs*)descs);
   URSE_CHECK_LAUNCH("urse_gemm_tn_grouped");
+  return URSE_OK;
+}
+
+// dW1[Mo, No] += A^T B (+ colsum),  dW2[Mo, No2] += A^T B2' (B2' = B2 shifted / masked as in urse_gemm_tn) in ONE pass
+// over A: the two weight gradients of one LSTM direction (A = dgates [M, 4H], B = layer input, B2 = h_{t-1}).
+extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
+                                 const void* B2, int64_t ldb2, float* C2, int64_t ldc2, int64_t R, int64_t Mo, int64_t No,
+                                 int64_t No2, int64_t shift, int64_t inner, int64_t period, int64_t invalid_step,
+                                 int64_t perm_h, int dtype, void* stream) {
+  URSE_CHECK_ARG(A && B && C && B2 && C2 && R > 0 && Mo > 0 && No > 0 && No2 > 0, "urse_gemm_tn_dual: bad argument");
+  static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr;
+  const bool big = dtype == URSE_BF16 && !no_dma && Mo >= 512 && R >= 16384 && R < (1L << 31) && inner < (1L << 31) &&
+                   (lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && (ldb2 * 2) % 16 == 0 && ((uintptr_t)A % 16) == 0 &&
+                   ((uintptr_t)B % 16) == 0 && ((uintptr_t)B2 % 16) == 0;
+  if (!big) {
+    int rc = urse_gemm_tn(A, lda, B, ldb, C, ldc, colsum, R, Mo, No, 0, 1, 0, 0, perm_h, dtype, stream);
+    if (rc) return rc;
+    return urse_gemm_tn(A, lda, B2, ldb2, C2, ldc2, nullptr, R, Mo, No2, shift, inner, period, invalid_step, perm_h, dtype, stream);
+  }
+  URSE_CHECK_ARG(lda >= Mo && ldb >= No && ldc >= No && ldb2 >= No2 && ldc2 >= No2, "urse_gemm_tn_dual: leading dimension too small");
+  TnArgs p;
+  p.A = (const char*)A; p.B = (const char*)B; p.C = C; p.colsum = colsum;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.R = R; p.Mo = Mo; p.No = No;
+  p.shift = shift; p.inner = inner > 0 ? inner : 1; p.period = period; p.invalid_step = invalid_step;
+  p.perm_h = perm_h;
+  p.B2 = (const char*)B2; p.C2 = C2; p.ldb2 = ldb2; p.ldc2 = ldc2; p.No2 = No2; p.pad_[0] = p.pad_[1] = 0;
+  const long bnx = 224;                                   // 7 column tiles per wave: 196 -> 224, 392 -> 448
+  p.nt1 = (No + bnx - 1) / bnx;
+  const long tl = ((Mo + 255) / 256) * (p.nt1 + (No2 + bnx - 1) / bnx);
+  long slices = g_tn_target_wgs / tl;
+  if (slices < 1) slices = 1;
+  long rps = (R + slices - 1) / slices;
+  rps = (rps + 31) / 32 * 32;
+  slices = (R + rps - 1) / rps;
+  p.rows_per_slice = rps;
+  hipLaunchKernelGGL(gemm_tn_dma_kernel<7>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+  URSE_CHECK_LAUNCH("urse_gemm_tn_dual");
   return URSE_OK;
 }

@@ -120,6 +120,16 @@ def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=
     return out
 
 
+def gemm_tn_dual(A, Bm, out, colsum, B2, out2, Mo, No, No2, shift, inner, period, invalid_step, perm_h=0):
+    """out[Mo, No] += A^T Bm (+ colsum) and out2[Mo, No2] += A^T B2' (shifted / masked) in one pass over A."""
+    require_cuda(A, Bm, B2, out, out2)
+    R = A.shape[0]
+    assert Bm.shape[0] == R and B2.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and B2.stride(1) == 1
+    assert out.dtype == torch.float32 and out2.dtype == torch.float32 and A.dtype == Bm.dtype == B2.dtype
+    call("gemm_tn_dual", A, A.stride(0), Bm, Bm.stride(0), out, out.stride(0), colsum, B2, B2.stride(0), out2, out2.stride(0), R,
+         Mo, No, No2, shift, inner, period, invalid_step, perm_h, _dt(A), stream_ptr())
+
+
 def tn_desc(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=0, invalid_step=0, perm_h=0):
     """one row of a urse_gemm_tn_grouped descriptor table (rows_per_slice is filled in by gemm_tn_grouped)."""
     R = A.shape[0]
@@ -128,7 +138,7 @@ def tn_desc(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=
     assert Bm.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and A.dtype == Bm.dtype
     assert out.dtype == torch.float32 and out.stride(-1) == 1 and out.stride(0) >= No
     return [A.data_ptr(), Bm.data_ptr(), out.data_ptr(), 0 if colsum is None else colsum.data_ptr(), A.stride(0),
-            Bm.stride(0), out.stride(0), R, Mo, No, shift, max(1, inner), period, invalid_step, 0, perm_h]
+            Bm.stride(0), out.stride(0), R, Mo, No, shift, max(1, inner), period, invalid_step, 0, perm_h] + [0] * 8
 
 
 def gemm_tn_grouped(rows, dtype, device, target_blocks=1024):
