@@ -414,9 +414,17 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// ring depth of the big TN kernel: 5 stages of 32 KB = the whole 160 KB LDS, four stages in flight (measured
+// 0.92 vs 1.01 ms for the 3136 x 196 wgrad against 4 stages); the NT kernel is faster with 4 (short K: longer prologue)
+#ifndef URSE_TN_NST
+#define URSE_TN_NST 5
+#endif
+#ifndef URSE_NT_NST
+#define URSE_NT_NST 4
+#endif
 template <int NTW>
 __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
-  constexpr int BMX = 256, BNX = 32 * NTW, NST = 4, STAGE = 32768;
+  constexpr int BMX = 256, BNX = 32 * NTW, NST = URSE_TN_NST, STAGE = 32768;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
   const bool dual = p.B2 != nullptr;
   const int tn = dual ? (int)(p.nt1 + (p.No2 + BNX - 1) / BNX) : (int)((p.No + BNX - 1) / BNX);
@@ -491,16 +499,20 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   const int off0 = row0 * 512 + pp * 8, off1 = (row0 + 4) * 512 + pp * 8;
   const int sw0 = q, sw1 = q + 4;                       // (row & 7) of the two rows
 
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, 2);
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0, s0);
+  int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed for this wave once at most the 8 younger DMAs (stages kt+1, kt+2) are outstanding; the
-    // barrier then makes every wave's part visible and retires the slot that stage kt+3 is about to overwrite
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // stage kt has landed for this wave once at most the 4*(NST-2) younger DMAs (stages kt+1 ..) are outstanding; the
+    // barrier then makes every wave's part visible and retires the slot that stage kt+NST-1 is about to overwrite
+    if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(kt + 3, (kt + 3) & 3);
-    const char* As = lds + (kt & 3) * STAGE;
+    int nslot = slot + NST - 1;
+    if (nslot >= NST) nslot -= NST;
+    issue(kt + NST - 1, nslot);
+    const char* As = lds + slot * STAGE;
+    if (++slot == NST) slot = 0;
     const char* Bs = As + 16384;
     short8_t a[4];
 #pragma unroll
@@ -575,7 +587,7 @@ __global__ void __launch_bounds__(BMX * 2) gemm_nt_dma_kernel(GemmDesc d) {
   // BMX = 256: 8 waves, 4 stages of 32 KB, one workgroup per CU (long K: least operand traffic per FLOP)
   // BMX = 128: 4 waves, 3 stages of 24 KB, two workgroups per CU (short K: one's epilogue overlaps the other's loop)
   constexpr int BNX = 32 * NTW, NWV = BMX / 32, NTHR = NWV * 64;
-  constexpr int NST = BMX == 256 ? 4 : 3, STAGE = (BMX + 256) * 64, BOFF = BMX * 64;
+  constexpr int NST = BMX == 256 ? URSE_NT_NST : 3, STAGE = (BMX + 256) * 64, BOFF = BMX * 64;
   constexpr int BI = 16 / NWV;                   // B wave-instructions per wave per stage (A: always 2)
   constexpr int DPW = 2 + BI;                    // DMAs per wave per stage
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
@@ -640,9 +652,10 @@ __global__ void __launch_bounds__(BMX * 2) gemm_nt_dma_kernel(GemmDesc d) {
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed for this wave once only the (NST-2) younger stages are outstanding; the barrier makes every
     // wave's part visible and retires the slot that stage kt+NST-1 is about to overwrite
-    if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if ((NST - 2) * DPW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if ((NST - 2) * DPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    static_assert((NST - 2) * DPW == (NST == 4 ? 8 : 6), "wait count");
+    static_assert((NST - 2) * DPW == 12 || (NST - 2) * DPW == 8 || (NST - 2) * DPW == 6, "wait count");
     __builtin_amdgcn_s_barrier();
     int nslot = slot + NST - 1;
     if (nslot >= NST) nslot -= NST;
