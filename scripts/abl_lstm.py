@@ -4,7 +4,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
-variants = {"base": [], "nowait": ["-DSABL_NO_WAIT"], "nowait_nopub": ["-DSABL_NO_WAIT", "-DSABL_NO_PUB"], "nowait_now": ["-DSABL_NO_WAIT", "-DSABL_NO_W"], "nowait_nost": ["-DSABL_NO_WAIT", "-DSABL_NO_ST"], "all": ["-DSABL_NO_WAIT", "-DSABL_NO_W", "-DSABL_NO_PUB", "-DSABL_NO_ST"]}
+variants = {"base": []}
 libs = {}
 for name, fl in variants.items():
     so = "/tmp/abl_%s.so" % name
@@ -48,9 +48,9 @@ def bwd_split(lib, path, rt):
     a = (B * K, T, K, T * K, K)
     return lib.urse_lstm_split_bwd(P(dh.data_ptr()), ctypes.c_int64(800), P(gx.data_ptr()), ctypes.c_int64(8 * H), P(c.data_ptr()),
         P(whhT.data_ptr()), P(xbuf.data_ptr()), P(errf.data_ptr()), H, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), P(st))
-for fn, fname in ((bwd_split, "bwd_split"),):
+for fn, fname in ((bwd, "bwd"),):
     for path in (("time",) if fname == "bwd_split" else ("time", "band")):
-        for rt in (1,):
+        for rt in (1, 2, 18):
             res = []
             for name, lib in libs.items():
                 assert fn(lib, path, rt) == 0

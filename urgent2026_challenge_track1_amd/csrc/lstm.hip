@@ -545,6 +545,7 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
   }
   if (dtype == URSE_BF16) {
     if (nw8) return (rt >= 2 && fits2) ? launch_bwd<bf16_t, 2, 8>(p, st) : launch_bwd<bf16_t, 1, 8>(p, st);
+    if (rt >= 2 && fits2) return launch_bwd<bf16_t, 2, 16>(p, st);
     return launch_bwd<bf16_t, 1, 16>(p, st);
   }
   return launch_bwd<float, 1, 16>(p, st);

@@ -164,6 +164,210 @@ __global__ void __launch_bounds__(256) stft_kernel(const float* __restrict__ x, 
   }
 }
 
+#ifndef URSE_STFT960_NFF
+#define URSE_STFT960_NFF 8
+#endif
+#define URSE_STFT960_NFF_THREADS (URSE_STFT960_NFF * 32)
+// ---------------------------------------------------------------------------------------------------------------
+// 960-point forward STFT (48 kHz: n_fft 960 / hop 480, the C2 front end), register FFT.
+// The generic kernel above walks five radix passes through LDS with run-time index arithmetic and is VALU-issue bound
+// (52 us for 74 MB).  Here one half-wave (32 lanes) owns one complex FFT = two real frames, as a 32 x 30 two-pass FFT:
+//   pass 1: lane n2 (30 lanes) loads x[30 n1 + n2], n1 = 0..31 (lanes read consecutive samples), and does a 32-point
+//           DFT in registers (radix-2 DIF, constant twiddles), multiplies by W_960^(n2 k1) and writes B[k1][n2] to LDS;
+//   pass 2: lane k1 (32 lanes) reads B[k1][0..29] and does a 30-point DFT in registers as a 2 x 3 x 5 prime-factor
+//           transform (Good's index map: no twiddles), X[k1 + 32 k2], written back to LDS in natural order;
+//   output: the two real frames' spectra are split out of the complex one (X[k], conj X[960-k]) and stored coalesced.
+// Two LDS round trips instead of five, index arithmetic folded at compile time.  8 FFTs (16 frames) per workgroup.
+__device__ __forceinline__ void dft32_dif(float2 (&v)[32]) {
+  // forward DFT, natural order in, bit-reversed order out: X[k] = v[brev5(k)]
+  constexpr float C32[16] = {1.000000000f, 0.980785280f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f,
+                             0.382683432f, 0.195090322f, 0.000000000f, -0.195090322f, -0.382683432f, -0.555570233f,
+                             -0.707106781f, -0.831469612f, -0.923879533f, -0.980785280f};
+  constexpr float S32[16] = {0.000000000f, 0.195090322f, 0.382683432f, 0.555570233f, 0.707106781f, 0.831469612f,
+                             0.923879533f, 0.980785280f, 1.000000000f, 0.980785280f, 0.923879533f, 0.831469612f,
+                             0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f};
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int half = 16 >> s;
+#pragma unroll
+    for (int blk = 0; blk < (1 << s); ++blk)
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const int i0 = blk * 2 * half + j, i1 = i0 + half;
+        const float2 a = v[i0], b = v[i1];
+        v[i0] = make_float2(a.x + b.x, a.y + b.y);
+        const float dx = a.x - b.x, dy = a.y - b.y;
+        const int m = j << s;                               // twiddle W_32^m = cos - i sin
+        if (m == 0) v[i1] = make_float2(dx, dy);
+        else if (m == 8) v[i1] = make_float2(dy, -dx);
+        else v[i1] = make_float2(dx * C32[m] + dy * S32[m], dy * C32[m] - dx * S32[m]);
+      }
+  }
+}
+
+__device__ __forceinline__ void dft3_inplace(float2& v0, float2& v1, float2& v2) {
+  const float sn = 0.86602540378443864676f;
+  const float2 sm = make_float2(v1.x + v2.x, v1.y + v2.y), d = make_float2(v1.x - v2.x, v1.y - v2.y);
+  const float2 m = make_float2(v0.x - 0.5f * sm.x, v0.y - 0.5f * sm.y);
+  const float2 r = make_float2(sn * d.y, -sn * d.x);
+  v0 = make_float2(v0.x + sm.x, v0.y + sm.y);
+  v1 = make_float2(m.x + r.x, m.y + r.y);
+  v2 = make_float2(m.x - r.x, m.y - r.y);
+}
+
+__device__ __forceinline__ void dft5_inplace(float2& v0, float2& v1, float2& v2, float2& v3, float2& v4) {
+  const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+  const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+  const float2 a14 = make_float2(v1.x + v4.x, v1.y + v4.y), b14 = make_float2(v1.x - v4.x, v1.y - v4.y);
+  const float2 a23 = make_float2(v2.x + v3.x, v2.y + v3.y), b23 = make_float2(v2.x - v3.x, v2.y - v3.y);
+  const float2 p1 = make_float2(v0.x + c1 * a14.x + c2 * a23.x, v0.y + c1 * a14.y + c2 * a23.y);
+  const float2 p2 = make_float2(v0.x + c2 * a14.x + c1 * a23.x, v0.y + c2 * a14.y + c1 * a23.y);
+  const float2 q1 = make_float2(s1 * b14.y + s2 * b23.y, -(s1 * b14.x + s2 * b23.x));
+  const float2 q2 = make_float2(s2 * b14.y - s1 * b23.y, -(s2 * b14.x - s1 * b23.x));
+  v0 = make_float2(v0.x + a14.x + a23.x, v0.y + a14.y + a23.y);
+  v1 = make_float2(p1.x + q1.x, p1.y + q1.y);
+  v4 = make_float2(p1.x - q1.x, p1.y - q1.y);
+  v2 = make_float2(p2.x + q2.x, p2.y + q2.y);
+  v3 = make_float2(p2.x - q2.x, p2.y - q2.y);
+}
+
+// 30-point forward DFT in place as a 2 x 3 x 5 prime-factor transform: element (a, b, c) lives at index
+// (15a + 10b + 6c) mod 30 on input AND output (the CRT and Good maps coincide for 30 = 2*3*5)
+__device__ __forceinline__ void dft30_pfa(float2 (&u)[30]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int base = 15 * a + 10 * b;
+      dft5_inplace(u[base % 30], u[(base + 6) % 30], u[(base + 12) % 30], u[(base + 18) % 30], u[(base + 24) % 30]);
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int base = 15 * a + 6 * c;
+      dft3_inplace(u[base % 30], u[(base + 10) % 30], u[(base + 20) % 30]);
+    }
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int i0 = (10 * b + 6 * c) % 30, i1 = (i0 + 15) % 30;
+      const float2 x0 = u[i0], x1 = u[i1];
+      u[i0] = make_float2(x0.x + x1.x, x0.y + x1.y);
+      u[i1] = make_float2(x0.x - x1.x, x0.y - x1.y);
+    }
+}
+
+__global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
+                                                      float2* __restrict__ out, int L, int T, int hop,
+                                                      int hann, const float2* __restrict__ tw_g) {
+#ifndef URSE_STFT960_NFF
+#define URSE_STFT960_NFF 8
+#endif
+  constexpr int N = 960, F = 481, NFF = URSE_STFT960_NFF;   // complex FFTs (frame pairs) per workgroup
+  constexpr int NTH = NFF * 32;
+  __shared__ float2 zbuf[NFF][N];
+  __shared__ float2 tw[N];
+  const int tid = threadIdx.x, lane = tid & 63, l = lane & 31;
+  const int f = 2 * (tid >> 6) + (lane >> 5);
+  const int b = blockIdx.y;
+  const int ta = blockIdx.x * 2 * NFF + 2 * f;
+  for (int i = tid; i < N; i += NTH) tw[i] = tw_g[i];
+  const float* xb = x + (size_t)b * L;
+  float2 v[32];
+  // branch-free loads (frames past T are clamped to a valid frame and multiplied by 0): all samples of a lane are in
+  // flight together.  With hop == 480 == 30 * 16 the second frame of the pair is the first one shifted by 16 rows of the
+  // 32 x 30 sample matrix, so only its last 16 rows are loaded.
+  const bool half_hop = hop * 2 == N;
+  const int tac = ta < T ? ta : T - 1, tbc = ta + 1 < T ? ta + 1 : T - 1;
+  const float ma = ta < T ? 1.f : 0.f, mb = ta + 1 < T ? 1.f : 0.f;
+  const int lq = l < 30 ? l : 29;
+  const int pa0 = tac * hop - N / 2 + lq, pb0 = tbc * hop - N / 2 + lq;
+  float xa_[32], xb_[32];
+#pragma unroll
+  for (int n1 = 0; n1 < 32; ++n1) {
+    int qa = pa0 + 30 * n1;
+    qa = qa < 0 ? -qa : qa;
+    qa = qa >= L ? 2 * (L - 1) - qa : qa;
+    xa_[n1] = xb[qa];
+  }
+  if (half_hop && tbc == tac + 1) {
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) xb_[n1] = xa_[n1 + 16];
+#pragma unroll
+    for (int n1 = 16; n1 < 32; ++n1) {
+      int qb = pb0 + 30 * n1;
+      qb = qb >= L ? 2 * (L - 1) - qb : qb;            // (the second frame's last rows never fall before sample 0)
+      xb_[n1] = xb[qb];
+    }
+  } else {
+#pragma unroll
+    for (int n1 = 0; n1 < 32; ++n1) {
+      int qb = pb0 + 30 * n1;
+      qb = qb < 0 ? -qb : qb;
+      qb = qb >= L ? 2 * (L - 1) - qb : qb;
+      xb_[n1] = xb[qb];
+    }
+  }
+  __syncthreads();                                          // twiddle table complete
+  if (l < 30) {
+    // window: periodic Hann = 0.5 - 0.5 cos(2 pi i / N) = 0.5 - 0.5 Re(W^i) straight from the twiddle table in LDS
+#pragma unroll
+    for (int n1 = 0; n1 < 32; ++n1) {
+      const int i = 30 * n1 + l;
+      const float w = hann ? 0.5f - 0.5f * tw[i].x : 1.0f;
+      v[n1] = make_float2(xa_[n1] * w * ma, xb_[n1] * w * mb);
+    }
+#ifndef STABL_NO_DFT
+    dft32_dif(v);
+#endif
+    constexpr int BREV[32] = {0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30,
+                              1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31};
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) {
+      const float2 a = v[BREV[k1]];
+      const float2 w = tw[l * k1];                          // W_960^(n2 k1), n2 k1 <= 899
+      zbuf[f][k1 * 30 + l] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+    }
+  }
+  __syncthreads();
+  {
+    float2 u[30];
+#pragma unroll
+    for (int n2 = 0; n2 < 30; ++n2) u[n2] = zbuf[f][l * 30 + n2];
+#ifndef STABL_NO_DFT
+    dft30_pfa(u);
+#endif
+    __syncthreads();                                        // every lane has read its row before rows are overwritten
+#pragma unroll
+    for (int k2 = 0; k2 < 30; ++k2) zbuf[f][l + 32 * k2] = u[k2];
+  }
+  __syncthreads();
+  int olen = T;
+  if (lens != nullptr) olen = (lens[b] + N - N) / hop + 1;
+  for (int idx = tid; idx < NFF * F; idx += NTH) {
+    const int ff = idx / F, k = idx - ff * F;
+    const float2 zk = zbuf[ff][k];
+    const float2 zc = zbuf[ff][k == 0 ? 0 : N - k];
+    const float2 xa = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+    const float2 xbv = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+    const int t = blockIdx.x * 2 * NFF + 2 * ff;
+#ifdef STABL_NO_STORE
+    if (xa.x != 123.456f) continue;
+#endif
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    if (t < T) {
+      const f32x2_t o = (t < olen) ? f32x2_t{xa.x, xa.y} : f32x2_t{0.f, 0.f};
+      __builtin_nontemporal_store(o, reinterpret_cast<f32x2_t*>(out + ((size_t)b * T + t) * F + k));
+    }
+    if (t + 1 < T) {
+      const f32x2_t o = (t + 1 < olen) ? f32x2_t{xbv.x, xbv.y} : f32x2_t{0.f, 0.f};
+      __builtin_nontemporal_store(o, reinterpret_cast<f32x2_t*>(out + ((size_t)b * T + t + 1) * F + k));
+    }
+  }
+}
+
 // iSTFT: each workgroup owns C*hop consecutive positions of the padded OLA axis and transforms
 // the 2*NF frames that cover them (halo frames are recomputed, nothing is accumulated in HBM).
 __global__ void __launch_bounds__(256) istft_kernel(const float2* __restrict__ spec, float* __restrict__ out, int T,
@@ -257,6 +461,13 @@ extern "C" int urse_stft_fwd(const float* wav, const int32_t* lens, float* spec,
   int rc = get_tables(n_fft, &tb);
   if (rc) return rc;
   const int T = L / hop + 1;
+  static const bool no960 = getenv("URSE_STFT_GENERIC") != nullptr;
+  if (n_fft == 960 && !no960) {
+    hipLaunchKernelGGL(stft960_kernel, dim3(ceil_div(T, 2 * URSE_STFT960_NFF), B), dim3(URSE_STFT960_NFF_THREADS), 0, (hipStream_t)stream, wav, lens,
+                       reinterpret_cast<float2*>(spec), L, T, hop, window == URSE_WIN_HANN ? 1 : 0, tb.tw);
+    URSE_CHECK_LAUNCH("urse_stft_fwd");
+    return URSE_OK;
+  }
   const int NF = pick_nf(n_fft, 1);
   dim3 grid(ceil_div(T, 2 * NF), B);
   hipLaunchKernelGGL(stft_kernel<0>, grid, dim3(stft_threads()), lds_bytes(n_fft, NF), (hipStream_t)stream, wav, lens,
