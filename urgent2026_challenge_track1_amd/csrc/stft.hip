@@ -267,7 +267,8 @@ __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const
 #endif
   constexpr int N = 960, F = 481, NFF = URSE_STFT960_NFF;   // complex FFTs (frame pairs) per workgroup
   constexpr int NTH = NFF * 32;
-  __shared__ float2 zbuf[NFF][N];
+  constexpr int ZS = 1000;                                  // per-FFT LDS stride: 8000 B = 16 banks of skew between half-waves
+  __shared__ float2 zbuf[NFF][ZS];
   __shared__ float2 tw[N];
   const int tid = threadIdx.x, lane = tid & 63, l = lane & 31;
   const int f = 2 * (tid >> 6) + (lane >> 5);
@@ -328,18 +329,17 @@ __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const
     for (int k1 = 0; k1 < 32; ++k1) {
       const float2 a = v[BREV[k1]];
       const float2 w = tw[l * k1];                          // W_960^(n2 k1), n2 k1 <= 899
-      zbuf[f][k1 * 30 + l] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+      zbuf[f][k1 * 31 + l] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);   // row pitch 31: conflict-free reads
     }
   }
-  __syncthreads();
+  // pass 1 and pass 2 of an FFT run in the same half-wave: LDS executes a wave's accesses in order, no barrier needed
   {
     float2 u[30];
 #pragma unroll
-    for (int n2 = 0; n2 < 30; ++n2) u[n2] = zbuf[f][l * 30 + n2];
+    for (int n2 = 0; n2 < 30; ++n2) u[n2] = zbuf[f][l * 31 + n2];
 #ifndef STABL_NO_DFT
     dft30_pfa(u);
 #endif
-    __syncthreads();                                        // every lane has read its row before rows are overwritten
 #pragma unroll
     for (int k2 = 0; k2 < 30; ++k2) zbuf[f][l + 32 * k2] = u[k2];
   }
