@@ -262,6 +262,7 @@ def main():
                           "frac": stft_bytes / (kt["stft_fwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "gate_gemm_tflops_per_step": 3 * gate_gemm_flops(B, T, K, args.channels, args.layers) / 1e12,
         "final_loss": float(loss.detach()),
+        "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
     }
     if rank == 0 and world == 1 and not args.no_metrics:
         out["metrics_bench"] = metrics_bench(dev)
