@@ -149,6 +149,13 @@ int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan);
 int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                           void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
                           int64_t outer, int64_t stride, int save, void* stream);
+/* Generalised cluster forward (csrc/lstm_cluster2.hip): same protocol and arguments, geometry chosen per hidden size
+ * (H = 768, the flow model: 24 workgroups per cluster; H = 392: 7).  plan = {C, clusters per direction, rows per cluster,
+ * hx bf16 elements}; hx is zeroed by the call; whhq from urse_lstm_pack_quads. */
+int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int64_t* plan);
+int urse_lstm_cluster2_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx, void* err_flag,
+                           int H, int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
+                           void* stream);
 /* Cluster BPTT (bf16), same protocol: whhTq from urse_lstm_pack_bwd_quads(whh, out [2*C*4*(H/8)*512 bf16], H, C);
  * dgx = exchange buffer of 2*2*ncl*64*4H bf16 elements. */
 int urse_lstm_pack_bwd_quads(const float* whh, void* out, int H, int C, void* stream);

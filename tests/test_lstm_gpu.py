@@ -218,3 +218,32 @@ def test_split_bptt_matches_streaming_kernel(lib, B, T, K, N):
     d = (g1.float() - g2.float()).abs()
     scale = g1.float().abs().max().item()
     assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, (d.max().item(), d.mean().item(), scale)
+
+
+@pytest.mark.parametrize("path,B,T,K,N", [("time", 2, 21, 48, 384), ("band", 1, 60, 10, 384), ("time", 3, 40, 34, 196), ("time", 1, 9, 5, 196)])
+def test_cluster2_kernel_matches_streaming_kernel(lib, path, B, T, K, N):
+    """generalised cluster forward (H = 768: 24 workgroups per cluster; H = 392: two unit quads per wave) == streaming kernel."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(6)
+    H, dtype, dev = 2 * N, torch.bfloat16, "cuda"
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    M = B * T * K
+    if path == "time":
+        sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+    else:
+        sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    assert ops.lstm_cluster2_plan(H, pk["Hp"], sm["n_seq"]) is not None
+    xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dtype)
+    gx1 = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    gx2 = gx1.clone()
+    h1, c1 = ops.lstm_fwd(gx1, pk["whh"], H, pk["Hp"], **sm)
+    h2, c2, err = ops.lstm_fwd_cluster2(gx2, pk["whhq"], H, pk["Hp"], **sm)
+    assert int(err.item()) == 0
+    assert torch.all(h2[:, 2 * H:] == 0)
+    assert (h1.float() - h2.float()).abs().max().item() <= 1e-2
+    assert (c1 - c2).abs().max().item() <= 2e-2
+    assert (gx1.float() - gx2.float()).abs().max().item() <= 2e-2
+    assert (h1.float() - h2.float()).abs().mean().item() <= 1e-4

@@ -429,7 +429,11 @@ class BSRNNCore(nn.Module):
                                       d["Np"], 0, dt, GN_EPS, add=temb)
         gx = ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
         sm = self._seqmap(path, B, T, K)
-        if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and \
+        if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H in ops.CLUSTER2_H and \
+                ops.lstm_cluster2_plan(H, d["Hp"], sm["n_seq"]) is not None:
+            hout, c, err = ops.lstm_fwd_cluster2(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
+            self._cluster_err = err
+        elif ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and \
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
             hout, c, err = ops.lstm_fwd_cluster(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
             self._cluster_err = err

@@ -1,0 +1,329 @@
+// Generalised persistent cluster LSTM forward (bf16): the protocol and math of lstm_cluster.hip's forward kernel with the
+// geometry as template parameters, so that other hidden sizes fit the register file:
+//   NW waves per workgroup, QPW unit quads (4 units x 4 gates = one MFMA column tile) per wave, NSLAB = Hp / 32 K slabs;
+//   a wave keeps QPW x NSLAB B fragments resident and one A read from the LDS h tile feeds QPW MFMAs.
+// Instantiated for the flow model (H = 768: <24, 8, 1>, 24 workgroups per cluster, 4.7 MB of W_hh per direction spread
+// over their registers -- its 48..96 time-path sequences otherwise keep 3..6 streaming workgroups busy for 501 steps) and,
+// as a variant, for H = 392 (<13, 8, 2>).  Hand-off: tag in data, see lstm_cluster.hip.
+#include "urse_common.h"
+
+namespace urse {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int C2ROWS = 64;
+
+struct Cluster2Args {
+  void* gx; long ldg;
+  const void* whhq;               // [2][nq][NSLAB][64][16 B] quad-ordered fragments (urse_lstm_pack_quads)
+  void* hout; long ldh;
+  float* c;
+  bf16_t* hx;                     // exchange [2 parity][2 dir][ncl][64][Hp], zeroed per launch
+  unsigned* err;
+  int H, Hp, save;
+  long inner, outer, stride;
+  int n_seq, seq_len;
+  int C, ncl, rows_per_cluster;
+};
+
+namespace c2 {
+__device__ __forceinline__ float quad_bcast(float v, int k) {
+  // value of quad-lane k, broadcast inside each group of 4 lanes (DPP quad_perm)
+  int r;
+  const int iv = __float_as_int(v);
+  switch (k) {
+    case 0: r = __builtin_amdgcn_mov_dpp(iv, 0x00, 0xf, 0xf, true); break;
+    case 1: r = __builtin_amdgcn_mov_dpp(iv, 0x55, 0xf, 0xf, true); break;
+    case 2: r = __builtin_amdgcn_mov_dpp(iv, 0xAA, 0xf, 0xf, true); break;
+    default: r = __builtin_amdgcn_mov_dpp(iv, 0xFF, 0xf, 0xf, true); break;
+  }
+  return __int_as_float(r);
+}
+
+// write-through (sc1) 16-byte accesses to the exchange buffer: bypass this CU's L1 on loads, leave L2 on stores, so the
+// hand-off needs no release / acquire fence (MI355X_MICROARCH "Valid forms": every payload store and load sc1, every
+// storing wave drains vmcnt, one lane per workgroup signals with an agent-scope atomic, the poller is an sc1 load).
+__device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off, uint4 v) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs, (int)off, 0, 16);
+}
+__device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
+  return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+}  // namespace c2
+
+template <int NSLAB, int NW, int QPW>
+__global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args p) {
+  using namespace c2;
+  constexpr int NTHR = NW * 64, UW = NW * QPW * 4, HPB = NSLAB * 64;       // units per workgroup, bytes per h row
+  constexpr int CPR = HPB / 16;                                              // 16-byte chunks per h row
+  constexpr int HL = (C2ROWS * CPR + NTHR - 1) / NTHR;                       // h-tile chunks per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.y;
+  const int cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
+  const int H = p.H, Hp = p.Hp;
+  constexpr int pitch = HPB + 16;
+  char* htile = smem;                                                        // [64][pitch]
+  bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + C2ROWS * pitch);         // [64][UW]
+  unsigned* deadflag = reinterpret_cast<unsigned*>(smem + C2ROWS * pitch + C2ROWS * UW * 2);
+  const int nq = (H + 3) >> 2;
+  const int ul = lc >> 2, q = lc & 3;                                        // unit within quad / quad lane
+  const int qd0 = (j * NW + w) * QPW;                                        // first unit quad of this wave
+
+  uint4 breg[QPW][NSLAB];                                                    // resident B fragments
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) {
+    const int qd = qd0 + qi < nq ? qd0 + qi : 0;
+    const char* src = reinterpret_cast<const char*>(p.whhq) + (((long)dir * nq + qd) * NSLAB) * 1024 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < NSLAB; ++ks) breg[qi][ks] = *reinterpret_cast<const uint4*>(src + ks * 1024);
+  }
+  for (int i = tid; i < C2ROWS * UW / 2; i += NTHR) reinterpret_cast<unsigned*>(hstage)[i] = 0u;   // pad units stay 0
+  if (tid == 0) *deadflag = 0u;
+  float cst[QPW][4];
+#pragma unroll
+  for (int a = 0; a < QPW; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cst[a][b] = 0.f;
+
+  const int seq0 = cl * p.rows_per_cluster;
+  int seq1 = seq0 + p.rows_per_cluster;
+  if (seq1 > p.n_seq) seq1 = p.n_seq;
+  const int nrows = seq1 - seq0;
+  bf16_t* gx = reinterpret_cast<bf16_t*>(p.gx);
+  bf16_t* hout = reinterpret_cast<bf16_t*>(p.hout);
+  const long gcol0 = (long)dir * 4 * H;
+  const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * C2ROWS * HPB);
+  const unsigned cl_bytes = (unsigned)(((long)dir * p.ncl + cl) * C2ROWS * HPB);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2u * plane_bytes), 0x00020000);
+  const int hchunks = H / 8;
+  constexpr unsigned TAGM = 0x40004000u;
+
+  // row of this lane for row tile rt (sequence lrow = rt*16 + lr*4 + q)
+  long rowb[4];
+  bool rvalid[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int lrow = rt * 16 + lr * 4 + q;
+    rvalid[rt] = lrow < nrows;
+    int seq = seq0 + lrow;
+    if (seq >= p.n_seq) seq = p.n_seq - 1;
+    rowb[rt] = (seq / p.inner) * p.outer + (seq % p.inner);
+  }
+  auto load_gx = [&](long toff, uint2 (&dst)[QPW][4]) {
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+      int u = (qd0 + qi) * 4 + ul;
+      if (u >= H) u = H - 1;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) dst[qi][rt] = *reinterpret_cast<const uint2*>(gx + (rowb[rt] + toff) * p.ldg + gcol0 + u * 4);
+    }
+  };
+  uint2 gxn[QPW][4];
+  load_gx((long)(dir ? p.seq_len - 1 : 0) * p.stride, gxn);
+  __syncthreads();
+
+  for (int step = 0; step < p.seq_len; ++step) {
+    const int t = dir ? (p.seq_len - 1 - step) : step;
+    const long toff = (long)t * p.stride;
+    const unsigned pprev = (unsigned)((step + 1) & 1), pcur = (unsigned)(step & 1);
+    const unsigned tag_cur = (((unsigned)step >> 1) & 1u) ^ 1u;
+    const unsigned tag_prev = (((unsigned)(step - 1) >> 1) & 1u) ^ 1u;
+    // 1. h_{t-1} rows -> LDS, every 16-byte piece polled until its tags are current
+    {
+      uint4 hn[HL];
+      unsigned pend = 0u;
+#pragma unroll
+      for (int i = 0; i < HL; ++i) {
+        hn[i] = make_uint4(0, 0, 0, 0);
+        const int idx = tid + i * NTHR;
+        const int row = idx / CPR, cc = idx - row * CPR;
+        if (step > 0 && idx < C2ROWS * CPR && row < nrows && cc < hchunks) pend |= 1u << i;
+      }
+      if (pend && *reinterpret_cast<volatile unsigned*>(deadflag)) pend = 0u;
+      const unsigned want = tag_prev ? TAGM : 0u;
+      unsigned spins = 0;
+      while (pend) {
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+          if (pend & (1u << i)) {
+            const int idx = tid + i * NTHR;
+            hn[i] = load_sc1(rs, pprev * plane_bytes + cl_bytes + (unsigned)(idx * 16));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+          if (pend & (1u << i)) {
+            const uint4 v = hn[i];
+            if ((v.x & TAGM) == want && (v.y & TAGM) == want && (v.z & TAGM) == want && (v.w & TAGM) == want) pend &= ~(1u << i);
+          }
+        }
+        if (pend) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 20)) { atomicExch(p.err, 1u); *reinterpret_cast<volatile unsigned*>(deadflag) = 1u; pend = 0u; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < HL; ++i) {
+        const int idx = tid + i * NTHR;
+        const int row = idx / CPR, cc = idx - row * CPR;
+        uint4 v = hn[i];
+        v.x &= ~TAGM; v.y &= ~TAGM; v.z &= ~TAGM; v.w &= ~TAGM;
+        if (idx < C2ROWS * CPR) *reinterpret_cast<uint4*>(htile + row * pitch + cc * 16) = v;
+      }
+    }
+    uint2 gxc[QPW][4];
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) gxc[qi][rt] = gxn[qi][rt];
+    __syncthreads();
+    if (step + 1 < p.seq_len) load_gx((long)(dir ? t - 1 : t + 1) * p.stride, gxn);
+    // 2. gates of the wave's quads for the 64 rows
+    uint2 gsave[QPW][4];
+    float csave[QPW][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f32x4_t acc[QPW];
+#pragma unroll
+      for (int qi = 0; qi < QPW; ++qi) acc[qi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const char* ar = htile + (rt * 16 + lc) * pitch + 16 * lr;
+#pragma unroll
+      for (int ks = 0; ks < NSLAB; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi)
+          acc[qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                            __builtin_bit_cast(bf16x8_t, breg[qi][ks]), acc[qi], 0, 0, 0);
+      }
+#pragma unroll
+      for (int qi = 0; qi < QPW; ++qi) {
+        const int qd = qd0 + qi;
+        const bool qvalid = qd < nq;
+        const bool uvalid = qvalid && qd * 4 + ul < H;
+        // acc[r] = gate (lc & 3) of unit (lc >> 2), row rt*16 + lr*4 + r: 4x4 transpose inside the lane quad
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v0 = quad_bcast(acc[qi][0], g), v1 = quad_bcast(acc[qi][1], g), v2 = quad_bcast(acc[qi][2], g),
+                      v3 = quad_bcast(acc[qi][3], g);
+          pre[g] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
+        }
+        const uint2 gxv = gxc[qi][rt];
+        const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
+        const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
+        const float iv = sigmoidf_(gi), fv = sigmoidf_(gf), gv = tanhf_(gg), ov = sigmoidf_(go);
+        const float cv = fv * cst[qi][rt] + iv * gv;
+        cst[qi][rt] = cv;
+        const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
+        if (qvalid) hstage[(rt * 16 + lr * 4 + q) * UW + (w * QPW + qi) * 4 + ul] = f32_to_bf16(hv);
+        gsave[qi][rt].x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
+        gsave[qi][rt].y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
+        csave[qi][rt] = cv;
+      }
+    }
+    __syncthreads();
+    // 3. h_t of this workgroup's units -> exchange buffer (write-through, tagged) and hout
+    constexpr int SC = UW * 2 / 16;
+    const unsigned tagv = tag_cur ? TAGM : 0u;
+    for (int idx = tid; idx < C2ROWS * SC; idx += NTHR) {
+      const int row = idx / SC, cc = idx - row * SC;
+      const int ucol = j * UW + cc * 8;
+      if (row >= nrows || ucol >= H) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
+      if (step + 1 < p.seq_len)
+        store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)(row * HPB + ucol * 2),
+                  make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv));
+      const int seq = seq0 + row;
+      const long grow = (seq / p.inner) * p.outer + (seq % p.inner) + toff;
+      *reinterpret_cast<uint4*>(hout + grow * p.ldh + (long)dir * H + ucol) = v;    // H % 8 == 0: whole chunks
+    }
+    if (p.save) {
+#pragma unroll
+      for (int qi = 0; qi < QPW; ++qi) {
+        const int u = (qd0 + qi) * 4 + ul;
+        if (qd0 + qi < nq && u < H) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+            if (rvalid[rt]) {
+              const long row = rowb[rt] + toff;
+              *reinterpret_cast<uint2*>(gx + row * p.ldg + gcol0 + u * 4) = gsave[qi][rt];
+              p.c[row * 2 * H + (long)dir * H + u] = csave[qi][rt];
+            }
+        }
+      }
+    }
+    __syncthreads();   // hstage / htile are rewritten by the next step
+  }
+}
+
+template <int NSLAB, int NW, int QPW>
+static int launch_cluster2(const Cluster2Args& p, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster2_kernel<NSLAB, NW, QPW>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  const size_t lds = (size_t)C2ROWS * (NSLAB * 64 + 16) + (size_t)C2ROWS * NW * QPW * 4 * 2 + 16;
+  hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<NSLAB, NW, QPW>), dim3(p.C * p.ncl, 2), dim3(NW * 64), lds, st, p);
+  URSE_CHECK_LAUNCH("urse_lstm_cluster2_fwd");
+  return URSE_OK;
+}
+
+static bool cluster2_geometry(int H, int Hp, int* nw, int* qpw) {
+  if (Hp % 32 || H % 8 || Hp < H) return false;
+  const int nslab = Hp / 32;
+  if (nslab == 24) { *nw = 8; *qpw = 1; return true; }
+  if (nslab == 13) { *nw = 8; *qpw = 2; return true; }
+  return false;
+}
+
+}  // namespace urse
+
+using namespace urse;
+
+// workspace query: {C, clusters per direction, rows per cluster, hx bf16 elements}; < 0 if the shape is unsupported
+extern "C" int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int64_t* plan) {
+  URSE_CHECK_ARG(plan && H > 0 && n_seq > 0, "urse_lstm_cluster2_plan: bad argument");
+  int nw, qpw;
+  if (!cluster2_geometry(H, Hp, &nw, &qpw)) {
+    set_error("urse_lstm_cluster2_plan: unsupported H=%d Hp=%d", H, Hp);
+    return URSE_ERR_UNSUPPORTED;
+  }
+  const int nq = (H + 3) / 4;
+  const int C = (nq + nw * qpw - 1) / (nw * qpw);
+  int ncl = 126 / C;                       // 2 directions * ncl * C <= 252 workgroups: all co-resident
+  if (ncl < 1) { set_error("urse_lstm_cluster2_plan: H=%d needs %d workgroups per cluster", H, C); return URSE_ERR_UNSUPPORTED; }
+  int rpc = (n_seq + ncl - 1) / ncl;
+  if (rpc > C2ROWS) {
+    set_error("urse_lstm_cluster2_plan: %d sequences exceed the cluster capacity", n_seq);
+    return URSE_ERR_UNSUPPORTED;
+  }
+  ncl = (n_seq + rpc - 1) / rpc;
+  plan[0] = C; plan[1] = ncl; plan[2] = rpc; plan[3] = (int64_t)2 * 2 * ncl * C2ROWS * Hp;
+  return URSE_OK;
+}
+
+extern "C" int urse_lstm_cluster2_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
+                                      void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer,
+                                      int64_t stride, int save, void* stream) {
+  URSE_CHECK_ARG(gx && whhq && hout && hx && err_flag && (c || !save), "urse_lstm_cluster2_fwd: null pointer");
+  int64_t plan[4];
+  int rc = urse_lstm_cluster2_plan(H, Hp, n_seq, plan);
+  if (rc) return rc;
+  URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldh >= 2L * H && (ldh * 2) % 16 == 0 && ((uintptr_t)hout % 16) == 0 &&
+                     ((uintptr_t)hx % 16) == 0 && seq_len > 0 && inner > 0,
+                 "urse_lstm_cluster2_fwd: bad leading dimension / alignment");
+  Cluster2Args p;
+  p.gx = gx; p.ldg = ldg; p.whhq = whhq; p.hout = hout; p.ldh = ldh; p.c = c; p.hx = (bf16_t*)hx; p.err = (unsigned*)err_flag;
+  p.H = H; p.Hp = Hp; p.save = save; p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
+  p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2];
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(hx, 0, sizeof(bf16_t) * plan[3], st);      // every tag bit starts clear
+  if (Hp / 32 == 24) return launch_cluster2<24, 8, 1>(p, st);
+  return launch_cluster2<13, 8, 2>(p, st);
+}

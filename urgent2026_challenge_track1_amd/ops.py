@@ -274,6 +274,34 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
     return hout, c, err
 
 
+# which hidden sizes take the generalised cluster kernel: "768" by default (H = 392 keeps lstm_cluster.hip unless asked)
+CLUSTER2_H = tuple(int(v) for v in os.environ.get("URSE_LSTM_CLUSTER2_H", "768").split(",") if v)
+
+
+def lstm_cluster2_plan(H, Hp, n_seq):
+    import ctypes
+    plan = (ctypes.c_int64 * 4)()
+    if _lib.load().urse_lstm_cluster2_plan(H, Hp, n_seq, plan) != 0:
+        return None
+    return list(plan)
+
+
+def lstm_fwd_cluster2(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save=True):
+    """generalised persistent cluster LSTM forward (bf16): see csrc/lstm_cluster2.hip."""
+    plan = lstm_cluster2_plan(H, Hp, n_seq)
+    M, dev = gx.shape[0], gx.device
+    key = ("c2", dev, H, Hp, n_seq)
+    if key not in _cluster_ws:
+        _cluster_ws[key] = (torch.empty(plan[3], device=dev, dtype=torch.bfloat16), torch.zeros(1, device=dev, dtype=torch.int32))
+    hx, err = _cluster_ws[key]
+    ldh = kpad(2 * H, gx.dtype)
+    hout = _hout_buffer(M, ldh, H, gx)
+    c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
+    timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster2_fwd", gx, gx.stride(0), whhq, hout, ldh, c, hx,
+               err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
+    return hout, c, err
+
+
 def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, rows16=0):
     """gx [M, 8H] (overwritten by gate activations if save) -> (hout [M, kpad(2H)], c [M, 2H] f32)."""
     M = gx.shape[0]
