@@ -173,7 +173,7 @@ int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int6
 /* Split BPTT (bf16) for few, long sequences (time path): 2-3 workgroups share 32 sequences and split the reduction of
  * the recurrent product; f32 partial sums are exchanged through `xbuf` (zeroed by the call) with the tag-in-data
  * hand-off (step parity in the mantissa LSB).  Arguments as urse_lstm_bidir_bwd (whhT from urse_lstm_pack).
- * urse_lstm_split_plan -> {nsplit, clusters per direction, xbuf f32 elements}, < 0 if unsupported (too many sequences
+ * urse_lstm_split_plan -> {nsplit, clusters per direction, xbuf f32 elements, sequences per cluster (32 | 16)}, < 0 if unsupported (too many sequences
  * for all workgroups to be co-resident, H % 8 != 0, ...).  err_flag: uint32 set to 1 if a hand-off timed out. */
 int urse_lstm_split_plan(int H, int n_seq, int64_t* plan);
 int urse_lstm_split_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT, void* xbuf,

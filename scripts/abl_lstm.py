@@ -39,7 +39,7 @@ def fwd_wide(lib, path, rt):
     else: a = (B * T, K, 1, K, 1)
     return lib.urse_lstm_wide_fwd(P(gx.data_ptr()), ctypes.c_int64(8 * H), P(whhb.data_ptr()), P(hout.data_ptr()), ctypes.c_int64(800),
         P(c.data_ptr()), H, Hp, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 1, P(st))
-plan = (ctypes.c_int64 * 3)()
+plan = (ctypes.c_int64 * 4)()
 assert libs["base"].urse_lstm_split_plan(H, B * K, plan) == 0
 print("split plan", list(plan))
 xbuf = torch.empty(plan[2], device=dev, dtype=torch.float32)

@@ -22,10 +22,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int SW = 16;             // waves per workgroup
 constexpr int SMAXO = 1;           // owned unit tiles per wave
-constexpr int SMAXT = 2;           // unit tiles per wave in the product
+// SMAXT (template parameter): unit tiles per wave in the product, ceil(ceil(H/16) / 16)
 constexpr int STHR = SW * 64;
-constexpr int SROWS = 32;          // sequences per cluster (2 MFMA row tiles)
-constexpr int SRT = 2;
+// sequences per cluster = 16 * SRT (template parameter: 2 for H <= 512, 1 where the LDS tiles of a bigger H need it)
 
 struct SplitBwdArgs {
   const void* dh; long ldd;
@@ -49,7 +48,9 @@ __device__ __forceinline__ uint4 split_load_sc1(__amdgpu_buffer_rsrc_t rs, unsig
   return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+template <int SRT, int SMAXT>
 __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
+  constexpr int SROWS = 16 * SRT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -325,25 +326,42 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
 
 using namespace urse;
 
-// workspace query: {nsplit, clusters per direction, xbuf f32 elements}; < 0 if the shape has no split kernel
+static size_t split_lds(int nut, int ns, int rows) {
+  const int tmax = (nut + ns - 1) / ns;
+  return (size_t)rows * (tmax * 128 + 16) + (size_t)rows * nut * 16 * 4 + (size_t)(ns - 1) * rows * tmax * 16 * 4 + 16;
+}
+
+// workspace query: {nsplit, clusters per direction, xbuf f32 elements, rows per cluster}; < 0 if the shape has no split kernel
 extern "C" int urse_lstm_split_plan(int H, int n_seq, int64_t* plan) {
   URSE_CHECK_ARG(plan && H > 0 && n_seq > 0, "urse_lstm_split_plan: bad argument");
   const int nut = (H + 15) / 16;
-  const int ncl = (n_seq + SROWS - 1) / SROWS;
-  int ns = 0;
-  for (int cand = 3; cand >= 2; --cand)
-    if (2L * ncl * cand <= 250 && nut >= 2 * cand) { ns = cand; break; }
-  if (!ns || H % 8 != 0 || nut > SMAXT * SW || (nut + ns - 1) / ns > SMAXO * SW) {
-    set_error("urse_lstm_split_plan: unsupported H=%d n_seq=%d", H, n_seq);
+  if (H % 8 != 0 || nut > 3 * SW) {
+    set_error("urse_lstm_split_plan: unsupported H=%d", H);
     return URSE_ERR_UNSUPPORTED;
   }
-  const int tmax = (nut + ns - 1) / ns;
-  const size_t lds = (size_t)SROWS * (tmax * 128 + 16) + (size_t)SROWS * nut * 16 * 4 + (size_t)(ns - 1) * SROWS * tmax * 16 * 4 + 16;
-  if (lds > 160 * 1024) {
-    set_error("urse_lstm_split_plan: H=%d exceeds LDS", H);
-    return URSE_ERR_UNSUPPORTED;
+  // prefer 32-row clusters; fall back to 16 rows where the LDS tiles of a large H do not fit; as many splits (<= 6) as keep
+  // every workgroup co-resident, give each at least two unit tiles and at most one owned tile per wave
+  for (int rows = 32; rows >= 16; rows -= 16) {
+    const int ncl = (n_seq + rows - 1) / rows;
+    for (int ns = rows == 32 ? 3 : 6; ns >= 2; --ns) {
+      const int tmax = (nut + ns - 1) / ns;
+      if (2L * ncl * ns > 250 || nut < 2 * ns || tmax > SMAXO * SW) continue;
+      if (split_lds(nut, ns, rows) > 160 * 1024) continue;
+      plan[0] = ns; plan[1] = ncl; plan[2] = (int64_t)2 * 2 * ncl * ns * rows * nut * 16; plan[3] = rows;
+      return URSE_OK;
+    }
   }
-  plan[0] = ns; plan[1] = ncl; plan[2] = (int64_t)2 * 2 * ncl * ns * SROWS * nut * 16;
+  set_error("urse_lstm_split_plan: unsupported H=%d n_seq=%d", H, n_seq);
+  return URSE_ERR_UNSUPPORTED;
+}
+
+template <int SRT, int SMAXT>
+static int launch_split(const SplitBwdArgs& p, size_t lds, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_split_kernel<SRT, SMAXT>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  hipLaunchKernelGGL((lstm_bwd_split_kernel<SRT, SMAXT>), dim3(p.ncl * p.nsplit, 2), dim3(STHR), lds, st, p);
+  URSE_CHECK_LAUNCH("urse_lstm_split_bwd");
   return URSE_OK;
 }
 
@@ -351,7 +369,7 @@ extern "C" int urse_lstm_split_bwd(const void* dh, int64_t ldd, void* gates, int
                                    void* xbuf, void* err_flag, int H, int n_seq, int seq_len, int64_t inner, int64_t outer,
                                    int64_t stride, void* stream) {
   URSE_CHECK_ARG(dh && gates && c && whhT && xbuf && err_flag, "urse_lstm_split_bwd: null pointer");
-  int64_t plan[3];
+  int64_t plan[4];
   int rc = urse_lstm_split_plan(H, n_seq, plan);
   if (rc) return rc;
   URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldd >= 2L * H && ((uintptr_t)xbuf % 16) == 0 && seq_len > 0 && inner > 0,
@@ -362,14 +380,14 @@ extern "C" int urse_lstm_split_bwd(const void* dh, int64_t ldd, void* gates, int
   p.err = (unsigned*)err_flag; p.H = H; p.nsplit = (int)plan[0]; p.ncl = (int)plan[1];
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
   hipStream_t st = (hipStream_t)stream;
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_split_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-  (void)once;
-  // every tag bit starts clear (see the hand-off protocol)
-  (void)hipMemsetAsync(xbuf, 0, sizeof(float) * plan[2], st);
-  const int nut = (H + 15) / 16, ns = (int)plan[0], tmax = (nut + ns - 1) / ns;
-  const size_t lds = (size_t)SROWS * (tmax * 128 + 16) + (size_t)SROWS * nut * 16 * 4 + (size_t)(ns - 1) * SROWS * tmax * 16 * 4 + 16;
-  hipLaunchKernelGGL(lstm_bwd_split_kernel, dim3(p.ncl * ns, 2), dim3(STHR), lds, st, p);
-  URSE_CHECK_LAUNCH("urse_lstm_split_bwd");
-  return URSE_OK;
+  (void)hipMemsetAsync(xbuf, 0, sizeof(float) * plan[2], st);   // every tag bit starts clear (see the hand-off protocol)
+  const int nut = (H + 15) / 16, rows = (int)plan[3];
+  const size_t lds = split_lds(nut, p.nsplit, rows);
+  const int maxt = (nut + SW - 1) / SW;
+  if (rows == 32) {
+    if (maxt <= 2) return launch_split<2, 2>(p, lds, st);
+    return launch_split<2, 3>(p, lds, st);
+  }
+  if (maxt <= 2) return launch_split<1, 2>(p, lds, st);
+  return launch_split<1, 3>(p, lds, st);
 }

@@ -352,12 +352,15 @@ def lstm_bwd_cluster(dh, gates, c, whhTq, H, Hp, n_seq, seq_len, inner, outer, s
 # 7.2 ms per time-path launch): the serial phases of a step (hand-off wait, dgates, barrier chain, publish) cost 8 us with
 # the weight stream switched off (scripts/abl_lstm.py).  Opt-in until it wins.
 USE_SPLIT_LSTM_BWD = os.environ.get("URSE_LSTM_SPLIT_BWD", "0") == "1"
+# ... except where few sequences meet a big hidden size (flow model, H = 768, 48-96 time-path sequences: the streaming kernel
+# keeps 3-6 workgroups busy at 67 us per step): there the 16-row, up-to-6-way split is the default
+SPLIT_BWD_MIN_H = int(os.environ.get("URSE_LSTM_SPLIT_BWD_MIN_H", "512"))
 
 
 def lstm_split_plan(H, n_seq):
     """None if the split BPTT kernel does not support this shape."""
     import ctypes
-    plan = (ctypes.c_int64 * 3)()
+    plan = (ctypes.c_int64 * 4)()
     if _lib.load().urse_lstm_split_plan(H, n_seq, plan) != 0:
         return None
     return list(plan)
