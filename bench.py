@@ -151,8 +151,8 @@ def metrics_bench(dev, pairs=256, batches=6, fs=16000, seconds=4.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--layers", type=int, default=6)
