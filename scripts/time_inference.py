@@ -1,0 +1,16 @@
+"""Forward-only latency / throughput of BSRNN_SE (N = 196, 6 layers, 48 kHz) at a few batch sizes.  Diagnostic."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from urgent2026_challenge_track1_amd.bsrnn import BSRNN_SE
+m = BSRNN_SE(num_channel=196, num_layer=6, compute_dtype=torch.bfloat16).cuda().eval()
+for B in (1, 4, 32):
+    x = 0.1 * torch.randn(B, 192000, device="cuda")
+    lens = torch.full((B,), 192000)
+    with torch.no_grad():
+        m(x, lens, 48000); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): y = m(x, lens, 48000)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print("B=%d x 4 s @ 48 kHz: %.1f ms per forward, %.1f utt/s, real-time factor %.5f" % (B, dt * 1e3, B / dt, dt / (4.0 * B)), flush=True)
