@@ -33,7 +33,6 @@ struct GemmDesc {  // 12 x int64, mirrored by ops.py
 
 constexpr int BM = 128, BN = 128;
 constexpr int SLAB = 64;      // bytes of K per LDS row
-constexpr int ROWB = 80;      // padded LDS row pitch (bytes)
 
 // bijective XCD-aware remap: blocks that share an XCD (bid % 8) get consecutive tile ids
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -99,17 +99,14 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   int seq1 = seq0 + p.rows_per_cluster;
   if (seq1 > p.n_seq) seq1 = p.n_seq;
   const int nrows = seq1 - seq0;
-  const int nch = (nrows + CROWS - 1) / CROWS;
   bf16_t* gx = reinterpret_cast<bf16_t*>(p.gx);
   bf16_t* hout = reinterpret_cast<bf16_t*>(p.hout);
   const long gcol0 = (long)dir * 4 * H;
   const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * p.rows_pad * Hp * 2);
   const unsigned cl_bytes = (unsigned)(((long)dir * p.ncl + cl) * p.rows_pad * Hp * 2);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2u * plane_bytes), 0x00020000);
-  unsigned* cnt = p.cnt + dir * p.ncl + cl;
   const int cpr = Hp * 2 / 16;                           // 16-B chunks per h row
   constexpr int HL = (CROWS * 52 + CTHR - 1) / CTHR;     // h-tile chunks per thread (Hp <= 416)
-  bool dead = false;
 
   // row bookkeeping of this lane for chunk ch, row tile rt
   auto row_of = [&](int ch, int rt, long toff, bool* valid) -> long {
@@ -127,17 +124,6 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
       dst[rt] = *reinterpret_cast<const uint2*>(gx + row * p.ldg + gcol0 + uc * 4);
     }
   };
-  auto load_h = [&](int ch, unsigned plane, uint4 (&dst)[HL]) {
-#pragma unroll
-    for (int i = 0; i < HL; ++i) {
-      const int idx = tid + i * CTHR;
-      const int row = idx / cpr, cc = idx - row * cpr;
-      dst[i] = make_uint4(0, 0, 0, 0);
-      if (idx < CROWS * cpr && ch * CROWS + row < nrows)
-        dst[i] = load_sc1(rs, plane * plane_bytes + cl_bytes + (unsigned)((ch * CROWS + row) * Hp * 2 + cc * 16));
-    }
-  };
-
   uint2 gxn[4];                                          // gate pre-activations, prefetched one step ahead
   load_gx(0, (long)(dir ? p.seq_len - 1 : 0) * p.stride, gxn);
   unsigned* deadflag = reinterpret_cast<unsigned*>(smem + CROWS * pitch + CROWS * UW * 2);

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dir = blockIdx.y;
   const int cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
-  const int H = p.H, Hp = p.Hp;
+  const int H = p.H;
   constexpr int pitch = HPB + 16;
   char* htile = smem;                                                        // [64][pitch]
   bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + C2ROWS * pitch);         // [64][UW]

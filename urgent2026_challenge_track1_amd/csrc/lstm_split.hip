@@ -145,7 +145,6 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
   const int in_chunks = (ns - 1) * SROWS * in_cpr;
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? step : (p.seq_len - 1 - step);
-    const bool first = dir ? (t == p.seq_len - 1) : (t == 0);   // first step of the forward recurrence: c_{-1} = 0
     const long toff = (long)t * p.stride;
     const unsigned pprev = (unsigned)((step + 1) & 1), pcur = (unsigned)(step & 1);
     const unsigned tag_cur = (((unsigned)step >> 1) & 1u) ^ 1u;

@@ -122,7 +122,6 @@ __global__ void __launch_bounds__(WTHR) lstm_fwd_wide_kernel(WideArgs p) {
         const char* wnext = wbase + (long)(b0 + gn) * BLKB;
         const int u = (b0 + g) * 16 + lc;
         const bool uvalid = u < H;
-        const int uc = uvalid ? u : H - 1;
         // acc starts from the gate pre-activations x*W_ih + b (prefetched during the previous group's cell phase):
         // 8 B per (row, unit), 16 lanes cover one 128-byte line
         f32x4_t acc[4][4];
