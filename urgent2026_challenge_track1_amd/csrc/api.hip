@@ -11,6 +11,17 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+int device_cu_count() {
+  static thread_local int cached_dev = -1, cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev != cached_dev) {
+    hipDeviceProp_t prop;
+    cached = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cached_dev = dev;
+  }
+  return cached;
+}
 }  // namespace urse
 
 extern "C" int urse_version(void) { return 1; }

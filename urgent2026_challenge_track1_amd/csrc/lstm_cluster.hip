@@ -575,8 +575,11 @@ extern "C" int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan) {
   }
   const int nq = (H + 3) / 4;
   const int C = (nq + CW - 1) / CW;
-  int ncl = 126 / C;                       // 2 directions * ncl * C <= 252 workgroups: all co-resident
-  if (ncl < 1) ncl = 1;
+  int ncl = (device_cu_count() - 4) / 2 / C;   // 2 directions * ncl * C workgroups, one per CU with a small margin: all co-resident
+  if (ncl < 1) {
+    set_error("urse_lstm_cluster_plan: %d workgroups per cluster do not fit this device", C);
+    return URSE_ERR_UNSUPPORTED;
+  }
   int rpc = (n_seq + ncl - 1) / ncl;
   if (rpc < 1) rpc = 1;
   const int max_rows = CROWS;              // one 64-row chunk per cluster (long-sequence / few-sequence regime)

@@ -296,7 +296,7 @@ extern "C" int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int64_t* plan) 
   }
   const int nq = (H + 3) / 4;
   const int C = (nq + nw * qpw - 1) / (nw * qpw);
-  int ncl = 126 / C;                       // 2 directions * ncl * C <= 252 workgroups: all co-resident
+  int ncl = (device_cu_count() - 4) / 2 / C;   // 2 directions * ncl * C workgroups, one per CU with a small margin: all co-resident
   if (ncl < 1) { set_error("urse_lstm_cluster2_plan: H=%d needs %d workgroups per cluster", H, C); return URSE_ERR_UNSUPPORTED; }
   int rpc = (n_seq + ncl - 1) / ncl;
   if (rpc > C2ROWS) {

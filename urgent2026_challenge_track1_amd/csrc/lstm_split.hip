@@ -344,7 +344,7 @@ extern "C" int urse_lstm_split_plan(int H, int n_seq, int64_t* plan) {
     const int ncl = (n_seq + rows - 1) / rows;
     for (int ns = rows == 32 ? 3 : 6; ns >= 2; --ns) {
       const int tmax = (nut + ns - 1) / ns;
-      if (2L * ncl * ns > 250 || nut < 2 * ns || tmax > SMAXO * SW) continue;
+      if (2L * ncl * ns > device_cu_count() - 6 || nut < 2 * ns || tmax > SMAXO * SW) continue;   // all workgroups resident
       if (split_lds(nut, ns, rows) > 160 * 1024) continue;
       plan[0] = ns; plan[1] = ncl; plan[2] = (int64_t)2 * 2 * ncl * ns * rows * nut * 16; plan[3] = rows;
       return URSE_OK;

@@ -78,4 +78,8 @@ __device__ __forceinline__ float tanhf_(float x) {
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// CUs of the current device (256 on a full MI355X; fewer in a partitioned mode).  Kernels whose workgroups wait for each
+// other (cluster / split LSTM) size their grids against it: every workgroup must be resident, one per CU.
+int device_cu_count();
+
 }  // namespace urse
