@@ -241,7 +241,10 @@ def main():
                  "lstm_fwd_time": "lstm_fwd_cluster_kernel", "lstm_fwd_band": "lstm_fwd_wide_kernel"}
     if (B, args.seconds, args.channels, args.layers, args.dtype) == (32, 4.0, 196, 6, "bf16"):
         import glob
-        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic_*.json")))[-1:]:
+        import re
+        files = glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic_*.json"))
+        ver = lambda f: tuple(int(v) for v in re.findall(r"\d+", os.path.basename(f)))      # (round, version)
+        for f in sorted(files, key=ver)[-1:]:
             for k, v in json.load(open(f)).items():
                 if pmc_names[dom] in k:
                     traffic, traffic_src = (v["fetch_GB"] + v["write_GB"]) * 1e9, os.path.basename(f)
