@@ -247,3 +247,26 @@ def test_cluster2_kernel_matches_streaming_kernel(lib, path, B, T, K, N):
     assert (c1 - c2).abs().max().item() <= 2e-2
     assert (gx1.float() - gx2.float()).abs().max().item() <= 2e-2
     assert (h1.float() - h2.float()).abs().mean().item() <= 1e-4
+
+
+def test_cooperative_kernel_timeout_is_reported(lib):
+    """the cluster / split kernels share one device error word; a set word makes the next check raise (fail loudly)."""
+    from urgent2026_challenge_track1_amd import ops, _lib
+    flag = ops.kernel_error_flag(torch.device("cuda", torch.cuda.current_device()))
+    dev = flag.device
+    ops.poll_kernel_errors(dev, sync=True)                      # clean
+    flag.fill_(1)
+    with pytest.raises(_lib.UrseError):
+        ops.poll_kernel_errors(dev, sync=True)
+    ops.poll_kernel_errors(dev)                                  # deferred form: first call only requests the copy ...
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.UrseError):
+        ops.poll_kernel_errors(dev)                              # ... the next one sees it
+    flag.zero_()
+    torch.cuda.synchronize()
+    try:
+        ops.poll_kernel_errors(dev)                              # reads the copy requested while the word was still set
+    except _lib.UrseError:
+        pass
+    torch.cuda.synchronize()
+    ops.poll_kernel_errors(dev)                                  # clean again

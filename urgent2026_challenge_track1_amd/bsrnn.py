@@ -648,7 +648,10 @@ class BSRNNCore(nn.Module):
             for l in range(self.num_layer):
                 z, _ = self.dualpath_fwd(z, l, "t", False)
                 z, _ = self.dualpath_fwd(z, l, "f", False)
-            return self.maskdec_fwd(z, spec_ri, False)[0]
+            out = self.maskdec_fwd(z, spec_ri, False)[0]
+            ops.poll_kernel_errors(spec_ri.device, sync=True)      # inference: fail now rather than return garbage
+            return out
+        ops.poll_kernel_errors(spec_ri.device)                     # training: deferred check of the previous steps
         anchor = self._flat.new_zeros((), requires_grad=True)
         z = _BandSplitFn.apply(anchor, spec_ri, self)
         for l in range(self.num_layer):

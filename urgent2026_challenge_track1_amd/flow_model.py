@@ -218,6 +218,7 @@ class FlowBSRNNCore(BSRNNCore):
         x_ri, y_ri, t = x_ri.contiguous().float(), y_ri.contiguous().float(), t.contiguous().float()
         tembs = self.time_embeddings(t)
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        ops.poll_kernel_errors(x_ri.device)      # deferred check (the sampler calls this 15 times: no host stall per call)
         if train:
             anchor = self._flat.new_zeros((), requires_grad=True)
             z = _FlowFrontFn.apply(anchor, x_ri, y_ri, self)
@@ -394,6 +395,7 @@ class FlowSEModel(nn.Module):
                 vec_t = torch.full((B,), float(ts[i]), device=Y_ri.device)
                 vf = self.vector_field_ri(xt, vec_t, Y_ri)
                 call("axpy", vf, xt, -step, xt.numel(), stream_ptr())
+            ops.poll_kernel_errors(Y_ri.device, sync=True)     # end of the trajectory: fail rather than return garbage
             return xt
 
     def enhance(self, y, fs, speech_length, N=15):

@@ -231,6 +231,37 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
     return out
 
 
+_err_state = {}
+
+
+def kernel_error_flag(device):
+    """the device word the cooperative LSTM kernels (cluster / split) set when a hand-off times out."""
+    st = _err_state.get(device)
+    if st is None:
+        st = _err_state[device] = {"flag": torch.zeros(1, device=device, dtype=torch.int32),
+                                   "host": torch.zeros(1, dtype=torch.int32).pin_memory(), "event": None}
+    return st["flag"]
+
+
+def poll_kernel_errors(device, sync=False):
+    """Fail loudly if a cooperative kernel reported a timed-out hand-off (its results are then garbage).
+    sync=False (training): checks the copy requested during the PREVIOUS call and requests a new one: no host stall.
+    sync=True (inference / tests): reads the flag now."""
+    kernel_error_flag(device)
+    st = _err_state[device]
+    if sync:
+        bad = int(st["flag"].item()) != 0
+    else:
+        bad = st["event"] is not None and st["event"].query() and int(st["host"][0]) != 0
+        st["host"].copy_(st["flag"], non_blocking=True)
+        st["event"] = torch.cuda.Event()
+        st["event"].record(torch.cuda.current_stream(device))
+    if bad:
+        raise _lib.UrseError("a cooperative LSTM kernel (cluster / split) timed out waiting for a peer workgroup: the device did "
+                             "not keep all its workgroups resident; results of that step are invalid "
+                             "(URSE_LSTM_CLUSTER=0 selects the streaming kernels)")
+
+
 def _hout_buffer(M, ldh, H, like):
     """hidden-state matrix [M, ldh]: the kernels write every row's 2H columns, only the K padding needs zeros."""
     hout = torch.empty(M, ldh, device=like.device, dtype=like.dtype)
@@ -264,7 +295,7 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
     if key not in _cluster_ws:
         _cluster_ws[key] = (torch.zeros(plan[4], device=dev, dtype=torch.bfloat16),
                             torch.zeros(plan[5], device=dev, dtype=torch.int32),
-                            torch.zeros(1, device=dev, dtype=torch.int32))
+                            kernel_error_flag(dev))
     hx, cnt, err = _cluster_ws[key]
     ldh = kpad(2 * H, gx.dtype)
     hout = _hout_buffer(M, ldh, H, gx)
@@ -292,7 +323,7 @@ def lstm_fwd_cluster2(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, sav
     M, dev = gx.shape[0], gx.device
     key = ("c2", dev, H, Hp, n_seq)
     if key not in _cluster_ws:
-        _cluster_ws[key] = (torch.empty(plan[3], device=dev, dtype=torch.bfloat16), torch.zeros(1, device=dev, dtype=torch.int32))
+        _cluster_ws[key] = (torch.empty(plan[3], device=dev, dtype=torch.bfloat16), kernel_error_flag(dev))
     hx, err = _cluster_ws[key]
     ldh = kpad(2 * H, gx.dtype)
     hout = _hout_buffer(M, ldh, H, gx)
@@ -341,7 +372,7 @@ def lstm_bwd_cluster(dh, gates, c, whhTq, H, Hp, n_seq, seq_len, inner, outer, s
     if key not in _cluster_ws:
         _cluster_ws[key] = (torch.zeros(2 * 2 * plan[1] * 64 * 4 * H, device=dev, dtype=torch.bfloat16),
                             torch.zeros(plan[5], device=dev, dtype=torch.int32),
-                            torch.zeros(1, device=dev, dtype=torch.int32))
+                            kernel_error_flag(dev))
     dgx, cnt, err = _cluster_ws[key]
     timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_cluster_bwd", dh, dh.stride(0), gates,
                gates.stride(0), c, whhTq, dgx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, stream_ptr())
@@ -372,7 +403,7 @@ def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
     dev = gates.device
     key = ("split", dev, H, n_seq)
     if key not in _cluster_ws:
-        _cluster_ws[key] = (torch.empty(plan[2], device=dev, dtype=torch.float32), torch.zeros(1, device=dev, dtype=torch.int32))
+        _cluster_ws[key] = (torch.empty(plan[2], device=dev, dtype=torch.float32), kernel_error_flag(dev))
     xbuf, err = _cluster_ws[key]
     timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_split_bwd", dh, dh.stride(0), gates, gates.stride(0), c,
                whhT, xbuf, err, H, n_seq, seq_len, inner, outer, stride, stream_ptr())
