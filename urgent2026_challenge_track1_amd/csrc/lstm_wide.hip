@@ -16,6 +16,8 @@
 //   * h_t goes to the other LDS buffer and from there to HBM with 16-byte stores after the barrier.
 // Same math, layouts and outputs as lstm.hip (gate-interleaved gx overwritten by the activations, f32 c, bf16 h);
 // replaces the cuDNN LSTM under espnet2 BSRNN's rnn_freq (reference twin baseline_code/models/bsrnn_flowse.py:303-306).
+#include <stdlib.h>
+
 #include "urse_common.h"
 #include "fft_lds.h"   // fastdiv
 
@@ -24,9 +26,10 @@ namespace urse {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int WW = 8;             // waves per workgroup
-constexpr int WTHR = WW * 64;
-constexpr int WROWS = 64;         // sequences per workgroup (4 MFMA row tiles)
+// Geometry (template parameters): RT row tiles (16 * RT sequences) and WW waves per workgroup.
+//   <4, 8>: 64 sequences, one workgroup per CU -- the least weight traffic per sequence;
+//   <2, 4>: 32 sequences, TWO workgroups per CU (54 KB of LDS, 4 waves x 256 VGPRs each) whose phases drift apart, so that
+//           one's cell math / stores overlap the other's weight stream and MFMAs.
 
 struct WideArgs {
   void* gx; long ldg;
@@ -39,8 +42,9 @@ struct WideArgs {
   unsigned m_cpr;                 // fastdiv magic of the 16-B chunks per h row
 };
 
-template <int NSLAB, int MAXG>
-__global__ void __launch_bounds__(WTHR) lstm_fwd_wide_kernel(WideArgs p) {
+template <int NSLAB, int MAXG, int RT, int WW>
+__global__ void __launch_bounds__(WW * 64, 2) lstm_fwd_wide_kernel(WideArgs p) {
+  constexpr int WTHR = WW * 64, WROWS = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps block bookkeeping and weight bases in SGPRs
@@ -78,12 +82,12 @@ __global__ void __launch_bounds__(WTHR) lstm_fwd_wide_kernel(WideArgs p) {
   const bool hvec = ((((long)dir * H * 2) | (p.ldh * 2)) & 15) == 0 && ((reinterpret_cast<uintptr_t>(p.hout) & 15) == 0);
   __syncthreads();
 
-  uint2 gxn[4][4];
+  uint2 gxn[RT][4];
   auto load_gx = [&](int blk, long toff_) {
     int uu = blk * 16 + lc;
     if (uu >= H) uu = H - 1;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = rowtab[rt * 16 + lr * 4 + r] + toff_;
@@ -91,16 +95,16 @@ __global__ void __launch_bounds__(WTHR) lstm_fwd_wide_kernel(WideArgs p) {
       }
   };
   if (nmy > 0) load_gx(b0, (long)(dir ? p.seq_len - 1 : 0) * p.stride);
-  float cnx[4][4];                               // c_{t-1} of the next group (prefetched with its pre-activations)
+  float cnx[RT][4];                               // c_{t-1} of the next group (prefetched with its pre-activations)
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) cnx[a][b] = 0.f;
   auto load_c = [&](int blk, long toff_) {
     int uu = blk * 16 + lc;
     if (uu >= H) uu = H - 1;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         cnx[rt][r] = p.c[(rowtab[rt * 16 + lr * 4 + r] + toff_) * 2 * H + (long)dir * H + uu];
@@ -124,9 +128,9 @@ __global__ void __launch_bounds__(WTHR) lstm_fwd_wide_kernel(WideArgs p) {
         const bool uvalid = u < H;
         // acc starts from the gate pre-activations x*W_ih + b (prefetched during the previous group's cell phase):
         // 8 B per (row, unit), 16 lanes cover one 128-byte line
-        f32x4_t acc[4][4];
+        f32x4_t acc[4][RT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint2 gv2 = gxn[rt][r];
@@ -137,22 +141,22 @@ __global__ void __launch_bounds__(WTHR) lstm_fwd_wide_kernel(WideArgs p) {
           }
         // c_{t-1} of this block comes back from the cell-state stream this lane wrote one step ago (16 registers per
         // block instead of 64 resident ones)
-        float cprev[4][4];
+        float cprev[RT][4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) cprev[rt][r] = cnx[rt][r];
-        uint4 an[4];
+        uint4 an[RT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) an[rt] = *reinterpret_cast<const uint4*>(hc + (rt * 16 + lc) * pitch + 16 * lr);
+        for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const uint4*>(hc + (rt * 16 + lc) * pitch + 16 * lr);
 #pragma unroll
         for (int ks = 0; ks < NSLAB; ++ks) {
-          uint4 a[4];
+          uint4 a[RT];
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) a[rt] = an[rt];
+          for (int rt = 0; rt < RT; ++rt) a[rt] = an[rt];
           if (ks + 1 < NSLAB) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
               an[rt] = *reinterpret_cast<const uint4*>(hc + (rt * 16 + lc) * pitch + (ks + 1) * 64 + 16 * lr);
           }
 #pragma unroll
@@ -161,7 +165,7 @@ __global__ void __launch_bounds__(WTHR) lstm_fwd_wide_kernel(WideArgs p) {
             const uint4 b = ring[slot];
 #ifndef ABL_NO_MFMA
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
               acc[gate][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[rt]),
                                                                       __builtin_bit_cast(bf16x8_t, b), acc[gate][rt], 0, 0, 0);
 #else
@@ -190,7 +194,7 @@ __global__ void __launch_bounds__(WTHR) lstm_fwd_wide_kernel(WideArgs p) {
         }
         // cell update: acc[gate][rt][r] = gate `gate` of (row rt*16 + lr*4 + r, unit u)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float gi = acc[0][rt][r], gf = acc[1][rt][r], gg = acc[2][rt][r], go = acc[3][rt][r];
@@ -261,14 +265,15 @@ __global__ void __launch_bounds__(256) lstm_pack_blocks_kernel(const float* __re
   }
 }
 
-template <int NSLAB, int MAXG>
+template <int NSLAB, int MAXG, int RT, int WW>
 static int launch_wide_fwd(const WideArgs& p, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_wide_kernel<NSLAB, MAXG>),
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_wide_kernel<NSLAB, MAXG, RT, WW>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
+  constexpr int WROWS = 16 * RT;
   const size_t lds = (size_t)2 * WROWS * (p.Hp * 2 + 16) + WROWS * sizeof(int);
   dim3 grid((p.n_seq + WROWS - 1) / WROWS, 2);
-  hipLaunchKernelGGL((lstm_fwd_wide_kernel<NSLAB, MAXG>), grid, dim3(WTHR), lds, st, p);
+  hipLaunchKernelGGL((lstm_fwd_wide_kernel<NSLAB, MAXG, RT, WW>), grid, dim3(WW * 64), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_wide_fwd");
   return URSE_OK;
 }
@@ -277,7 +282,7 @@ static bool wide_shape(int H, int Hp, int* nslab, int* maxg) {
   if (H <= 0 || Hp % 32 || Hp < H) return false;
   const int nblk = (H + 15) / 16;
   *nslab = Hp / 32;
-  *maxg = (nblk + WW - 1) / WW;
+  *maxg = (nblk + 8 - 1) / 8;
   return (*nslab == 13 && *maxg == 4) || (*maxg == 1 && *nslab >= 1 && *nslab <= 4);
 }
 
@@ -311,11 +316,15 @@ extern "C" int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void*
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
   p.m_cpr = fastdiv_magic((unsigned)((H * 2 + 15) / 16));
   hipStream_t st = (hipStream_t)stream;
-  if (nslab == 13) return launch_wide_fwd<13, 4>(p, st);
+  static const int variant = getenv("URSE_WIDE_VARIANT") ? atoi(getenv("URSE_WIDE_VARIANT")) : 0;
+  if (nslab == 13) {
+    if (variant == 1) return launch_wide_fwd<13, 7, 2, 4>(p, st);      // 32 sequences, two workgroups per CU
+    return launch_wide_fwd<13, 4, 4, 8>(p, st);
+  }
   switch (nslab) {
-    case 1: return launch_wide_fwd<1, 1>(p, st);
-    case 2: return launch_wide_fwd<2, 1>(p, st);
-    case 3: return launch_wide_fwd<3, 1>(p, st);
-    default: return launch_wide_fwd<4, 1>(p, st);
+    case 1: return launch_wide_fwd<1, 1, 4, 8>(p, st);
+    case 2: return launch_wide_fwd<2, 1, 4, 8>(p, st);
+    case 3: return launch_wide_fwd<3, 1, 4, 8>(p, st);
+    default: return launch_wide_fwd<4, 1, 4, 8>(p, st);
   }
 }
