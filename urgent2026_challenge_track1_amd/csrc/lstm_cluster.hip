@@ -70,8 +70,8 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   const int dir = blockIdx.y;
   const int cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
-  const int H = p.H, Hp = p.Hp;
-  const int pitch = Hp * 2 + 16;
+  const int H = p.H;
+  constexpr int Hp = NSLAB * 32, pitch = Hp * 2 + 16;      // compile-time: the index arithmetic below folds to shifts / multiplies
   char* htile = smem;                                    // [CROWS][pitch]
   bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + CROWS * pitch);   // [CROWS][UW]
   const int nq = (H + 3) >> 2;
@@ -105,17 +105,34 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * p.rows_pad * Hp * 2);
   const unsigned cl_bytes = (unsigned)(((long)dir * p.ncl + cl) * p.rows_pad * Hp * 2);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2u * plane_bytes), 0x00020000);
-  const int cpr = Hp * 2 / 16;                           // 16-B chunks per h row
+  constexpr int cpr = Hp * 2 / 16;                       // 16-B chunks per h row
   constexpr int HL = (CROWS * 52 + CTHR - 1) / CTHR;     // h-tile chunks per thread (Hp <= 416)
 
-  // row bookkeeping of this lane for chunk ch, row tile rt
-  auto row_of = [&](int ch, int rt, long toff, bool* valid) -> long {
-    const int lrow = ch * CROWS + rt * 16 + lr * 4 + q;
-    *valid = lrow < nrows;
+  // row bookkeeping of this lane (row tile rt: sequence rt*16 + lr*4 + q), hoisted out of the time loop: the run-time
+  // divisions by `inner` cost more than the cell math of a step
+  long rowb[4];
+  bool rowv[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int lrow = rt * 16 + lr * 4 + q;
+    rowv[rt] = lrow < nrows;
     int seq = seq0 + lrow;
     if (seq >= p.n_seq) seq = p.n_seq - 1;
-    return (seq / p.inner) * p.outer + (seq % p.inner) + toff;
+    rowb[rt] = (seq / p.inner) * p.outer + (seq % p.inner);
+  }
+  auto row_of = [&](int, int rt, long toff, bool* valid) -> long {
+    *valid = rowv[rt];
+    return rowb[rt] + toff;
   };
+  // the one (row, 16-byte piece) of the staged h tile this thread publishes / stores per step
+  constexpr int SCx = UW * 2 / 16;
+  const int st_row = tid / SCx, st_cc = tid - st_row * SCx;
+  long st_grow = 0;
+  {
+    int seq = seq0 + st_row;
+    if (seq >= p.n_seq) seq = p.n_seq - 1;
+    st_grow = (seq / p.inner) * p.outer + (seq % p.inner);
+  }
   auto load_gx = [&](int ch, long toff, uint2 (&dst)[4]) {
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
@@ -234,18 +251,18 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
     // 3. h_t of this workgroup's units -> exchange buffer FIRST (write-through, tagged), then the plain stores
     constexpr int SC = UW * 2 / 16;   // 7 chunks per row
     const unsigned tagv = tag_cur ? TAGM : 0u;
-    for (int idx = tid; idx < CROWS * SC; idx += CTHR) {
-      const int row = idx / SC, cc = idx - row * SC;
+    static_assert(CROWS * SC <= CTHR, "one staged piece per thread");
+    if (tid < CROWS * SC) {
+      const int row = st_row, cc = st_cc;
       const int ucol = j * UW + cc * 8;
-      if (r0 + row >= nrows || ucol >= H) continue;
-      uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
-      const uint4 vt = make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv);
+      if (r0 + row < nrows && ucol < H) {
+        uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
+        const uint4 vt = make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv);
 #ifndef CABL_NO_XSTORE
-      if (step + 1 < p.seq_len) store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)((r0 + row) * Hp * 2 + ucol * 2), vt);
+        if (step + 1 < p.seq_len) store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)((r0 + row) * Hp * 2 + ucol * 2), vt);
 #endif
-      const int seq = seq0 + r0 + row;
-      const long grow = (seq / p.inner) * p.outer + (seq % p.inner) + toff;
-      *reinterpret_cast<uint4*>(hout + grow * p.ldh + (long)dir * H + ucol) = v;    // H % 8 == 0: whole chunks
+        *reinterpret_cast<uint4*>(hout + (st_grow + toff) * p.ldh + (long)dir * H + ucol) = v;    // H % 8 == 0: whole chunks
+      }
     }
     if (p.save && uvalid) {
 #pragma unroll
