@@ -49,7 +49,8 @@ __global__ void __launch_bounds__(WW * 64, 2) lstm_fwd_wide_kernel(WideArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps block bookkeeping and weight bases in SGPRs
   const int dir = blockIdx.y;
-  const int H = p.H, Hp = p.Hp, pitch = Hp * 2 + 16;
+  const int H = p.H;
+  constexpr int Hp = NSLAB * 32, pitch = Hp * 2 + 16;      // compile-time: LDS offsets of the k loop fold into immediates
   const int seq0 = blockIdx.x * WROWS;
   const int nrows = min(WROWS, p.n_seq - seq0);
   int* rowtab = reinterpret_cast<int*>(smem + 2 * WROWS * pitch);   // row index of (sequence, t = 0)
