@@ -237,7 +237,7 @@ def main():
     # comes from the committed rocprofv3 passes of this same command (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
     # FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes); null if no summary matches this configuration
     traffic, traffic_src = None, None
-    pmc_names = {"lstm_bwd_time": "lstm_bwd_kernel<unsigned short, 1, 2, 16>", "lstm_bwd_band": "lstm_bwd_kernel<unsigned short, 2, 4, 8>",
+    pmc_names = {"lstm_bwd_time": "lstm_bwd_kernel<unsigned short, 1, 2, 16", "lstm_bwd_band": "lstm_bwd_kernel<unsigned short, 2, 4, 8",
                  "lstm_fwd_time": "lstm_fwd_cluster_kernel", "lstm_fwd_band": "lstm_fwd_wide_kernel"}
     if (B, args.seconds, args.channels, args.layers, args.dtype) == (32, 4.0, 196, 6, "bf16"):
         import glob

@@ -48,9 +48,9 @@ def bwd_split(lib, path, rt):
     a = (B * K, T, K, T * K, K)
     return lib.urse_lstm_split_bwd(P(dh.data_ptr()), ctypes.c_int64(800), P(gx.data_ptr()), ctypes.c_int64(8 * H), P(c.data_ptr()),
         P(whhT.data_ptr()), P(xbuf.data_ptr()), P(errf.data_ptr()), H, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), P(st))
-for fn, fname in ((fwd_wide, "fwd_wide"),):
-    for path in ("band",):
-        for rt in (1,):
+for fn, fname in ((bwd, "bwd"),):
+    for path in ("time", "band"):
+        for rt in (0,):
             res = []
             for name, lib in libs.items():
                 assert fn(lib, path, rt) == 0
