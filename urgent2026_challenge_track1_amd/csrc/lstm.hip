@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
 }
 
 // HC: hidden size known at compile time (0 = run-time p.H): tile pitch, slab count and unit-tile count fold into constants
-template <typename T, int RT, int MAXUT, int NW, int HC = 0>
+// HPC: only the LDS tile pitch is folded (the 32-row variant spills when its loop bounds become constants too)
+template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0>
 __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T), R = 16 * RT;
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   const int dir = blockIdx.y, s0 = blockIdx.x * R;
   const int H = HC ? HC : p.H, nut = (H + 15) >> 4, G4 = 4 * H;
-  const int pitch = G4 * ES + 16;
+  const int pitch = HPC ? 4 * HPC * ES + 16 : G4 * ES + 16;
   const int nbuf = p.dbuf ? 2 : 1;         // double-buffered dgates tile: one barrier per step
   float dcs[MAXUT][RT][4], dhr[MAXUT][RT][4], ccur[MAXUT][RT][4];
   int rowbase[RT][4];                      // negative: sequence beyond n_seq (clamped, never stored)
@@ -457,6 +458,15 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
     static bool once = (allow_big_lds(lstm_bwd_kernel<T, RT, MU, NW>), true);                    \
     (void)once;                                                                                  \
     hipLaunchKernelGGL((lstm_bwd_kernel<T, RT, MU, NW>), grid, dim3(NW * 64), lds, st, pa);      \
+  }
+  if constexpr (sizeof(T) == 2 && NW == 8 && RT == 2) {
+    if (p.H == 392 && upw <= 4) {
+      static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392>), true);
+      (void)once;
+      hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392>), grid, dim3(NW * 64), lds, st, pa);
+      URSE_CHECK_LAUNCH("urse_lstm_bwd");
+      return URSE_OK;
+    }
   }
   if constexpr (sizeof(T) == 2 && NW == 16 && RT == 1) {
     if (p.H == 392) {     // the model's size on the time path: compile-time geometry (7.2 -> 7.0 ms; the 32-row variant spills with it)
