@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
         const int row = idx / CPR, cc = idx - row * CPR;
         if (step > 0 && idx < C2ROWS * CPR && row < nrows && cc < hchunks) pend |= 1u << i;
       }
-      if (pend && *reinterpret_cast<volatile unsigned*>(deadflag)) pend = 0u;
+      if (pend && __hip_atomic_load(deadflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) pend = 0u;
       const unsigned want = tag_prev ? TAGM : 0u;
       unsigned spins = 0;
       while (pend) {
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
         }
         if (pend) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 20)) { atomicExch(p.err, 1u); *reinterpret_cast<volatile unsigned*>(deadflag) = 1u; pend = 0u; }
+          if (++spins > (1u << 20)) { atomicExch(p.err, 1u); __hip_atomic_store(deadflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); pend = 0u; }
         }
       }
 #pragma unroll

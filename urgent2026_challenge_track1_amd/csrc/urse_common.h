@@ -69,11 +69,14 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return r;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// The cell updates of the recurrences evaluate five of these per (sequence, unit, step): an IEEE division costs ~10 VALU
+// instructions (v_div_scale / v_rcp / 4 fma / v_div_fmas / v_div_fixup), v_rcp_f32 one (1 ulp), and the argument is in
+// [1, inf) where v_rcp_f32 has no special cases to fix up.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
-  // tanh(x) = 1 - 2/(exp(2x)+1); exact enough (<= 2 ulp f32) and safe for |x| large
+  // tanh(x) = 1 - 2/(exp(2x)+1); <= 2 ulp f32 and safe for |x| large (e = inf -> rcp = 0 -> 1)
   const float e = __expf(2.0f * x);
-  return 1.0f - 2.0f / (e + 1.0f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
