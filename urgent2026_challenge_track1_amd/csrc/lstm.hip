@@ -242,8 +242,9 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   const char* whhT = reinterpret_cast<const char*>(p.whhT) + ((long)dir * nut * nslab) * 1024 + lane * 16;
   const T* dh = reinterpret_cast<const T*>(p.dh);
   T* gates = reinterpret_cast<T*>(p.gates);
-  const long gcol0 = (long)dir * G4;
-  const long prev_off = dir ? p.m.stride : -p.m.stride;
+  // 32-bit row indices / leading dimensions (checked on the host): an address costs one v_mad_i64_i32
+  const int ldg_i = (int)p.ldg, ldd_i = (int)p.ldd, ldc_i = 2 * H, stride_i = (int)p.m.stride;
+  const int gcol_i = dir * G4, hcol_i = dir * H, prev_i = dir ? stride_i : -stride_i;
 
   {
     const long toff0 = (long)(dir ? 0 : p.m.seq_len - 1) * p.m.stride;
@@ -264,7 +265,6 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   for (int step = 0; step < p.m.seq_len; ++step) {
     const int t = dir ? step : (p.m.seq_len - 1 - step);
     const bool first = dir ? (t == p.m.seq_len - 1) : (t == 0);   // first step of the forward recurrence: c_{-1} = 0
-    const long toff = (long)t * p.m.stride;
     char* tile = smem + (step % nbuf) * R * pitch;
 #pragma unroll
     for (int ui = 0; ui < MAXUT; ++ui) {
@@ -279,10 +279,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const long row = rowb(rt, r) + toff;
-              gpre[rt][r] = *reinterpret_cast<const V4*>(gates + row * p.ldg + gcol0 + u * 4);
-              cpre[rt][r] = first ? 0.f : p.c[row * 2 * H + (long)dir * H + u + prev_off * 2 * H];
-              dhpre[rt][r] = dh[row * p.ldd + (long)dir * H + u];
+              const int row = (int)rowb(rt, r) + t * stride_i;
+              gpre[rt][r] = *reinterpret_cast<const V4*>(gates + ((long)row * ldg_i + (gcol_i + u * 4)));
+              cpre[rt][r] = first ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + u)];
+              dhpre[rt][r] = dh[(long)row * ldd_i + (hcol_i + u)];
             }
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
@@ -303,7 +303,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
               ccur[ui][rt][r] = cpre[rt][r];          // c_{t-1} is the next processed step's c_t
               const V4 pk = Vec4<T>::pack(dg);
               *reinterpret_cast<V4*>(tile + (rt * 16 + lr * 4 + r) * pitch + (u * 4) * ES) = pk;
-              if (rowbase[rt][r] >= 0) *reinterpret_cast<V4*>(gates + (rowb(rt, r) + toff) * p.ldg + gcol0 + u * 4) = pk;
+              if (rowbase[rt][r] >= 0)
+                *reinterpret_cast<V4*>(gates + ((long)(rowbase[rt][r] + t * stride_i) * ldg_i + (gcol_i + u * 4))) = pk;
             }
         }
       }
@@ -553,6 +554,8 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
   int rc = check_map(p.m, H, es, "urse_lstm_bidir_bwd");
   if (rc) return rc;
   URSE_CHECK_ARG(ldg >= 8L * H && ldd >= 2L * H && ldg % 4 == 0, "urse_lstm_bidir_bwd: leading dimension too small");
+  URSE_CHECK_ARG(ldg < (1L << 31) && ldd < (1L << 31) && stride * seq_len + (n_seq / inner + 1) * outer < (1L << 31),
+                 "urse_lstm_bidir_bwd: row indices must fit 32 bits");
   hipStream_t st = (hipStream_t)stream;
   int rt = rows16 & 15;
   bool nw8 = (rows16 >> 4) & 1;

@@ -101,7 +101,6 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   const int nrows = seq1 - seq0;
   bf16_t* gx = reinterpret_cast<bf16_t*>(p.gx);
   bf16_t* hout = reinterpret_cast<bf16_t*>(p.hout);
-  const long gcol0 = (long)dir * 4 * H;
   const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * p.rows_pad * Hp * 2);
   const unsigned cl_bytes = (unsigned)(((long)dir * p.ncl + cl) * p.rows_pad * Hp * 2);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2u * plane_bytes), 0x00020000);
@@ -110,7 +109,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
 
   // row bookkeeping of this lane (row tile rt: sequence rt*16 + lr*4 + q), hoisted out of the time loop: the run-time
   // divisions by `inner` cost more than the cell math of a step
-  long rowb[4];
+  int rowb[4];                                            // 32-bit row indices: one v_mad_i64_i32 per address
   bool rowv[4];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
@@ -118,31 +117,25 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
     rowv[rt] = lrow < nrows;
     int seq = seq0 + lrow;
     if (seq >= p.n_seq) seq = p.n_seq - 1;
-    rowb[rt] = (seq / p.inner) * p.outer + (seq % p.inner);
+    rowb[rt] = (int)((seq / p.inner) * p.outer + (seq % p.inner));
   }
-  auto row_of = [&](int, int rt, long toff, bool* valid) -> long {
-    *valid = rowv[rt];
-    return rowb[rt] + toff;
-  };
+  const int ldg_i = (int)p.ldg, ldh_i = (int)p.ldh, ldc_i = 2 * H, stride_i = (int)p.stride, gcol_i = dir * 4 * H, hcol_i = dir * H;
   // the one (row, 16-byte piece) of the staged h tile this thread publishes / stores per step
   constexpr int SCx = UW * 2 / 16;
   const int st_row = tid / SCx, st_cc = tid - st_row * SCx;
-  long st_grow = 0;
+  int st_grow = 0;
   {
     int seq = seq0 + st_row;
     if (seq >= p.n_seq) seq = p.n_seq - 1;
-    st_grow = (seq / p.inner) * p.outer + (seq % p.inner);
+    st_grow = (int)((seq / p.inner) * p.outer + (seq % p.inner));
   }
-  auto load_gx = [&](int ch, long toff, uint2 (&dst)[4]) {
+  auto load_gx = [&](int, int toff, uint2 (&dst)[4]) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      bool v;
-      const long row = row_of(ch, rt, toff, &v);
-      dst[rt] = *reinterpret_cast<const uint2*>(gx + row * p.ldg + gcol0 + uc * 4);
-    }
+    for (int rt = 0; rt < 4; ++rt)
+      dst[rt] = *reinterpret_cast<const uint2*>(gx + ((long)(rowb[rt] + toff) * ldg_i + (gcol_i + uc * 4)));
   };
   uint2 gxn[4];                                          // gate pre-activations, prefetched one step ahead
-  load_gx(0, (long)(dir ? p.seq_len - 1 : 0) * p.stride, gxn);
+  load_gx(0, (dir ? p.seq_len - 1 : 0) * stride_i, gxn);
   unsigned* deadflag = reinterpret_cast<unsigned*>(smem + CROWS * pitch + CROWS * UW * 2);
   if (tid == 0) *deadflag = 0u;
   const int hchunks = H / 8;                             // 16-byte chunks of a row that carry data (H % 8 == 0)
@@ -157,7 +150,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   // workgroups published only after consuming the data being overwritten.
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? (p.seq_len - 1 - step) : step;
-    const long toff = (long)t * p.stride;
+    const int toff = t * stride_i;
     const unsigned pprev = (unsigned)((step + 1) & 1), pcur = (unsigned)(step & 1);
     const unsigned tag_cur = (((unsigned)step >> 1) & 1u) ^ 1u;
     const unsigned tag_prev = (((unsigned)(step - 1) >> 1) & 1u) ^ 1u;
@@ -213,7 +206,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
     for (int rt = 0; rt < 4; ++rt) gxc[rt] = gxn[rt];
     __syncthreads();
     // prefetch the gate pre-activations of the next step (independent of the recurrence)
-    if (step + 1 < p.seq_len) load_gx(0, (long)(dir ? t - 1 : t + 1) * p.stride, gxn);
+    if (step + 1 < p.seq_len) load_gx(0, (dir ? t - 1 : t + 1) * stride_i, gxn);
     // 2. gates for (64 rows) x (this wave's quad)
     uint2 gsave[4];
     float csave[4];
@@ -261,17 +254,16 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
 #ifndef CABL_NO_XSTORE
         if (step + 1 < p.seq_len) store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)((r0 + row) * Hp * 2 + ucol * 2), vt);
 #endif
-        *reinterpret_cast<uint4*>(hout + (st_grow + toff) * p.ldh + (long)dir * H + ucol) = v;    // H % 8 == 0: whole chunks
+        *reinterpret_cast<uint4*>(hout + ((long)(st_grow + toff) * ldh_i + (hcol_i + ucol))) = v;    // H % 8 == 0: whole chunks
       }
     }
     if (p.save && uvalid) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        bool v;
-        const long row = row_of(ch, rt, toff, &v);
-        if (v) {
-          *reinterpret_cast<uint2*>(gx + row * p.ldg + gcol0 + u * 4) = gsave[rt];
-          p.c[row * 2 * H + (long)dir * H + u] = csave[rt];
+        if (rowv[rt]) {
+          const int row = rowb[rt] + toff;
+          *reinterpret_cast<uint2*>(gx + ((long)row * ldg_i + (gcol_i + u * 4))) = gsave[rt];
+          p.c[(long)row * ldc_i + (hcol_i + u)] = csave[rt];
         }
       }
     }
@@ -622,6 +614,8 @@ extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, vo
   URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldh >= 2L * H && (ldh * 2) % 16 == 0 &&
                      ((uintptr_t)hout % 16) == 0 && ((uintptr_t)hx % 16) == 0,
                  "urse_lstm_cluster_fwd: bad leading dimension / alignment");
+  URSE_CHECK_ARG(ldg < (1L << 31) && ldh < (1L << 31) && stride * seq_len + (n_seq / inner + 1) * outer < (1L << 31),
+                 "urse_lstm_cluster_fwd: row indices must fit 32 bits");
   ClusterArgs p;
   p.gx = gx; p.ldg = ldg; p.whhq = whhq; p.hout = hout; p.ldh = ldh; p.c = c; p.hx = (bf16_t*)hx;
   p.cnt = (unsigned*)counters; p.err = (unsigned*)err_flag; p.H = H; p.Hp = Hp; p.save = save;

@@ -78,44 +78,46 @@ __global__ void __launch_bounds__(WW * 64, 2) lstm_fwd_wide_kernel(WideArgs p) {
   }
   bf16_t* gx = reinterpret_cast<bf16_t*>(p.gx);
   bf16_t* hout = reinterpret_cast<bf16_t*>(p.hout);
-  const long gcol0 = (long)dir * 4 * H;
   const int cpr = (H * 2 + 15) / 16;
   const bool hvec = ((((long)dir * H * 2) | (p.ldh * 2)) & 15) == 0 && ((reinterpret_cast<uintptr_t>(p.hout) & 15) == 0);
   __syncthreads();
 
   uint2 gxn[RT][4];
-  auto load_gx = [&](int blk, long toff_) {
+  // row indices and leading dimensions are 32-bit (M < 2^31 rows is checked on the host): an address is then one
+  // v_mad_i64_i32 instead of a 64 x 64-bit multiply (address arithmetic was a third of this kernel's VALU work)
+  const int ldg_i = (int)p.ldg, ldc_i = 2 * H, ldh_i = (int)p.ldh, gcol_i = dir * 4 * H, stride_i = (int)p.stride;
+  auto load_gx = [&](int blk, int toff_) {
     int uu = blk * 16 + lc;
     if (uu >= H) uu = H - 1;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long row = rowtab[rt * 16 + lr * 4 + r] + toff_;
-        gxn[rt][r] = *reinterpret_cast<const uint2*>(gx + row * p.ldg + gcol0 + uu * 4);
+        const int row = rowtab[rt * 16 + lr * 4 + r] + toff_;
+        gxn[rt][r] = *reinterpret_cast<const uint2*>(gx + ((long)row * ldg_i + (gcol_i + uu * 4)));
       }
   };
-  if (nmy > 0) load_gx(b0, (long)(dir ? p.seq_len - 1 : 0) * p.stride);
+  if (nmy > 0) load_gx(b0, (dir ? p.seq_len - 1 : 0) * stride_i);
   float cnx[RT][4];                               // c_{t-1} of the next group (prefetched with its pre-activations)
 #pragma unroll
   for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) cnx[a][b] = 0.f;
-  auto load_c = [&](int blk, long toff_) {
+  auto load_c = [&](int blk, int toff_) {
     int uu = blk * 16 + lc;
     if (uu >= H) uu = H - 1;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        cnx[rt][r] = p.c[(rowtab[rt * 16 + lr * 4 + r] + toff_) * 2 * H + (long)dir * H + uu];
+        cnx[rt][r] = p.c[(long)(rowtab[rt * 16 + lr * 4 + r] + toff_) * ldc_i + (dir * H + uu)];
   };
 
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? (p.seq_len - 1 - step) : step;
-    const long toff = (long)t * p.stride;
-    const long toff_prev = (long)(dir ? t + 1 : t - 1) * p.stride;
-    const long toff_next = (long)(dir ? t - 1 : t + 1) * p.stride;
+    const int toff = t * stride_i;
+    const int toff_prev = (dir ? t + 1 : t - 1) * stride_i;
+    const int toff_next = (dir ? t - 1 : t + 1) * stride_i;
     const char* hc = smem + (step & 1) * WROWS * pitch;
     char* hn = smem + ((step & 1) ^ 1) * WROWS * pitch;
 
@@ -214,13 +216,13 @@ __global__ void __launch_bounds__(WW * 64, 2) lstm_fwd_wide_kernel(WideArgs p) {
               *reinterpret_cast<bf16_t*>(hn + lrow * pitch + u * 2) = f32_to_bf16(hv);
 #ifndef ABL_NO_ST
               if (lrow < nrows) {
-                const long row = rowtab[lrow] + toff;
-                p.c[row * 2 * H + (long)dir * H + u] = cv;
+                const int row = rowtab[lrow] + toff;
+                p.c[(long)row * ldc_i + (dir * H + u)] = cv;
                 if (p.save) {
                   uint2 sv;
                   sv.x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
                   sv.y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
-                  *reinterpret_cast<uint2*>(gx + row * p.ldg + gcol0 + u * 4) = sv;
+                  *reinterpret_cast<uint2*>(gx + ((long)row * ldg_i + (gcol_i + u * 4))) = sv;
                 }
               }
 #endif
@@ -234,8 +236,8 @@ __global__ void __launch_bounds__(WW * 64, 2) lstm_fwd_wide_kernel(WideArgs p) {
       const int row = fastdiv(idx, p.m_cpr), cc = idx - row * cpr;
       if (row >= nrows) continue;
       const uint4 v = *reinterpret_cast<const uint4*>(hn + row * pitch + cc * 16);
-      const long grow = rowtab[row] + toff;
-      bf16_t* dst = hout + grow * p.ldh + (long)dir * H + cc * 8;
+      const int grow = rowtab[row] + toff;
+      bf16_t* dst = hout + ((long)grow * ldh_i + (dir * H + cc * 8));
       if (hvec && cc * 8 + 8 <= H) {
         *reinterpret_cast<uint4*>(dst) = v;
       } else {
@@ -310,6 +312,8 @@ extern "C" int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void*
   int nslab, maxg;
   URSE_CHECK_ARG(wide_shape(H, Hp, &nslab, &maxg), "urse_lstm_wide_fwd: unsupported H=%d Hp=%d", H, Hp);
   URSE_CHECK_ARG(n_seq > 0 && seq_len > 0 && inner > 0, "urse_lstm_wide_fwd: bad sequence geometry");
+  URSE_CHECK_ARG(ldg < (1L << 31) && ldh < (1L << 31) && stride * seq_len + (n_seq / inner + 1) * outer < (1L << 31),
+                 "urse_lstm_wide_fwd: row indices must fit 32 bits");
   URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldh >= 2L * H && ((uintptr_t)gx % 8) == 0,
                  "urse_lstm_wide_fwd: bad leading dimension / alignment");
   WideArgs p;
