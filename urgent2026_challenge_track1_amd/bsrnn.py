@@ -513,7 +513,7 @@ class BSRNNCore(nn.Module):
         if not self._deferred:
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(device=device)
+            self._side = ops.low_priority_stream(device)
         start = torch.cuda.Event()
         start.record(torch.cuda.current_stream())
         self._side.wait_event(start)

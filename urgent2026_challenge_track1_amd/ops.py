@@ -347,6 +347,28 @@ def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, ro
 USE_WIDE_LSTM = os.environ.get("URSE_LSTM_WIDE", "1") != "0"
 # run the dual-path weight-gradient GEMMs on a second stream beside the time path's BPTT kernel (which fills 136 CUs)
 TN_OVERLAP = os.environ.get("URSE_TN_OVERLAP", "1") != "0"
+def low_priority_stream(device):
+    """The stream of the deferred weight-gradient GEMMs.  URSE_SIDE_STREAM_PRIORITY=low makes it a HIP stream of the LOWEST
+    priority (torch only offers normal / high), so that its work only takes CUs the compute stream leaves idle; measured
+    WORSE than equal priority (196 vs 189 ms/step): the band path's BPTT runs alone (30 -> 25 ms/step) but all the GEMM work
+    then piles up beside the time path's BPTT (48 -> 58 ms/step).  Default: normal priority."""
+    if os.environ.get("URSE_SIDE_STREAM_PRIORITY", "normal") != "low":
+        return torch.cuda.Stream(device=device)
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        least, greatest = ctypes.c_int(), ctypes.c_int()
+        st = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+                raise RuntimeError("priority range")
+            if hip.hipStreamCreateWithPriority(ctypes.byref(st), ctypes.c_uint(1), ctypes.c_int(least.value)) != 0:   # 1 = non-blocking
+                raise RuntimeError("stream create")
+        return torch.cuda.ExternalStream(st.value, device=device)
+    except Exception:
+        return torch.cuda.Stream(device=device)
+
+
 TN_SHADOW_WGS = int(os.environ.get("URSE_TN_SHADOW_WGS", "120"))
 TN_OVERLAP_BAND = os.environ.get("URSE_TN_OVERLAP_BAND", "1") != "0"   # also start deferred wgrads beside the band path's BPTT
 # the wide kernel wins once there are enough 64-sequence workgroups to fill the chip in both directions
