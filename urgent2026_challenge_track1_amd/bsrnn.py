@@ -465,7 +465,7 @@ class BSRNNCore(nn.Module):
             # the time path's BPTT occupies 136 of the 256 CUs for ~7 ms (and the band path's last round of workgroups
             # leaves most CUs idle): the weight-gradient GEMMs deferred by the previous half layers run beside it on a
             # second stream (they only feed the optimizer / all-reduce)
-            self._run_deferred_wgrads(skip.device)
+            self._run_deferred_wgrads(skip.device, ops.TN_SHADOW_WGS if path == "t" else ops.TN_SHADOW_WGS_BAND)
         if ops.USE_CLUSTER_LSTM_BWD and pk.get(p + "whhTq") is not None and \
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
             dg, self._cluster_err = ops.lstm_bwd_cluster(dh, gates, c, pk[p + "whhTq"], H, d["Hp"], **sm)
@@ -508,7 +508,7 @@ class BSRNNCore(nn.Module):
         return dskip
 
     # deferred weight-gradient GEMMs (see dualpath_bwd) --------------------------------------------------------------
-    def _run_deferred_wgrads(self, device):
+    def _run_deferred_wgrads(self, device, target_wgs):
         """launch everything deferred so far on the side stream, gated on the compute stream's current position."""
         if not self._deferred:
             return
@@ -518,7 +518,7 @@ class BSRNNCore(nn.Module):
         start.record(torch.cuda.current_stream())
         self._side.wait_event(start)
         with torch.cuda.stream(self._side):
-            call("gemm_tn_set_target", ops.TN_SHADOW_WGS)      # they share the chip with a BPTT kernel on 136 CUs
+            call("gemm_tn_set_target", target_wgs)            # they share the chip with a BPTT kernel
             for fn, _ in self._deferred:
                 fn()
             call("gemm_tn_set_target", 256)
