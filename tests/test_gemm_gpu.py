@@ -39,6 +39,28 @@ def test_gemm_nt(lib, dtype, M, N, K):
         assert (got3.double() - ref3).abs().max().item() <= 1e-2 * max(1.0, ref3.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(2300, 3136, 224), (2049, 2000, 96), (2177, 500, 160)])
+def test_gemm_nt_wide_tile_matches_default(lib, monkeypatch, M, N, K):
+    """the 128 x 448 tile (write-bound gate projection) against the 256 x 224 one: ragged M / N edges, every epilogue"""
+    from urgent2026_challenge_track1_amd import ops
+    A, W = _mk((M, K), torch.bfloat16, 1).cuda(), _mk((N, K), torch.bfloat16, 2).cuda()
+    bias = _mk((N,), torch.float32, 3).cuda()
+    h = torch.tanh(_mk((M, N), torch.float32, 9)).to(torch.bfloat16).cuda()
+    res = _mk((M, N), torch.float32, 4).cuda()
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("URSE_NT_WIDE", mode)
+        r = res.clone()
+        ops.gemm_nt(A, W, bias, resid=r, out=r)
+        outs[mode] = (ops.gemm_nt(A, W, bias, out_dtype=torch.bfloat16), ops.gemm_nt(A, W, bias, out_dtype=torch.float32),
+                      ops.gemm_nt(A, W, bias, act=1, out_dtype=torch.bfloat16),
+                      ops.gemm_nt(A, W, None, act=2, resid=h, out_dtype=torch.bfloat16), r)
+    ref = A.double() @ W.double().T + bias.double()
+    assert (outs["1"][1].double() - ref).abs().max().item() <= 2e-5 * (K ** 0.5) * 4 * max(1.0, ref.abs().max().item() / 10)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)          # same k order per output element -> bit-identical
+
+
 def test_gemm_nt_identity_asymmetric(lib):
     """A = I with an asymmetric B catches a transposed C write or fragment map."""
     from urgent2026_challenge_track1_amd import ops

@@ -581,40 +581,46 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
 // 16 B); physical chunk = k-chunk ^ ((row >> 2) & 3), applied on the DMA source address and on the ds_read_b128
 // fragment reads, so the 16 rows of a fragment hit 16 different 16-byte bank groups.  Epilogue as gemm_nt_kernel
 // (bias / tanh / tanh-backward / residual, output staged through LDS for 16-byte coalesced stores).
-template <typename TO, int NTW, int ACT, int BMX>
-__global__ void __launch_bounds__(BMX * 2) gemm_nt_dma_kernel(GemmDesc d) {
-  // BMX = 256: 8 waves, 4 stages of 32 KB, one workgroup per CU (long K: least operand traffic per FLOP)
-  // BMX = 128: 4 waves, 3 stages of 24 KB, two workgroups per CU (short K: one's epilogue overlaps the other's loop)
-  constexpr int BNX = 32 * NTW, NWV = BMX / 32, NTHR = NWV * 64;
-  constexpr int NST = BMX == 256 ? URSE_NT_NST : 3, STAGE = (BMX + 256) * 64, BOFF = BMX * 64;
-  constexpr int BI = 16 / NWV;                   // B wave-instructions per wave per stage (A: always 2)
-  constexpr int DPW = 2 + BI;                    // DMAs per wave per stage
-  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
+template <typename TO, int NTW, int ACT, int BMX, int WNC = 2>
+__global__ void __launch_bounds__(BMX / 64 * WNC * 64) gemm_nt_dma_kernel(GemmDesc d) {
+  // tile = BMX rows x (16 * NTW * WNC) columns; waves BMX/64 (m) x WNC (n), each 64 x 16*NTW
+  // <256, 2>: 8 waves, 256 x 224/256, 4 stages of 32 KB (long K: least operand traffic per FLOP)
+  // <128, 4>: 8 waves, 128 x 448, 4 stages of 36 KB (short K, write-bound outputs: 896-byte row segments reach 5.4 TB/s
+  //           of HBM write rate where 448-byte segments reach 3.7, scripts/diag/write_pattern.py)
+  // <128, 2>: 4 waves, 128 x 224, 3 stages of 24 KB, two workgroups per CU
+  constexpr int BNX = 16 * NTW * WNC, NWV = BMX / 64 * WNC, NTHR = NWV * 64;
+  constexpr int BNR = WNC == 2 ? 256 : 16 * NTW * WNC;                     // B image rows
+  constexpr int NST = NWV == 8 ? URSE_NT_NST : 3, STAGE = (BMX + BNR) * 64, BOFF = BMX * 64;
+  constexpr int AI = (BMX / 16 + NWV - 1) / NWV;  // A wave-instructions per wave per stage
+  constexpr int BI = (BNR / 16 + NWV - 1) / NWV;  // B wave-instructions per wave per stage (the surplus ones read the zero page)
+  constexpr int DPW = AI + BI;                    // DMAs per wave per stage
+  static_assert(AI * NWV * 16 == BMX, "A image blocks divide evenly over the waves");
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE + 1024];   // + one block for surplus (zero page) DMAs
   const int tn = (int)((d.N + BNX - 1) / BNX), tm = (int)((d.M + BMX - 1) / BMX);
   const int bid = xcd_remap(blockIdx.x, tm * tn);
   const int tile_m = bid / tn, tile_n = bid - tile_m * tn;
   const long m0 = (long)tile_m * BMX, n0 = (long)tile_n * BNX;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WNC, wn = w % WNC;
   const int nk = (int)(d.K / 32);
   const char* zsrc = reinterpret_cast<const char*>(g_tn_zero_page) + lane * 16;
   const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 4) & 3);     // source k-chunk of this lane's slot
   const int lc = lane & 15, lr = lane >> 4;
   const int foff = lc * 64 + ((lr ^ ((lc >> 2) & 3)) << 4);    // fragment byte offset inside a 16-row block
 
-  // DMA: wave w fills image rows 32w .. 32w+31 of A (two 16-row wave-instructions) and 16*BI*w .. of B
-  const char* pa[2];
+  // DMA: wave w fills the 16-row blocks AI*w .. of the A image and BI*w .. of the B image
+  const char* pa[AI];
   const char* pb[BI];
-  bool aok[2], bok[BI];
+  bool aok[AI], bok[BI];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int rowl = 32 * w + 16 * j + srow;
-    aok[j] = m0 + rowl < d.M;
+  for (int j = 0; j < AI; ++j) {
+    const int rowl = 16 * (AI * w + j) + srow;
+    aok[j] = rowl < BMX && m0 + rowl < d.M;
     pa[j] = d.A + ((m0 + rowl) * d.lda) * 2 + schunk * 16;
   }
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
-    const int rowl = 16 * BI * w + 16 * j + srow;
+    const int rowl = 16 * (BI * w + j) + srow;
     bok[j] = rowl < BNX && n0 + rowl < d.N;
     pb[j] = d.B + ((n0 + rowl) * d.ldb) * 2 + schunk * 16;
   }
@@ -622,10 +628,12 @@ __global__ void __launch_bounds__(BMX * 2) gemm_nt_dma_kernel(GemmDesc d) {
     char* sbase = lds + slot * STAGE;
     const bool kin = kt < nk;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) glds16((kin && aok[j]) ? pa[j] + (long)kt * 64 : zsrc, sbase + w * 2048 + j * 1024);
+    for (int j = 0; j < AI; ++j) glds16((kin && aok[j]) ? pa[j] + (long)kt * 64 : zsrc, sbase + (AI * w + j) * 1024);
 #pragma unroll
-    for (int j = 0; j < BI; ++j)
-      glds16((kin && bok[j]) ? pb[j] + (long)kt * 64 : zsrc, sbase + BOFF + (w * BI + j) * 1024);
+    for (int j = 0; j < BI; ++j) {
+      const int blk = BI * w + j;          // a surplus block (keeps the per-wave DMA count uniform) lands in the spare block
+      glds16((kin && bok[j]) ? pb[j] + (long)kt * 64 : zsrc, blk < BNR / 16 ? sbase + BOFF + blk * 1024 : lds + NST * STAGE);
+    }
   };
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) issue(s, s);
@@ -652,9 +660,10 @@ __global__ void __launch_bounds__(BMX * 2) gemm_nt_dma_kernel(GemmDesc d) {
     // stage kt has landed for this wave once only the (NST-2) younger stages are outstanding; the barrier makes every
     // wave's part visible and retires the slot that stage kt+NST-1 is about to overwrite
     if ((NST - 2) * DPW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if ((NST - 2) * DPW == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if ((NST - 2) * DPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    static_assert((NST - 2) * DPW == 12 || (NST - 2) * DPW == 8 || (NST - 2) * DPW == 6, "wait count");
+    static_assert((NST - 2) * DPW == 12 || (NST - 2) * DPW == 10 || (NST - 2) * DPW == 8 || (NST - 2) * DPW == 6, "wait count");
     __builtin_amdgcn_s_barrier();
     int nslot = slot + NST - 1;
     if (nslot >= NST) nslot -= NST;
@@ -792,6 +801,11 @@ static int dispatch_nt(const GemmDesc* descs, const GemmDesc& single, int groups
   return URSE_OK;
 }
 
+// measured (scripts/abl_nt_wide.py): 128x448 tiles win only on the [M, 8H] gate projection (K=224, bf16 out: 1.32 -> 1.22 ms);
+// at N=800 / K>=512 / f32 out the 256x224 tile stays ahead
+static int g_nt_wide_default = 1;
+static long g_nt_wide_maxk = 256;
+
 extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                             const float* bias, const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K,
                             int in_dtype, int out_dtype, int act, void* stream) {
@@ -809,13 +823,18 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
     if (const char* e = getenv("URSE_NT_NTW")) ntw = atoi(e) == 8 ? 8 : 7;
     int bmx = 256;                        // (the 128-row, two-workgroups-per-CU variant measured no faster at any K)
     if (const char* e = getenv("URSE_NT_BMX")) bmx = atoi(e) == 128 ? 128 : 256;
-    const long tl = ((M + bmx - 1) / bmx) * ((N + 32L * ntw - 1) / (32L * ntw));
+    // 128 x 448 tiles (896-byte output row segments) for the write-bound shapes: short K, wide N
+    int wide = g_nt_wide_default && K <= g_nt_wide_maxk && N >= 1792 && out_dtype == URSE_BF16 && (N + 447) / 448 * 448 <= pad7 + 64;
+    if (const char* e = getenv("URSE_NT_WIDE")) wide = atoi(e) != 0 && N >= 448;
+    const long tl = wide ? ((M + 127) / 128) * ((N + 447) / 448) : ((M + bmx - 1) / bmx) * ((N + 32L * ntw - 1) / (32L * ntw));
     URSE_CHECK_ARG(tl < (1L << 31), "urse_gemm_nt: too many tiles");
     dim3 grid((unsigned)tl);
     hipStream_t st = (hipStream_t)stream;
 #define URSE_NT_DMA(TO_, NTW_, ACT_, BMX_) \
   hipLaunchKernelGGL((gemm_nt_dma_kernel<TO_, NTW_, ACT_, BMX_>), grid, dim3(BMX_ * 2), 0, st, d)
-#define URSE_NT_DMA_B(TO_, NTW_, ACT_) do { if (bmx == 128) URSE_NT_DMA(TO_, NTW_, ACT_, 128); else URSE_NT_DMA(TO_, NTW_, ACT_, 256); } while (0)
+#define URSE_NT_DMA_W(TO_, ACT_) \
+  hipLaunchKernelGGL((gemm_nt_dma_kernel<TO_, 7, ACT_, 128, 4>), grid, dim3(512), 0, st, d)
+#define URSE_NT_DMA_B(TO_, NTW_, ACT_) do { if (wide) URSE_NT_DMA_W(TO_, ACT_); else if (bmx == 128) URSE_NT_DMA(TO_, NTW_, ACT_, 128); else URSE_NT_DMA(TO_, NTW_, ACT_, 256); } while (0)
 #define URSE_NT_DMA_ACT(TO_, NTW_) \
   do { if (act == 0) URSE_NT_DMA_B(TO_, NTW_, 0); else if (act == 1) URSE_NT_DMA_B(TO_, NTW_, 1); else URSE_NT_DMA_B(TO_, NTW_, 2); } while (0)
     if (out_dtype == URSE_BF16) {
