@@ -71,6 +71,10 @@ int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C
  * {A, B, C, bias, resid, lda, ldb, ldc, M, N, K, ldr}; grid.x = max_blocks (largest tile count). */
 int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_dtype, int out_dtype, int act,
                          void* stream);
+/* same, with a host mirror of the records: the library validates every group, sizes the grid itself and runs the
+ * groups on the LDS-DMA ring kernel when all of them are bf16 with K % 32 == 0, N >= 160, M >= 1024. */
+int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_descs, int groups, int in_dtype, int out_dtype,
+                           int act, void* stream);
 /* C[Mo,No] (f32) += sum_r A[r,Mo] * B'[r,No]  and optionally colsum[Mo] += sum_r A[r,:].
  * B'[r] = B[r+shift], zero when period > 0 and ((r / inner) % period) == invalid_step
  * (the h_{t-1} operand of the recurrent weight gradient).  perm_h > 0: the columns of A are in the LSTM

@@ -185,3 +185,43 @@ def test_gemm_tn_dual_matches_two_calls(lib, dtype, R, H, N, inner, period, rev)
     ops.gemm_tn(A, Hh, r2, Mo=4 * H, No=H, shift=sh, inner=inner, period=period, invalid_step=inv, perm_h=H)
     for got, ref in ((c1, r1), (c2, r2), (cs, rs)):
         assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("act,out_dtype", [(0, torch.float32), (1, torch.bfloat16), (2, torch.bfloat16)])
+def test_gemm_nt_grouped_h_ring_kernel_matches_small_kernel(lib, monkeypatch, act, out_dtype):
+    """grouped records (one per band: own N, K, pointers) on the LDS-DMA ring kernel against the 128 x 128 kernel and
+    against float64, every epilogue; M not a multiple of the tile"""
+    from urgent2026_challenge_track1_amd import ops
+    from urgent2026_challenge_track1_amd.bsrnn import nt_grouped
+    M, shapes = 1300, [(784, 224), (196, 800), (160, 32), (230, 96)]
+    keep, rows, refs = [], [], []
+    for g, (N, K) in enumerate(shapes):
+        A, W = _mk((M, K), torch.bfloat16, 10 + g).cuda(), (_mk((N, K), torch.bfloat16, 20 + g) * 0.2).cuda()
+        bias = _mk((N,), torch.float32, 30 + g).cuda() if act != 2 else None
+        h = torch.tanh(_mk((M, N), torch.float32, 40 + g)).to(out_dtype).cuda() if act == 2 else None
+        ldc = N + 8
+        C = torch.zeros(M, ldc, dtype=out_dtype, device="cuda")
+        keep += [A, W, bias, h, C]
+        rows.append([A.data_ptr(), W.data_ptr(), C.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                     0 if h is None else h.data_ptr(), K, K, ldc, M, N, K, 0 if h is None else N])
+        ref = A.double() @ W.double().T
+        if act == 1:
+            ref = torch.tanh(ref + bias.double())
+        elif act == 2:
+            ref = ref * (1 - h.double() ** 2)
+        else:
+            ref = ref + bias.double()
+        refs.append((C, N, ref))
+    outs = {}
+    for mode in ("ring", "small"):
+        if mode == "small":
+            monkeypatch.setenv("URSE_NT_GROUPED_NO_DMA", "1")
+        for C, _, _ in refs:
+            C.zero_()
+        nt_grouped(rows, "cuda", ops.BF16, ops._dt(refs[0][0]), act=act)
+        outs[mode] = [C.clone() for C, _, _ in refs]
+    for (C, N, ref), a, b in zip(refs, outs["ring"], outs["small"]):
+        tol = 1e-2 if out_dtype == torch.bfloat16 else 2e-3
+        assert (a[:, :N].double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        assert (a[:, :N].double() - b[:, :N].double()).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        assert torch.count_nonzero(a[:, N:]) == 0          # nothing written past a group's N

@@ -14,7 +14,9 @@ the autograd graph (custom Functions whose backward writes parameter gradients s
 the flat gradient buffer).
 """
 import math
+import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -23,6 +25,7 @@ from ._lib import call, stream_ptr
 
 SUBBANDS_481 = tuple([5] + [4] * 19 + [10] * 6 + [40] * 7 + [60])   # reference bsrnn_flowse.py:29
 SUBBANDS_769 = tuple([5] + [4] * 26 + [10] * 10 + [50] * 10 + [60])  # reference bsrnn_flowse.py:36
+_DIAG_SKIP_WGRADS = os.environ.get("URSE_DIAG_SKIP_WGRADS", "0") == "1"
 GN_EPS = 1e-5
 
 
@@ -75,12 +78,13 @@ def _view(buf, h):
     return buf[off:off + r * c].view(r, c)
 
 
-def _descs(rows, device):
-    return torch.tensor(rows, dtype=torch.int64, device=device)
-
-
-def _tiles(M, N):
-    return ((M + 127) // 128) * ((N + 127) // 128)
+def nt_grouped(rows, device, in_dt, out_dt, act=0):
+    """one launch over per-band GEMM records {A, B, C, bias, resid, lda, ldb, ldc, M, N, K, ldr}; the library sees the
+    host copy too and picks the kernel / grid (include/urse.h: urse_gemm_nt_grouped_h)."""
+    host = np.asarray(rows, dtype=np.int64)
+    assert host.ndim == 2 and host.shape[1] == 12
+    call("gemm_nt_grouped_h", torch.from_numpy(host).to(device), host.ctypes.data, host.shape[0], in_dt, out_dt, act,
+         stream_ptr())
 
 
 class BSRNNCore(nn.Module):
@@ -376,7 +380,7 @@ class BSRNNCore(nn.Module):
             rows.append([_ptr(xnb, r[2]), _ptr(w), _ptr(out, k * width + col0),
                          _ptr(self._flat, self._off[prefix + ".b"] + k * N), 0,
                          tb["ldx"], w.shape[1], K * width, M, N, r[3], 0])
-        call("gemm_nt_grouped", _descs(rows, dev), K, _tiles(M, N), ops._dt(xnb), ops._dt(out), 0, stream_ptr())
+        nt_grouped(rows, dev, ops._dt(xnb), ops._dt(out))
         return out, (xnb, stats, tb)
 
     def bandsplit_bwd(self, spec, saved, dz, prefix="bs", dzT=None, width=None, col0=0, ready=True):
@@ -405,7 +409,7 @@ class BSRNNCore(nn.Module):
                          2 * sb, Np, 0])
             w_off += N * 2 * sb
         ops.gemm_tn_grouped(tn_rows, dt, dev)     # all per-band weight / bias gradients in one launch
-        call("gemm_nt_grouped", _descs(rows, dev), K, _tiles(M, 128), ops._dt(dzT), ops.F32, 0, stream_ptr())
+        nt_grouped(rows, dev, ops._dt(dzT), ops.F32)
         n_gb = 2 * sum(self.subbands)
         call("bandsplit_norm_bwd", spec, dxnb, tb["bands"], stats, self._g(prefix + ".gamma", n_gb),
              self._g(prefix + ".beta", n_gb), B, T, F, K, tb["ldx"], GN_EPS, stream_ptr())
@@ -480,6 +484,8 @@ class BSRNNCore(nn.Module):
         tag = "l%d%s" % (l, path)
 
         def wgrads():
+            if _DIAG_SKIP_WGRADS:                       # timing diagnostic only (gradients wrong): bound on what the TN GEMMs cost
+                return
             ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N, No=2 * H)
             gb = self._g(p + "bih", 8 * H)
             gwih = self._g(p + "wih", 8 * H * N).view(8 * H, N)
@@ -574,10 +580,8 @@ class BSRNNCore(nn.Module):
                               _ptr(self._flat, self._off[p + "b2"] + b2_off), 0, ld4N, ld4N, P, M, 4 * sb, ld4N, 0])
                 b2_off += 4 * sb
             xns.append(xn); sts.append(st); hids.append(hid); pres.append(pre)
-        call("gemm_nt_grouped", _descs(rows1, dev), 2 * K, _tiles(M, 4 * N), ops._dt(xns[0]), ops._dt(hids[0]), 1,
-             stream_ptr())
-        call("gemm_nt_grouped", _descs(rows2, dev), 2 * K, _tiles(M, 4 * max(self.subbands[:K])), ops._dt(hids[0]),
-             ops.F32, 0, stream_ptr())
+        nt_grouped(rows1, dev, ops._dt(xns[0]), ops._dt(hids[0]), act=1)
+        nt_grouped(rows2, dev, ops._dt(hids[0]), ops.F32)
         out = torch.empty(B, T, F, 2, dtype=torch.float32, device=dev)
         call("glu_mask_apply_fwd", pres[0], pres[1], spec, out, tb["bands"], tb["f2k"], M, F, P, stream_ptr())
         return out, ((xns, sts, hids, pres, tb) if save else None)
@@ -603,8 +607,7 @@ class BSRNNCore(nn.Module):
                                _ptr(hids[i], k * M * ld4N), P, r[6], ld4N, M, 4 * N, r[6], ld4N])
                 rows_b.append([_ptr(dhp[i], k * M * ld4N), _ptr(pk[p + "w1T", k]), _ptr(dxn[i], k * N), 0, 0, ld4N,
                                ld4N, K * N, M, N, ld4N, 0])
-        call("gemm_nt_grouped", _descs(rows_a, dev), 2 * K, _tiles(M, 4 * N), ops._dt(dpre[0]), ops._dt(dhp[0]), 2,
-             stream_ptr())
+        nt_grouped(rows_a, dev, ops._dt(dpre[0]), ops._dt(dhp[0]), act=2)
         tn_rows = []
         for i, tag in enumerate("mr"):
             p = "md%s." % tag
@@ -621,7 +624,7 @@ class BSRNNCore(nn.Module):
                 w2_off += 16 * sb * N
                 b2_off += 4 * sb
         ops.gemm_tn_grouped(tn_rows, dt, dev)     # 4 x K weight / bias gradients in one launch
-        call("gemm_nt_grouped", _descs(rows_b, dev), 2 * K, _tiles(M, N), ops._dt(dhp[0]), ops.F32, 0, stream_ptr())
+        nt_grouped(rows_b, dev, ops._dt(dhp[0]), ops.F32)
         dskip = None
         for i, tag in enumerate("mr"):
             p = "md%s." % tag

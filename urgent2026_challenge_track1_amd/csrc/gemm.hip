@@ -581,8 +581,8 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
 // 16 B); physical chunk = k-chunk ^ ((row >> 2) & 3), applied on the DMA source address and on the ds_read_b128
 // fragment reads, so the 16 rows of a fragment hit 16 different 16-byte bank groups.  Epilogue as gemm_nt_kernel
 // (bias / tanh / tanh-backward / residual, output staged through LDS for 16-byte coalesced stores).
-template <typename TO, int NTW, int ACT, int BMX, int WNC = 2>
-__global__ void __launch_bounds__(BMX / 64 * WNC * 64) gemm_nt_dma_kernel(GemmDesc d) {
+template <typename TO, int NTW, int ACT, int BMX, int WNC>
+__device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d) {
   // tile = BMX rows x (16 * NTW * WNC) columns; waves BMX/64 (m) x WNC (n), each 64 x 16*NTW
   // <256, 2>: 8 waves, 256 x 224/256, 4 stages of 32 KB (long K: least operand traffic per FLOP)
   // <128, 4>: 8 waves, 128 x 448, 4 stages of 36 KB (short K, write-bound outputs: 896-byte row segments reach 5.4 TB/s
@@ -597,6 +597,7 @@ __global__ void __launch_bounds__(BMX / 64 * WNC * 64) gemm_nt_dma_kernel(GemmDe
   static_assert(AI * NWV * 16 == BMX, "A image blocks divide evenly over the waves");
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE + 1024];   // + one block for surplus (zero page) DMAs
   const int tn = (int)((d.N + BNX - 1) / BNX), tm = (int)((d.M + BMX - 1) / BMX);
+  if ((int)blockIdx.x >= tm * tn) return;            // grouped launch: grid.x is the largest group's tile count
   const int bid = xcd_remap(blockIdx.x, tm * tn);
   const int tile_m = bid / tn, tile_n = bid - tile_m * tn;
   const long m0 = (long)tile_m * BMX, n0 = (long)tile_n * BNX;
@@ -773,6 +774,19 @@ __global__ void __launch_bounds__(BMX / 64 * WNC * 64) gemm_nt_dma_kernel(GemmDe
   }
 }
 
+template <typename TO, int NTW, int ACT, int BMX, int WNC = 2>
+__global__ void __launch_bounds__(BMX / 64 * WNC * 64) gemm_nt_dma_kernel(GemmDesc d) {
+  gemm_nt_dma_body<TO, NTW, ACT, BMX, WNC>(d);
+}
+
+// grouped form (one descriptor per band, blockIdx.y = group): the per-band 1x1 convolutions of the mask decoder /
+// band split at B*T = 12,832 rows per band
+template <typename TO, int ACT>
+__global__ void __launch_bounds__(512) gemm_nt_dma_grouped_kernel(const GemmDesc* __restrict__ descs) {
+  const GemmDesc d = descs[blockIdx.y];
+  gemm_nt_dma_body<TO, 7, ACT, 256, 2>(d);
+}
+
 static int check_desc_host(const GemmDesc& d, int es, const char* who) {
   URSE_CHECK_ARG(d.A && d.B && d.C, "%s: null operand", who);
   URSE_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "%s: empty problem", who);
@@ -857,6 +871,40 @@ extern "C" int urse_gemm_nt_grouped(const void* descs, int groups, int max_block
   memset(&dummy, 0, sizeof(dummy));
   return dispatch_nt((const GemmDesc*)descs, dummy, groups, max_blocks, in_dtype, out_dtype, act,
                      (hipStream_t)stream);
+}
+
+// grouped form with a host mirror of the descriptors: the library validates them, sizes the grid and picks the kernel
+// (LDS-DMA ring when every group is bf16 with K % 32 == 0 and N >= 160, the 128 x 128 kernel otherwise)
+extern "C" int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_descs, int groups, int in_dtype,
+                                      int out_dtype, int act, void* stream) {
+  URSE_CHECK_ARG(descs && host_descs && groups > 0 && groups < 65536, "urse_gemm_nt_grouped_h: bad argument");
+  const GemmDesc* hd = reinterpret_cast<const GemmDesc*>(host_descs);
+  const int es = in_dtype == URSE_BF16 ? 2 : 4;
+  bool dma = in_dtype == URSE_BF16 && !getenv("URSE_NT_NO_DMA") && !getenv("URSE_NT_GROUPED_NO_DMA");
+  long t128 = 0, tdma = 0;
+  for (int g = 0; g < groups; ++g) {
+    const GemmDesc& d = hd[g];
+    if (int rc = check_desc_host(d, es, "urse_gemm_nt_grouped_h")) return rc;
+    dma = dma && d.K % 32 == 0 && d.N >= 160 && d.M >= 1024;
+    t128 = std::max(t128, ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN));
+    tdma = std::max(tdma, ((d.M + 255) / 256) * ((d.N + 223) / 224));
+  }
+  URSE_CHECK_ARG(t128 < (1L << 31), "urse_gemm_nt_grouped_h: too many tiles");
+  if (!dma) {
+    GemmDesc dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    return dispatch_nt((const GemmDesc*)descs, dummy, groups, (int)t128, in_dtype, out_dtype, act, (hipStream_t)stream);
+  }
+  dim3 grid((unsigned)tdma, (unsigned)groups);
+  hipStream_t st = (hipStream_t)stream;
+  const GemmDesc* dd = (const GemmDesc*)descs;
+#define URSE_NT_G(TO_, ACT_) hipLaunchKernelGGL((gemm_nt_dma_grouped_kernel<TO_, ACT_>), grid, dim3(512), 0, st, dd)
+#define URSE_NT_G_ACT(TO_) do { if (act == 0) URSE_NT_G(TO_, 0); else if (act == 1) URSE_NT_G(TO_, 1); else URSE_NT_G(TO_, 2); } while (0)
+  if (out_dtype == URSE_BF16) URSE_NT_G_ACT(bf16_t);
+  else if (out_dtype == URSE_F32) URSE_NT_G_ACT(float);
+  else { set_error("urse_gemm_nt_grouped_h: bad output dtype %d", out_dtype); return URSE_ERR_INVALID_ARG; }
+  URSE_CHECK_LAUNCH("urse_gemm_nt_grouped_h");
+  return URSE_OK;
 }
 
 // workgroups the big TN kernels aim for (one per CU).  A caller that runs them beside another kernel on part of the

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import call, require_cuda, stream_ptr
-from .bsrnn import BSRNNCore, GN_EPS, _PackPlan, _descs, _ptr, _tiles, _view, _DualPathFn
+from .bsrnn import BSRNNCore, GN_EPS, _PackPlan, _ptr, _view, _DualPathFn, nt_grouped
 from .d_model import _DTYPES, StepLR
 
 SUB_CH = 16
@@ -140,8 +140,7 @@ class FlowBSRNNCore(BSRNNCore):
                 rows.append([_ptr(xn, k * Np), _ptr(pk[p + "w1", k]), _ptr(U, f0 * SUB_CH), _ptr(pk[p + "b1", k]), 0,
                              K * Np, Np, Fs * SUB_CH, M, SUB_CH * sb, Np, 0])
             xns.append(xn); sts.append(st); Us.append(U)
-        call("gemm_nt_grouped", _descs(rows, dev), 2 * K, _tiles(M, SUB_CH * max(self.subbands[:K])), ops._dt(xns[0]),
-             ops.F32, 1, stream_ptr())
+        nt_grouped(rows, dev, ops._dt(xns[0]), ops.F32, act=1)
         for i, tag in enumerate("mr"):
             p = "gd%s." % tag
             pre = torch.empty(B, T, Fs, 4, dtype=torch.float32, device=dev)
@@ -201,7 +200,7 @@ class FlowBSRNNCore(BSRNNCore):
                 rows.append([_ptr(dUp, f0 * SUB_CH), _ptr(w1T), _ptr(dxn[i], k * N), 0, 0, ldu, kp, K * N, M, N, kp, 0])
                 w_off += n_out * N
                 b_off += n_out
-        call("gemm_nt_grouped", _descs(rows, dev), 2 * K, _tiles(M, N), ops._dt(keep[0]), ops.F32, 0, stream_ptr())
+        nt_grouped(rows, dev, ops._dt(keep[0]), ops.F32)
         dskip = None
         for i, tag in enumerate("mr"):
             p = "gd%s." % tag
