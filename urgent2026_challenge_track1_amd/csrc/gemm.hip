@@ -460,20 +460,44 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
     aok[j] = acol[j] < p.lda;
     bok[j] = cel < BNX && bcol[j] < ldb_;
   }
-  auto issue = [&](int kt, int slot) {
+  // issue() is called for consecutive stages, so each lane's rows, source pointers and the (r / inner) % period phase
+  // of the masked operand advance by constants: no multiply / divide in the loop (the kernel was VALU- and
+  // LDS-latency-bound at 2.4x its MFMA time, not memory-bound: rows pinned into L2 ran no faster)
+  const int r_end_i = (int)r_end, shift_i = (int)shift_, R_i = (int)p.R;
+  const unsigned inner_u = (unsigned)p.inner, per_u = (unsigned)period_, inval_u = (unsigned)p.invalid_step;
+  const unsigned step_q = per_u ? (32u / inner_u) % per_u : 0u, step_r = 32u % inner_u;
+  const long a_step = 64 * p.lda, b_step = 64 * ldb_;   // bytes per 32 rows
+  int rr[2];
+  const char* pa[2];
+  const char* pb[2];
+  unsigned ph[2], rm[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    rr[j] = (int)r_begin + 4 * w + 2 * j + half;
+    pa[j] = p.A + ((long)rr[j] * p.lda + acol[j]) * 2;
+    pb[j] = Bop + (((long)rr[j] + shift_) * ldb_ + bcol[j]) * 2;
+    ph[j] = per_u ? ((unsigned)rr[j] / inner_u) % per_u : 0u;
+    rm[j] = (unsigned)rr[j] % inner_u;
+  }
+  auto issue = [&](int slot) {
     char* sbase = lds + slot * STAGE + 4 * w * 512;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const long r = r_begin + (long)kt * 32 + 4 * w + 2 * j + half;
-      const bool rin = kt < nk && r < r_end;
-      const char* sa = (rin && aok[j]) ? p.A + (r * p.lda + acol[j]) * 2 : zsrc;
-      bool ok = rin && bok[j];
-      const long rs = r + shift_;
-      if (period_) ok = ok && ((((unsigned)r / (unsigned)p.inner) % (unsigned)period_) != (unsigned)p.invalid_step);
-      ok = ok && rs >= 0 && rs < p.R;
-      const char* sb = ok ? Bop + (rs * ldb_ + bcol[j]) * 2 : zsrc;
-      glds16(sa, sbase + j * 1024);
-      glds16(sb, sbase + 16384 + j * 1024);
+      const bool rin = rr[j] < r_end_i;                 // (also false for every stage past the slice's last one)
+      const int rs = rr[j] + shift_i;
+      const bool ok = rin && bok[j] && (per_u == 0 || ph[j] != inval_u) && rs >= 0 && rs < R_i;
+      glds16((rin && aok[j]) ? pa[j] : zsrc, sbase + j * 1024);
+      glds16(ok ? pb[j] : zsrc, sbase + 16384 + j * 1024);
+      rr[j] += 32;
+      pa[j] += a_step;
+      pb[j] += b_step;
+      if (per_u) {
+        rm[j] += step_r;
+        const unsigned c = rm[j] >= inner_u ? 1u : 0u;
+        rm[j] -= c ? inner_u : 0u;
+        ph[j] += step_q + c;
+        ph[j] -= ph[j] >= per_u ? per_u : 0u;
+      }
     }
   };
 
@@ -499,7 +523,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   const int sw0 = q, sw1 = q + 4;                       // (row & 7) of the two rows
 
 #pragma unroll
-  for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0, s0);
+  for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
   int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed for this wave once at most the 4*(NST-2) younger DMAs (stages kt+1 ..) are outstanding; the
@@ -509,7 +533,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
     __builtin_amdgcn_s_barrier();
     int nslot = slot + NST - 1;
     if (nslot >= NST) nslot -= NST;
-    issue(kt + NST - 1, nslot);
+    issue(nslot);
     const char* As = lds + slot * STAGE;
     if (++slot == NST) slot = 0;
     const char* Bs = As + 16384;
@@ -523,6 +547,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
           (__attribute__((address_space(3))) short4_t*)(As + off1 + ((S ^ sw1) << 5)));
       a[i] = short8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
     }
+    short8_t b[NTW];                                  // every fragment read is in flight before the first MFMA
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       const int S = wn * NTW + j;
@@ -530,10 +555,15 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
           (__attribute__((address_space(3))) short4_t*)(Bs + off0 + ((S ^ sw0) << 5)));
       short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (__attribute__((address_space(3))) short4_t*)(Bs + off1 + ((S ^ sw1) << 5)));
-      const short8_t b = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      b[j] = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b, acc[i][j]);
-      if (do_colsum_b) accb[j] = Frag<bf16_t>::mma(ones, b, accb[j]);
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+    if (do_colsum_b) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) accb[j] = Frag<bf16_t>::mma(ones, b[j], accb[j]);
     }
     if (do_colsum) {
 #pragma unroll
@@ -932,7 +962,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   p.B2 = nullptr; p.C2 = nullptr; p.ldb2 = p.ldc2 = p.No2 = p.nt1 = 0; p.pad_[0] = p.pad_[1] = 0;
   static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr;
   if (dtype == URSE_BF16 && !no_dma && perm_h == 0 && shift == 0 && period == 0 && Mo < 512 && Mo >= 160 && No >= 512 &&
-      R >= 16384 && R < (1L << 31)) {
+      R >= 16384 && R < (1L << 30)) {
     // wide-and-short gradient (fc weight [196, 784]): run the big kernel on the transposed problem
     TnArgs q = p;
     q.A = (const char*)B; q.lda = ldb; q.Mo = No;
@@ -954,7 +984,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     URSE_CHECK_LAUNCH("urse_gemm_tn");
     return URSE_OK;
   }
-  if (dtype == URSE_BF16 && !no_dma && Mo >= 512 && No >= 160 && R >= 16384 && inner < (1L << 31) && R < (1L << 31)) {
+  if (dtype == URSE_BF16 && !no_dma && Mo >= 512 && No >= 160 && R >= 16384 && inner < (1L << 31) && R < (1L << 30) && shift > -(1L << 30) && shift < (1L << 30) && period < (1L << 31)) {
     // big weight gradients: 256-wide tiles on the LDS-DMA ring, one workgroup per CU
     const long pad7 = (No + 223) / 224 * 224, pad8 = (No + 255) / 256 * 256;
     const int ntw = pad7 < pad8 ? 7 : 8;
@@ -1013,7 +1043,7 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
                                  int64_t perm_h, int dtype, void* stream) {
   URSE_CHECK_ARG(A && B && C && B2 && C2 && R > 0 && Mo > 0 && No > 0 && No2 > 0, "urse_gemm_tn_dual: bad argument");
   static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr;
-  const bool big = dtype == URSE_BF16 && !no_dma && Mo >= 512 && R >= 16384 && R < (1L << 31) && inner < (1L << 31) &&
+  const bool big = dtype == URSE_BF16 && !no_dma && Mo >= 512 && R >= 16384 && R < (1L << 30) && shift > -(1L << 30) && shift < (1L << 30) && period < (1L << 31) && inner < (1L << 31) &&
                    (lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && (ldb2 * 2) % 16 == 0 && ((uintptr_t)A % 16) == 0 &&
                    ((uintptr_t)B % 16) == 0 && ((uintptr_t)B2 % 16) == 0;
   if (!big) {
