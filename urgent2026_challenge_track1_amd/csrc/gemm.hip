@@ -415,13 +415,24 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
 
 // ring depth of the big TN kernel: 5 stages of 32 KB = the whole 160 KB LDS, four stages in flight (measured
 // 0.92 vs 1.01 ms for the 3136 x 196 wgrad against 4 stages); the NT kernel is faster with 4 (short K: longer prologue)
+#ifndef URSE_TN_PIPE
+#define URSE_TN_PIPE 2   // 0 one stage per barrier, 1 half-step software pipeline, 2 two stages per barrier
+#endif
 #ifndef URSE_TN_NST
 #define URSE_TN_NST 5
 #endif
 #ifndef URSE_NT_NST
 #define URSE_NT_NST 4
 #endif
-template <int NTW>
+// CSM: 0 no column sums, 1 column sums of A (bias gradient), 2 column sums of B (transposed problem) - a template
+// parameter because the unused accumulators would cost 16 / 32 registers of a kernel that sits at the 256 limit
+// LDS swizzle key of an image row (32 rows x 512 B, sixteen 32-byte segments per row): one transposed fragment read
+// touches the rows 8g + q (g = 0,1 within a 32-lane bank group, q = 0..3) - the key must differ in its low THREE bits
+// over those eight rows (a bank is (byte / 4) mod 64, i.e. segment mod 8): q | bit 3 of the row << 2.  (row & 7 put
+// rows q and 8 + q on the same banks: every fragment read was a 2-way conflict.)
+__device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <int NTW, int CSM>
 __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   constexpr int BMX = 256, BNX = 32 * NTW, NST = URSE_TN_NST, STAGE = 32768;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
@@ -453,7 +464,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int rowl = 4 * w + 2 * j + half;
-    const int seg = (chunk >> 1) ^ (rowl & 7);
+    const int seg = (chunk >> 1) ^ tn_swz(rowl);
     const int cel = seg * 16 + (chunk & 1) * 8;          // element column inside the tile
     acol[j] = m0 + cel;
     bcol[j] = n0 + cel;
@@ -461,8 +472,9 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
     bok[j] = cel < BNX && bcol[j] < ldb_;
   }
   // issue() is called for consecutive stages, so each lane's rows, source pointers and the (r / inner) % period phase
-  // of the masked operand advance by constants: no multiply / divide in the loop (the kernel was VALU- and
-  // LDS-latency-bound at 2.4x its MFMA time, not memory-bound: rows pinned into L2 ran no faster)
+  // of the masked operand advance by constants: no multiply / divide in the loop.  (The kernel is issue-bound, not
+  // memory-bound: rows pinned into L2 ran no faster.  Moving the row logic to the scalar unit - it is wave-uniform
+  // per half-wave - was slower still, 2.92 vs 2.47 ms: one scalar unit serves the CU's eight waves.)
   const int r_end_i = (int)r_end, shift_i = (int)shift_, R_i = (int)p.R;
   const unsigned inner_u = (unsigned)p.inner, per_u = (unsigned)period_, inval_u = (unsigned)p.invalid_step;
   const unsigned step_q = per_u ? (32u / inner_u) % per_u : 0u, step_r = 32u % inner_u;
@@ -486,8 +498,15 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
       const bool rin = rr[j] < r_end_i;                 // (also false for every stage past the slice's last one)
       const int rs = rr[j] + shift_i;
       const bool ok = rin && bok[j] && (per_u == 0 || ph[j] != inval_u) && rs >= 0 && rs < R_i;
+#ifdef TABL_NO_DMA
+      asm volatile("" :: "v"(rin && aok[j] ? pa[j] : zsrc), "v"(ok ? pb[j] : zsrc));
+#elif defined(TABL_ZERO_DMA)
+      glds16(zsrc, sbase + j * 1024);
+      glds16(zsrc, sbase + 16384 + j * 1024);
+#else
       glds16((rin && aok[j]) ? pa[j] : zsrc, sbase + j * 1024);
       glds16(ok ? pb[j] : zsrc, sbase + 16384 + j * 1024);
+#endif
       rr[j] += 32;
       pa[j] += a_step;
       pb[j] += b_step;
@@ -506,22 +525,169 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  f32x4_t accs[4];
+  f32x4_t accs[CSM == 1 ? 4 : 1];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) accs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < (CSM == 1 ? 4 : 1); ++i) accs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const bool trans = p.perm_h == TN_TRANSPOSED;
-  const bool do_colsum = (p.colsum != nullptr) && !trans && tile_n == 0 && wn == 0;   // (dual: tile 0 belongs to B)
-  const bool do_colsum_b = (p.colsum != nullptr) && trans && tile_m == 0 && wm == 0;
-  f32x4_t accb[NTW];
+  const bool do_colsum = CSM == 1 && tile_n == 0 && wn == 0;   // (dual: tile 0 belongs to B)
+  const bool do_colsum_b = CSM == 2 && tile_m == 0 && wm == 0;
+  f32x4_t accb[CSM == 2 ? NTW : 1];
 #pragma unroll
-  for (int jj = 0; jj < NTW; ++jj) accb[jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int jj = 0; jj < (CSM == 2 ? NTW : 1); ++jj) accb[jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const short8_t ones = short8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
   const int row0 = 8 * g + q;                           // fragment rows row0 (k 0..3 of the lane) and row0 + 4
   const int off0 = row0 * 512 + pp * 8, off1 = (row0 + 4) * 512 + pp * 8;
-  const int sw0 = q, sw1 = q + 4;                       // (row & 7) of the two rows
+  const int sw0 = tn_swz(row0), sw1 = tn_swz(row0 + 4);     // swizzle keys of the two rows
 
+  if constexpr (URSE_TN_PIPE == 1 && NTW == 7) {   // (NTW = 8 does not fit the extra fragment registers: 13-30 spills)
+  // Software-pipelined k loop.  One k-step = two halves: H1 = the four A fragments x B fragments 0..NH-1, H2 = the
+  // rest.  The reads of H2(kt) are issued before the MFMAs of H1(kt), the reads of H1(kt+1) before the MFMAs of
+  // H2(kt), so every LDS read runs in the shadow of the wave's own MFMAs (before: all eight waves read, then all
+  // multiplied - LDS and MFMA time added up, 2,470 clocks per k-step against 1,024 of MFMA).  One barrier per
+  // k-step, in the middle:
+  //   wait vmcnt -> this wave's DMAs of stage kt+1 have landed; lgkmcnt(0) -> its reads of slot(kt) are done;
+  //   barrier    -> stage kt+1 is visible to all, slot(kt) is free -> stage kt+NST is issued into it.
+  // Stages in flight at the wait: kt+2 .. kt+NST-1 = NST-2 stages of 4 DMAs per wave.
+  constexpr int NH = 4;
+  auto rd_a = [&](const char* As, short8_t (&a)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int S = wm * 4 + i;
+      short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(As + off0 + ((S ^ sw0) << 5)));
+      short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(As + off1 + ((S ^ sw1) << 5)));
+      a[i] = short8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    }
+  };
+  auto rd_b = [&](const char* Bs, int j) -> short8_t {
+    const int S = wn * NTW + j;
+    short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) short4_t*)(Bs + off0 + ((S ^ sw0) << 5)));
+    short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) short4_t*)(Bs + off1 + ((S ^ sw1) << 5)));
+    return short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+  };
+  auto wait_stage = [&]() {
+    if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
+  wait_stage();                                          // stage 0 (stages 1 .. NST-2 may still fly)
+  __builtin_amdgcn_s_barrier();
+  issue(NST - 1);
+  short8_t aE[4], aO[4], b[NTW];
+  rd_a(lds, aE);
+#pragma unroll
+  for (int j = 0; j < NH; ++j) b[j] = rd_b(lds + 16384, j);
+  int slot = 0;
+  auto kstep = [&](short8_t (&ac)[4], short8_t (&an)[4]) {
+    const char* Bs = lds + slot * STAGE + 16384;
+#pragma unroll
+    for (int j = NH; j < NTW; ++j) b[j] = rd_b(Bs, j);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(ac[i], b[j], acc[i][j]);
+    if constexpr (CSM == 2) if (do_colsum_b) {
+#pragma unroll
+      for (int j = 0; j < NH; ++j) accb[j] = Frag<bf16_t>::mma(ones, b[j], accb[j]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    wait_stage();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(slot);                                         // stage kt + NST into the slot just retired
+    if (++slot == NST) slot = 0;
+    const char* An = lds + slot * STAGE;
+    rd_a(An, an);
+    short8_t bn[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) bn[j] = rd_b(An + 16384, j);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = NH; j < NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(ac[i], b[j], acc[i][j]);
+    if constexpr (CSM == 2) if (do_colsum_b) {
+#pragma unroll
+      for (int j = NH; j < NTW; ++j) accb[j] = Frag<bf16_t>::mma(ones, b[j], accb[j]);
+    }
+    if constexpr (CSM == 1) if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accs[i] = Frag<bf16_t>::mma(ac[i], ones, accs[i]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int j = 0; j < NH; ++j) b[j] = bn[j];
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    kstep(aE, aO);
+    kstep(aO, aE);
+  }
+  if (kt < nk) kstep(aE, aO);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else if constexpr (URSE_TN_PIPE == 2 && NST == 5) {
+  // two stages per barrier: the per-k-step barrier cost 200 of 1,000 ns (scripts/abl_tn_parts.py).  At the wait of
+  // iteration kt the stages 0 .. kt+2 have been issued and only the youngest may be outstanding (4 DMAs per wave);
+  // after the barrier the slots of stages kt-2, kt-1 are free and take stages kt+3, kt+4.
+  auto compute = [&](int sl) {
+    const char* As = lds + sl * STAGE;
+    const char* Bs = As + 16384;
+    short8_t a[4], b[NTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int S = wm * 4 + i;
+      short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(As + off0 + ((S ^ sw0) << 5)));
+      short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(As + off1 + ((S ^ sw1) << 5)));
+      a[i] = short8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int S = wn * NTW + j;
+      short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(Bs + off0 + ((S ^ sw0) << 5)));
+      short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(Bs + off1 + ((S ^ sw1) << 5)));
+      b[j] = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+    if constexpr (CSM == 2) if (do_colsum_b) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) accb[j] = Frag<bf16_t>::mma(ones, b[j], accb[j]);
+    }
+    if constexpr (CSM == 1) if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accs[i] = Frag<bf16_t>::mma(a[i], ones, accs[i]);
+    }
+  };
+  issue(0); issue(1); issue(2);
+  int slot = 0;
+  for (int kt = 0; kt < nk; kt += 2) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int s1 = slot + 1 >= NST ? slot + 1 - NST : slot + 1;
+    const int s3 = slot + 3 >= NST ? slot + 3 - NST : slot + 3;
+    const int s4 = slot + 4 >= NST ? slot + 4 - NST : slot + 4;
+    issue(s3);
+    issue(s4);
+    compute(slot);
+    if (kt + 1 < nk) compute(s1);
+    slot = slot + 2 >= NST ? slot + 2 - NST : slot + 2;
+  }
+  } else {
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
   int slot = 0;
@@ -530,7 +696,9 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
     // barrier then makes every wave's part visible and retires the slot that stage kt+NST-1 is about to overwrite
     if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#ifndef TABL_NO_BARRIER
     __builtin_amdgcn_s_barrier();
+#endif
     int nslot = slot + NST - 1;
     if (nslot >= NST) nslot -= NST;
     issue(nslot);
@@ -546,6 +714,9 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
       short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (__attribute__((address_space(3))) short4_t*)(As + off1 + ((S ^ sw1) << 5)));
       a[i] = short8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#ifdef TABL_NO_READ
+      a[i] = ones; asm volatile("" : "+v"(a[i]));
+#endif
     }
     short8_t b[NTW];                                  // every fragment read is in flight before the first MFMA
 #pragma unroll
@@ -556,19 +727,30 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
       short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (__attribute__((address_space(3))) short4_t*)(Bs + off1 + ((S ^ sw1) << 5)));
       b[j] = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#ifdef TABL_NO_READ
+      b[j] = ones; asm volatile("" : "+v"(b[j]));
+#endif
     }
+#ifdef TABL_NO_MFMA
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) asm volatile("" :: "v"(b[j]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a[i]));
+#else
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
-    if (do_colsum_b) {
+#endif
+    if constexpr (CSM == 2) if (do_colsum_b) {
 #pragma unroll
       for (int j = 0; j < NTW; ++j) accb[j] = Frag<bf16_t>::mma(ones, b[j], accb[j]);
     }
-    if (do_colsum) {
+    if constexpr (CSM == 1) if (do_colsum) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) accs[i] = Frag<bf16_t>::mma(a[i], ones, accs[i]);
     }
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (zero page) DMAs must not outlive the workgroup
 
@@ -587,14 +769,14 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
         }
       }
   }
-  if (do_colsum_b && (lane >> 4) == 0) {
+  if constexpr (CSM == 2) if (do_colsum_b && (lane >> 4) == 0) {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       const long col = n0 + (wn * NTW + j) * 16 + (lane & 15);
       if (col < p.No) atomicAdd(p.colsum + col, accb[j][0]);
     }
   }
-  if (do_colsum && (lane & 15) == 0) {
+  if constexpr (CSM == 1) if (do_colsum && (lane & 15) == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -606,9 +788,16 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+static void launch_tn_dma(int ntw, int csm, dim3 grid, hipStream_t st, const TnArgs& p) {
+#define URSE_TN_L(N_, C_) hipLaunchKernelGGL((gemm_tn_dma_kernel<N_, C_>), grid, dim3(512), 0, st, p)
+  if (ntw == 7) { if (csm == 0) URSE_TN_L(7, 0); else if (csm == 1) URSE_TN_L(7, 1); else URSE_TN_L(7, 2); }
+  else { if (csm == 0) URSE_TN_L(8, 0); else if (csm == 1) URSE_TN_L(8, 1); else URSE_TN_L(8, 2); }
+#undef URSE_TN_L
+}
+
 // NT, large shapes (bf16 operands): 256 x (32*NTW) tile per workgroup of 8 waves (4 x 2, 64 x 16*NTW each), K in
 // 32-element steps on the same 4-stage LDS-DMA ring as gemm_tn_dma_kernel.  Image rows are 64 bytes (4 chunks of
-// 16 B); physical chunk = k-chunk ^ ((row >> 2) & 3), applied on the DMA source address and on the ds_read_b128
+// 16 B); physical chunk = k-chunk ^ ((row >> 1) & 3), applied on the DMA source address and on the ds_read_b128
 // fragment reads, so the 16 rows of a fragment hit 16 different 16-byte bank groups.  Epilogue as gemm_nt_kernel
 // (bias / tanh / tanh-backward / residual, output staged through LDS for 16-byte coalesced stores).
 template <typename TO, int NTW, int ACT, int BMX, int WNC>
@@ -635,9 +824,12 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WNC, wn = w % WNC;
   const int nk = (int)(d.K / 32);
   const char* zsrc = reinterpret_cast<const char*>(g_tn_zero_page) + lane * 16;
-  const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 4) & 3);     // source k-chunk of this lane's slot
+  const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 3) & 3);     // source k-chunk of this lane's slot
   const int lc = lane & 15, lr = lane >> 4;
-  const int foff = lc * 64 + ((lr ^ ((lc >> 2) & 3)) << 4);    // fragment byte offset inside a 16-row block
+  // fragment byte offset inside a 16-row block.  Swizzle key (row >> 1) & 3: ds_read_b128 is served in the four 16-lane
+  // groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32 (MI355X_MICROARCH.md, LDS), and only this key spreads each group
+  // over all 64 banks ((row >> 2) & 3, used before, left every read a 2-way conflict - same as no swizzle at all)
+  const int foff = lc * 64 + ((lr ^ ((lc >> 1) & 3)) << 4);
 
   // DMA: wave w fills the 16-row blocks AI*w .. of the A image and BI*w .. of the B image
   const char* pa[AI];
@@ -979,8 +1171,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     slices = (R + rps - 1) / rps;
     q.rows_per_slice = rps;
     dim3 grid((unsigned)(tl * slices));
-    if (ntw == 7) hipLaunchKernelGGL(gemm_tn_dma_kernel<7>, grid, dim3(512), 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL(gemm_tn_dma_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, q);
+    launch_tn_dma(ntw, colsum ? 2 : 0, grid, (hipStream_t)stream, q);
     URSE_CHECK_LAUNCH("urse_gemm_tn");
     return URSE_OK;
   }
@@ -997,8 +1188,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     slices = (R + rps - 1) / rps;
     p.rows_per_slice = rps;
     dim3 grid((unsigned)(tl * slices));
-    if (ntw == 7) hipLaunchKernelGGL(gemm_tn_dma_kernel<7>, grid, dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_tn_dma_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, p);
+    launch_tn_dma(ntw, colsum ? 1 : 0, grid, (hipStream_t)stream, p);
     URSE_CHECK_LAUNCH("urse_gemm_tn");
     return URSE_OK;
   }
@@ -1067,7 +1257,7 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
   rps = (rps + 31) / 32 * 32;
   slices = (R + rps - 1) / rps;
   p.rows_per_slice = rps;
-  hipLaunchKernelGGL(gemm_tn_dma_kernel<7>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+  launch_tn_dma(7, colsum ? 1 : 0, dim3((unsigned)(tl * slices)), (hipStream_t)stream, p);
   URSE_CHECK_LAUNCH("urse_gemm_tn_dual");
   return URSE_OK;
 }
