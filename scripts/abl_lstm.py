@@ -4,7 +4,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
-variants = {"base": []}
+variants = {"base": [], "pin_w": ["-DBABL_PIN_W"], "no_mm": ["-DBABL_NO_MM"], "no_p1load": ["-DBABL_NO_P1LOAD"],
+            "no_store": ["-DBABL_NO_STORE"], "no_p1load_no_store": ["-DBABL_NO_P1LOAD", "-DBABL_NO_STORE"],
+            "pin_w_no_p1": ["-DBABL_PIN_W", "-DBABL_NO_P1LOAD", "-DBABL_NO_STORE"]}
 libs = {}
 for name, fl in variants.items():
     so = "/tmp/abl_%s.so" % name
@@ -49,7 +51,7 @@ def bwd_split(lib, path, rt):
     return lib.urse_lstm_split_bwd(P(dh.data_ptr()), ctypes.c_int64(800), P(gx.data_ptr()), ctypes.c_int64(8 * H), P(c.data_ptr()),
         P(whhT.data_ptr()), P(xbuf.data_ptr()), P(errf.data_ptr()), H, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), P(st))
 for fn, fname in ((bwd, "bwd"),):
-    for path in ("time", "band"):
+    for path in ("time",):
         for rt in (0,):
             res = []
             for name, lib in libs.items():

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   const int dir = blockIdx.y, s0 = blockIdx.x * R;
   const int H = p.H, Hp = p.Hp, nut = (H + 15) >> 4;
-  const int pitch = Hp * ES + 16;
+  const int pitch = lds_frag_pitch(Hp * ES);
   for (int i = tid; i < 2 * R * pitch / 4; i += NTHR) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
   float cst[MAXUT][RT][4];
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   const int dir = blockIdx.y, s0 = blockIdx.x * R;
   const int H = HC ? HC : p.H, nut = (H + 15) >> 4, G4 = 4 * H;
-  const int pitch = HPC ? 4 * HPC * ES + 16 : G4 * ES + 16;
+  const int pitch = HPC ? lds_frag_pitch(4 * HPC * ES) : lds_frag_pitch(G4 * ES);
   const int nbuf = p.dbuf ? 2 : 1;         // double-buffered dgates tile: one barrier per step
   float dcs[MAXUT][RT][4], dhr[MAXUT][RT][4], ccur[MAXUT][RT][4];
   int rowbase[RT][4];                      // negative: sequence beyond n_seq (clamped, never stored)
@@ -280,9 +280,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int row = (int)rowb(rt, r) + t * stride_i;
+#ifdef BABL_NO_P1LOAD
+              gpre[rt][r] = V4{}; cpre[rt][r] = (float)row; dhpre[rt][r] = T(row & 1);
+#else
               gpre[rt][r] = *reinterpret_cast<const V4*>(gates + ((long)row * ldg_i + (gcol_i + u * 4)));
               cpre[rt][r] = first ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + u)];
               dhpre[rt][r] = dh[(long)row * ldd_i + (hcol_i + u)];
+#endif
             }
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
@@ -303,14 +307,19 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
               ccur[ui][rt][r] = cpre[rt][r];          // c_{t-1} is the next processed step's c_t
               const V4 pk = Vec4<T>::pack(dg);
               *reinterpret_cast<V4*>(tile + (rt * 16 + lr * 4 + r) * pitch + (u * 4) * ES) = pk;
+#ifndef BABL_NO_STORE
               if (rowbase[rt][r] >= 0)
                 *reinterpret_cast<V4*>(gates + ((long)(rowbase[rt][r] + t * stride_i) * ldg_i + (gcol_i + u * 4))) = pk;
+#endif
             }
         }
       }
     }
     if (step + 1 == p.m.seq_len) break;
     __syncthreads();
+#ifdef BABL_NO_MM
+    if (p.m.seq_len > 0) continue;
+#endif
 #pragma unroll
     for (int ui = 0; ui < MAXUT; ++ui) {
       const int ut = w + NW * ui;
@@ -331,7 +340,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #pragma unroll
           for (int i = 0; i < KB; ++i) {
             const int ks = (k0 + i < nslab) ? k0 + i : nslab - 1;
+#ifdef BABL_PIN_W
+            b[i] = *reinterpret_cast<const uint4*>(whhT + (ks & 7) * 1024);   // diagnostic: 8 KB working set
+#else
             b[i] = *reinterpret_cast<const uint4*>(wr + ks * 1024);
+#endif
           }
 #pragma unroll
           for (int i = 0; i < KB; ++i) {
@@ -428,7 +441,7 @@ static void allow_big_lds(K kernel) {
 template <typename T, int RT, int NW>
 static int launch_fwd(const LstmFwdArgs& p, hipStream_t st) {
   constexpr int R = 16 * RT;
-  const size_t lds = (size_t)2 * R * (p.Hp * sizeof(T) + 16);
+  const size_t lds = (size_t)2 * R * lds_frag_pitch(p.Hp * (int)sizeof(T));
   URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_fwd: Hp %d with %d rows exceeds LDS", p.Hp, R);
   dim3 grid(ceil_div(p.m.n_seq, R), 2);
   const int upw = ((p.H + 15) / 16 + NW - 1) / NW;   // unit tiles per wave
@@ -447,7 +460,7 @@ static int launch_fwd(const LstmFwdArgs& p, hipStream_t st) {
 template <typename T, int RT, int NW>
 static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
   constexpr int R = 16 * RT;
-  size_t lds = (size_t)R * (4 * p.H * sizeof(T) + 16);
+  size_t lds = (size_t)R * lds_frag_pitch(4 * p.H * (int)sizeof(T));
   URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_bwd: H %d with %d rows exceeds LDS", p.H, R);
   LstmBwdArgs pa = p;
   pa.dbuf = (2 * lds <= 150 * 1024) ? 1 : 0;
@@ -559,7 +572,7 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
   hipStream_t st = (hipStream_t)stream;
   int rt = rows16 & 15;
   bool nw8 = (rows16 >> 4) & 1;
-  const bool fits2 = (size_t)32 * (8 * H + 16) <= 160 * 1024;
+  const bool fits2 = (size_t)32 * lds_frag_pitch(8 * H) <= 160 * 1024;
   if (rt == 0) {
     // many short sequences (band path): 32 sequences per workgroup of 8 waves halve the weight stream per sequence
     // (measured 3.9 vs 4.4 ms at C2); few long ones (time path) keep 16 per workgroup to fill the chip

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   const int dir = blockIdx.y;
   const int cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
   const int H = p.H;
-  constexpr int Hp = NSLAB * 32, pitch = Hp * 2 + 16;      // compile-time: the index arithmetic below folds to shifts / multiplies
+  constexpr int Hp = NSLAB * 32, pitch = lds_frag_pitch(Hp * 2);      // compile-time: the index arithmetic below folds to shifts / multiplies
   char* htile = smem;                                    // [CROWS][pitch]
   bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + CROWS * pitch);   // [CROWS][UW]
   const int nq = (H + 3) >> 2;
@@ -510,7 +510,7 @@ static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  const size_t lds = (size_t)CROWS * (p.Hp * 2 + 16) + (size_t)CROWS * UW * 2 + 16;
+  const size_t lds = (size_t)CROWS * lds_frag_pitch(p.Hp * 2) + (size_t)CROWS * UW * 2 + 16;
   dim3 grid(p.C * p.ncl, 2);
   hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH>), grid, dim3(CTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_cluster_fwd");

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
   const int dir = blockIdx.y;
   const int cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
   const int H = p.H;
-  constexpr int pitch = HPB + 16;
+  constexpr int pitch = lds_frag_pitch(HPB);
   char* htile = smem;                                                        // [64][pitch]
   bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + C2ROWS * pitch);         // [64][UW]
   unsigned* deadflag = reinterpret_cast<unsigned*>(smem + C2ROWS * pitch + C2ROWS * UW * 2);
@@ -268,7 +268,7 @@ static int launch_cluster2(const Cluster2Args& p, hipStream_t st) {
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster2_kernel<NSLAB, NW, QPW>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  const size_t lds = (size_t)C2ROWS * (NSLAB * 64 + 16) + (size_t)C2ROWS * NW * QPW * 4 * 2 + 16;
+  const size_t lds = (size_t)C2ROWS * lds_frag_pitch(NSLAB * 64) + (size_t)C2ROWS * NW * QPW * 4 * 2 + 16;
   hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<NSLAB, NW, QPW>), dim3(p.C * p.ncl, 2), dim3(NW * 64), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_cluster2_fwd");
   return URSE_OK;

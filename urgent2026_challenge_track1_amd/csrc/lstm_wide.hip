@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(WW * 64, 2) lstm_fwd_wide_kernel(WideArgs p) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps block bookkeeping and weight bases in SGPRs
   const int dir = blockIdx.y;
   const int H = p.H;
-  constexpr int Hp = NSLAB * 32, pitch = Hp * 2 + 16;      // compile-time: LDS offsets of the k loop fold into immediates
+  constexpr int Hp = NSLAB * 32, pitch = lds_frag_pitch(Hp * 2);      // compile-time: LDS offsets of the k loop fold into immediates
   const int seq0 = blockIdx.x * WROWS;
   const int nrows = min(WROWS, p.n_seq - seq0);
   int* rowtab = reinterpret_cast<int*>(smem + 2 * WROWS * pitch);   // row index of (sequence, t = 0)
@@ -274,7 +274,7 @@ static int launch_wide_fwd(const WideArgs& p, hipStream_t st) {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   constexpr int WROWS = 16 * RT;
-  const size_t lds = (size_t)2 * WROWS * (p.Hp * 2 + 16) + WROWS * sizeof(int);
+  const size_t lds = (size_t)2 * WROWS * lds_frag_pitch(p.Hp * 2) + WROWS * sizeof(int);
   dim3 grid((p.n_seq + WROWS - 1) / WROWS, 2);
   hipLaunchKernelGGL((lstm_fwd_wide_kernel<NSLAB, MAXG, RT, WW>), grid, dim3(WW * 64), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_wide_fwd");
