@@ -417,6 +417,10 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
 // 0.92 vs 1.01 ms for the 3136 x 196 wgrad against 4 stages); the NT kernel is faster with 4 (short K: longer prologue)
 #ifndef URSE_TN_PIPE
 #define URSE_TN_PIPE 2   // 0 one stage per barrier, 1 half-step software pipeline, 2 two stages per barrier
+                         // (also tried: both stages' fragments read before the first MFMA - 2.53 vs 2.47 ms, dropped)
+#endif
+#ifndef URSE_TN_SETPRIO
+#define URSE_TN_SETPRIO 1
 #endif
 #ifndef URSE_TN_NST
 #define URSE_TN_NST 5
@@ -660,10 +664,16 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
           (__attribute__((address_space(3))) short4_t*)(Bs + off1 + ((S ^ sw1) << 5)));
       b[j] = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
     }
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if constexpr (CSM == 2) if (do_colsum_b) {
 #pragma unroll
       for (int j = 0; j < NTW; ++j) accb[j] = Frag<bf16_t>::mma(ones, b[j], accb[j]);
