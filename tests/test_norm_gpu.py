@@ -1,5 +1,5 @@
 """GPU parity: GroupNorm forward / backward kernels against torch autograd on the same normalisation
-(statistics over (T, W) per (batch, group), per-channel affine repeating every N columns), both backward reduce kernels."""
+(statistics over (T, W) per (batch, group), per-channel affine repeating every N columns)."""
 import pytest
 import torch
 
@@ -19,11 +19,8 @@ def _ref(x, gamma, beta, B, T, Kg, W, N, gstride, eps):
 
 @pytest.mark.parametrize("B,T,Kg,W,N,gstride", [(2, 37, 1, 5 * 196, 196, 0), (3, 21, 4, 196, 196, 196), (2, 19, 3, 2 * 20, 20, 20),
                                                  (2, 11, 2, 3 * 12, 12, 12)])
-@pytest.mark.parametrize("scalar", [False, True])
-def test_groupnorm_fwd_bwd_matches_autograd(lib, monkeypatch, B, T, Kg, W, N, gstride, scalar):
+def test_groupnorm_fwd_bwd_matches_autograd(lib, B, T, Kg, W, N, gstride):
     from urgent2026_challenge_track1_amd import ops
-    if scalar:
-        monkeypatch.setenv("URSE_GN_BWD_SCALAR", "1")
     g = torch.Generator().manual_seed(B * 100 + T)
     x = torch.randn(B, T, Kg, W, generator=g)
     ng = max(1, Kg if gstride else 1) * max(N, gstride)

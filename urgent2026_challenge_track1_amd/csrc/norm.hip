@@ -148,70 +148,6 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// float4 form of pass 1 (N % 4 == 0): thread <-> (vector slot, 4 channels); the block walks its rows' W/N channel vectors
-// VPB at a time with 16-byte loads (the scalar form above ran at 2.5 TB/s with 196 of 256 lanes busy), per-channel
-// partials of the VPB slots are combined through LDS before the atomics
-__global__ void __launch_bounds__(256) gn_bwd_reduce4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             const double* __restrict__ stats,
-                                                             const float* __restrict__ gamma, double* __restrict__ sums,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             GnShape s, float eps, int rows_per_block) {
-  __shared__ double red[8];
-  __shared__ float4 part[2][256];
-  const int b = blockIdx.z, kg = blockIdx.y;
-  const int t0 = blockIdx.x * rows_per_block;
-  int t1 = t0 + rows_per_block;
-  if (t1 > s.T) t1 = s.T;
-  const int n4 = s.N >> 2, vpb = 256 / n4, vpr = s.W / s.N;          // vectors per block pass / per row
-  const int slot = threadIdx.x / n4, c4 = threadIdx.x - slot * n4;
-  const long pitch = (long)s.Kg * s.W;
-  const long base = ((long)b * s.T) * pitch + (long)kg * s.W;
-  float mean, rstd;
-  gn_mean_rstd(stats, (long)b * s.Kg + kg, (double)s.T * s.W, eps, &mean, &rstd);
-  float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
-  float a1 = 0.f, a2 = 0.f;
-  if (slot < vpb) {
-    const float4 g = *reinterpret_cast<const float4*>(gamma + (long)kg * s.gstride + c4 * 4);
-    const int nvec = (t1 - t0) * vpr;
-    int t = t0 + slot / vpr, v = slot - (slot / vpr) * vpr;            // (row, vector) of this slot, advanced by vpb
-    const int dt = vpb / vpr, dv = vpb - dt * vpr;
-    for (int i = slot; i < nvec; i += vpb) {
-      const long off = base + (long)t * pitch + (long)v * s.N + c4 * 4;
-      const float4 xv = *reinterpret_cast<const float4*>(x + off);
-      const float4 d = *reinterpret_cast<const float4*>(dy + off);
-      const float4 xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-      dg.x += d.x * xh.x; dg.y += d.y * xh.y; dg.z += d.z * xh.z; dg.w += d.w * xh.w;
-      db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
-      a1 += d.x * g.x + d.y * g.y + d.z * g.z + d.w * g.w;
-      a2 += d.x * g.x * xh.x + d.y * g.y * xh.y + d.z * g.z * xh.z + d.w * g.w * xh.w;
-      t += dt; v += dv;
-      if (v >= vpr) { v -= vpr; ++t; }
-    }
-  }
-  part[0][threadIdx.x] = dg;
-  part[1][threadIdx.x] = db;
-  double s1 = wave_sum_d((double)a1), s2 = wave_sum_d((double)a2);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) { red[w] = s1; red[4 + w] = s2; }
-  __syncthreads();
-  if (threadIdx.x < n4) {
-    float4 sg = part[0][threadIdx.x], sb = part[1][threadIdx.x];
-    for (int q = 1; q < vpb; ++q) {
-      const float4 pg = part[0][q * n4 + threadIdx.x], pb = part[1][q * n4 + threadIdx.x];
-      sg.x += pg.x; sg.y += pg.y; sg.z += pg.z; sg.w += pg.w;
-      sb.x += pb.x; sb.y += pb.y; sb.z += pb.z; sb.w += pb.w;
-    }
-    float* gd = dgamma + (long)kg * s.gstride + threadIdx.x * 4;
-    float* bd = dbeta + (long)kg * s.gstride + threadIdx.x * 4;
-    atomicAdd(gd, sg.x); atomicAdd(gd + 1, sg.y); atomicAdd(gd + 2, sg.z); atomicAdd(gd + 3, sg.w);
-    atomicAdd(bd, sb.x); atomicAdd(bd + 1, sb.y); atomicAdd(bd + 2, sb.z); atomicAdd(bd + 3, sb.w);
-  }
-  if (threadIdx.x == 0) {
-    atomicAdd(sums + ((long)b * s.Kg + kg) * 2, red[0] + red[1] + red[2] + red[3]);
-    atomicAdd(sums + ((long)b * s.Kg + kg) * 2 + 1, red[4] + red[5] + red[6] + red[7]);
-  }
-}
-
 // backward pass 2: dx = rstd * (gamma*dy - s1/n - xhat*s2/n) (+ dres), float4 per thread
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const double* __restrict__ stats,
@@ -335,14 +271,8 @@ extern "C" int urse_groupnorm_bwd(const float* x, const float* dy, const double*
   if (nblk > T) nblk = T;
   const int rpb = ceil_div(T, nblk);
   dim3 grid(ceil_div(T, rpb), Kg, B);
-  const bool vec4 = N % 4 == 0 && N / 4 <= 256 && W % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
-                    ((uintptr_t)gamma % 16) == 0 && gstride % 4 == 0 && !getenv("URSE_GN_BWD_SCALAR");
-  if (vec4)
-    hipLaunchKernelGGL(gn_bwd_reduce4_kernel, grid, dim3(256), 0, st, x, dy, stats, gamma, sums, dgamma, dbeta, s, eps,
-                       rpb);
-  else
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, st, x, dy, stats, gamma, sums, dgamma, dbeta, s, eps,
-                       rpb);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, st, x, dy, stats, gamma, sums, dgamma, dbeta, s, eps,
+                     rpb);
   const long total = (long)B * T * Kg * (W / N) * (N / 4);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, dy, stats, sums, gamma, dres,
                      dx, s, eps, (bf16_t*)dx_packed, ldp);
