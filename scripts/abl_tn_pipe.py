@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
 libs = {}
-for name, fl in {"flat": ["-DURSE_TN_PIPE=0"], "pair": ["-DURSE_TN_PIPE=2"], "pipe": ["-DURSE_TN_PIPE=1"]}.items():
+for name, fl in {"flat": ["-DURSE_TN_PIPE=0"], "pair": ["-DURSE_TN_PIPE=2"], "pipe": ["-DURSE_TN_PIPE=4"]}.items():
     so = "/tmp/abltp_%s.so" % name
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", *fl,
                            os.path.join(CS, "gemm.hip"), os.path.join(CS, "api.hip"), "-o", so])

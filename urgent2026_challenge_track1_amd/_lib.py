@@ -10,7 +10,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liburse_hip.so")
+LIB_PATH = os.environ.get("URSE_LIB_PATH") or os.path.join(_HERE, "liburse_hip.so")   # (override: A/B of diagnostic builds)
 HEADER_PATH = os.path.join(_HERE, "..", "include", "urse.h")
 
 _lib = None

@@ -11,6 +11,7 @@
 // espnet2's BSRNN (reference twin: baseline_code/models/bsrnn_flowse.py:66-81,296-307).
 #include <stdlib.h>
 
+#include <type_traits>
 #include "urse_common.h"
 
 namespace urse {
@@ -418,6 +419,9 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
 #ifndef URSE_TN_PIPE
 #define URSE_TN_PIPE 2   // 0 one stage per barrier, 1 half-step software pipeline, 2 two stages per barrier
                          // (also tried: both stages' fragments read before the first MFMA - 2.53 vs 2.47 ms, dropped)
+                         // 4: as 2 with the DMA issue between the MFMA groups - 8 % faster alone (2.23 vs 2.46 ms), but the
+                         //    train step is 7 ms SLOWER with it (same-box A/B 189 vs 181 ms): the kernels it shares CUs with
+                         //    pay for its denser issue stream; off
 #endif
 #ifndef URSE_TN_SETPRIO
 #define URSE_TN_SETPRIO 1
@@ -486,45 +490,54 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   const unsigned inner_u = (unsigned)p.inner, per_u = (unsigned)period_, inval_u = (unsigned)p.invalid_step;
   const unsigned step_q = per_u ? (32u / inner_u) % per_u : 0u, step_r = 32u % inner_u;
   const long a_step = 64 * p.lda, b_step = 64 * ldb_;   // bytes per 32 rows
-  int rr[2];
-  const char* pa[2];
-  const char* pb[2];
-  unsigned ph[2], rm[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    rr[j] = (int)r_begin + 4 * w + 2 * j + half;
-    pa[j] = p.A + ((long)rr[j] * p.lda + acol[j]) * 2;
-    pb[j] = Bop + (((long)rr[j] + shift_) * ldb_ + bcol[j]) * 2;
-    ph[j] = per_u ? ((unsigned)rr[j] / inner_u) % per_u : 0u;
-    rm[j] = (unsigned)rr[j] % inner_u;
-  }
-  auto issue = [&](int slot) {
-    char* sbase = lds + slot * STAGE + 4 * w * 512;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool rin = rr[j] < r_end_i;                 // (also false for every stage past the slice's last one)
-      const int rs = rr[j] + shift_i;
-      const bool ok = rin && bok[j] && (per_u == 0 || ph[j] != inval_u) && rs >= 0 && rs < R_i;
+  struct Src {                                           // one of the wave's two (A, B) wave-instructions per stage
+    int rr;
+    const char* pa;
+    const char* pb;
+    unsigned ph, rm;
+    bool aok, bok;
+  };
+  Src q0, q1;
+  auto init_src = [&](Src& q, int j) __attribute__((always_inline)) {
+    q.rr = (int)r_begin + 4 * w + 2 * j + half;
+    q.pa = p.A + ((long)q.rr * p.lda + acol[j]) * 2;
+    q.pb = Bop + (((long)q.rr + shift_) * ldb_ + bcol[j]) * 2;
+    q.ph = per_u ? ((unsigned)q.rr / inner_u) % per_u : 0u;
+    q.rm = (unsigned)q.rr % inner_u;
+    q.aok = aok[j];
+    q.bok = bok[j];
+  };
+  init_src(q0, 0);
+  init_src(q1, 1);
+  auto issue_one = [&](Src& q, char* dst) __attribute__((always_inline)) {
+    const bool rin = q.rr < r_end_i;                     // (also false for every stage past the slice's last one)
+    const int rs = q.rr + shift_i;
+    const bool ok = rin && q.bok && (per_u == 0 || q.ph != inval_u) && rs >= 0 && rs < R_i;
 #ifdef TABL_NO_DMA
-      asm volatile("" :: "v"(rin && aok[j] ? pa[j] : zsrc), "v"(ok ? pb[j] : zsrc));
+    asm volatile("" :: "v"(rin && q.aok ? q.pa : zsrc), "v"(ok ? q.pb : zsrc));
 #elif defined(TABL_ZERO_DMA)
-      glds16(zsrc, sbase + j * 1024);
-      glds16(zsrc, sbase + 16384 + j * 1024);
+    glds16(zsrc, dst);
+    glds16(zsrc, dst + 16384);
 #else
-      glds16((rin && aok[j]) ? pa[j] : zsrc, sbase + j * 1024);
-      glds16(ok ? pb[j] : zsrc, sbase + 16384 + j * 1024);
+    glds16((rin && q.aok) ? q.pa : zsrc, dst);
+    glds16(ok ? q.pb : zsrc, dst + 16384);
 #endif
-      rr[j] += 32;
-      pa[j] += a_step;
-      pb[j] += b_step;
-      if (per_u) {
-        rm[j] += step_r;
-        const unsigned c = rm[j] >= inner_u ? 1u : 0u;
-        rm[j] -= c ? inner_u : 0u;
-        ph[j] += step_q + c;
-        ph[j] -= ph[j] >= per_u ? per_u : 0u;
-      }
+    q.rr += 32;
+    q.pa += a_step;
+    q.pb += b_step;
+    if (per_u) {
+      q.rm += step_r;
+      const unsigned c = q.rm >= inner_u ? 1u : 0u;
+      q.rm -= c ? inner_u : 0u;
+      q.ph += step_q + c;
+      q.ph -= q.ph >= per_u ? per_u : 0u;
     }
+  };
+  auto issue0 = [&](int slot) __attribute__((always_inline)) { issue_one(q0, lds + slot * STAGE + 4 * w * 512); };
+  auto issue1 = [&](int slot) __attribute__((always_inline)) { issue_one(q1, lds + slot * STAGE + 4 * w * 512 + 1024); };
+  auto issue = [&](int slot) __attribute__((always_inline)) {
+    issue0(slot);
+    issue1(slot);
   };
 
   f32x4_t acc[4][NTW];
@@ -641,6 +654,93 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   }
   if (kt < nk) kstep(aE, aO);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else if constexpr (URSE_TN_PIPE == 4 && NST == 5) {
+  // as variant 2, but a stage's DMA issue (address selects, phase update: ~50 VALU instructions per wave) sits BETWEEN
+  // the two halves of a stage's MFMAs instead of right behind the barrier, where all eight waves did it at once with the
+  // MFMA pipes idle
+  // two stages per barrier: the per-k-step barrier cost 200 of 1,000 ns (scripts/abl_tn_parts.py).  At the wait of
+  // iteration kt the stages 0 .. kt+2 have been issued and only the youngest may be outstanding (4 DMAs per wave);
+  // after the barrier the slots of stages kt-2, kt-1 are free and take stages kt+3, kt+4.
+  auto compute = [&](int sl, int nsl) {
+    const char* As = lds + sl * STAGE;
+    const char* Bs = As + 16384;
+    short8_t a[4], b[NTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int S = wm * 4 + i;
+      short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(As + off0 + ((S ^ sw0) << 5)));
+      short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(As + off1 + ((S ^ sw1) << 5)));
+      a[i] = short8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int S = wn * NTW + j;
+      short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(Bs + off0 + ((S ^ sw0) << 5)));
+      short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(Bs + off1 + ((S ^ sw1) << 5)));
+      b[j] = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    issue0(nsl);
+    __builtin_amdgcn_sched_barrier(0);
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int j = 2; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    issue1(nsl);
+    __builtin_amdgcn_sched_barrier(0);
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int j = 4; j < NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    if constexpr (CSM == 2) if (do_colsum_b) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) accb[j] = Frag<bf16_t>::mma(ones, b[j], accb[j]);
+    }
+    if constexpr (CSM == 1) if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accs[i] = Frag<bf16_t>::mma(a[i], ones, accs[i]);
+    }
+  };
+  issue(0); issue(1); issue(2);
+  int slot = 0;
+  for (int kt = 0; kt < nk; kt += 2) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int s1 = slot + 1 >= NST ? slot + 1 - NST : slot + 1;
+    const int s3 = slot + 3 >= NST ? slot + 3 - NST : slot + 3;
+    const int s4 = slot + 4 >= NST ? slot + 4 - NST : slot + 4;
+    compute(slot, s3);
+    if (kt + 1 < nk) compute(s1, s4);
+    else issue(s4);
+    slot = slot + 2 >= NST ? slot + 2 - NST : slot + 2;
+  }
   } else if constexpr (URSE_TN_PIPE == 2 && NST == 5) {
   // two stages per barrier: the per-k-step barrier cost 200 of 1,000 ns (scripts/abl_tn_parts.py).  At the wait of
   // iteration kt the stages 0 .. kt+2 have been issued and only the youngest may be outstanding (4 DMAs per wave);
