@@ -213,10 +213,17 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
   }
 }
 
+// wave priority of the BPTT kernels (measured neutral against the wgrad GEMMs on the second queue: 180.3 vs 179.9 ms/step)
+#ifndef URSE_BWD_PRIO
+#define URSE_BWD_PRIO 0
+#endif
 // HC: hidden size known at compile time (0 = run-time p.H): tile pitch, slab count and unit-tile count fold into constants
 // HPC: only the LDS tile pitch is folded (the 32-row variant spills when its loop bounds become constants too)
 template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0>
 __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
+#if URSE_BWD_PRIO
+  __builtin_amdgcn_s_setprio(URSE_BWD_PRIO);   // the BPTT is on the step's critical path; the wgrad GEMMs it shares CUs with are not
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T), R = 16 * RT;
   typedef typename Vec4<T>::raw V4;
