@@ -111,7 +111,9 @@ def test_gemm_tn_shifted_operand(lib, inner, period, rev):
 
 @pytest.mark.parametrize("R,Mo,No,inner,period,rev,perm", [(20000, 608, 200, 1, 0, False, 0), (17 * 34 * 40, 1568, 392, 34, 40, False, 392),
                                                            (17 * 34 * 40, 1568, 392, 34, 40, True, 392), (16500, 3136, 196, 1, 0, False, 392),
-                                                           (17000, 196, 784, 1, 0, False, 0), (20000, 200, 600, 1, 0, False, 0)])
+                                                           (17000, 196, 784, 1, 0, False, 0), (20000, 200, 600, 1, 0, False, 0),
+                                                           (34 * 500 + 7, 1568, 392, 1, 34, False, 392), (34 * 500 + 7, 1568, 392, 1, 34, True, 392),
+                                                           (16397, 800, 250, 5, 7, True, 0)])
 def test_gemm_tn_large_dma_path(lib, R, Mo, No, inner, period, rev, perm):
     """shapes that take the 256-wide LDS-DMA kernel: ragged tile edges, shifted / masked B rows, gate un-permute,
     column sums, split-R atomics."""
