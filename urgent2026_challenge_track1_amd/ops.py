@@ -370,7 +370,7 @@ def low_priority_stream(device):
 
 
 TN_SHADOW_WGS = int(os.environ.get("URSE_TN_SHADOW_WGS", "120"))
-TN_SHADOW_WGS_BAND = int(os.environ.get("URSE_TN_SHADOW_WGS_BAND", "120"))   # ... beside the band path's BPTT (all CUs busy but its tail)
+TN_SHADOW_WGS_BAND = int(os.environ.get("URSE_TN_SHADOW_WGS_BAND", "84"))   # ... beside the band path's BPTT (all CUs busy but its tail)
 TN_OVERLAP_BAND = os.environ.get("URSE_TN_OVERLAP_BAND", "1") != "0"   # also start deferred wgrads beside the band path's BPTT
 # the wide kernel wins once there are enough 64-sequence workgroups to fill the chip in both directions
 WIDE_MIN_SEQ = int(os.environ.get("URSE_LSTM_WIDE_MIN_SEQ", str(64 * 128)))
