@@ -166,6 +166,7 @@ def _pretouch(dev, gib):
     torch.cuda.synchronize(dev)
     del blocks
     torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)            # (peak_hbm_gb reports the model's own footprint)
 
 
 def main():

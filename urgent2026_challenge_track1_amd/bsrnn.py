@@ -479,7 +479,7 @@ class BSRNNCore(nn.Module):
         else:
             dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, **sm)   # dgates, gate-interleaved columns
         if overlap and path == "t":
-            self._join_deferred_wgrads()
+            self._join_deferred_wgrads(keep=ops.TN_JOIN_LAG)
         st, L = sm["stride"], sm["seq_len"]
         tag = "l%d%s" % (l, path)
 
@@ -533,10 +533,15 @@ class BSRNNCore(nn.Module):
         self._inflight = (self._inflight or []) + [(done, self._deferred)]
         self._deferred = []
 
-    def _join_deferred_wgrads(self):
+    def _join_deferred_wgrads(self, keep=0):
+        """wait (on the compute stream) for the side stream's batches, except the `keep` most recent ones."""
         if self._inflight is None:
             return
-        batches, self._inflight = self._inflight, None
+        n = len(self._inflight) - keep
+        if n <= 0:
+            return
+        batches, rest = self._inflight[:n], self._inflight[n:]
+        self._inflight = rest or None
         for done, items in batches:
             torch.cuda.current_stream().wait_event(done)
             for _, tag in items:                         # gradients final: tell the reducer (and drop the closures)
