@@ -469,7 +469,8 @@ class BSRNNCore(nn.Module):
             # the time path's BPTT occupies 136 of the 256 CUs for ~7 ms (and the band path's last round of workgroups
             # leaves most CUs idle): the weight-gradient GEMMs deferred by the previous half layers run beside it on a
             # second stream (they only feed the optimizer / all-reduce)
-            self._run_deferred_wgrads(skip.device, ops.TN_SHADOW_WGS if path == "t" else ops.TN_SHADOW_WGS_BAND)
+            self._run_deferred_wgrads(skip.device, ops.TN_SHADOW_WGS if path == "t" else ops.TN_SHADOW_WGS_BAND,
+                                      None if path == "t" else ops.TN_BAND_PARTS)
         if ops.USE_CLUSTER_LSTM_BWD and pk.get(p + "whhTq") is not None and \
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
             dg, self._cluster_err = ops.lstm_bwd_cluster(dh, gates, c, pk[p + "whhTq"], H, d["Hp"], **sm)
@@ -483,24 +484,34 @@ class BSRNNCore(nn.Module):
         st, L = sm["stride"], sm["seq_len"]
         tag = "l%d%s" % (l, path)
 
-        def wgrads():
+        # three launches per half layer, deferred separately (the band path's BPTT gets only the first ops.TN_BAND_PARTS of
+        # them for company, see _run_deferred_wgrads); the half layer's gradients are final with the last one
+        def wg_fc():
             if _DIAG_SKIP_WGRADS:                       # timing diagnostic only (gradients wrong): bound on what the TN GEMMs cost
                 return
             ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N, No=2 * H)
-            gb = self._g(p + "bih", 8 * H)
-            gwih = self._g(p + "wih", 8 * H * N).view(8 * H, N)
-            # per direction ONE pass over the [M, 4H] dgates yields dW_ih (+ bias gradient) and dW_hh
-            for dr, (sh, inv) in enumerate(((-st, 0), (st, L - 1))):
+
+        def wg_dir(dr, sh, inv, last):
+            def run():
+                if _DIAG_SKIP_WGRADS:
+                    return
+                gb = self._g(p + "bih", 8 * H)
+                gwih = self._g(p + "wih", 8 * H * N).view(8 * H, N)
+                # per direction ONE pass over the [M, 4H] dgates yields dW_ih (+ bias gradient) and dW_hh
                 ops.gemm_tn_dual(dg[:, dr * 4 * H:(dr + 1) * 4 * H], xn, gwih[dr * 4 * H:(dr + 1) * 4 * H],
                                  gb[dr * 4 * H:(dr + 1) * 4 * H], hout[:, dr * H:(dr + 1) * H],
                                  self._g(p + "whh", 4 * H * H, dr * 4 * H * H).view(4 * H, H), 4 * H, N, H, sh, st, L, inv,
                                  perm_h=H)
-            call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())
+                if last:
+                    call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())
+            return run
 
+        parts = [(wg_fc, None), (wg_dir(0, -st, 0, False), None), (wg_dir(1, st, L - 1, True), tag)]
         if overlap:
-            self._deferred.append((wgrads, tag))       # the closure keeps doT / hout / dg / xn alive until it has run
+            self._deferred.extend(parts)               # the closures keep doT / hout / dg / xn alive until they have run
         else:
-            wgrads()
+            for fn, _ in parts:
+                fn()
         dxn = ops.gemm_nt(dg, pk[p + "wihT"], out_dtype=torch.float32, N=N)
         if dt == torch.bfloat16 and N % 4 == 0:
             dskip, packed = ops.groupnorm_bwd(skip, dxn, stats, self._p(p + "gamma", N), dout, self._g(p + "gamma", N),
@@ -514,10 +525,12 @@ class BSRNNCore(nn.Module):
         return dskip
 
     # deferred weight-gradient GEMMs (see dualpath_bwd) --------------------------------------------------------------
-    def _run_deferred_wgrads(self, device, target_wgs):
-        """launch everything deferred so far on the side stream, gated on the compute stream's current position."""
-        if not self._deferred:
+    def _run_deferred_wgrads(self, device, target_wgs, limit=None):
+        """launch what is deferred so far (the first `limit` launches of it) on the side stream, gated on the compute
+        stream's current position."""
+        if not self._deferred or limit == 0:
             return
+        now, later = (self._deferred, []) if limit is None else (self._deferred[:limit], self._deferred[limit:])
         if self._side is None:
             self._side = ops.low_priority_stream(device)
         start = torch.cuda.Event()
@@ -525,13 +538,13 @@ class BSRNNCore(nn.Module):
         self._side.wait_event(start)
         with torch.cuda.stream(self._side):
             call("gemm_tn_set_target", target_wgs)            # they share the chip with a BPTT kernel
-            for fn, _ in self._deferred:
+            for fn, _ in now:
                 fn()
             call("gemm_tn_set_target", 256)
             done = torch.cuda.Event()
             done.record(self._side)
-        self._inflight = (self._inflight or []) + [(done, self._deferred)]
-        self._deferred = []
+        self._inflight = (self._inflight or []) + [(done, now)]
+        self._deferred = later
 
     def _join_deferred_wgrads(self, keep=0):
         """wait (on the compute stream) for the side stream's batches, except the `keep` most recent ones."""
@@ -545,7 +558,8 @@ class BSRNNCore(nn.Module):
         for done, items in batches:
             torch.cuda.current_stream().wait_event(done)
             for _, tag in items:                         # gradients final: tell the reducer (and drop the closures)
-                self._ready(tag)
+                if tag is not None:
+                    self._ready(tag)
 
     def _flush_deferred_wgrads(self):
         """end of backward: whatever is still deferred runs on the compute stream."""
@@ -553,7 +567,8 @@ class BSRNNCore(nn.Module):
         items, self._deferred = self._deferred, []
         for fn, tag in items:
             fn()
-            self._ready(tag)
+            if tag is not None:
+                self._ready(tag)
 
     # ------------------------------------------------------------------------------------------
     # mask decoder + complex mask apply

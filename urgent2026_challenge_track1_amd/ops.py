@@ -373,6 +373,10 @@ TN_SHADOW_WGS = int(os.environ.get("URSE_TN_SHADOW_WGS", "120"))
 TN_SHADOW_WGS_BAND = int(os.environ.get("URSE_TN_SHADOW_WGS_BAND", "84"))   # ... beside the band path's BPTT (all CUs busy but its tail)
 # batches the join behind the time path's BPTT leaves running (their operands stay alive that much longer)
 TN_JOIN_LAG = int(os.environ.get("URSE_TN_JOIN_LAG", "2"))   # same-box: 176.7 (0), 175.3 (1), 174.4 (2), 174.3 (4) ms/step
+# how many of the deferred launches (3 per half layer: fc, dir 0, dir 1) start beside the band path's BPTT; the rest wait
+# for the time path's, which leaves 120 CUs idle (unset / negative = all)
+TN_BAND_PARTS = int(os.environ.get("URSE_TN_BAND_PARTS", "-1"))
+TN_BAND_PARTS = None if TN_BAND_PARTS < 0 else TN_BAND_PARTS
 TN_OVERLAP_BAND = os.environ.get("URSE_TN_OVERLAP_BAND", "1") != "0"   # also start deferred wgrads beside the band path's BPTT
 # the wide kernel wins once there are enough 64-sequence workgroups to fill the chip in both directions
 WIDE_MIN_SEQ = int(os.environ.get("URSE_LSTM_WIDE_MIN_SEQ", str(64 * 128)))
