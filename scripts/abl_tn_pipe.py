@@ -1,4 +1,4 @@
-"""A/B of the TN ring kernel's k loop: software-pipelined halves (URSE_TN_PIPE=1) against read-all-then-multiply, on
+"""A/B of the TN ring kernel's k loop: URSE_TN_PIPE variants (0 flat, 2 two stages per barrier, 4 = 2 + DMA issue between the MFMA groups), on
 one LSTM direction's dual wgrad at C2; also checks the two builds agree bit for bit on a fixed input."""
 import ctypes, os, subprocess, sys, time
 import torch

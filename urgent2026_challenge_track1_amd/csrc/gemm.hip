@@ -417,7 +417,8 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
 // ring depth of the big TN kernel: 5 stages of 32 KB = the whole 160 KB LDS, four stages in flight (measured
 // 0.92 vs 1.01 ms for the 3136 x 196 wgrad against 4 stages); the NT kernel is faster with 4 (short K: longer prologue)
 #ifndef URSE_TN_PIPE
-#define URSE_TN_PIPE 2   // 0 one stage per barrier, 1 half-step software pipeline, 2 two stages per barrier
+#define URSE_TN_PIPE 2   // 0 one stage per barrier, 2 two stages per barrier (a half-step software pipeline, reads of the next
+                         // half issued under the MFMAs of this one, measured 2.72 vs 2.68 ms and was removed)
                          // (also tried: both stages' fragments read before the first MFMA - 2.53 vs 2.47 ms, dropped)
                          // 4: as 2 with the DMA issue between the MFMA groups - 8 % faster alone (2.23 vs 2.46 ms), but the
                          //    train step is 7 ms SLOWER with it (same-box A/B 189 vs 181 ms): the kernels it shares CUs with
@@ -561,100 +562,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   const int off0 = row0 * 512 + pp * 8, off1 = (row0 + 4) * 512 + pp * 8;
   const int sw0 = tn_swz(row0), sw1 = tn_swz(row0 + 4);     // swizzle keys of the two rows
 
-  if constexpr (URSE_TN_PIPE == 1 && NTW == 7) {   // (NTW = 8 does not fit the extra fragment registers: 13-30 spills)
-  // Software-pipelined k loop.  One k-step = two halves: H1 = the four A fragments x B fragments 0..NH-1, H2 = the
-  // rest.  The reads of H2(kt) are issued before the MFMAs of H1(kt), the reads of H1(kt+1) before the MFMAs of
-  // H2(kt), so every LDS read runs in the shadow of the wave's own MFMAs (before: all eight waves read, then all
-  // multiplied - LDS and MFMA time added up, 2,470 clocks per k-step against 1,024 of MFMA).  One barrier per
-  // k-step, in the middle:
-  //   wait vmcnt -> this wave's DMAs of stage kt+1 have landed; lgkmcnt(0) -> its reads of slot(kt) are done;
-  //   barrier    -> stage kt+1 is visible to all, slot(kt) is free -> stage kt+NST is issued into it.
-  // Stages in flight at the wait: kt+2 .. kt+NST-1 = NST-2 stages of 4 DMAs per wave.
-  constexpr int NH = 4;
-  auto rd_a = [&](const char* As, short8_t (&a)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int S = wm * 4 + i;
-      short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) short4_t*)(As + off0 + ((S ^ sw0) << 5)));
-      short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) short4_t*)(As + off1 + ((S ^ sw1) << 5)));
-      a[i] = short8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-    }
-  };
-  auto rd_b = [&](const char* Bs, int j) -> short8_t {
-    const int S = wn * NTW + j;
-    short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) short4_t*)(Bs + off0 + ((S ^ sw0) << 5)));
-    short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) short4_t*)(Bs + off1 + ((S ^ sw1) << 5)));
-    return short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-  };
-  auto wait_stage = [&]() {
-    if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  };
-#pragma unroll
-  for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
-  wait_stage();                                          // stage 0 (stages 1 .. NST-2 may still fly)
-  __builtin_amdgcn_s_barrier();
-  issue(NST - 1);
-  short8_t aE[4], aO[4], b[NTW];
-  rd_a(lds, aE);
-#pragma unroll
-  for (int j = 0; j < NH; ++j) b[j] = rd_b(lds + 16384, j);
-  int slot = 0;
-  auto kstep = [&](short8_t (&ac)[4], short8_t (&an)[4]) {
-    const char* Bs = lds + slot * STAGE + 16384;
-#pragma unroll
-    for (int j = NH; j < NTW; ++j) b[j] = rd_b(Bs, j);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int j = 0; j < NH; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(ac[i], b[j], acc[i][j]);
-    if constexpr (CSM == 2) if (do_colsum_b) {
-#pragma unroll
-      for (int j = 0; j < NH; ++j) accb[j] = Frag<bf16_t>::mma(ones, b[j], accb[j]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    wait_stage();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(slot);                                         // stage kt + NST into the slot just retired
-    if (++slot == NST) slot = 0;
-    const char* An = lds + slot * STAGE;
-    rd_a(An, an);
-    short8_t bn[NH];
-#pragma unroll
-    for (int j = 0; j < NH; ++j) bn[j] = rd_b(An + 16384, j);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int j = NH; j < NTW; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(ac[i], b[j], acc[i][j]);
-    if constexpr (CSM == 2) if (do_colsum_b) {
-#pragma unroll
-      for (int j = NH; j < NTW; ++j) accb[j] = Frag<bf16_t>::mma(ones, b[j], accb[j]);
-    }
-    if constexpr (CSM == 1) if (do_colsum) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) accs[i] = Frag<bf16_t>::mma(ac[i], ones, accs[i]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int j = 0; j < NH; ++j) b[j] = bn[j];
-  };
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    kstep(aE, aO);
-    kstep(aO, aE);
-  }
-  if (kt < nk) kstep(aE, aO);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  } else if constexpr (URSE_TN_PIPE == 4 && NST == 5) {
+  if constexpr (URSE_TN_PIPE == 4 && NST == 5) {
   // as variant 2, but a stage's DMA issue (address selects, phase update: ~50 VALU instructions per wave) sits BETWEEN
   // the two halves of a stage's MFMAs instead of right behind the barrier, where all eight waves did it at once with the
   // MFMA pipes idle
