@@ -181,6 +181,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-metrics", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL) for real runs; gloo lets two ranks share ONE GPU to exercise the N > 1 path on a 1-GPU box")
     ap.add_argument("--pretouch-gib", type=int, default=160,
                     help="first-touch this much HBM (or all that is free) before the model is built; 0 = off")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
@@ -192,13 +194,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dist_backend != "nccl":
+        local %= max(1, torch.cuda.device_count())       # (debug: several ranks on one device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.pretouch_gib > 0:
         _pretouch(dev, args.pretouch_gib)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from urgent2026_challenge_track1_amd import ops
     from urgent2026_challenge_track1_amd.config import Config
@@ -242,10 +249,17 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     timing = ops.disable_timing()
+    sync_ok = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+        # after the same number of averaged-gradient steps from the same initial weights every rank must hold the same model
+        cs = torch.stack([core.flat_params.double().sum(), core.flat_params.double().abs().sum()])
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        sync_ok = bool(torch.equal(hi, lo))
     kt = {n: (sum(a.elapsed_time(b) for a, b in v) / max(1, len(v)), len(v)) for n, v in timing.items()}
 
     T, Fb, K = L // 480 + 1, 481, 34
@@ -292,6 +306,8 @@ def main():
         "final_loss": float(loss.detach()),
         "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
     }
+    if sync_ok is not None:
+        out["ranks_hold_identical_weights"] = sync_ok
     if rank == 0 and world == 1 and not args.no_metrics:
         out["metrics_bench"] = metrics_bench(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -76,3 +76,21 @@ def test_fit_checkpoint_inference_roundtrip(lib, tmp_path):
     y, fs3 = read_audio(str(tmp_path / "out" / "wav" / "utt1.wav"))
     assert fs3 == fs and y.shape[1] == L and abs(abs(y).max() - 0.9) < 1e-3
     assert (tmp_path / "out" / "inf.scp").read_text().split()[0] == "utt1"
+
+
+def test_two_ranks_on_one_gpu_hold_identical_weights():
+    """the N > 1 path of bench.py (broadcast, bucketed all-reduce driven by the backward's ready tags, deferred wgrads on
+    the second queue) with two gloo ranks sharing cuda:0 and different data per rank: after the steps both hold the same
+    weights bit for bit"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--dist-backend", "gloo", "--pretouch-gib", "0", "--batch", "2", "--seconds", "1", "--channels", "32", "--layers", "2"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["ranks_hold_identical_weights"] is True
+    assert d["config"]["global_batch"] == 4
