@@ -61,6 +61,27 @@ def test_gemm_nt_wide_tile_matches_default(lib, monkeypatch, M, N, K):
         assert torch.equal(a, b)          # same k order per output element -> bit-identical
 
 
+@pytest.mark.parametrize("M,N,K,act", [(8300, 3136, 224, 0), (9001, 1800, 96, 1), (8200, 2000, 160, 0)])
+def test_gemm_nt_weight_stationary_matches_ring_kernel(lib, monkeypatch, M, N, K, act):
+    """short K, wide N, bf16 out: the weight-stationary kernel (resident 224 x K weight slice, 256-row tiles streamed)
+    against the ring kernel - same k order per output element, so bit-identical - and against float64; ragged M and N"""
+    from urgent2026_challenge_track1_amd import ops
+    A, W = _mk((M, K), torch.bfloat16, 1).cuda(), (_mk((N, K), torch.bfloat16, 2) * 0.2).cuda()
+    bias = _mk((N,), torch.float32, 3).cuda()
+    ldc = N + 8
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("URSE_NT_BRES", mode)
+        C = torch.zeros(M, ldc, dtype=torch.bfloat16, device="cuda")
+        ops.gemm_nt(A, W, bias, act=act, out=C[:, :N])
+        outs[mode] = C
+    ref = A.double() @ W.double().T + bias.double()
+    if act:
+        ref = torch.tanh(ref)
+    assert (outs["1"][:, :N].double() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs["0"], outs["1"])              # (also: nothing written past column N)
+
+
 def test_gemm_nt_identity_asymmetric(lib):
     """A = I with an asymmetric B catches a transposed C write or fragment map."""
     from urgent2026_challenge_track1_amd import ops

@@ -1037,6 +1037,131 @@ __global__ void __launch_bounds__(512) gemm_nt_dma_grouped_kernel(const GemmDesc
   gemm_nt_dma_body<TO, 7, ACT, 256, 2>(d);
 }
 
+// B-stationary NT for short K and wide N (the gate projection: K = 224, N = 3136, bf16 out).  In the ring kernel above a
+// 128 x 448 tile re-loads 200 KB of (L2-resident) weights for 57 KB of activations, and a workgroup's LDS-DMA ring
+// sustains only ~30 GB/s: the weight re-loads, not the output, set its 1.36 ms.  Here a workgroup keeps its 224 weight
+// rows x K resident in LDS (98 KB) and walks 256-row tiles of M; only the activations stream, through a 3-stage ring of
+// 16 KB, which is also the epilogue's staging area (64 rows per pass).  Workgroups of different column slices take the
+// same M tiles in the same order, so an activation tile comes from HBM once and from L2 / the Infinity Cache after.
+template <int ACT>
+__global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_per_slice) {
+  constexpr int BMX = 256, NTW = 7, BNX = 224, NST = 3, STAGE = BMX * 64, KSTEPS = 7, BRES = KSTEPS * 14 * 1024;
+  __shared__ __attribute__((aligned(1024))) char lds[BRES + NST * STAGE];
+  char* ring = lds + BRES;
+  const int tm = (int)((d.M + BMX - 1) / BMX);
+  const int tile_n = blockIdx.x / wg_per_slice, part = blockIdx.x - tile_n * wg_per_slice;
+  const long n0 = (long)tile_n * BNX;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+  const int nk = (int)(d.K / 32);
+  const char* zsrc = reinterpret_cast<const char*>(g_tn_zero_page) + lane * 16;
+  const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 3) & 3);
+  const int lc = lane & 15, lr = lane >> 4;
+  const int foff = lc * 64 + ((lr ^ ((lc >> 1) & 3)) << 4);
+  // resident weights: block (kt, b) = the 16 rows 16b .. of k-step kt, same image as a ring stage's B part
+  for (int blk = w; blk < nk * 14; blk += 8) {
+    const int kt = blk / 14, b = blk - kt * 14;
+    const long row = n0 + b * 16 + srow;
+    glds16(row < d.N ? d.B + (row * d.ldb) * 2 + schunk * 16 + (long)kt * 64 : zsrc, lds + blk * 1024);
+  }
+  f32x4_t bv[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const long col = n0 + (wn * NTW + j) * 16 + lr * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = (d.bias && col + r < d.N) ? d.bias[col + r] : 0.f;
+  }
+  bf16_t* C = reinterpret_cast<bf16_t*>(d.C);
+  for (int mt = part; mt < tm; mt += wg_per_slice) {
+    const long m0 = (long)mt * BMX;
+    const char* pa[2];
+    bool aok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long row = m0 + 16 * (2 * w + j) + srow;
+      aok[j] = row < d.M;
+      pa[j] = d.A + (row * d.lda) * 2 + schunk * 16;
+    }
+    auto issue = [&](int kt, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        glds16((kt < nk && aok[j]) ? pa[j] + (long)kt * 64 : zsrc, ring + slot * STAGE + (2 * w + j) * 1024);
+    };
+    issue(0, 0);
+    issue(1, 1);
+    f32x4_t acc[4][NTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // all but this wave's two newest DMAs (stage kt+1) have landed: stage kt and, the first time, the resident weights
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      int nslot = slot + 2;
+      if (nslot >= NST) nslot -= NST;
+      issue(kt + 2, nslot);
+      const char* As = ring + slot * STAGE + wm * 4096 + foff;
+      const char* Bs = lds + kt * (14 * 1024) + wn * NTW * 1024 + foff;
+      short8_t a[4], b[NTW];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const short8_t*>(As + i * 1024);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) b[j] = *reinterpret_cast<const short8_t*>(Bs + j * 1024);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(b[j], a[i], acc[i][j]);   // D[n][m], as in the ring kernel
+      if (++slot == NST) slot = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // epilogue: 64 rows per pass through the (idle) ring, 16-byte non-temporal stores
+    constexpr int CP = BNX * 2 + 16, RPP = 64, CPR = BNX / 8, DROW = 512 / CPR, DCH = 512 - DROW * CPR;
+    static_assert(RPP * CP <= NST * STAGE, "staging does not fit the ring");
+#pragma unroll 1
+    for (int pass = 0; pass < BMX / RPP; ++pass) {
+      if (pass > 0) __syncthreads();
+      if (wm == pass) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          const int lcol = (wn * NTW + j) * 16 + lr * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f32x4_t v = acc[i][j] + bv[j];
+            if (ACT == 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
+            }
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(ring + (i * 16 + lc) * CP + lcol * 2) = pk;
+          }
+        }
+      }
+      __syncthreads();
+      int lrow = tid / CPR, ch = tid - lrow * CPR;
+      for (; lrow < RPP; lrow += DROW) {
+        const long row = m0 + pass * RPP + lrow, col = n0 + ch * 8;
+        if (row < d.M && col < d.N) {
+          const char* src = ring + lrow * CP + ch * 16;
+          if (col + 8 <= d.N) {
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4_t*>(src), reinterpret_cast<f32x4_t*>(C + row * d.ldc + col));
+          } else {
+            const bf16_t* sv = reinterpret_cast<const bf16_t*>(src);
+            for (int e = 0; e < 8 && col + e < d.N; ++e) C[row * d.ldc + col + e] = sv[e];
+          }
+        }
+        ch += DCH;
+        if (ch >= CPR) { ch -= CPR; ++lrow; }
+      }
+    }
+    __syncthreads();                                    // the ring is staging no more: the next tile's DMAs may land
+  }
+}
+
 static int check_desc_host(const GemmDesc& d, int es, const char* who) {
   URSE_CHECK_ARG(d.A && d.B && d.C, "%s: null operand", who);
   URSE_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "%s: empty problem", who);
@@ -1067,6 +1192,7 @@ static int dispatch_nt(const GemmDesc* descs, const GemmDesc& single, int groups
 
 // measured (scripts/abl_nt_wide.py): 128x448 tiles win only on the [M, 8H] gate projection (K=224, bf16 out: 1.32 -> 1.22 ms);
 // at N=800 / K>=512 / f32 out the 256x224 tile stays ahead
+static int g_nt_bres_wgs = 256;      // persistent workgroups of the weight-stationary NT kernel (one per CU)
 static int g_nt_wide_default = 1;
 static long g_nt_wide_maxk = 256;
 
@@ -1081,6 +1207,21 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
   URSE_CHECK_ARG(!resid || act == 2 || out_dtype == URSE_F32, "urse_gemm_nt: residual epilogue writes f32");
   URSE_CHECK_ARG(act != 2 || resid, "urse_gemm_nt: act 2 (tanh backward) needs the aux operand");
   static const bool no_dma = getenv("URSE_NT_NO_DMA") != nullptr;
+  const char* bres_env = getenv("URSE_NT_BRES");
+  const int bres_mode = bres_env ? atoi(bres_env) : 1;
+  if (bres_mode && in_dtype == URSE_BF16 && out_dtype == URSE_BF16 && !no_dma && M >= 8192 && N >= 1792 && K % 32 == 0 &&
+      K >= 96 && K <= 224 && !resid && act != 2 && (ldc * 2) % 16 == 0 && ((uintptr_t)C % 16) == 0) {
+    // weight-stationary tiles: see gemm_nt_bres_kernel
+    const int tn = (int)((N + 223) / 224);
+    int per = g_nt_bres_wgs / tn;
+    if (per < 1) per = 1;
+    dim3 grid((unsigned)(tn * per));
+    hipStream_t st = (hipStream_t)stream;
+    if (act == 0) hipLaunchKernelGGL(gemm_nt_bres_kernel<0>, grid, dim3(512), 0, st, d, per);
+    else hipLaunchKernelGGL(gemm_nt_bres_kernel<1>, grid, dim3(512), 0, st, d, per);
+    URSE_CHECK_LAUNCH("urse_gemm_nt");
+    return URSE_OK;
+  }
   if (in_dtype == URSE_BF16 && !no_dma && M >= 2048 && N >= 160 && K % 32 == 0 && K >= 96) {
     const long pad7 = (N + 223) / 224 * 224, pad8 = (N + 255) / 256 * 256;
     int ntw = pad7 <= pad8 ? 7 : 8;
