@@ -8,7 +8,7 @@ def bench(fn, n=5):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-for name, M, N, K, act in (("ih fwd", 32 * 401 * 34, 3136, 224, 0), ("ragged", 32 * 401 * 34 - 77, 3000, 160, 1), ("small M", 9000, 1800, 96, 0)):
+for name, M, N, K, act in (("ih fwd", 32 * 401 * 34, 3136, 224, 0), ("ragged", 32 * 401 * 34 - 77, 3000, 160, 1), ("small M", 9000, 1800, 96, 0), ("dgrad fc", 32 * 401 * 34, 800, 224, 0), ("N=448", 32 * 401 * 34, 448, 224, 0)):
     a = (torch.randn(M, K, device=dev) * 0.1).to(bf)
     w = (torch.randn(N, K, device=dev) * 0.1).to(bf)
     b = torch.randn(N, device=dev)

@@ -1072,36 +1072,42 @@ __global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_pe
     for (int r = 0; r < 4; ++r) bv[j][r] = (d.bias && col + r < d.N) ? d.bias[col + r] : 0.f;
   }
   bf16_t* C = reinterpret_cast<bf16_t*>(d.C);
-  for (int mt = part; mt < tm; mt += wg_per_slice) {
-    const long m0 = (long)mt * BMX;
-    const char* pa[2];
-    bool aok[2];
+  // stage j of a tile lives in ring slot (j + 2) % 3: slot 2 is the one the epilogue's staging (slots 0-1) leaves alone, so the
+  // NEXT tile's first stage is fetched into it while this tile is being written out
+  auto tile_src = [&](int mt, const char* (&pa)[2], bool (&aok)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const long row = m0 + 16 * (2 * w + j) + srow;
-      aok[j] = row < d.M;
+      const long row = (long)mt * BMX + 16 * (2 * w + j) + srow;
+      aok[j] = mt < tm && row < d.M;
       pa[j] = d.A + (row * d.lda) * 2 + schunk * 16;
     }
-    auto issue = [&](int kt, int slot) __attribute__((always_inline)) {
+  };
+  auto issue = [&](const char* (&pa)[2], bool (&aok)[2], int kt, int slot) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        glds16((kt < nk && aok[j]) ? pa[j] + (long)kt * 64 : zsrc, ring + slot * STAGE + (2 * w + j) * 1024);
-    };
-    issue(0, 0);
-    issue(1, 1);
+    for (int j = 0; j < 2; ++j)
+      glds16((kt < nk && aok[j]) ? pa[j] + (long)kt * 64 : zsrc, ring + slot * STAGE + (2 * w + j) * 1024);
+  };
+  const char* pa[2];
+  bool aok[2];
+  tile_src(part, pa, aok);
+  issue(pa, aok, 0, 2);
+  for (int mt = part; mt < tm; mt += wg_per_slice) {
+    const long m0 = (long)mt * BMX;
+    issue(pa, aok, 1, 0);
     f32x4_t acc[4][NTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    int slot = 0;
+    int slot = 2;                                        // slot of stage kt
     for (int kt = 0; kt < nk; ++kt) {
-      // all but this wave's two newest DMAs (stage kt+1) have landed: stage kt and, the first time, the resident weights
+      // all but this wave's two newest DMAs (stage kt+1) have landed: stage kt, the previous tile's stores and, the first
+      // time, the resident weights
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      int nslot = slot + 2;
+      int nslot = slot + 2;                              // stage kt+2 -> the slot stage kt-1 has left
       if (nslot >= NST) nslot -= NST;
-      issue(kt + 2, nslot);
+      issue(pa, aok, kt + 2, nslot);
       const char* As = ring + slot * STAGE + wm * 4096 + foff;
       const char* Bs = lds + kt * (14 * 1024) + wn * NTW * 1024 + foff;
       short8_t a[4], b[NTW];
@@ -1115,14 +1121,20 @@ __global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_pe
         for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(b[j], a[i], acc[i][j]);   // D[n][m], as in the ring kernel
       if (++slot == NST) slot = 0;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the trailing zero-page stages included)
     __syncthreads();
-    // epilogue: 64 rows per pass through the (idle) ring, 16-byte non-temporal stores
+    tile_src(mt + wg_per_slice, pa, aok);
+    issue(pa, aok, 0, 2);                                // next tile's first stage, in flight under the epilogue
+    // epilogue: 64 rows per pass through slots 0-1 of the (idle) ring, 16-byte non-temporal stores; LDS-only barriers, so
+    // neither the prefetch nor the stores are waited for here
     constexpr int CP = BNX * 2 + 16, RPP = 64, CPR = BNX / 8, DROW = 512 / CPR, DCH = 512 - DROW * CPR;
-    static_assert(RPP * CP <= NST * STAGE, "staging does not fit the ring");
+    static_assert(RPP * CP <= 2 * STAGE, "staging must leave slot 2 alone");
 #pragma unroll 1
     for (int pass = 0; pass < BMX / RPP; ++pass) {
-      if (pass > 0) __syncthreads();
+      if (pass > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       if (wm == pass) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -1141,7 +1153,8 @@ __global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_pe
           }
         }
       }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       int lrow = tid / CPR, ch = tid - lrow * CPR;
       for (; lrow < RPP; lrow += DROW) {
         const long row = m0 + pass * RPP + lrow, col = n0 + ch * 8;
@@ -1158,8 +1171,11 @@ __global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_pe
         if (ch >= CPR) { ch -= CPR; ++lrow; }
       }
     }
-    __syncthreads();                                    // the ring is staging no more: the next tile's DMAs may land
+    // slots 0-1 are staging no more once every wave has read its share: the next tile's second stage may land
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the last (zero-page) prefetch must not outlive the workgroup
 }
 
 static int check_desc_host(const GemmDesc& d, int es, const char* who) {
@@ -1192,6 +1208,7 @@ static int dispatch_nt(const GemmDesc* descs, const GemmDesc& single, int groups
 
 // measured (scripts/abl_nt_wide.py): 128x448 tiles win only on the [M, 8H] gate projection (K=224, bf16 out: 1.32 -> 1.22 ms);
 // at N=800 / K>=512 / f32 out the 256x224 tile stays ahead
+static long g_nt_bres_min_n = getenv("URSE_NT_BRES_MIN_N") ? atol(getenv("URSE_NT_BRES_MIN_N")) : 1792;   // (448 also takes the fc dgrad: 0.37 -> 0.28 ms alone, but 170.6 vs 169.7 ms/step)
 static int g_nt_bres_wgs = 256;      // persistent workgroups of the weight-stationary NT kernel (one per CU)
 static int g_nt_wide_default = 1;
 static long g_nt_wide_maxk = 256;
@@ -1209,7 +1226,7 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
   static const bool no_dma = getenv("URSE_NT_NO_DMA") != nullptr;
   const char* bres_env = getenv("URSE_NT_BRES");
   const int bres_mode = bres_env ? atoi(bres_env) : 1;
-  if (bres_mode && in_dtype == URSE_BF16 && out_dtype == URSE_BF16 && !no_dma && M >= 8192 && N >= 1792 && K % 32 == 0 &&
+  if (bres_mode && in_dtype == URSE_BF16 && out_dtype == URSE_BF16 && !no_dma && M >= 8192 && N >= g_nt_bres_min_n && K % 32 == 0 &&
       K >= 96 && K <= 224 && !resid && act != 2 && (ldc * 2) % 16 == 0 && ((uintptr_t)C % 16) == 0) {
     // weight-stationary tiles: see gemm_nt_bres_kernel
     const int tn = (int)((N + 223) / 224);
