@@ -60,37 +60,57 @@ __device__ __forceinline__ void gn_mean_rstd(const double* stats, long g, double
   *rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// Index walk shared by the two apply kernels: block <-> (chunk of (t, v) pairs, kg, b), so the group's statistics are uniform
+// per block (one f64 evaluation per thread, not per element) and a thread steps through its N-vectors with adds only.
+// (Before: a flat index split by four 64-bit divisions, and the f64 mean / rstd re-derived, per element.)
+constexpr int GN_ITER = 16;
+struct GnWalk {
+  int t, v, dt, dv, wn, left;
+  __device__ __forceinline__ void init(int tv0, int vpb, int wn_, int ntv) {
+    wn = wn_;
+    t = tv0 / wn; v = tv0 - t * wn;
+    dt = vpb / wn; dv = vpb - dt * wn;
+    left = tv0 < ntv ? (ntv - tv0 + vpb - 1) / vpb : 0;
+    if (left > GN_ITER) left = GN_ITER;
+  }
+  __device__ __forceinline__ void next() {
+    t += dt; v += dv;
+    if (v >= wn) { v -= wn; ++t; }
+  }
+};
+
 // one thread per 4 channels of one N-vector; output rows are [B*T*Kg*(W/N)][Np]
 template <typename TO>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ add, TO* __restrict__ y, GnShape s,
                                                        float eps) {
-  const int n4 = s.Np >> 2;
-  const long total = (long)s.B * s.T * s.Kg * (s.W / s.N) * n4;
-  const double cnt = (double)s.T * s.W;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const long vec = idx / n4;
-    const int c = (int)(idx - vec * n4) * 4;
-    // vec indexes [B][T][Kg][W/N]
-    const int per_row = s.Kg * (s.W / s.N);
-    const long bt = vec / per_row;
-    const int rem = (int)(vec - bt * per_row);
-    const int kg = rem / (s.W / s.N);
-    const int b = (int)(bt / s.T);
+  const int n4 = s.Np >> 2, vpb = 256 / n4, wn = s.W / s.N;
+  const int b = blockIdx.z, kg = blockIdx.y;
+  const int slot = threadIdx.x / n4, c = (threadIdx.x - slot * n4) * 4;
+  if (slot >= vpb) return;
+  float mean, rstd;
+  gn_mean_rstd(stats, (long)b * s.Kg + kg, (double)s.T * s.W, eps, &mean, &rstd);
+  float g[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < s.N) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g[j] = gamma[(long)kg * s.gstride + c + j];
+      be[j] = beta[(long)kg * s.gstride + c + j];
+      ad[j] = add ? add[(long)b * s.N + c + j] : 0.f;   // per-(utterance, channel) additive term (flow time embedding)
+    }
+  }
+  GnWalk wk;
+  wk.init(blockIdx.x * (vpb * GN_ITER) + slot, vpb, wn, s.T * wn);
+  for (int i = 0; i < wk.left; ++i, wk.next()) {
+    const long vec = (((long)b * s.T + wk.t) * s.Kg + kg) * wn + wk.v;
     TO o[4];
     if (c < s.N) {
-      float mean, rstd;
-      gn_mean_rstd(stats, (long)b * s.Kg + kg, cnt, eps, &mean, &rstd);
       const float4 v = *reinterpret_cast<const float4*>(x + vec * s.N + c);
-      const float* g = gamma + (long)kg * s.gstride + c;
-      const float* be = beta + (long)kg * s.gstride + c;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // per-(utterance, channel) additive term (flow time embedding)
-      if (add) { const float* ap = add + (long)b * s.N + c; a0 = ap[0]; a1 = ap[1]; a2 = ap[2]; a3 = ap[3]; }
-      o[0] = from_f32<TO>((v.x - mean) * rstd * g[0] + be[0] + a0);
-      o[1] = from_f32<TO>((v.y - mean) * rstd * g[1] + be[1] + a1);
-      o[2] = from_f32<TO>((v.z - mean) * rstd * g[2] + be[2] + a2);
-      o[3] = from_f32<TO>((v.w - mean) * rstd * g[3] + be[3] + a3);
+      o[0] = from_f32<TO>((v.x - mean) * rstd * g[0] + be[0] + ad[0]);      // (same arithmetic as ever: results unchanged)
+      o[1] = from_f32<TO>((v.y - mean) * rstd * g[1] + be[1] + ad[1]);
+      o[2] = from_f32<TO>((v.z - mean) * rstd * g[2] + be[2] + ad[2]);
+      o[3] = from_f32<TO>((v.w - mean) * rstd * g[3] + be[3] + ad[3]);
     } else {
       o[0] = o[1] = o[2] = o[3] = from_f32<TO>(0.f);
     }
@@ -155,25 +175,25 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ dres, float* __restrict__ dx,
                                                            GnShape s, float eps, bf16_t* __restrict__ dxp, int ldp) {
-  const int n4 = s.N >> 2;
-  const long total = (long)s.B * s.T * s.Kg * (s.W / s.N) * n4;
+  const int n4 = s.N >> 2, vpb = 256 / n4, wn = s.W / s.N;
+  const int b = blockIdx.z, kg = blockIdx.y;
+  const int slot = threadIdx.x / n4, c = (threadIdx.x - slot * n4) * 4;
+  if (slot >= vpb) return;
+  const long g = (long)b * s.Kg + kg;
   const double cnt = (double)s.T * s.W;
-  const int per_row = s.Kg * (s.W / s.N);
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const long vec = idx / n4;
-    const int c = (int)(idx - vec * n4) * 4;
-    const long bt = vec / per_row;
-    const int rem = (int)(vec - bt * per_row);
-    const int kg = rem / (s.W / s.N);
-    const int b = (int)(bt / s.T);
-    const long g = (long)b * s.Kg + kg;
-    float mean, rstd;
-    gn_mean_rstd(stats, g, cnt, eps, &mean, &rstd);
-    const float m1 = (float)(sums[g * 2] / cnt), m2 = (float)(sums[g * 2 + 1] / cnt);
+  float mean, rstd;
+  gn_mean_rstd(stats, g, cnt, eps, &mean, &rstd);
+  const float m1 = (float)(sums[g * 2] / cnt), m2 = (float)(sums[g * 2 + 1] / cnt);
+  float ga[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ga[j] = gamma[(long)kg * s.gstride + c + j];
+  GnWalk wk;
+  wk.init(blockIdx.x * (vpb * GN_ITER) + slot, vpb, wn, s.T * wn);
+  for (int i = 0; i < wk.left; ++i, wk.next()) {
+    const long vec = (((long)b * s.T + wk.t) * s.Kg + kg) * wn + wk.v;
     const long off = vec * s.N + c;
     const float4 xv = *reinterpret_cast<const float4*>(x + off);
     const float4 dv = *reinterpret_cast<const float4*>(dy + off);
-    const float* ga = gamma + (long)kg * s.gstride + c;
     float4 o;
     o.x = rstd * (ga[0] * dv.x - m1 - (xv.x - mean) * rstd * m2);
     o.y = rstd * (ga[1] * dv.y - m1 - (xv.y - mean) * rstd * m2);
@@ -244,13 +264,13 @@ extern "C" int urse_groupnorm_fwd(const float* x, const float* gamma, const floa
   const int rpb = ceil_div(T, nblk);
   dim3 grid(ceil_div(T, rpb), Kg, B);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, stats, s, rpb);
-  const long total = (long)B * T * Kg * (W / N) * (Np / 4);
+  URSE_CHECK_ARG(Np / 4 <= 256, "urse_groupnorm_fwd: Np %d too wide", Np);
+  const int vpb_f = 256 / (Np / 4);
+  dim3 grid_a(ceil_div((long)T * (W / N), (long)vpb_f * GN_ITER), Kg, B);
   if (out_dtype == URSE_BF16)
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, add,
-                       (bf16_t*)y, s, eps);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (bf16_t*)y, s, eps);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, add,
-                       (float*)y, s, eps);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (float*)y, s, eps);
   URSE_CHECK_LAUNCH("urse_groupnorm_fwd");
   return URSE_OK;
 }
@@ -273,9 +293,11 @@ extern "C" int urse_groupnorm_bwd(const float* x, const float* dy, const double*
   dim3 grid(ceil_div(T, rpb), Kg, B);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, st, x, dy, stats, gamma, sums, dgamma, dbeta, s, eps,
                      rpb);
-  const long total = (long)B * T * Kg * (W / N) * (N / 4);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, dy, stats, sums, gamma, dres,
-                     dx, s, eps, (bf16_t*)dx_packed, ldp);
+  URSE_CHECK_ARG(N / 4 <= 256, "urse_groupnorm_bwd: N %d too wide", N);
+  const int vpb_b = 256 / (N / 4);
+  dim3 grid_a(ceil_div((long)T * (W / N), (long)vpb_b * GN_ITER), Kg, B);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid_a, dim3(256), 0, st, x, dy, stats, sums, gamma, dres, dx, s, eps,
+                     (bf16_t*)dx_packed, ldp);
   URSE_CHECK_LAUNCH("urse_groupnorm_bwd");
   return URSE_OK;
 }
