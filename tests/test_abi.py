@@ -26,6 +26,20 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     assert rc == -1
 
 
+def test_grouped_gemm_validates_the_host_mirror_before_launching(lib):
+    """urse_gemm_nt_grouped_h reads the host copy of the per-band records: a bad one is an error code, not a launch"""
+    import numpy as np
+    good = [4096, 8192, 12288, 0, 0, 64, 64, 64, 16, 32, 64, 0]       # {A, B, C, bias, resid, lda, ldb, ldc, M, N, K, ldr}
+    bad_k = list(good); bad_k[10] = 40; bad_k[5] = bad_k[6] = 40       # K not a multiple of 32 (bf16)
+    bad_ld = list(good); bad_ld[7] = 16                                 # ldc < N
+    for rec in (bad_k, bad_ld):
+        host = np.asarray([good, rec], dtype=np.int64)
+        rc = lib.urse_gemm_nt_grouped_h(ctypes.c_void_p(4096), ctypes.c_void_p(host.ctypes.data), 2, 1, 1, 0, None)
+        assert rc == -1 and b"urse_gemm_nt_grouped_h" in lib.urse_last_error()
+    rc = lib.urse_gemm_nt_grouped_h(None, None, 2, 1, 1, 0, None)
+    assert rc == -1
+
+
 def test_product_path_has_no_cpu_fallback(lib):
     import torch
     from urgent2026_challenge_track1_amd import ops
