@@ -40,6 +40,38 @@ extern "C" {
 int urse_version(void);
 const char* urse_last_error(void);
 
+/* Dispatch bookkeeping (host side, no device work): every dispatcher that chooses between kernel variants counts
+ * the variant it launched.  The parity tests of the benchmarked configuration read the counters to prove that the
+ * kernels they compared with the oracle are the ones bench.py times.  urse_launch_count: launches of `variant`
+ * since the last reset (-1 for an unknown id). */
+#define URSE_KV_NT_BRES 0          /* gemm_nt_bres_kernel: weight-stationary gate projection */
+#define URSE_KV_NT_RING 1          /* gemm_nt_dma_kernel<.., 256, 2>: LDS-DMA ring, 256-row tiles */
+#define URSE_KV_NT_RING_WIDE 2     /* gemm_nt_dma_kernel<.., 128, 4>: 128 x 448 tiles */
+#define URSE_KV_NT_128 3           /* gemm_nt_kernel: 128 x 128 register-staged tiles */
+#define URSE_KV_NT_GROUPED_RING 4  /* gemm_nt_dma_grouped_kernel */
+#define URSE_KV_NT_GROUPED_128 5
+#define URSE_KV_TN_RING 6          /* gemm_tn_dma_kernel, single operand */
+#define URSE_KV_TN_RING_T 7        /* gemm_tn_dma_kernel on the transposed problem (fc weight gradient) */
+#define URSE_KV_TN_DUAL 8          /* gemm_tn_dma_kernel, dual operand (dW_ih + dW_hh in one pass) */
+#define URSE_KV_TN_128 9           /* gemm_tn_kernel */
+#define URSE_KV_TN_GROUPED 10
+#define URSE_KV_LSTM_FWD_STREAM 11 /* lstm_fwd_kernel */
+#define URSE_KV_LSTM_FWD_WIDE 12   /* lstm_fwd_wide_kernel */
+#define URSE_KV_LSTM_FWD_CLUSTER 13
+#define URSE_KV_LSTM_FWD_CLUSTER2 14
+#define URSE_KV_LSTM_BWD_STREAM16 15 /* lstm_bwd_kernel, 16 sequences per workgroup */
+#define URSE_KV_LSTM_BWD_STREAM32 16 /* lstm_bwd_kernel, 32 sequences per workgroup of 8 waves */
+#define URSE_KV_LSTM_BWD_CLUSTER 17
+#define URSE_KV_LSTM_BWD_SPLIT 18
+#define URSE_KV_STFT960 19         /* register-FFT forward STFT of the 960-point front end */
+#define URSE_KV_STFT_GENERIC 20
+#define URSE_KV_ISTFT_GENERIC 21
+#define URSE_KV_ISTFT960 22
+#define URSE_KV_LSTM_BWD_WS 23     /* weight-stationary cluster BPTT (lstm_bwd_ws.hip) */
+#define URSE_KV_COUNT 32
+int urse_launch_count(int variant);
+int urse_launch_counts_reset(void);
+
 /* ---- framed STFT / iSTFT ------------------------------------------------------------------
  * espnet2 Stft.forward / Stft.inverse as called from baseline_code/models/bsrnn.py:37,40 and
  * baseline_code/flow_model.py:136,145 (torch.stft / torch.istft: center, reflect pad, periodic
@@ -243,6 +275,10 @@ int urse_joint_peak_scale(float* speech, float* noisy, float* noise, int B, int6
                           void* stream);
 /* y = a*x + b*y (f32). */
 int urse_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream);
+/* y = torch.nan_to_num(x, nan=0) (baseline_code/flow_model.py:156-157): NaN -> 0, +-inf -> +-FLT_MAX; y may alias x. */
+int urse_nan_to_num(const float* x, float* y, int64_t n, void* stream);
+/* x *= s[0] with the scalar read from device memory (an upstream autograd scale applied without a host sync). */
+int urse_scale_by_device_scalar(float* x, const float* s, int64_t n, void* stream);
 
 /* ---- losses and optimizer ---------------------------------------------------------------------------
  * espnet2 MultiResL1SpecLoss(window_sz, eps, normalize_variance=True, time_domain_weight) and SISNRLoss
@@ -258,6 +294,11 @@ int urse_mrl1_loss_fwd(const float* target, const float* estimate, float* loss, 
 int urse_mrl1_loss_bwd(const float* target, const float* estimate, const float* G, const double* sums,
                        const float* grad_loss, float* grad_estimate, double* c1, int B, int L, float eps,
                        void* stream);
+/* The same with the reference's NaN-loss guard (baseline_code/d_model.py:75-77: a NaN batch loss is replaced by
+ * `se_speech.mean() * 0`, i.e. the step runs on zero gradients): when any loss[b] is NaN the whole gradient is zero. */
+int urse_mrl1_loss_bwd_guarded(const float* target, const float* estimate, const float* G, const double* sums,
+                               const float* grad_loss, const float* loss, float* grad_estimate, double* c1, int B,
+                               int L, float eps, void* stream);
 /* loss f32 [B] = 10 log10((1-coh)/coh) (= -SI-SDR in dB), zero-mean. */
 int urse_sisnr_fwd(const float* ref, const float* inf, float* loss, double* sums, int B, int L, void* stream);
 /* out f64 [1] = sum g^2. */
@@ -268,6 +309,19 @@ int urse_grad_sumsq(const float* g, double* out, int64_t n, void* stream);
 int urse_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                          const double* normsq, float max_norm, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+/* The same step with torch.optim.AdamW's treatment of parameters WITHOUT a gradient (bands above fs/2 get .grad None
+ * in the reference, baseline_code/train_se.py:82 find_unused_parameters: no decay, no moment update, no step count).
+ * slot u8 [n]: parameter slot of every element (0 = always used).  used f32 [n_slot]: > 0 when the slot received a
+ * gradient on some rank this step (it lives behind the flat gradients so the all-reduce sums it; zeroed with them).
+ * steps int32 [n_slot]: per-slot AdamW step counts, advanced by the call for the slots it updates.  bias_corr f32
+ * [n_slot, 2]: scratch.  skip_flag (uint32, may be NULL): non-zero skips the whole update (a cooperative LSTM kernel
+ * reported a timed-out hand-off: the gradients are garbage); a non-finite norm does the same. */
+int urse_clip_adamw_step_slots(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               const double* normsq, float max_norm, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, const uint8_t* slot, float* used, int32_t* steps, float* bias_corr,
+                               int n_slot, const uint32_t* skip_flag, float grad_scale, int zero_grad, void* stream);
+/* used[i] = i < n_used ? 1 : 0 for i < n_slot: the training forward marks slot 0 and the bands its spectrum holds. */
+int urse_fill_used_flags(float* used, int n_slot, int n_used, void* stream);
 
 /* ---- batched intrusive metrics ----------------------------------------------------------------------
  * evaluation_metrics/calculate_intrusive_se_metrics.py: estoi_metric (:37-48) -> pystoi.stoi(extended=True),

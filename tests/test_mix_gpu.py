@@ -132,3 +132,46 @@ def test_simulate_batch_matches_oracle_chain(lib):
         clean, noisy, noise = mix_ref.joint_peak_normalise(clean, noisy, noise)
         for got, ref in ((s, clean), (n, noisy), (z, noise)):
             assert np.abs(got[b, :lens[b]].cpu().numpy() - ref[0]).max() <= 2e-5, b
+
+
+def test_simulate_recipes_matches_the_reference_simulator(lib):
+    """``mixing.simulate_recipes`` (what DynamicMixingDataset batches go through on the device) against samples the
+    reference's own ``process_one_sample(on_the_fly=True)`` produced (tests/golden/ref_mix.npz): the four recipes as ONE
+    batch - none, RIR, clipping, RIR + packet loss then clipping."""
+    import ast
+    import os
+    from urgent2026_challenge_track1_amd import mixing
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_mix.npz"))
+    fs, sp, nz, rir = int(g["fs"]), g["sp"], g["nz_equal"], g["rir"]
+    L, R = sp.shape[1], rir.shape[1]
+    recipes, rir_lens = [], []
+    for i in range(4):
+        rir_uid, aug = g["sample%d_recipe" % i].tolist()
+        params, order = {}, []
+        for a in aug.split("/"):
+            if a.startswith("clipping"):
+                lo, hi = a[len("clipping(min="):-1].split(",max=")
+                params["clipping"] = dict(min_quantile=float(lo), max_quantile=float(hi))
+                order.append("clipping")
+            elif a.startswith("packet_loss"):
+                params["packet_loss"] = dict(packet_loss_indices=ast.literal_eval(a[a.index("=[") + 1:a.index("]") + 1]),
+                                             packet_duration_ms=20)
+                order.append("packet_loss")
+        recipes.append(dict(snr=float(g["sample%d_snr" % i]), params=params, order=order, noise_offset=0, highpass=True))
+        rir_lens.append(R if rir_uid != "none" else 0)
+    B = 4
+    t = lambda a: torch.tensor(np.repeat(a.astype(np.float32), B, axis=0)).cuda()
+    rir_b = t(rir)
+    for b in range(B):
+        if rir_lens[b] == 0:
+            rir_b[b] = 0
+    stops = [mixing.early_rir_stop(rir, fs)] * B
+    skipped = {}
+    speech, noisy = mixing.simulate_recipes(t(sp), [L] * B, t(nz), [L] * B, rir_b, rir_lens, stops, fs, recipes, skipped)
+    assert skipped == {}
+    for i in range(4):
+        rs, rn = g["sample%d_speech" % i][0], g["sample%d_noisy" % i][0]
+        es = np.abs(speech[i].cpu().numpy() - rs).max()
+        en = np.abs(noisy[i].cpu().numpy() - rn).max()
+        # inputs are rounded to f32 on the way in (the reference computes in f64 from f64 files); 0.9-peak signals
+        assert es <= 2e-5 and en <= 2e-5, (i, es, en)

@@ -159,6 +159,7 @@ class BSRNNCore(nn.Module):
         return order
 
     back_tag = "md"
+    band_groups = ("bs", "mdm", "mdr")      # parameter groups that hold one tensor per band
 
     # ------------------------------------------------------------------------------------------
     # flat parameter / gradient buffers
@@ -195,8 +196,23 @@ class BSRNNCore(nn.Module):
                 plist.append((p, total))
                 total += p.numel()
         assert len(plist) == len([q for q in self.parameters() if q.requires_grad])
+        # slot map of the optimizer: 0 = parameters every batch uses, 1 + k = parameters of band k (without a gradient
+        # when fs puts fewer than k + 1 bands in the spectrum: torch.optim.AdamW skips those, and so does ours)
+        nb = len(self.subbands)
+        slot = np.zeros(total, dtype=np.uint8)
+        for name, ps in order:
+            if len(ps) == nb and name.split(".")[0] in self.band_groups:
+                o = offs[name]
+                for k, q in enumerate(ps):
+                    slot[o:o + q.numel()] = 1 + k
+                    o += q.numel()
+        self.n_slot = 1 + nb
+        self._slot_map = torch.from_numpy(slot).to(first.device)
         flat = torch.zeros(total, dtype=torch.float32, device=first.device)
-        grad = torch.zeros(total, dtype=torch.float32, device=first.device)
+        # the gradients are followed by one "used" flag per slot: part of the last all-reduce bucket, so that a band
+        # counts as used when ANY rank used it (what DDP's find_unused_parameters does), zeroed with the gradients
+        self._n_params = total
+        grad = torch.zeros(total + (self.n_slot + 3) // 4 * 4, dtype=torch.float32, device=first.device)
         with torch.no_grad():
             for p, o in plist:
                 flat[o:o + p.numel()].copy_(p.data.reshape(-1).float())
@@ -215,14 +231,29 @@ class BSRNNCore(nn.Module):
 
     @property
     def flat_grads(self):
+        """gradients of every parameter, then the per-slot "used" flags (see _ensure_flat)."""
         self._ensure_flat()
         return self._flat_grad
+
+    @property
+    def used_flags(self):
+        self._ensure_flat()
+        return self._flat_grad[self._n_params:self._n_params + self.n_slot]
+
+    @property
+    def slot_map(self):
+        self._ensure_flat()
+        return self._slot_map
+
+    def mark_used_bands(self, K):
+        """training forward at K bands: slots 0..K get a gradient this step, the bands above do not."""
+        call("fill_used_flags", self.used_flags, self.n_slot, 1 + K, stream_ptr())
 
     def grad_groups(self):
         """[(tag, offset, numel)] in the order backward completes them (for bucketed all-reduce)."""
         self._ensure_flat()
         names = list(self._off.keys())
-        ends = [self._off[n] for n in names[1:]] + [self._flat.numel()]
+        ends = [self._off[n] for n in names[1:]] + [self._flat_grad.numel()]     # (the last group carries the used flags)
         spans = {n: (self._off[n], e - self._off[n]) for n, e in zip(names, ends)}
         groups = []
 
@@ -437,7 +468,7 @@ class BSRNNCore(nn.Module):
                 ops.lstm_cluster2_plan(H, d["Hp"], sm["n_seq"]) is not None:
             hout, c, err = ops.lstm_fwd_cluster2(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
             self._cluster_err = err
-        elif ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and \
+        elif ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and \
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
             hout, c, err = ops.lstm_fwd_cluster(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
             self._cluster_err = err
@@ -478,7 +509,7 @@ class BSRNNCore(nn.Module):
                 ops.lstm_split_plan(H, sm["n_seq"]) is not None:
             dg, self._cluster_err = ops.lstm_bwd_split(dh, gates, c, pk[p + "whhT"], H, **sm)
         else:
-            dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, **sm)   # dgates, gate-interleaved columns
+            dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, rows16=ops.BWD_ROWS16.get(path, 0), **sm)   # dgates, gate-interleaved columns
         if overlap and path == "t":
             self._join_deferred_wgrads(keep=ops.TN_JOIN_LAG)
         st, L = sm["stride"], sm["seq_len"]
@@ -663,6 +694,12 @@ class BSRNNCore(nn.Module):
         """spec_ri f32 [B, T, F, 2] -> masked spectrum f32 [B, T, F, 2] (num_spk = 1 squeezed)."""
         ops.require_cuda(spec_ri)
         self._prepare()
+        if self._inflight is not None or self._deferred:
+            # an aborted backward left weight-gradient GEMMs on the side stream: they still read doT / hout / dg, which
+            # the closures below keep alive - wait for them before dropping the closures (the allocator would hand the
+            # buffers to this forward on the compute stream otherwise)
+            if self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
         self._deferred, self._inflight, self._grad_pack = [], None, None     # nothing survives an aborted backward
         spec_ri = spec_ri.contiguous().float()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
@@ -676,6 +713,7 @@ class BSRNNCore(nn.Module):
             return out
         ops.poll_kernel_errors(spec_ri.device)                     # training: deferred check of the previous steps
         anchor = self._flat.new_zeros((), requires_grad=True)
+        self.mark_used_bands(self._band_tables(spec_ri.shape[2], self.compute_dtype, spec_ri.device)["K"])
         z = _BandSplitFn.apply(anchor, spec_ri, self)
         for l in range(self.num_layer):
             z = _DualPathFn.apply(z, self, l, "t")

@@ -1,6 +1,8 @@
 // Error plumbing and version entry of the C ABI (include/urse.h).
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "urse_common.h"
 
 namespace urse {
@@ -22,7 +24,20 @@ int device_cu_count() {
   }
   return cached;
 }
+static std::atomic<int> g_launches[URSE_KV_COUNT];
+void note_launch(int variant) {
+  if (variant >= 0 && variant < URSE_KV_COUNT) g_launches[variant].fetch_add(1, std::memory_order_relaxed);
+}
 }  // namespace urse
+
+extern "C" int urse_launch_count(int variant) {
+  if (variant < 0 || variant >= URSE_KV_COUNT) return -1;
+  return urse::g_launches[variant].load(std::memory_order_relaxed);
+}
+extern "C" int urse_launch_counts_reset(void) {
+  for (int i = 0; i < URSE_KV_COUNT; ++i) urse::g_launches[i].store(0, std::memory_order_relaxed);
+  return URSE_OK;
+}
 
 extern "C" int urse_version(void) { return 1; }
 extern "C" const char* urse_last_error(void) { return urse::g_err; }

@@ -240,6 +240,34 @@ extern "C" int urse_axpby(const float* x, float* y, float a, float b, int64_t n,
   return URSE_OK;
 }
 
+// ---- torch.nan_to_num(x, nan=0): NaN -> 0, +-inf -> +-FLT_MAX  (flow_model.py:156-157), and x <- x * s[0] (device scalar)
+namespace urse {
+__global__ void __launch_bounds__(256) nan_to_num_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (isnan(v)) v = 0.f;
+    else if (isinf(v)) v = v > 0.f ? 3.402823466e+38f : -3.402823466e+38f;
+    y[i] = v;
+  }
+}
+__global__ void __launch_bounds__(256) scale_by_kernel(float* __restrict__ x, const float* __restrict__ s, long n) {
+  const float a = *s;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= a;
+}
+}  // namespace urse
+extern "C" int urse_nan_to_num(const float* x, float* y, int64_t n, void* stream) {
+  URSE_CHECK_ARG(x && y && n > 0, "urse_nan_to_num: bad argument");
+  hipLaunchKernelGGL(nan_to_num_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n);
+  URSE_CHECK_LAUNCH("urse_nan_to_num");
+  return URSE_OK;
+}
+extern "C" int urse_scale_by_device_scalar(float* x, const float* s, int64_t n, void* stream) {
+  URSE_CHECK_ARG(x && s && n > 0, "urse_scale_by_device_scalar: bad argument");
+  hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, s, (long)n);
+  URSE_CHECK_LAUNCH("urse_scale_by_device_scalar");
+  return URSE_OK;
+}
+
 // ---- peak normalisation: x <- x / max|x| * peak   (inference.py:60) -------------------------------------
 namespace urse {
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, unsigned* __restrict__ out, long n) {

@@ -1234,6 +1234,7 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
     if (per < 1) per = 1;
     dim3 grid((unsigned)(tn * per));
     hipStream_t st = (hipStream_t)stream;
+    note_launch(URSE_KV_NT_BRES);
     if (act == 0) hipLaunchKernelGGL(gemm_nt_bres_kernel<0>, grid, dim3(512), 0, st, d, per);
     else hipLaunchKernelGGL(gemm_nt_bres_kernel<1>, grid, dim3(512), 0, st, d, per);
     URSE_CHECK_LAUNCH("urse_gemm_nt");
@@ -1259,6 +1260,7 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
 #define URSE_NT_DMA_B(TO_, NTW_, ACT_) do { if (wide) URSE_NT_DMA_W(TO_, ACT_); else if (bmx == 128) URSE_NT_DMA(TO_, NTW_, ACT_, 128); else URSE_NT_DMA(TO_, NTW_, ACT_, 256); } while (0)
 #define URSE_NT_DMA_ACT(TO_, NTW_) \
   do { if (act == 0) URSE_NT_DMA_B(TO_, NTW_, 0); else if (act == 1) URSE_NT_DMA_B(TO_, NTW_, 1); else URSE_NT_DMA_B(TO_, NTW_, 2); } while (0)
+    note_launch(wide ? URSE_KV_NT_RING_WIDE : URSE_KV_NT_RING);
     if (out_dtype == URSE_BF16) {
       if (ntw == 7) URSE_NT_DMA_ACT(bf16_t, 7); else URSE_NT_DMA_ACT(bf16_t, 8);
     } else {
@@ -1269,6 +1271,7 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
   }
   const long blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   URSE_CHECK_ARG(blocks < (1L << 31), "urse_gemm_nt: too many tiles");
+  note_launch(URSE_KV_NT_128);
   return dispatch_nt(nullptr, d, 1, (int)blocks, in_dtype, out_dtype, act, (hipStream_t)stream);
 }
 
@@ -1277,6 +1280,7 @@ extern "C" int urse_gemm_nt_grouped(const void* descs, int groups, int max_block
   URSE_CHECK_ARG(descs && groups > 0 && max_blocks > 0, "urse_gemm_nt_grouped: bad argument");
   GemmDesc dummy;
   memset(&dummy, 0, sizeof(dummy));
+  note_launch(URSE_KV_NT_GROUPED_128);
   return dispatch_nt((const GemmDesc*)descs, dummy, groups, max_blocks, in_dtype, out_dtype, act,
                      (hipStream_t)stream);
 }
@@ -1290,10 +1294,12 @@ extern "C" int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_des
   const int es = in_dtype == URSE_BF16 ? 2 : 4;
   bool dma = in_dtype == URSE_BF16 && !getenv("URSE_NT_NO_DMA") && !getenv("URSE_NT_GROUPED_NO_DMA");
   long t128 = 0, tdma = 0;
+  const char* mm = getenv("URSE_NT_GROUPED_MIN_M");      // (tests lower it to run the ring kernel on small batches)
+  const long min_m = mm ? atol(mm) : 1024;
   for (int g = 0; g < groups; ++g) {
     const GemmDesc& d = hd[g];
     if (int rc = check_desc_host(d, es, "urse_gemm_nt_grouped_h")) return rc;
-    dma = dma && d.K % 32 == 0 && d.N >= 160 && d.M >= 1024;
+    dma = dma && d.K % 32 == 0 && d.N >= 160 && d.M >= min_m;
     t128 = std::max(t128, ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN));
     tdma = std::max(tdma, ((d.M + 255) / 256) * ((d.N + 223) / 224));
   }
@@ -1301,6 +1307,7 @@ extern "C" int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_des
   if (!dma) {
     GemmDesc dummy;
     memset(&dummy, 0, sizeof(dummy));
+    note_launch(URSE_KV_NT_GROUPED_128);
     return dispatch_nt((const GemmDesc*)descs, dummy, groups, (int)t128, in_dtype, out_dtype, act, (hipStream_t)stream);
   }
   dim3 grid((unsigned)tdma, (unsigned)groups);
@@ -1308,6 +1315,7 @@ extern "C" int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_des
   const GemmDesc* dd = (const GemmDesc*)descs;
 #define URSE_NT_G(TO_, ACT_) hipLaunchKernelGGL((gemm_nt_dma_grouped_kernel<TO_, ACT_>), grid, dim3(512), 0, st, dd)
 #define URSE_NT_G_ACT(TO_) do { if (act == 0) URSE_NT_G(TO_, 0); else if (act == 1) URSE_NT_G(TO_, 1); else URSE_NT_G(TO_, 2); } while (0)
+  note_launch(URSE_KV_NT_GROUPED_RING);
   if (out_dtype == URSE_BF16) URSE_NT_G_ACT(bf16_t);
   else if (out_dtype == URSE_F32) URSE_NT_G_ACT(float);
   else { set_error("urse_gemm_nt_grouped_h: bad output dtype %d", out_dtype); return URSE_ERR_INVALID_ARG; }
@@ -1357,6 +1365,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     slices = (R + rps - 1) / rps;
     q.rows_per_slice = rps;
     dim3 grid((unsigned)(tl * slices));
+    note_launch(URSE_KV_TN_RING_T);
     launch_tn_dma(ntw, colsum ? 2 : 0, grid, (hipStream_t)stream, q);
     URSE_CHECK_LAUNCH("urse_gemm_tn");
     return URSE_OK;
@@ -1374,6 +1383,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     slices = (R + rps - 1) / rps;
     p.rows_per_slice = rps;
     dim3 grid((unsigned)(tl * slices));
+    note_launch(URSE_KV_TN_RING);
     launch_tn_dma(ntw, colsum ? 1 : 0, grid, (hipStream_t)stream, p);
     URSE_CHECK_LAUNCH("urse_gemm_tn");
     return URSE_OK;
@@ -1394,6 +1404,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   p.rows_per_slice = rps;
   URSE_CHECK_ARG(tiles * slices < (1L << 31), "urse_gemm_tn: too many tiles");
   dim3 grid((unsigned)(tiles * slices));
+  note_launch(URSE_KV_TN_128);
   if (dtype == URSE_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
   URSE_CHECK_LAUNCH("urse_gemm_tn");
@@ -1403,6 +1414,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
 extern "C" int urse_gemm_tn_grouped(const void* descs, int groups, int max_blocks, int dtype, void* stream) {
   URSE_CHECK_ARG(descs && groups > 0 && max_blocks > 0 && groups < 65536, "urse_gemm_tn_grouped: bad argument");
   dim3 grid((unsigned)max_blocks, (unsigned)groups);
+  note_launch(URSE_KV_TN_GROUPED);
   if (dtype == URSE_BF16)
     hipLaunchKernelGGL(gemm_tn_grouped_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const TnArgs*)descs);
   else
@@ -1443,6 +1455,7 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
   rps = (rps + 31) / 32 * 32;
   slices = (R + rps - 1) / rps;
   p.rows_per_slice = rps;
+  note_launch(URSE_KV_TN_DUAL);
   launch_tn_dma(7, colsum ? 1 : 0, dim3((unsigned)(tl * slices)), (hipStream_t)stream, p);
   URSE_CHECK_LAUNCH("urse_gemm_tn_dual");
   return URSE_OK;

@@ -218,8 +218,17 @@ __global__ void __launch_bounds__(256) dot_kernel(const float* __restrict__ x, c
 __global__ void __launch_bounds__(256) mrl1_bwd_kernel(const float* __restrict__ t, const float* __restrict__ e,
                                                        const float* __restrict__ G, const double* __restrict__ sums,
                                                        const double* __restrict__ c1, const float* __restrict__ gl,
-                                                       float* __restrict__ de, int L, double eps) {
+                                                       float* __restrict__ de, int L, double eps,
+                                                       const float* __restrict__ loss, int B) {
   const int b = blockIdx.y;
+  if (loss) {            // NaN-loss guard of d_model.py:75-77: the step runs on zero gradients
+    bool bad = false;
+    for (int j = 0; j < B; ++j) bad |= isnan(loss[j]);
+    if (bad) {
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) de[(long)b * L + i] = 0.f;
+      return;
+    }
+  }
   const Mrl1Scalars sc = mrl1_scalars(sums + (long)b * 5, L, eps);
   const double a = sc.set / (sc.sig_t * sc.D);
   const float k_t = (float)(c1[b] / (sc.sig_t * sc.D));
@@ -285,6 +294,67 @@ __global__ void __launch_bounds__(256) clip_adamw_kernel(float* __restrict__ p, 
     }
     if (zero_grad) g[i] = 0.f;
   }
+}
+
+// per-slot bookkeeping of the slotted AdamW step: a slot whose `used` flag is set (slot 0 always) advances its step
+// count and gets its bias corrections; the others get {0, 0} = "leave these elements alone"
+__global__ void adamw_slots_kernel(const double* __restrict__ normsq, float grad_scale, const float* __restrict__ used,
+                                   int* __restrict__ steps, float* __restrict__ bias_corr, int n_slot,
+                                   const unsigned* __restrict__ skip_flag, float beta1, float beta2) {
+  const int s = threadIdx.x;
+  if (s >= n_slot) return;
+  const double nsq = *normsq * (double)grad_scale * (double)grad_scale;
+  const bool go = isfinite(nsq) && !(skip_flag && *skip_flag != 0u);
+  float b1 = 0.f, b2 = 0.f;
+  if (go && (s == 0 || used[s] > 0.f)) {
+    const int st = steps[s] + 1;
+    steps[s] = st;
+    b1 = 1.f - powf(beta1, (float)st);
+    b2 = sqrtf(1.f - powf(beta2, (float)st));
+  }
+  bias_corr[2 * s] = b1;
+  bias_corr[2 * s + 1] = b2;
+}
+
+__global__ void __launch_bounds__(256) clip_adamw_slots_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                               float* __restrict__ m, float* __restrict__ v, long n,
+                                                               const double* __restrict__ normsq, float max_norm, float lr,
+                                                               float beta1, float beta2, float eps, float wd,
+                                                               const unsigned char* __restrict__ slot,
+                                                               const float* __restrict__ bias_corr, int n_slot,
+                                                               float grad_scale, int zero_grad) {
+  __shared__ float bc[2 * 256];
+  for (int i = threadIdx.x; i < 2 * n_slot; i += blockDim.x) bc[i] = bias_corr[i];
+  __syncthreads();
+  const double nsq = *normsq * (double)grad_scale * (double)grad_scale;
+  float coef = grad_scale;
+  if (max_norm > 0.f) {
+    const float c = max_norm / ((float)sqrt(nsq) + 1e-6f);
+    if (c < 1.f) coef *= c;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int s = slot[i];
+    const float bc1 = bc[2 * s], bc2s = bc[2 * s + 1];
+    if (bc1 > 0.f) {
+      const float gr = g[i] * coef;
+      float pv = p[i] * (1.f - lr * wd);
+      const float mv = m[i] + (gr - m[i]) * (1.f - beta1);
+      const float vv = v[i] * beta2 + gr * gr * (1.f - beta2);
+      pv -= (lr / bc1) * mv / (sqrtf(vv) / bc2s + eps);
+      p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+__global__ void fill_used_kernel(float* __restrict__ x, int n, int n_used) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = i < n_used ? 1.f : 0.f;
+}
+
+__global__ void zero_f32_kernel(float* __restrict__ x, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = 0.f;
 }
 
 }  // namespace urse
@@ -356,8 +426,23 @@ extern "C" int urse_mrl1_loss_bwd(const float* target, const float* estimate, co
   const int chunk = 16384;
   hipLaunchKernelGGL(dot_kernel, dim3(ceil_div(L, chunk), B), dim3(256), 0, st, G, estimate, c1, L, chunk);
   hipLaunchKernelGGL(mrl1_bwd_kernel, dim3(ceil_div(L, 1024), B), dim3(256), 0, st, target, estimate, G, sums, c1,
-                     grad_loss, grad_estimate, L, (double)eps);
+                     grad_loss, grad_estimate, L, (double)eps, (const float*)nullptr, B);
   URSE_CHECK_LAUNCH("urse_mrl1_loss_bwd");
+  return URSE_OK;
+}
+
+extern "C" int urse_mrl1_loss_bwd_guarded(const float* target, const float* estimate, const float* G, const double* sums,
+                                          const float* grad_loss, const float* loss, float* grad_estimate, double* c1,
+                                          int B, int L, float eps, void* stream) {
+  URSE_CHECK_ARG(target && estimate && G && sums && grad_loss && loss && grad_estimate && c1 && B > 0 && L > 1,
+                 "urse_mrl1_loss_bwd_guarded: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(c1, 0, sizeof(double) * B, st);
+  const int chunk = 16384;
+  hipLaunchKernelGGL(dot_kernel, dim3(ceil_div(L, chunk), B), dim3(256), 0, st, G, estimate, c1, L, chunk);
+  hipLaunchKernelGGL(mrl1_bwd_kernel, dim3(ceil_div(L, 1024), B), dim3(256), 0, st, target, estimate, G, sums, c1,
+                     grad_loss, grad_estimate, L, (double)eps, loss, B);
+  URSE_CHECK_LAUNCH("urse_mrl1_loss_bwd_guarded");
   return URSE_OK;
 }
 
@@ -391,5 +476,30 @@ extern "C" int urse_clip_adamw_step(float* params, float* grads, float* exp_avg,
                      exp_avg_sq, (long)n, normsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale,
                      zero_grad);
   URSE_CHECK_LAUNCH("urse_clip_adamw_step");
+  return URSE_OK;
+}
+
+extern "C" int urse_clip_adamw_step_slots(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                          const double* normsq, float max_norm, float lr, float beta1, float beta2,
+                                          float eps, float weight_decay, const uint8_t* slot, float* used, int32_t* steps,
+                                          float* bias_corr, int n_slot, const uint32_t* skip_flag, float grad_scale,
+                                          int zero_grad, void* stream) {
+  URSE_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && normsq && slot && used && steps && bias_corr && n > 0 &&
+                     n_slot >= 1 && n_slot <= 256,
+                 "urse_clip_adamw_step_slots: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adamw_slots_kernel, dim3(1), dim3(256), 0, st, normsq, grad_scale, used, steps, bias_corr, n_slot,
+                     skip_flag, beta1, beta2);
+  hipLaunchKernelGGL(clip_adamw_slots_kernel, dim3(2048), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, (long)n,
+                     normsq, max_norm, lr, beta1, beta2, eps, weight_decay, slot, bias_corr, n_slot, grad_scale, zero_grad);
+  if (zero_grad) hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(256), 0, st, used, n_slot);
+  URSE_CHECK_LAUNCH("urse_clip_adamw_step_slots");
+  return URSE_OK;
+}
+
+extern "C" int urse_fill_used_flags(float* used, int n_slot, int n_used, void* stream) {
+  URSE_CHECK_ARG(used && n_slot >= 1 && n_slot <= 256 && n_used >= 0, "urse_fill_used_flags: bad argument");
+  hipLaunchKernelGGL(fill_used_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, used, n_slot, n_used);
+  URSE_CHECK_LAUNCH("urse_fill_used_flags");
   return URSE_OK;
 }

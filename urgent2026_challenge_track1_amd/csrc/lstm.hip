@@ -551,6 +551,7 @@ extern "C" int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void*
   int rt = rows16 & 15;
   bool nw8 = (rows16 >> 4) & 1;
   if (rt == 0) { rt = 1; nw8 = false; }
+  note_launch(URSE_KV_LSTM_FWD_STREAM);
   if (dtype == URSE_BF16) {
     if (nw8) {
       if (rt >= 4) return launch_fwd<bf16_t, 4, 8>(p, st);
@@ -587,6 +588,7 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
     rt = (many && fits2) ? 2 : 1;
     nw8 = many && fits2;
   }
+  note_launch(dtype == URSE_BF16 && rt >= 2 && fits2 ? URSE_KV_LSTM_BWD_STREAM32 : URSE_KV_LSTM_BWD_STREAM16);
   if (dtype == URSE_BF16) {
     if (nw8) return (rt >= 2 && fits2) ? launch_bwd<bf16_t, 2, 8>(p, st) : launch_bwd<bf16_t, 1, 8>(p, st);
     if (rt >= 2 && fits2) return launch_bwd<bf16_t, 2, 16>(p, st);

@@ -568,6 +568,7 @@ extern "C" int urse_lstm_cluster_bwd(const void* dh, int64_t ldd, void* gates, i
   (void)hipMemsetAsync(counters, 0, sizeof(unsigned) * plan[5], st);
   const int nslab = 4 * H * 2 / 64;
   const int kpw = (nslab + 2) / 3;
+  note_launch(URSE_KV_LSTM_BWD_CLUSTER);
   if (kpw <= 2) return launch_cluster_bwd<2>(p, st);
   if (kpw <= 17) return launch_cluster_bwd<17>(p, st);
   set_error("urse_lstm_cluster_bwd: H=%d not supported", H);
@@ -625,6 +626,7 @@ extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, vo
   // the exchange planes start with every tag bit clear (see the hand-off protocol in the kernel)
   (void)hipMemsetAsync(hx, 0, sizeof(bf16_t) * plan[4], st);
   const int nslab = Hp / 32;
+  note_launch(URSE_KV_LSTM_FWD_CLUSTER);
   if (nslab == 13) return launch_cluster<13, 1>(p, st);
   if (nslab == 2) return launch_cluster<2, 1>(p, st);
   return launch_cluster<1, 1>(p, st);

@@ -324,6 +324,7 @@ extern "C" int urse_lstm_cluster2_fwd(void* gx, int64_t ldg, const void* whhq, v
   p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2];
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(hx, 0, sizeof(bf16_t) * plan[3], st);      // every tag bit starts clear
+  note_launch(URSE_KV_LSTM_FWD_CLUSTER2);
   if (Hp / 32 == 24) return launch_cluster2<24, 8, 1>(p, st);
   return launch_cluster2<13, 8, 2>(p, st);
 }

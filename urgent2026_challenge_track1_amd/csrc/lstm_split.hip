@@ -383,6 +383,7 @@ extern "C" int urse_lstm_split_bwd(const void* dh, int64_t ldd, void* gates, int
   const int nut = (H + 15) / 16, rows = (int)plan[3];
   const size_t lds = split_lds(nut, p.nsplit, rows);
   const int maxt = (nut + SW - 1) / SW;
+  note_launch(URSE_KV_LSTM_BWD_SPLIT);
   if (rows == 32) {
     if (maxt <= 2) return launch_split<2, 2>(p, lds, st);
     return launch_split<2, 3>(p, lds, st);

@@ -322,6 +322,7 @@ extern "C" int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void*
   p.m_cpr = fastdiv_magic((unsigned)((H * 2 + 15) / 16));
   hipStream_t st = (hipStream_t)stream;
   static const int variant = getenv("URSE_WIDE_VARIANT") ? atoi(getenv("URSE_WIDE_VARIANT")) : 0;
+  note_launch(URSE_KV_LSTM_FWD_WIDE);
   if (nslab == 13) {
     if (variant == 1) return launch_wide_fwd<13, 7, 2, 4>(p, st);      // 32 sequences, two workgroups per CU
     return launch_wide_fwd<13, 4, 4, 8>(p, st);

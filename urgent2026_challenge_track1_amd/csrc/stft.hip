@@ -463,6 +463,7 @@ extern "C" int urse_stft_fwd(const float* wav, const int32_t* lens, float* spec,
   const int T = L / hop + 1;
   static const bool no960 = getenv("URSE_STFT_GENERIC") != nullptr;
   if (n_fft == 960 && !no960) {
+    note_launch(URSE_KV_STFT960);
     hipLaunchKernelGGL(stft960_kernel, dim3(ceil_div(T, 2 * URSE_STFT960_NFF), B), dim3(URSE_STFT960_NFF_THREADS), 0, (hipStream_t)stream, wav, lens,
                        reinterpret_cast<float2*>(spec), L, T, hop, window == URSE_WIN_HANN ? 1 : 0, tb.tw);
     URSE_CHECK_LAUNCH("urse_stft_fwd");
@@ -470,6 +471,7 @@ extern "C" int urse_stft_fwd(const float* wav, const int32_t* lens, float* spec,
   }
   const int NF = pick_nf(n_fft, 1);
   dim3 grid(ceil_div(T, 2 * NF), B);
+  note_launch(URSE_KV_STFT_GENERIC);
   hipLaunchKernelGGL(stft_kernel<0>, grid, dim3(stft_threads()), lds_bytes(n_fft, NF), (hipStream_t)stream, wav, lens,
                      reinterpret_cast<float2*>(spec), L, T, tb.plan, hop, tb.win[window], tb.tw, NF);
   URSE_CHECK_LAUNCH("urse_stft_fwd");
@@ -508,6 +510,7 @@ extern "C" int urse_istft_fwd(const float* spec, float* wav, int B, int T, int n
   // padded axis covers positions [0, n + hop*(T-1)); only [half, half + L_out) is written
   const long need = (long)n_fft / 2 + L_out;
   dim3 grid(ceil_div(need, (long)C * hop), B);
+  note_launch(URSE_KV_ISTFT_GENERIC);
   hipLaunchKernelGGL(istft_kernel, grid, dim3(stft_threads()), lds_bytes(n_fft, NF), (hipStream_t)stream,
                      reinterpret_cast<const float2*>(spec), wav, T, L_out, tb.plan, hop, tb.win[window], tb.tw, NF, C,
                      ov);

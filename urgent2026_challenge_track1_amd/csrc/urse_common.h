@@ -11,6 +11,9 @@
 namespace urse {
 
 void set_error(const char* fmt, ...);
+// which kernel variant a dispatcher picked (URSE_KV_* of include/urse.h): read back through urse_launch_count() by the
+// parity tests, which must prove that the kernels of the benchmarked configuration are the ones they compared
+void note_launch(int variant);
 
 #define URSE_CHECK_ARG(cond, ...)                      \
   do {                                                 \

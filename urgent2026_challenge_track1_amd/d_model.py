@@ -49,6 +49,23 @@ class SEModel(nn.Module):
     def log(self, name, value, **_):
         self.logged[name] = value
 
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cuda"):
+        """Lightning's ``SEModel.load_from_checkpoint(ckpt, map_location=...)`` as inference.py:31 calls it: a dict with
+        ``state_dict`` (``se_model.*`` names) and ``hyper_parameters['cfg']``; raises on a checkpoint of another model."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        cfg = ck.get("hyper_parameters", {}).get("cfg", None) if isinstance(ck, dict) else None
+        if cfg is None:
+            cfg = Config(model_configs={"num_channel": 196, "num_layer": 6})
+        elif not isinstance(cfg, Config):   # a Lightning checkpoint of the reference pickles its own Config class
+            cfg = Config(**dict(vars(cfg)))
+        sd = ck["state_dict"] if "state_dict" in ck else ck
+        if not any(k.startswith("se_model.") or k.startswith("bsrnn.") for k in sd):
+            raise KeyError("not an SEModel checkpoint (no se_model.* parameters): %s" % path)
+        model = cls(cfg)
+        model.se_model.load_state_dict({k[len("se_model."):] if k.startswith("se_model.") else k: v for k, v in sd.items()})
+        return model.to(map_location)
+
     def forward_step(self, batch, stage="train"):
         clean_speech, noisy_speech, fs, speech_length = batch
         B, C, T = clean_speech.shape
@@ -56,8 +73,9 @@ class SEModel(nn.Module):
         clean_speech = clean_speech.view(B, T).float()
         noisy_speech = noisy_speech.view(B, T).float()
         se_speech = self.se_model(noisy_speech, speech_length, fs)[0]
+        # (nan_guard: a NaN batch loss trains on zero gradients, d_model.py:75-77, decided on the device)
         loss = ops.mr_l1_loss(clean_speech, se_speech, self.mr_l1_windows, self.mr_l1_eps,
-                              self.mr_l1_td_weight).mean()
+                              self.mr_l1_td_weight, nan_guard=True).mean()
         with torch.no_grad():
             sisnr_loss = ops.si_snr_loss(clean_speech, se_speech).mean()
         # device scalars: no host sync inside the step (the reference .item()s here, d_model.py:82-87)
@@ -66,10 +84,10 @@ class SEModel(nn.Module):
         self.log("%s_sisnr_%s" % (stage, int(fs)), -sisnr_loss)
         return loss
 
-    def training_step(self, batch):
+    def training_step(self, batch, batch_idx=0):
         return self.forward_step(batch)
 
-    def validation_step(self, batch):
+    def validation_step(self, batch, batch_idx=0):
         with torch.no_grad():
             return {"loss": self.forward_step(batch, stage="val").detach()}
 
@@ -77,7 +95,7 @@ class SEModel(nn.Module):
         core = self.se_model.core
         opt = ops.FusedClipAdamW(core.flat_params, core.flat_grads, lr=self.cfg.learning_rate,
                                  eps=self.cfg.adam_epsilon, weight_decay=self.cfg.weight_decay,
-                                 max_norm=self.cfg.gradient_clip)
+                                 max_norm=self.cfg.gradient_clip, core=core)
         sched = StepLR(opt, self.cfg.lr_step_size, self.cfg.lr_gamma)
         return [opt], [sched]
 

@@ -1,108 +1,99 @@
-"""Batch contract, data-parallel shard rule and audio I/O of the training loop.
+"""Batch contract, data-parallel shard rule, dynamic-mixing producer and audio I/O of the training loop.
 
-Mirrors ``baseline_code/dataset.py``: ``read_kv_scp`` (:79-86), ``PreSimulatedDataset`` (:104-151),
-``GroupedBatchSampler`` (:338-401: per-fs groups, length-sorted, ``indices[rank::world]`` shard at :361, buckets of
-100*batch, shuffles seeded with ``random.seed(epoch + rank)``), ``collate_fn`` (:404-441: right-pad, batch =
-``(clean[B,1,T], noisy[B,1,T], fs int32 0-d, lengths int32[B])``) and ``AudioDataModule`` (:444-524; validation is not
-sharded).  ``soundfile`` is not available here, so WAV I/O is a small RIFF reader/writer (PCM16/24/32, float32).
-``SyntheticPairDataset`` is the SURVEY 8(d) generator used by ``bench.py`` and the smoke test.
+Same surface as ``baseline_code/dataset.py`` (``read_kv_scp`` :79-86, ``read_source_scp`` :89-101,
+``PreSimulatedDataset`` :104-151, ``DynamicMixingDataset`` :154-335, ``GroupedBatchSampler`` :338-401, ``collate_fn``
+:404-441, ``AudioDataModule`` :444-524) with one structural difference: ``DynamicMixingDataset`` does not run the
+simulator on the host.  A worker only DRAWS the recipe (same ``np.random`` call sequence as ``run_simulation`` :232-278
++ ``generate_data_param.process_one_sample`` :294-418, so the same seed gives the same recipe) and reads the raw
+sources; ``collate_dynamic`` stacks them, and the DSP (high-pass, RIR, SNR mixing, clipping, packet loss, peak
+normalisation) runs batched on the GPU in ``mixing.simulate_batch`` when the trainer calls ``materialise`` on the batch.
+
+What must agree with the reference for identical shards is the order of RNG calls, not the text: it is pinned by
+``tests/golden/ref_mix.npz`` (batches and recipes produced by the reference's own classes, ``make_golden_mix.py``).
+``soundfile`` is not available here: WAV and FLAC are decoded by ``audio_io`` (own RIFF / FLAC readers).
 """
 import random
-import struct
 from collections import defaultdict
 
 import numpy as np
 import torch
 from torch.utils.data import BatchSampler, DataLoader
 
+from .audio_io import audio_frames, read_audio, write_audio  # noqa: F401  (re-exported: inference / metrics use them)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# scp tables
+# ------------------------------------------------------------------------------------------------------------------
+def _scp_rows(path, n_fields):
+    with open(path, "r") as f:
+        for line in f:
+            parts = line.strip().split()
+            if len(parts) != n_fields:
+                raise ValueError("%s: expected %d fields, got %r" % (path, n_fields, line))
+            yield parts
+
 
 def read_kv_scp(scp):
-    rtv = {}
-    with open(scp, "r") as f:
-        for line in f:
-            uid, value = line.strip().split()
-            assert uid not in rtv, uid
-            rtv[uid] = value
-    return rtv
+    """``uid value`` lines -> dict (duplicate uids are an error)."""
+    table = {}
+    for uid, value in _scp_rows(scp, 2):
+        if uid in table:
+            raise AssertionError(uid)
+        table[uid] = value
+    return table
 
 
-def read_audio(path):
-    """-> (float32 [1, T], fs).  RIFF/WAVE PCM 16/24/32-bit or IEEE float32, first channel only kept as [1,T]."""
-    with open(path, "rb") as f:
-        data = f.read()
-    assert data[:4] == b"RIFF" and data[8:12] == b"WAVE", "not a RIFF/WAVE file: %s" % path
-    pos, fmt, pcm = 12, None, None
-    while pos + 8 <= len(data):
-        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
-        body = data[pos + 8:pos + 8 + size]
-        if cid == b"fmt ":
-            fmt = struct.unpack("<HHIIHH", body[:16])
-        elif cid == b"data":
-            pcm = body
-        pos += 8 + size + (size & 1)
-    tag, ch, fs, _, _, bits = fmt
-    if tag == 0xFFFE:   # WAVE_FORMAT_EXTENSIBLE: sub-format in the first 2 bytes of the GUID
-        tag = 3 if bits == 32 and b"\x03\x00" == data[data.find(b"fmt ") + 32:data.find(b"fmt ") + 34] else 1
-    if tag == 3 and bits == 32:
-        x = np.frombuffer(pcm, dtype="<f4").astype(np.float32)
-    elif tag == 1 and bits == 16:
-        x = np.frombuffer(pcm, dtype="<i2").astype(np.float32) / 32768.0
-    elif tag == 1 and bits == 32:
-        x = np.frombuffer(pcm, dtype="<i4").astype(np.float32) / 2147483648.0
-    elif tag == 1 and bits == 24:
-        b = np.frombuffer(pcm, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
-        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
-        x = ((v ^ 0x800000) - 0x800000).astype(np.float32) / 8388608.0
-    else:
-        raise ValueError("unsupported WAV encoding tag=%d bits=%d (%s)" % (tag, bits, path))
-    x = x.reshape(-1, ch)[:, :1].T
-    return np.ascontiguousarray(x), fs
+def read_source_scp(scp):
+    """``uid fs path`` lines -> ({fs: {uid: path}}, {fs: [uid]}, {uid: path})."""
+    by_fs, flat = defaultdict(dict), {}
+    for uid, fs, path in _scp_rows(scp, 3):
+        if uid in by_fs[int(fs)]:
+            raise AssertionError((uid, fs))
+        by_fs[int(fs)][uid] = path
+        flat[uid] = path
+    return by_fs, {fs: list(d) for fs, d in by_fs.items()}, flat
 
 
-def write_audio(path, x, fs, subtype="PCM_16"):
-    x = np.asarray(x, dtype=np.float32).reshape(-1)
-    if subtype == "FLOAT":
-        pcm, tag, bits = x.astype("<f4").tobytes(), 3, 32
-    else:
-        pcm, tag, bits = np.clip(np.round(x * 32768.0), -32768, 32767).astype("<i2").tobytes(), 1, 16
-    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(pcm), b"WAVE", b"fmt ", 16, tag, 1, fs, fs * bits // 8,
-                      bits // 8, bits, b"data", len(pcm))
-    with open(path, "wb") as f:
-        f.write(hdr + pcm)
-
-
+# ------------------------------------------------------------------------------------------------------------------
+# datasets
+# ------------------------------------------------------------------------------------------------------------------
 class PreSimulatedDataset(torch.utils.data.Dataset):
+    """(clean [1,T], noisy [1,T], fs, T) from the four tables of a simulated set; ``max_duration`` (in SAMPLES, quirk
+    C.4) crops both signals at one ``random.randint`` offset."""
+
     def __init__(self, clean_speech, noisy_speech, utt2fs, speech_length, max_duration=-1):
-        self.clean_speech = read_kv_scp(clean_speech)
-        self.noisy_speech = read_kv_scp(noisy_speech)
-        self.utt2fs = {k: int(v) for k, v in read_kv_scp(utt2fs).items()}
-        self.speech_length = {k: int(v) for k, v in read_kv_scp(speech_length).items()}
-        self.uid = list(self.clean_speech.keys())
+        self.clean_speech, self.noisy_speech = read_kv_scp(clean_speech), read_kv_scp(noisy_speech)
+        self.utt2fs = {u: int(v) for u, v in read_kv_scp(utt2fs).items()}
+        self.speech_length = {u: int(v) for u, v in read_kv_scp(speech_length).items()}
+        self.uid = list(self.clean_speech)
         self.max_duration = max_duration
-        assert len(self.clean_speech) == len(self.noisy_speech) == len(self.utt2fs) == len(self.speech_length)
-
-    def get_source_length(self):
-        if self.max_duration > 0:
-            return [min(self.speech_length[k], self.max_duration) for k in self.uid]
-        return [self.speech_length[k] for k in self.uid]
-
-    def get_srs(self):
-        return [self.utt2fs[k] for k in self.uid]
+        sizes = {len(self.clean_speech), len(self.noisy_speech), len(self.utt2fs), len(self.speech_length)}
+        assert len(sizes) == 1, "the four tables must list the same utterances"
 
     def __len__(self):
-        return len(self.clean_speech)
+        return len(self.uid)
+
+    def get_srs(self):
+        return [self.utt2fs[u] for u in self.uid]
+
+    def get_source_length(self):
+        cap = self.max_duration if self.max_duration > 0 else None
+        return [self.speech_length[u] if cap is None else min(self.speech_length[u], cap) for u in self.uid]
 
     def __getitem__(self, index):
         uid = self.uid[index]
-        audio, fs = read_audio(self.clean_speech[uid])
-        assert fs == self.utt2fs[uid]
-        noisy, fs = read_audio(self.noisy_speech[uid])
-        assert fs == self.utt2fs[uid]
-        if self.max_duration > 0 and audio.shape[1] > self.max_duration:   # max_duration is in SAMPLES (quirk C.4)
-            start = random.randint(0, audio.shape[1] - self.max_duration)
-            audio = audio[:, start:start + self.max_duration]
-            noisy = noisy[:, start:start + self.max_duration]
-        return audio, noisy, fs, audio.shape[1]
+        pair = []
+        for table in (self.clean_speech, self.noisy_speech):
+            wav, fs = read_audio(table[uid])
+            assert fs == self.utt2fs[uid], (uid, fs)
+            pair.append(wav)
+        clean, noisy = pair
+        T = clean.shape[1]
+        if 0 < self.max_duration < T:
+            start = random.randint(0, T - self.max_duration)
+            clean, noisy = (w[:, start:start + self.max_duration] for w in (clean, noisy))
+        return clean, noisy, fs, clean.shape[1]
 
 
 class SyntheticPairDataset(torch.utils.data.Dataset):
@@ -128,9 +119,8 @@ class SyntheticPairDataset(torch.utils.data.Dataset):
     def __len__(self):
         return self.n
 
-    def __getitem__(self, i):
-        fs, L = self._len(i)
-        rng = np.random.default_rng(self.seed * 1000003 + i)
+    @staticmethod
+    def speech_like(rng, L, fs):
         n = rng.standard_normal(L)
         k = np.fft.rfftfreq(L)
         clean = np.fft.irfft(np.fft.rfft(n) / (1.0 - 0.95 * np.exp(-2j * np.pi * k)), n=L)
@@ -140,7 +130,12 @@ class SyntheticPairDataset(torch.utils.data.Dataset):
         edge = min(int(0.4 * fs), L // 4)
         clean[:edge] *= 1e-3
         clean[L - edge:] *= 1e-3
-        clean *= 0.9 / np.abs(clean).max()
+        return clean * (0.9 / np.abs(clean).max())
+
+    def __getitem__(self, i):
+        fs, L = self._len(i)
+        rng = np.random.default_rng(self.seed * 1000003 + i)
+        clean = self.speech_like(rng, L, fs)
         snr = rng.uniform(-5.0, 20.0)
         noise = rng.standard_normal(L)
         noise *= np.sqrt((clean ** 2).mean() / ((noise ** 2).mean() * 10 ** (snr / 10)))
@@ -149,97 +144,371 @@ class SyntheticPairDataset(torch.utils.data.Dataset):
         return (clean * sc).astype(np.float32)[None], (noisy * sc).astype(np.float32)[None], fs, L
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# dynamic mixing: recipe on the host, DSP on the device
+# ------------------------------------------------------------------------------------------------------------------
+class SimulationConfigs:
+    """the probabilities / ranges of ``baseline_code/dataset.py:20-76`` (values are the contract; layout is ours)."""
+    snr_low_bound, snr_high_bound = -5.0, 20.0
+    reuse_noise, reuse_rir = True, True
+    prob_wind_noise = 0.05
+    prob_reverberation = 0.5
+    wind_noise_config = dict(threshold=[0.1, 0.3], ratio=[1, 20], attack=[5, 100], release=[5, 100], sc_gain=[0.8, 1.2],
+                             clipping_threshold=[0.85, 1.0], clipping_chance=0.75, wind_noise_snr_low_bound=-10.0,
+                             wind_noise_snr_high_bound=15.0)
+    num_augmentations = {0: 0.25, 1: 0.40, 2: 0.20, 3: 0.15}
+    augmentations = dict(
+        bandwidth_limitation=dict(weight=1.0, resample_methods="random"),
+        clipping=dict(weight=1.0, clipping_min_quantile=[0.0, 0.1], clipping_max_quantile=[0.9, 1.0]),
+        codec=dict(weight=1.0, config=[dict(format="mp3", encoder=None, qscale=[1, 10]),
+                                       dict(format="ogg", encoder=["vorbis"], qscale=[-1, 10])]),
+        packet_loss=dict(weight=1.0, packet_duration_ms=20, max_continuous_packet_loss=10, packet_loss_rate=[0.05, 0.25]),
+    )
+    augmentations_name = list(augmentations)
+
+
+BANDWIDTH_RATES = (8000, 16000, 22050, 24000, 32000, 44100, 48000)            # generate_data_param.py:14
+BANDWIDTH_METHODS = ("kaiser_best", "kaiser_fast", "scipy", "polyphase")       # generate_data_param.py:16-26
+
+
+def _pick_source(fs, table, rs):
+    """``select_sample`` (generate_data_param.py:421-455) for the on-the-fly case (nothing is marked used): a sample at
+    ``fs`` if there is one, else one at a higher rate found by walking a shuffled list of the rates."""
+    if table.get(fs):
+        return rs.choice(list(table[fs]))
+    rates = list(table)
+    rs.shuffle(rates)
+    for other in rates:
+        if other > fs and table[other]:
+            return rs.choice(list(table[other]))
+    return None
+
+
+def _lost_packets(n_samples, fs, cfg, rs):
+    """``packet_loss`` index draw (generate_data_param.py:58-91)."""
+    dur_ms = n_samples / fs * 1000
+    n_packets = int(dur_ms // cfg["packet_duration_ms"])
+    rate = rs.uniform(*cfg["packet_loss_rate"])
+    n_lost = int(round(rate * dur_ms / cfg["packet_duration_ms"], 0))
+    cap = cfg["max_continuous_packet_loss"]
+    runs = []
+    for _ in range(n_lost):
+        runs.append(rs.randint(1, cap))
+        if n_lost - sum(runs) <= cap:
+            runs.append(n_lost - sum(runs))
+            break
+    starts = rs.choice(range(n_packets), len(runs), replace=False)
+    lost = []
+    for s, n in zip(starts, runs):
+        lost += list(range(s, s + n))
+    return list(set(lost))       # (built exactly like this in the reference: the order of the list is the set's)
+
+
+def draw_recipe(speech_length, fs, noise_table, rir_table, wind_table, cfg=SimulationConfigs, rs=np.random):
+    """One mixing recipe, drawn with the reference's sequence of ``np.random`` calls: wind-noise coin, number and choice
+    of augmentations (re-drawn while wind noise meets clipping), noise sample, [wind-noise parameters,] SNR, RIR coin and
+    sample, per-augmentation parameters.  Returns the reference's ``info`` fields plus the parsed parameters."""
+    names = list(cfg.augmentations)
+    w = np.array([cfg.augmentations[a]["weight"] for a in names], dtype=float)
+    w = w / w.sum()
+    wind = rs.random() < cfg.prob_wind_noise
+    n_aug = rs.choice(list(cfg.num_augmentations), p=list(cfg.num_augmentations.values()))
+    chosen = []
+    if n_aug:
+        chosen = rs.choice(names, p=w, size=n_aug, replace=False)
+        while wind and "clipping" in chosen:
+            chosen = rs.choice(names, p=w, size=n_aug, replace=False)
+    text, params = "", {}
+    if wind:
+        noise_uid = _pick_source(fs, wind_table, rs)
+        wc = cfg.wind_noise_config
+        vals = [rs.uniform(*wc[k]) for k in ("threshold", "ratio", "attack", "release", "sc_gain", "clipping_threshold")]
+        clip = rs.random() < wc["clipping_chance"]
+        text = ("wind_noise(threshold=%s,ratio=%s,attack=%s,release=%s,sc_gain=%s,clipping=%s,clipping_threshold=%s)/"
+                % (vals[0], vals[1], vals[2], vals[3], vals[4], clip, vals[5]))
+        params["wind_noise"] = dict(zip(("threshold", "ratio", "attack", "release", "sc_gain", "clipping_threshold"), vals),
+                                    clipping=clip)
+        snr = rs.uniform(wc["wind_noise_snr_low_bound"], wc["wind_noise_snr_high_bound"])
+    else:
+        noise_uid = _pick_source(fs, noise_table, rs)
+        snr = rs.uniform(cfg.snr_low_bound, cfg.snr_high_bound)
+    if noise_uid is None:
+        raise ValueError("Noise sample not found for fs=%d+ Hz" % fs)
+    # (the reference keeps the RIR when the draw EXCEEDS prob_reverberation, generate_data_param.py:337-345)
+    if rir_table is None or cfg.prob_reverberation <= 0.0 or rs.rand() <= cfg.prob_reverberation:
+        rir_uid = None
+    else:
+        rir_uid = _pick_source(fs, rir_table, rs)
+    if len(chosen) == 0:
+        if not wind:
+            text = "none"
+    for i, a in enumerate(chosen):
+        spec = cfg.augmentations[a]
+        if a == "bandwidth_limitation":
+            lower = [r for r in BANDWIDTH_RATES if r < fs]
+            if lower:
+                method = rs.choice(BANDWIDTH_METHODS)
+                fs_new = rs.choice(lower)
+            else:
+                method, fs_new = "none", fs
+            text += "%s-%s->%s" % (a, method, fs_new)
+            params[a] = dict(res_type=str(method), fs_new=int(fs_new))
+        elif a == "clipping":
+            lo, hi = rs.uniform(*spec["clipping_min_quantile"]), rs.uniform(*spec["clipping_max_quantile"])
+            text += "%s(min=%s,max=%s)" % (a, lo, hi)
+            params[a] = dict(min_quantile=float(lo), max_quantile=float(hi))
+        elif a == "codec":
+            c = rs.choice(spec["config"], 1)[0]
+            enc, q = c["encoder"], c["qscale"]
+            if isinstance(enc, list):
+                enc = rs.choice(enc, 1)[0]
+            if isinstance(q, list):
+                q = rs.randint(*q)
+            text += "%s(format=%s,encoder=%s,qscale=%s)" % (a, c["format"], enc, q)
+            params[a] = dict(format=c["format"], encoder=enc, qscale=q)
+        elif a == "packet_loss":
+            idx = _lost_packets(speech_length, fs, spec, rs)
+            text += "%s(packet_loss_indices=%s,packet_duration_ms=%s)" % (a, idx, spec["packet_duration_ms"])
+            params[a] = dict(packet_loss_indices=[int(v) for v in idx], packet_duration_ms=spec["packet_duration_ms"])
+        else:
+            raise NotImplementedError(a)
+        if i < len(chosen) - 1:
+            text += "/"
+    return dict(noise_uid=noise_uid, rir_uid="none" if rir_uid is None else rir_uid, snr=snr, augmentation=text, fs=fs,
+                length=speech_length, params=params, order=[str(a) for a in chosen], wind=bool(wind))
+
+
+class DynamicMixingDataset(torch.utils.data.Dataset):
+    """Index -> (raw speech, raw noise, raw RIR or None, recipe, fs, length).  Constructor arguments as the reference's
+    (:155); ``reader`` / ``frames`` replace the soundfile calls (tests and bench.py serve in-memory sources)."""
+
+    def __init__(self, speech_source_scp, noise_source_scp, rir_scp, windnoise_scp, speech_length_file,
+                 use_high_pass=True, retry_when_fails=False, max_duration=240000, reader=read_audio, frames=audio_frames):
+        super().__init__()
+        self.speech_source, self.speech_uids, self.speech_source_flt = read_source_scp(speech_source_scp)
+        self.noise_source, self.noise_uids, self.noise_source_flt = read_source_scp(noise_source_scp)
+        self.rirs, self.rir_uids, self.rirs_flt = read_source_scp(rir_scp)
+        self.wind_noises, self.wind_noises_uids, self.wind_noises_flt = read_source_scp(windnoise_scp)
+        self.all_noise_flt = dict(self.noise_source_flt, **self.wind_noises_flt)
+        self.max_duration = max_duration
+        self.source_length = {u: min(int(v), max_duration) for u, v in read_kv_scp(speech_length_file).items()}
+        self.samplerates = list(self.speech_source)
+        self._index = [(fs, j) for fs in self.samplerates for j in range(len(self.speech_source[fs]))]
+        self.use_high_pass, self.retry_when_fails = use_high_pass, retry_when_fails
+        self._read, self._frames = reader, frames
+        self.skipped = defaultdict(int)          # augmentations drawn but not applicable on the device path
+
+    def __len__(self):
+        return len(self._index)
+
+    def _get_from_index(self, index):
+        return self._index[index]
+
+    def get_srs(self):
+        return [fs for fs, _ in self._index]
+
+    def get_source_length(self):
+        return [self.source_length[self.speech_uids[fs][j]] for fs, j in self._index]
+
+    def _crop(self, wav):
+        """the random crop of the simulator's ``read_audio(max_duration)`` (simulate_data_from_param.py:355-359)."""
+        if 0 < self.max_duration < wav.shape[1]:
+            start = random.randint(0, wav.shape[1] - self.max_duration)
+            wav = wav[:, start:start + self.max_duration]
+        return wav
+
+    def _load(self, path, fs):
+        wav, got = self._read(path)
+        if got != fs:
+            raise ValueError("%s is sampled at %d Hz, the recipe needs %d Hz: the reference resamples with soxr here "
+                             "(simulate_data_from_param.py:350-352), which this build does not restate - list sources "
+                             "per sampling rate" % (path, got, fs))
+        return self._crop(wav[:1])
+
+    def __getitem__(self, index):
+        fs, j = self._index[index]
+        uid = self.speech_uids[fs][j]
+        path = self.speech_source[fs][uid]
+        length = min(self.max_duration, self._frames(path))
+        recipe = draw_recipe(length, fs, self.noise_source, self.rirs, self.wind_noises)
+        recipe.update(speech_uid=uid, id=uid, snr_dB=recipe["snr"], highpass=self.use_high_pass)
+        speech = self._load(path, fs)
+        noise = self._load(self.all_noise_flt[recipe["noise_uid"]], fs)
+        rir = self._load(self.rirs_flt[recipe["rir_uid"]], fs) if recipe["rir_uid"] != "none" else None
+        # the offset of mix_noise's wrap / crop (:108-119) comes from an unseeded default_rng() when mixing on the fly (:471)
+        ls, ln = speech.shape[1], noise.shape[1]
+        recipe["noise_offset"] = int(np.random.default_rng().integers(0, abs(ls - ln))) if ls != ln else 0
+        return dict(speech=speech, noise=noise, rir=rir, recipe=recipe, fs=fs, length=speech.shape[1])
+
+
+class RawMixBatch:
+    """What ``collate_dynamic`` hands to the trainer: padded raw sources + recipes of one fs.  ``materialise(device)``
+    runs the simulator on the GPU and returns the ``collate_fn`` tuple ``(clean[B,1,T], noisy[B,1,T], fs, lengths)``."""
+
+    def __init__(self, items):
+        assert len({it["fs"] for it in items}) == 1, "mixed sampling rates in one batch"
+        self.fs = items[0]["fs"]
+        self.recipes = [it["recipe"] for it in items]
+        self.lengths = [it["length"] for it in items]
+
+        def stack(key, width):
+            out = torch.zeros(len(items), width, dtype=torch.float32)
+            lens = []
+            for b, it in enumerate(items):
+                a = it[key]
+                n = 0 if a is None else a.shape[1]
+                if n:
+                    out[b, :n] = torch.as_tensor(a[0], dtype=torch.float32)
+                lens.append(n)
+            return out, lens
+        self.speech, _ = stack("speech", max(self.lengths))
+        self.noise, self.noise_lens = stack("noise", max(it["noise"].shape[1] for it in items))
+        rmax = max([it["rir"].shape[1] for it in items if it["rir"] is not None] or [0])
+        self.rir, self.rir_lens = stack("rir", rmax) if rmax else (None, [0] * len(items))
+        self.rir_early = [0] * len(items)
+        if rmax:
+            from .mixing import early_rir_stop
+            self.rir_early = [early_rir_stop(it["rir"], self.fs) if it["rir"] is not None else 0 for it in items]
+
+    def pin_memory(self):
+        for k in ("speech", "noise", "rir"):
+            t = getattr(self, k)
+            if t is not None:
+                setattr(self, k, t.pin_memory())
+        return self
+
+    def materialise(self, device, skipped=None):
+        from . import mixing
+        out = mixing.simulate_recipes(self.speech.to(device, non_blocking=True), self.lengths,
+                                      self.noise.to(device, non_blocking=True), self.noise_lens,
+                                      None if self.rir is None else self.rir.to(device, non_blocking=True), self.rir_lens,
+                                      self.rir_early, self.fs, self.recipes, skipped)
+        clean, noisy = out
+        B, T = clean.shape
+        return (clean.view(B, 1, T), noisy.view(B, 1, T), torch.tensor(self.fs, dtype=torch.int32),
+                torch.tensor(self.lengths, dtype=torch.int32))
+
+
+def collate_dynamic(items):
+    return RawMixBatch(items)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# shard rule + batching
+# ------------------------------------------------------------------------------------------------------------------
 class GroupedBatchSampler(BatchSampler):
+    """Per sampling rate: indices sorted by length, every ``world_size``-th one from ``rank`` on (the data-parallel
+    shard), cut into buckets of ``bucket_size_mult * batch_size``.  An epoch shuffles the bucket list, each bucket and
+    finally the batch list with the ``random`` module seeded by ``epoch + rank``; the shuffles are in place, so they
+    accumulate over epochs exactly as in the reference (quirk C.3).
+
+    ``max_batches``: ranks see different batch counts when the per-fs groups do not divide evenly (the reference then
+    hangs in DDP); the trainer sets it to the minimum over ranks so that every rank runs the same number of steps."""
+
     def __init__(self, dataset, batch_size, rank, world_size, seed=0, drop_last=False, bucket_size_mult=100,
                  sampler=None):
-        self.batch_size = batch_size
-        self.drop_last = drop_last
+        self.batch_size, self.drop_last = batch_size, drop_last
         self.bucket_size = batch_size * bucket_size_mult
-        self.epoch = 0
-        self.world_size = world_size
-        self.rank = rank
-        self.seed = seed
-        self.generator = torch.Generator().manual_seed(seed + rank + self.epoch)
-        sr_groups = defaultdict(list)
-        for idx, sr in enumerate(dataset.get_srs()):
-            sr_groups[sr].append(idx)
+        self.rank, self.world_size, self.seed, self.epoch = rank, world_size, seed, 0
+        self.generator = torch.Generator().manual_seed(seed + rank)
+        self.max_batches = None
+        lengths = dataset.get_source_length()
+        by_rate = defaultdict(list)
+        for i, fs in enumerate(dataset.get_srs()):
+            by_rate[fs].append(i)
         self.buckets = []
-        source_length = dataset.get_source_length()
-        for sr, indices in sr_groups.items():
-            sorted_indices = sorted(indices, key=lambda x: source_length[x])
-            sorted_indices = sorted_indices[self.rank::self.world_size]      # the data-parallel shard rule
-            for i in range(0, len(sorted_indices), self.bucket_size):
-                self.buckets.append(sorted_indices[i:i + self.bucket_size])
+        for members in by_rate.values():
+            shard = sorted(members, key=lengths.__getitem__)[rank::world_size]
+            self.buckets += [shard[k:k + self.bucket_size] for k in range(0, len(shard), self.bucket_size)]
 
     def set_epoch(self, epoch):
         self.epoch = epoch
-        self.generator.manual_seed(self.seed + self.rank + self.epoch)
+        self.generator.manual_seed(self.seed + self.rank + epoch)
+
+    def _batches_of(self, bucket):
+        full, rest = divmod(len(bucket), self.batch_size)
+        n = full + (1 if rest and not self.drop_last else 0)
+        return [bucket[k * self.batch_size:(k + 1) * self.batch_size] for k in range(n)]
 
     def __iter__(self):
         random.seed(self.epoch + self.rank)
         random.shuffle(self.buckets)
-        all_batches = []
+        plan = []
         for bucket in self.buckets:
             random.shuffle(bucket)
-            for i in range(0, len(bucket), self.batch_size):
-                batch = bucket[i:i + self.batch_size]
-                if len(batch) < self.batch_size and self.drop_last:
-                    continue
-                all_batches.append(batch)
-        random.shuffle(all_batches)
-        return iter(all_batches)
+            plan += self._batches_of(bucket)
+        random.shuffle(plan)
+        return iter(plan if self.max_batches is None else plan[:self.max_batches])
+
+    def __len__(self):
+        n = sum(len(self._batches_of(b)) for b in self.buckets)
+        return n if self.max_batches is None else min(n, self.max_batches)
 
     def state_dict(self):
         return {"seed": self.seed, "epoch": self.epoch}
 
-    def __len__(self):
-        total = 0
-        for bucket in self.buckets:
-            n = len(bucket)
-            total += n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
-        return total
-
 
 def collate_fn(batch):
-    speechs = [torch.as_tensor(item[0]) for item in batch]
-    noisy_speechs = [torch.as_tensor(item[1]) for item in batch]
-    srs = [item[2] for item in batch]
-    lengths = [item[3] for item in batch]
-    assert all(sr == srs[0] for sr in srs), "mixed sampling rates in one batch"
-    max_length = max(a.shape[1] for a in speechs)
-    pad = lambda a: torch.nn.functional.pad(a, (0, max_length - a.shape[1]), value=0.0)
-    return (torch.stack([pad(a) for a in speechs], dim=0), torch.stack([pad(a) for a in noisy_speechs], dim=0),
-            torch.tensor(srs[0], dtype=torch.int32), torch.tensor(lengths, dtype=torch.int32))
+    """[(clean [1,Ti], noisy [1,Ti], fs, Ti)] -> (clean [B,1,Tmax], noisy [B,1,Tmax], fs int32 0-d, lengths int32 [B]),
+    right-padded with zeros; the sample dtype is kept (the reference's ``torch.tensor(item)``)."""
+    rates = {item[2] for item in batch}
+    assert len(rates) == 1, "mixed sampling rates in one batch"
+    width = max(np.shape(item[0])[1] for item in batch)
+    out = []
+    for col in (0, 1):
+        first = torch.as_tensor(batch[0][col])
+        padded = first.new_zeros((len(batch), first.shape[0], width))
+        for b, item in enumerate(batch):
+            a = torch.as_tensor(item[col])
+            padded[b, :, :a.shape[1]] = a
+        out.append(padded)
+    return (out[0], out[1], torch.tensor(rates.pop(), dtype=torch.int32),
+            torch.tensor([item[3] for item in batch], dtype=torch.int32))
 
 
 class AudioDataModule:
+    """``AudioDataModule(config)`` of the reference (:444-524) without Lightning; rank / world come from the trainer."""
+
     def __init__(self, config, rank=0, world_size=1):
         self.config, self.rank, self.world_size = config, rank, world_size
         self.num_worker, self.batch_size = config.num_worker, config.batch_size
         td, vd = config.train_set_path, config.valid_set_path
+        self.dynamic = False
         if str(td).startswith("synthetic"):            # "synthetic[:n_items]" -> on-the-fly SURVEY 8(d) pairs
             n = int(str(td).split(":")[1]) if ":" in str(td) else 64
-            self.train_dataset = SyntheticPairDataset(n, seed=config.seed)
-            self.val_dataset = SyntheticPairDataset(max(self.batch_size, n // 8), seed=config.seed + 1)
+            fs_list = tuple(getattr(config, "synthetic_fs", (48000,)))
+            self.train_dataset = SyntheticPairDataset(n, fs_list=fs_list, seconds=getattr(config, "synthetic_seconds", 4.0),
+                                                      seed=config.seed)
+            self.val_dataset = SyntheticPairDataset(max(self.batch_size, n // 8), fs_list=fs_list[:1],
+                                                    seconds=getattr(config, "synthetic_seconds", 4.0), seed=config.seed + 1)
         else:
             if config.train_set_dynamic_mixing:
-                raise NotImplementedError("DynamicMixingDataset (dataset.py:154-335) is the next §8(f) row")
-            mk = lambda d, md: PreSimulatedDataset("%s/spk1.scp" % d, "%s/wav.scp" % d, "%s/utt2fs" % d,
-                                                   "%s/speech_length.scp" % d, max_duration=md)
-            self.train_dataset = mk(td, config.max_duration)
-            self.val_dataset = mk(vd, -1)
+                self.dynamic = True
+                self.train_dataset = DynamicMixingDataset(
+                    speech_source_scp="%s/speech_sources.scp" % td, noise_source_scp="%s/noise_scoures.scp" % td,
+                    speech_length_file="%s/source_length.scp" % td, rir_scp="%s/rirs.scp" % td,
+                    windnoise_scp="%s/wind_noise_scoures.scp" % td, retry_when_fails=False,
+                    max_duration=config.max_duration, use_high_pass=config.use_high_pass)
+            else:
+                self.train_dataset = self._presimulated(td, config.max_duration)
+            self.val_dataset = self._presimulated(vd, -1)
         self.train_batch_sampler = None
 
-    def _loader(self, ds, sampler):
+    @staticmethod
+    def _presimulated(d, max_duration):
+        return PreSimulatedDataset("%s/spk1.scp" % d, "%s/wav.scp" % d, "%s/utt2fs" % d, "%s/speech_length.scp" % d,
+                                   max_duration=max_duration)
+
+    def _loader(self, ds, sampler, collate):
         nw = self.num_worker
-        return DataLoader(ds, batch_sampler=sampler, num_workers=nw, pin_memory=False,
-                          persistent_workers=nw > 0, collate_fn=collate_fn)
+        return DataLoader(ds, batch_sampler=sampler, num_workers=nw, pin_memory=False, persistent_workers=nw > 0,
+                          collate_fn=collate)
 
     def train_dataloader(self):
-        self.train_batch_sampler = GroupedBatchSampler(self.train_dataset, self.batch_size, self.rank,
-                                                       self.world_size, drop_last=True)
-        return self._loader(self.train_dataset, self.train_batch_sampler)
+        self.train_batch_sampler = GroupedBatchSampler(self.train_dataset, self.batch_size, self.rank, self.world_size,
+                                                       drop_last=True)
+        return self._loader(self.train_dataset, self.train_batch_sampler, collate_dynamic if self.dynamic else collate_fn)
 
     def val_dataloader(self):       # not sharded: every rank validates the full set (dataset.py:507-516)
-        return self._loader(self.val_dataset, GroupedBatchSampler(self.val_dataset, self.batch_size, 0, 1,
-                                                                  drop_last=True))
+        return self._loader(self.val_dataset, GroupedBatchSampler(self.val_dataset, self.batch_size, 0, 1, drop_last=True),
+                            collate_fn)

@@ -62,9 +62,11 @@ class GradBucketReducer:
         if self.on_gpu and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works = []
-        # any bucket whose groups never fired (e.g. exception) is reduced now so ranks stay in step
+        # every bucket must have been reduced by now: a bucket with tags still pending means this rank would step on
+        # local, un-averaged gradients while its peers wait in an all-reduce - fail loudly instead
         for i, (tags, lo, hi) in enumerate(self.buckets):
-            if self._pending[i] and len(self._pending[i]) != len(tags):
-                raise RuntimeError("backward finished with a partially reduced bucket: %s" % sorted(self._pending[i]))
+            if self._pending[i] and self.world > 1:
+                raise RuntimeError("backward finished without reducing bucket %d (pending parameter groups: %s)"
+                                   % (i, sorted(self._pending[i])))
             self._pending[i] = set(tags)
         return 1.0 / self.world

@@ -30,6 +30,7 @@ class _TCond(nn.Module):
 
 class FlowBSRNNCore(BSRNNCore):
     back_tag = "gd"
+    band_groups = ("bsx", "bsy", "gdm", "gdr")
 
     def __init__(self, input_dim=769, num_channel=384, num_layer=6, compute_dtype=torch.bfloat16):
         super().__init__(input_dim, num_channel, num_layer, 48000, False, 1, compute_dtype)
@@ -220,6 +221,7 @@ class FlowBSRNNCore(BSRNNCore):
         ops.poll_kernel_errors(x_ri.device)      # deferred check (the sampler calls this 15 times: no host stall per call)
         if train:
             anchor = self._flat.new_zeros((), requires_grad=True)
+            self.mark_used_bands(self._band_tables(x_ri.shape[2], self.compute_dtype, x_ri.device)["K"])
             z = _FlowFrontFn.apply(anchor, x_ri, y_ri, self)
             for l in range(self.num_layer):
                 z = _DualPathFn.apply(z, self, l, "t", tembs[l])
@@ -277,8 +279,8 @@ class _FlowLossFn(torch.autograd.Function):
     def backward(ctx, g):
         out = ctx.grad
         ctx.grad = None
-        if float(g) != 1.0:      # upstream scale other than 1 (not used by the training loop): scale in place
-            call("axpby", out.view(-1), out.view(-1), float(g), 0.0, out.numel(), stream_ptr())
+        # the upstream scale (1 in the training loop) is applied on the device: no host sync inside the step
+        call("scale_by_device_scalar", out.view(-1), g.reshape(1).float().contiguous(), out.numel(), stream_ptr())
         return out, None
 
 
@@ -308,12 +310,32 @@ class FlowEMA:
             self.core.param_version += 1
             self.collected = None
 
-    def state_dict(self):
-        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_flat": self.shadow}
+    def state_dict(self, model=None):
+        """torch_ema layout (``shadow_params`` = one tensor per parameter of ``model.parameters()``, in that order; that is
+        what the reference stores under checkpoint['ema'], flow_model.py:96) plus our flat copy."""
+        sd = {"decay": self.decay, "num_updates": self.num_updates, "shadow_flat": self.shadow.detach().cpu(),
+              "collected_params": None}
+        if model is not None:
+            sd["shadow_params"] = [(p.detach() if o is None else self.shadow[o:o + p.numel()].view(p.shape)).cpu().clone()
+                                   for p, o in self._slices(model)]
+        return sd
 
-    def load_state_dict(self, sd):
+    def _slices(self, model):
+        """(parameter, offset of its shadow in the flat buffer | None for the frozen time-embedding frequencies)."""
+        flat = self.core.flat_params
+        lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+        return [(p, (p.data_ptr() - lo) // 4 if lo <= p.data_ptr() < hi else None) for p in model.parameters()]
+
+    def load_state_dict(self, sd, model=None):
         self.decay, self.num_updates = sd["decay"], sd["num_updates"]
-        self.shadow.copy_(sd["shadow_flat"])
+        if "shadow_flat" in sd:
+            self.shadow.copy_(sd["shadow_flat"])
+        elif model is not None and "shadow_params" in sd:       # a checkpoint written by torch_ema itself
+            for (p, o), s in zip(self._slices(model), sd["shadow_params"]):
+                if o is not None:
+                    self.shadow[o:o + p.numel()].copy_(s.reshape(-1))
+        else:
+            raise KeyError("EMA state without shadow parameters")
 
 
 class FlowSEModel(nn.Module):
@@ -330,7 +352,58 @@ class FlowSEModel(nn.Module):
         self.dnn = FlowBSRNNCore(self.n_fft // 2 + 1, g("bsrnn_hidden", 384), g("num_layer", 6), dtype)
         self.ema_decay = g("ema_decay", 0.999)
         self.ema = None
+        self._error_loading_ema = False
         self.logged = {}
+
+    def log(self, name, value, **_):
+        self.logged[name] = value
+
+    # ---- EMA weights for evaluation (flow_model.py:98-113): eval() swaps them in, train() restores ---------------------
+    def train(self, mode=True, no_ema=False):
+        res = super().train(mode)
+        if self.ema is not None and not self._error_loading_ema:
+            if not mode and not no_ema:
+                if self.ema.collected is None:      # (the reference would overwrite its stored copy on a second eval())
+                    self.ema.store()
+                self.ema.copy_to()
+            elif self.ema.collected is not None:
+                self.ema.restore()
+        return res
+
+    def eval(self, no_ema=False):
+        return self.train(False, no_ema=no_ema)
+
+    def on_save_checkpoint(self, checkpoint):
+        if self.ema is None:
+            self.init_ema()
+        checkpoint["ema"] = self.ema.state_dict(self)
+
+    def on_load_checkpoint(self, checkpoint):
+        ema = checkpoint.get("ema", None)
+        if ema is None:
+            self._error_loading_ema = True
+            import warnings
+            warnings.warn("EMA state_dict not found in checkpoint!")
+            return
+        if self.ema is None:
+            self.init_ema()
+        self.ema.load_state_dict(ema, self)
+
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cuda"):
+        """Lightning's ``FlowSEModel.load_from_checkpoint`` as inference.py:33 uses it."""
+        from .config import Config
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        cfg = ck.get("hyper_parameters", {}).get("cfg", None)
+        cfg = Config(**vars(cfg)) if cfg is not None and not isinstance(cfg, Config) else (cfg or Config())
+        model = cls(cfg)
+        sd = ck["state_dict"] if "state_dict" in ck else ck
+        if not any(k.startswith("dnn.") for k in sd):
+            raise KeyError("not a FlowSEModel checkpoint (no dnn.* parameters): %s" % path)
+        model.load_state_dict({k: v for k, v in sd.items() if k.startswith("dnn.")})
+        model = model.to(map_location)
+        model.on_load_checkpoint(ck)
+        return model
 
     # ---- features ----------------------------------------------------------------------------------------------
     def _stft_cfg(self, fs):
@@ -425,8 +498,11 @@ class FlowSEModel(nn.Module):
         clean_speech, noisy_speech, fs, speech_length = batch
         B, C, T = clean_speech.shape
         assert C == 1
-        x0 = self.speech_to_feature_ri(clean_speech.view(B, T), fs, speech_length)
-        y = self.speech_to_feature_ri(noisy_speech.view(B, T), fs, speech_length)
+        clean_speech, noisy_speech = (w.reshape(B, T).float().contiguous() for w in (clean_speech, noisy_speech))
+        for w in (clean_speech, noisy_speech):          # torch.nan_to_num(., nan=0) (:156-157)
+            call("nan_to_num", w, w, w.numel(), stream_ptr())
+        x0 = self.speech_to_feature_ri(clean_speech, fs, speech_length)
+        y = self.speech_to_feature_ri(noisy_speech, fs, speech_length)
         dev = x0.device
         if t is None:
             t = torch.clamp((1 - torch.rand(B, device=dev)) * (self.T_rev - self.t_eps) + self.t_eps, max=self.T_rev)
@@ -436,19 +512,31 @@ class FlowSEModel(nn.Module):
         call("flow_prepare", x0, y, z_ri.contiguous(), t.contiguous().float(), xt, cvf, B, x0[0].numel() // 2,
              float(self.sigma_min), float(self.sigma_max), stream_ptr())
         vf = self.vector_field_ri(xt, t, y)
-        loss = _FlowLossFn.apply(vf, cvf)
-        self.logged["train_loss"] = loss.detach()
+        return _FlowLossFn.apply(vf, cvf)
+
+    def training_step(self, batch, batch_idx=0):
+        loss = self.forward_step(batch)
+        self.log("train_loss", loss.detach())
         return loss
 
-    def training_step(self, batch):
-        return self.forward_step(batch)
+    def validation_step(self, batch, batch_idx=0):
+        """flow_model.py:213-231: the flow loss on the batch, and on batch 0 a 10-step Euler enhancement scored by SI-SNR."""
+        with torch.no_grad():
+            loss = self.forward_step(batch)
+            self.log("val_loss", loss.detach())
+            if batch_idx == 0:
+                clean_speech, noisy_speech, fs, speech_length = batch
+                B, C, T = clean_speech.shape
+                predicted = self.enhance(noisy_speech.reshape(B, T).float(), fs, speech_length, N=10)
+                self.log("sisnr", -ops.si_snr_loss(clean_speech.reshape(B, T).float(), predicted).mean())
+        return {"val_loss": loss.detach(), "loss": loss.detach()}
 
     def configure_optimizers(self):
         core = self.dnn
         opt = ops.FusedClipAdamW(core.flat_params, core.flat_grads, lr=getattr(self.cfg, "learning_rate", 1e-4),
                                  eps=getattr(self.cfg, "adam_epsilon", 1e-8),
                                  weight_decay=getattr(self.cfg, "weight_decay", 1e-6),
-                                 max_norm=getattr(self.cfg, "gradient_clip", 0.5))
+                                 max_norm=getattr(self.cfg, "gradient_clip", 0.5), core=core)
         return [opt], [StepLR(opt, getattr(self.cfg, "lr_step_size", 1), getattr(self.cfg, "lr_gamma", 0.85))]
 
     def optimizer_step(self, optimizer, reducer=None):

@@ -8,29 +8,27 @@ import torch
 
 from . import ops
 from ._lib import call, stream_ptr
-from .config import Config
 from .d_model import SEModel
 from .dataset import read_audio, write_audio
+from .flow_model import FlowSEModel
 
 
 def load_from_checkpoint(path, map_location="cuda"):
-    ck = torch.load(path, map_location="cpu", weights_only=False)
-    cfg = ck.get("hyper_parameters", {}).get("cfg", None)
-    if cfg is None:
-        cfg = Config(model_configs={"num_channel": 196, "num_layer": 6})
-    elif not isinstance(cfg, Config):       # a Lightning checkpoint of the reference pickles its own Config class
-        cfg = Config(**{k: v for k, v in vars(cfg).items()})
-    model = SEModel(cfg)
-    sd = ck["state_dict"] if "state_dict" in ck else ck
-    model.se_model.load_state_dict({k[len("se_model."):] if k.startswith("se_model.") else k: v for k, v in sd.items()})
-    return model.to(map_location)
+    """inference.py:30-33: try the discriminative model, fall back to the flow model."""
+    try:
+        return SEModel.load_from_checkpoint(path, map_location=map_location)
+    except Exception:
+        return FlowSEModel.load_from_checkpoint(path, map_location=map_location)
 
 
 def enhance_file(model, wav_np, sr, device):
     wav = torch.as_tensor(wav_np).float().to(device).view(1, -1)
     length = torch.tensor([wav.shape[-1]])
     with torch.no_grad():
-        enhanced, _ = model.se_model(wav, length, sr)
+        if isinstance(model, SEModel):                       # inference.py:55-58
+            enhanced, _ = model.se_model(wav, length, sr)
+        else:
+            enhanced = model.enhance(wav, sr, length)
         enhanced = enhanced.contiguous()
         scratch = torch.empty(1, dtype=torch.int32, device=enhanced.device)
         call("peak_normalize", enhanced, enhanced.numel(), 0.9, scratch, stream_ptr())

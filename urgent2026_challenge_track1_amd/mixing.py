@@ -148,3 +148,67 @@ def simulate_batch(speech, lens, noise_raw, noise_lens, fs, snr_db, noise_offset
         speech = speech.clone()
     joint_peak_normalise(speech, noisy, noise)
     return speech, noisy, fs, noise
+
+
+def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_early_stops, fs, recipes, skipped=None):
+    """``process_one_sample(on_the_fly=True)`` (simulate_data_from_param.py:440-590) for a batch of raw sources and the
+    recipes ``dataset.draw_recipe`` drew for them (one fs per batch) -> (speech, noisy) f32 [B, L].
+
+    Utterances without an RIR convolve with a unit impulse (exact identity).  ``clipping`` / ``packet_loss`` are applied in
+    each recipe's own order: pass p handles every utterance's p-th augmentation, the others ride along with identity
+    parameters (quantiles 0 / 1, no packets).  ``bandwidth_limitation`` (librosa resamplers), ``codec`` (ffmpeg) and the
+    wind-noise side-chain compressor (ffmpeg) have no device implementation: the recipe still DRAWS them (so the random
+    stream matches the reference) but they are not applied - wind noise is mixed additively at its drawn SNR - and each
+    omission is counted in ``skipped``."""
+    ops.require_cuda(speech, noise_raw)
+    B, L = speech.shape
+    dev = speech.device
+    skipped = {} if skipped is None else skipped
+
+    def count(name):
+        skipped[name] = skipped.get(name, 0) + 1
+    if recipes[0].get("highpass", True):
+        speech = high_pass(speech, lens, fs)
+    noisy = speech
+    if rir is not None and any(n > 0 for n in rir_lens):
+        rir = rir.clone()
+        full, early = [], []
+        for b in range(B):
+            if rir_lens[b] > 0:
+                full.append(int(rir_lens[b]))
+                early.append(min(int(rir_lens[b]), int(rir_early_stops[b])))
+            else:
+                rir[b, 0] = 1.0
+                full.append(1)
+                early.append(1)
+        noisy = add_reverberation(speech, lens, rir, full)
+        speech = add_reverberation(speech, lens, rir, early)
+    for r in recipes:
+        if r.get("wind"):
+            count("wind_noise")
+    noisy, noise = mix_noise(noisy, noise_raw, noise_lens, lens, [float(r["snr"]) for r in recipes],
+                             torch.tensor([int(r.get("noise_offset", 0)) for r in recipes], dtype=torch.int32))
+    todo = []
+    for r in recipes:
+        mine = []
+        for a in r.get("order", []):
+            if a in ("clipping", "packet_loss"):
+                mine.append(a)
+            else:
+                count(a)
+        todo.append(mine)
+    for p in range(max([len(t) for t in todo] or [0])):
+        lo = [recipes[b]["params"]["clipping"]["min_quantile"] if len(todo[b]) > p and todo[b][p] == "clipping" else 0.0
+              for b in range(B)]
+        hi = [recipes[b]["params"]["clipping"]["max_quantile"] if len(todo[b]) > p and todo[b][p] == "clipping" else 1.0
+              for b in range(B)]
+        if any(len(todo[b]) > p and todo[b][p] == "clipping" for b in range(B)):
+            clipping(noisy, lens, lo, hi)
+        idx = [recipes[b]["params"]["packet_loss"]["packet_loss_indices"]
+               if len(todo[b]) > p and todo[b][p] == "packet_loss" else [] for b in range(B)]
+        if any(idx):
+            packet_loss(noisy, fs, idx)
+    if speech.data_ptr() == noisy.data_ptr():
+        speech = speech.clone()
+    joint_peak_normalise(speech, noisy, noise)
+    return speech, noisy

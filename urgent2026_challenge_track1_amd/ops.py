@@ -39,6 +39,23 @@ def timed_call(tname, name, *args):
         call(name, *args)
 
 
+# kernel variants the dispatchers of the library count (include/urse.h: URSE_KV_*)
+KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_ring", "nt_grouped_128", "tn_ring", "tn_ring_t",
+                   "tn_dual", "tn_128", "tn_grouped", "lstm_fwd_stream", "lstm_fwd_wide", "lstm_fwd_cluster",
+                   "lstm_fwd_cluster2", "lstm_bwd_stream16", "lstm_bwd_stream32", "lstm_bwd_cluster", "lstm_bwd_split",
+                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_bwd_ws")
+
+
+def launch_counts(reset=False):
+    """{variant: launches since the last reset}: which kernels the dispatchers actually picked (parity tests of the
+    benchmarked configuration assert on it)."""
+    lib = _lib.load()
+    out = {n: lib.urse_launch_count(i) for i, n in enumerate(KERNEL_VARIANTS)}
+    if reset:
+        lib.urse_launch_counts_reset()
+    return out
+
+
 def _f32c(t):
     return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
 
@@ -383,6 +400,9 @@ TN_BAND_PARTS = None if TN_BAND_PARTS < 0 else TN_BAND_PARTS
 TN_OVERLAP_BAND = os.environ.get("URSE_TN_OVERLAP_BAND", "1") != "0"   # also start deferred wgrads beside the band path's BPTT
 # the wide kernel wins once there are enough 64-sequence workgroups to fill the chip in both directions
 WIDE_MIN_SEQ = int(os.environ.get("URSE_LSTM_WIDE_MIN_SEQ", str(64 * 128)))
+# the cluster forward takes any path whose sequences fit its 18 x 64 capacity; at C2 that is the time path only (the band path
+# has 12,832).  Tests of the C2 kernel set on small batches set this so that the band path skips it as it does at C2.
+BAND_PATH_NO_CLUSTER = os.environ.get("URSE_LSTM_BAND_NO_CLUSTER", "0") == "1"
 
 
 def lstm_fwd_wide(gx, whhb, H, Hp, n_seq, seq_len, inner, outer, stride, save=True):
@@ -442,6 +462,12 @@ def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
     return gates, err
 
 
+# geometry override of the streaming BPTT per path ("t" / "f"): 0 = the library decides from the number of sequences
+# (32-sequence workgroups of 8 waves once there are >= 4096 of them); 2 | 16 forces that geometry - the parity tests of
+# the benchmarked kernel set use it to run the C2 kernels on batches a CPU oracle can follow
+BWD_ROWS16 = {}
+
+
 def lstm_bwd(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride, rows16=0):
     """gates (saved activations) is overwritten with d(pre-activations)."""
     timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_bidir_bwd", dh, dh.stride(0), gates,
@@ -457,7 +483,7 @@ import ctypes as _ct
 
 class _MRL1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, estimate, target, windows, eps, td_weight):
+    def forward(ctx, estimate, target, windows, eps, td_weight, nan_guard=False):
         B, L = estimate.shape
         dev = estimate.device
         loss = torch.empty(B, device=dev, dtype=torch.float32)
@@ -468,24 +494,30 @@ class _MRL1(torch.autograd.Function):
         warr = (_ct.c_int32 * len(windows))(*windows)
         call("mrl1_loss_fwd", target, estimate, loss, G, sums, acc, B, L, warr, len(windows), float(eps),
              float(td_weight), stream_ptr())
-        ctx.saved = (estimate, target, G, sums, eps)
+        ctx.saved = (estimate, target, G, sums, eps, loss if nan_guard else None)
         return loss
 
     @staticmethod
     def backward(ctx, gl):
-        estimate, target, G, sums, eps = ctx.saved
+        estimate, target, G, sums, eps, loss = ctx.saved
         B, L = estimate.shape
         de = torch.empty_like(estimate)
         c1 = torch.empty(B, device=estimate.device, dtype=torch.float64)
-        call("mrl1_loss_bwd", target, estimate, G, sums, _f32c(gl), de, c1, B, L, float(eps), stream_ptr())
+        if loss is None:
+            call("mrl1_loss_bwd", target, estimate, G, sums, _f32c(gl), de, c1, B, L, float(eps), stream_ptr())
+        else:
+            call("mrl1_loss_bwd_guarded", target, estimate, G, sums, _f32c(gl), loss, de, c1, B, L, float(eps), stream_ptr())
         ctx.saved = None
-        return de, None, None, None, None
+        return de, None, None, None, None, None
 
 
-def mr_l1_loss(target, estimate, window_sz=(256, 512, 768, 1024), eps=1e-6, time_domain_weight=0.5):
-    """espnet2 MultiResL1SpecLoss(normalize_variance=True, reduction='sum').forward(target, estimate) -> [B]."""
+def mr_l1_loss(target, estimate, window_sz=(256, 512, 768, 1024), eps=1e-6, time_domain_weight=0.5, nan_guard=False):
+    """espnet2 MultiResL1SpecLoss(normalize_variance=True, reduction='sum').forward(target, estimate) -> [B].
+    nan_guard: the reference's NaN-loss skip (d_model.py:75-77) without a host sync: if any loss[b] is NaN the gradient
+    of the whole batch is zero (the step then runs on zero gradients, as `se_speech.mean() * 0` makes it there)."""
     require_cuda(target, estimate)
-    return _MRL1.apply(_f32c(estimate), _f32c(target), tuple(int(w) for w in window_sz), eps, time_domain_weight)
+    return _MRL1.apply(_f32c(estimate), _f32c(target), tuple(int(w) for w in window_sz), eps, time_domain_weight,
+                       bool(nan_guard))
 
 
 def si_snr_loss(ref, inf):
@@ -500,22 +532,42 @@ def si_snr_loss(ref, inf):
 
 
 class FusedClipAdamW:
-    """clip_grad_norm_(max_norm) + torch.optim.AdamW semantics on flat f32 buffers, one kernel."""
+    """clip_grad_norm_(max_norm) + torch.optim.AdamW semantics on flat f32 buffers, one kernel.
+
+    With ``core`` (a BSRNNCore): parameters that got no gradient this step (the bands above fs/2; on several ranks: the
+    bands NO rank used) are left alone exactly as torch.optim.AdamW leaves parameters whose ``.grad`` is None - no
+    weight decay, no moment decay, no step count (each band keeps its own) - and an update whose gradients came out of a
+    cooperative LSTM kernel that reported a timed-out hand-off is skipped like one with a non-finite norm."""
 
     def __init__(self, flat_params, flat_grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6,
-                 max_norm=0.5):
+                 max_norm=0.5, core=None):
         require_cuda(flat_params, flat_grads)
-        self.p, self.g = flat_params, flat_grads
+        n = flat_params.numel()
+        self.p, self.g = flat_params, flat_grads[:n]
         self.m = torch.zeros_like(flat_params)
         self.v = torch.zeros_like(flat_params)
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.step_count = 0
         self.normsq = torch.zeros(1, device=flat_params.device, dtype=torch.float64)
+        self.core = core
+        if core is not None:
+            dev = flat_params.device
+            self.slot, self.used, self.n_slot = core.slot_map, core.used_flags, core.n_slot
+            assert self.slot.numel() == n and flat_grads.numel() >= n + self.n_slot
+            self.slot_steps = torch.zeros(self.n_slot, dtype=torch.int32, device=dev)
+            self.bias_corr = torch.zeros(self.n_slot, 2, dtype=torch.float32, device=dev)
+            self.skip_flag = kernel_error_flag(dev)
 
     def step(self, grad_scale=1.0, zero_grad=True):
         n = self.p.numel()
         self.step_count += 1
         call("grad_sumsq", self.g, self.normsq, n, stream_ptr())
+        if self.core is not None:
+            call("clip_adamw_step_slots", self.p, self.g, self.m, self.v, n, self.normsq, float(self.max_norm or 0.0),
+                 float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.slot,
+                 self.used, self.slot_steps, self.bias_corr, self.n_slot, self.skip_flag, float(grad_scale), int(zero_grad),
+                 stream_ptr())
+            return
         call("clip_adamw_step", self.p, self.g, self.m, self.v, n, self.normsq, float(self.max_norm or 0.0),
              float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
              self.step_count, float(grad_scale), int(zero_grad), stream_ptr())
@@ -525,10 +577,18 @@ class FusedClipAdamW:
         return self.normsq.sqrt()
 
     def state_dict(self):
-        return {"exp_avg": self.m, "exp_avg_sq": self.v, "step": self.step_count, "lr": self.lr}
+        sd = {"exp_avg": self.m, "exp_avg_sq": self.v, "step": self.step_count, "lr": self.lr}
+        if self.core is not None:
+            sd["slot_steps"] = self.slot_steps
+        return sd
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
         self.lr = float(sd.get("lr", self.lr))
+        if self.core is not None:
+            if "slot_steps" in sd:
+                self.slot_steps.copy_(sd["slot_steps"])
+            else:
+                self.slot_steps.fill_(self.step_count)

@@ -17,32 +17,64 @@ import time
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .config import Config, config_parser
 from .d_model import SEModel
-from .dataset import AudioDataModule
+from .dataset import AudioDataModule, RawMixBatch
 from .ddp import GradBucketReducer
+from .flow_model import FlowSEModel
 
 
 def ckpt_dir(cfg):
     return "./exp/%s/%s/version_%s/checkpoints" % (cfg.train_tag, cfg.train_name, cfg.train_version)
 
 
+def build_model(cfg):
+    """model select of train_se.py:50-53."""
+    return FlowSEModel(cfg) if getattr(cfg, "model_type", "discriminative") == "flowse" else SEModel(cfg)
+
+
+def core_of(model):
+    return model.dnn if isinstance(model, FlowSEModel) else model.se_model.core
+
+
+def model_state(model):
+    """Lightning-shaped parameter names: ``se_model.*`` (SEModel) / ``dnn.*`` (FlowSEModel)."""
+    if isinstance(model, FlowSEModel):
+        return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    return {"se_model." + k: v.detach().cpu().clone() for k, v in model.se_model.state_dict().items()}
+
+
 def save_checkpoint(path, model, opt, sched, epoch, step, val_loss):
-    sd = {"se_model." + k: v.detach().cpu().clone() for k, v in model.se_model.state_dict().items()}
-    torch.save({"state_dict": sd, "hyper_parameters": {"cfg": model.cfg}, "epoch": epoch, "global_step": step,
-                "val_loss": val_loss, "optimizer_states": [{k: (v.cpu() if torch.is_tensor(v) else v)
-                                                            for k, v in opt.state_dict().items()}],
-                "lr_schedulers": [sched.state_dict()], "urse_version": 1}, path)
+    # a cooperative LSTM kernel that timed out leaves garbage gradients (the optimizer skipped that update): never
+    # write a checkpoint past an unexamined error
+    ops.poll_kernel_errors(core_of(model).flat_params.device, sync=True)
+    ck = {"state_dict": model_state(model), "hyper_parameters": {"cfg": model.cfg}, "epoch": epoch, "global_step": step,
+          "val_loss": val_loss, "optimizer_states": [{k: (v.cpu() if torch.is_tensor(v) else v)
+                                                      for k, v in opt.state_dict().items()}],
+          "lr_schedulers": [sched.state_dict()], "urse_version": 1}
+    if hasattr(model, "on_save_checkpoint"):
+        model.on_save_checkpoint(ck)               # FlowSEModel: checkpoint['ema'] (flow_model.py:95-96)
+    torch.save(ck, path)
 
 
 def load_model_state(model, state_dict):
+    ck = state_dict
     if "state_dict" in state_dict:
         state_dict = state_dict["state_dict"]
+    if isinstance(model, FlowSEModel):
+        model.load_state_dict({k: v for k, v in state_dict.items() if k.startswith("dnn.")})
+        if "ema" in ck:
+            model.on_load_checkpoint(ck)
+        return
     sd = {k[len("se_model."):] if k.startswith("se_model.") else k: v for k, v in state_dict.items()}
     model.se_model.load_state_dict(sd)
 
 
-def to_device(batch, dev):
+def to_device(batch, dev, skipped=None):
+    """host batch -> device batch; a dynamic-mixing batch is SIMULATED here, on the device (mixing.simulate_recipes)."""
+    if isinstance(batch, RawMixBatch):
+        return batch.materialise(dev, skipped)
     clean, noisy, fs, lens = batch
     return clean.to(dev, non_blocking=True), noisy.to(dev, non_blocking=True), fs, lens
 
@@ -50,30 +82,48 @@ def to_device(batch, dev):
 def validate(model, loader, dev):
     tot, n = 0.0, 0
     model.eval()
-    for batch in loader:
-        tot += float(model.validation_step(to_device(batch, dev))["loss"])
+    for i, batch in enumerate(loader):
+        tot += float(model.validation_step(to_device(batch, dev), i)["loss"])
         n += 1
     model.train()
     return tot / max(n, 1)
+
+
+def equalise_batch_counts(sampler, world, dev):
+    """GroupedBatchSampler gives ranks different batch counts when a per-fs group does not divide evenly; every rank
+    must run the same number of optimisation steps per epoch (same LR schedule, paired all-reduces, a clean end), so all
+    ranks truncate to the minimum.  (The reference inherits the unevenness and hangs in DDP.)"""
+    sampler.max_batches = None
+    n = torch.tensor([len(sampler)], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(n, op=dist.ReduceOp.MIN)
+    sampler.max_batches = int(n.item())
+    return sampler.max_batches
 
 
 def fit(cfg, max_steps=None, log_every=50):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("URSE_DIST_BACKEND", "nccl") != "nccl":
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("URSE_DIST_BACKEND", "nccl")     # nccl = RCCL; gloo lets ranks share one GPU (tests)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     torch.manual_seed(cfg.seed)
 
-    model = SEModel(cfg)
+    model = build_model(cfg)
     if cfg.init_from != "none":
         load_model_state(model, torch.load(cfg.init_from, map_location="cpu", weights_only=False))
         if rank == 0:
             print("Init param loaded from %s" % cfg.init_from)
     model = model.to(dev)
-    core = model.se_model.core
+    core = core_of(model)
     (opt,), (sched,) = model.configure_optimizers()
     epoch0, step = 0, 0
     os.makedirs(ckpt_dir(cfg), exist_ok=True)
@@ -90,16 +140,20 @@ def fit(cfg, max_steps=None, log_every=50):
     if world > 1:
         dist.broadcast(core.flat_params, 0)
         core.param_version += 1
+    if isinstance(model, FlowSEModel) and model.ema is None:
+        model.init_ema()                       # (after the broadcast: the EMA starts from the shared weights)
     reducer = GradBucketReducer(core) if world > 1 else None
 
     dm = AudioDataModule(cfg, rank, world)
     train_loader, val_loader = dm.train_dataloader(), dm.val_dataloader()
     best = []   # [(val_loss, path)]
     t0 = time.time()
+    skipped = {}                                # augmentations the recipes drew but the device path cannot apply
     for epoch in range(epoch0, cfg.num_train_epochs):
         # the reference never advances the sampler epoch (quirk C.3: on_train_epoch_start is not a DataModule hook)
+        equalise_batch_counts(dm.train_batch_sampler, world, dev)
         for batch in train_loader:
-            loss = model.training_step(to_device(batch, dev))
+            loss = model.training_step(to_device(batch, dev, skipped))
             loss.backward()
             model.optimizer_step(opt, reducer)
             step += 1
@@ -120,6 +174,8 @@ def fit(cfg, max_steps=None, log_every=50):
             if max_steps is not None and step >= max_steps:
                 return model, step
         sched.step()
+    if rank == 0 and skipped:
+        print("augmentations drawn but not applied on the device path: %s" % skipped, flush=True)
     return model, step
 
 
@@ -129,8 +185,6 @@ def main(argv=None):
     cfg.read_yaml()
     if int(os.environ.get("RANK", "0")) == 0:
         print(vars(cfg))
-    if getattr(cfg, "model_type", "discriminative") == "flowse":
-        raise NotImplementedError("FlowSEModel training is driven through flow_model.py")
     fit(cfg)
     if dist.is_initialized():
         dist.destroy_process_group()
