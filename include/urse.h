@@ -373,6 +373,19 @@ int urse_flow_loss(const float* vf, const float* cvf, double* loss, float* grad,
 /* torch_ema update: shadow -= one_minus_decay * (shadow - params). */
 int urse_ema_update(float* shadow, const float* params, float one_minus_decay, int64_t n, void* stream);
 
+/* ---- PESQ ----------------------------------------------------------------------------------------------------------------
+ * evaluation_metrics/calculate_intrusive_se_metrics.py:52-88 pesq_metric -> pesq.pesq(fs, ref, deg, mode, on_error=RETURN_VALUES):
+ * ITU-T P.862 with the P.862.1 ('nb', fs 8000) / P.862.2 ('wb', fs 16000) MOS-LQO mapping.  One workgroup per pair.
+ * ref, deg f32 [pairs, L] (row pitch ld), lens int32 [pairs] or NULL (= L).  mos f32 [pairs]: MOS-LQO, NaN where the
+ * reference returns NO_UTTERANCES_DETECTED; raw f32 [pairs] (may be NULL): the raw P.862 score.  trace int32 [pairs, 286]:
+ * the integer outputs of the alignment stages {crude delay, utterances, first / last frame, bad intervals, 0, 0, 0,
+ * utterance start[50], end[50], delay[50], bad-interval (first, last) frame[64]} - what "bit-exact through the integer
+ * stage" is checked on.  workspace: urse_pesq_workspace_bytes(pairs, L, fs) bytes of device memory. */
+#define URSE_PESQ_TRACE 286
+int urse_pesq_workspace_bytes(int pairs, int L, int fs, int64_t* bytes);
+int urse_pesq_batch(const float* ref, const float* deg, int64_t ld, const int32_t* lens, int pairs, int L, int fs, int wb,
+                    float* mos, float* raw, int32_t* trace, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,7 +69,9 @@ def test_sdr_matches_oracle(lib, L):
 
 
 def test_metrics_driver_files(lib, tmp_path):
-    """scp in -> {METRIC}.scp + RESULTS.txt out, same formats as the reference script."""
+    """scp in -> PESQ.scp + ESTOI.scp + RESULTS.txt out, same formats and METRICS = ("PESQ", "ESTOI") as the reference script;
+    two ranks splitting the pairs i % world write the same files as one."""
+    from oracle import pesq_ref
     from urgent2026_challenge_track1_amd import calculate_intrusive_se_metrics as drv
     from urgent2026_challenge_track1_amd.dataset import write_audio
     ref, inf = _pairs(3, 20000, 16000, 9)
@@ -79,11 +81,22 @@ def test_metrics_driver_files(lib, tmp_path):
             write_audio(str(tmp_path / ("i%d.wav" % p)), inf[p], 16000, "FLOAT")
             fr.write("utt%d %s\n" % (p, tmp_path / ("r%d.wav" % p)))
             fi.write("utt%d %s\n" % (p, tmp_path / ("i%d.wav" % p)))
-    drv.main(drv.parser().parse_args(["--ref_scp", str(tmp_path / "ref.scp"), "--inf_scp", str(tmp_path / "inf.scp"),
-                                      "--output_dir", str(tmp_path / "out")]))
+    base = ["--ref_scp", str(tmp_path / "ref.scp"), "--inf_scp", str(tmp_path / "inf.scp")]
+    drv.main(drv.parser().parse_args(base + ["--output_dir", str(tmp_path / "out")]))
     lines = (tmp_path / "out" / "ESTOI.scp").read_text().strip().split("\n")
     assert [l.split()[0] for l in lines] == ["utt0", "utt1", "utt2"]
     exp = [metrics_ref.estoi(ref[p], inf[p], 16000) for p in range(3)]
     assert max(abs(float(l.split()[1]) - e) for l, e in zip(lines, exp)) <= 1e-4
-    res = (tmp_path / "out" / "RESULTS.txt").read_text()
-    assert res.startswith("ESTOI: %.4f\n" % np.mean(exp)) and "SDR: " in res
+    plines = (tmp_path / "out" / "PESQ.scp").read_text().strip().split("\n")
+    pexp = [pesq_ref.pesq(16000, ref[p], inf[p], "wb") for p in range(3)]
+    assert max(abs(float(l.split()[1]) - e) for l, e in zip(plines, pexp)) <= 2e-3
+    res = (tmp_path / "out" / "RESULTS.txt").read_text().split("\n")
+    assert res[0].startswith("PESQ: ") and abs(float(res[0].split()[1]) - np.mean(pexp)) <= 2e-3
+    assert res[1] == "ESTOI: %.4f" % np.mean(exp)
+    # the same pairs split over two processes (rank 1 first, rank 0 merges)
+    for rank in (1, 0):
+        drv.main(drv.parser().parse_args(base + ["--output_dir", str(tmp_path / "out2"), "--rank", str(rank), "--world", "2",
+                                                 "--metrics", "PESQ", "ESTOI", "SDR"]))
+    for m in ("PESQ", "ESTOI"):
+        assert (tmp_path / "out2" / ("%s.scp" % m)).read_text() == (tmp_path / "out" / ("%s.scp" % m)).read_text()
+    assert "SDR: " in (tmp_path / "out2" / "RESULTS.txt").read_text()

@@ -93,6 +93,79 @@ def sdr_batch(ref, inf, clamp_db=50.0):
     return out
 
 
+PESQ_TRACE = 286      # include/urse.h URSE_PESQ_TRACE
+
+
+def _poly_resample(x, fs_in, fs_out):
+    """scipy.signal.resample_poly(x, up, down) with its default Kaiser(5.0) design, on the batched polyphase kernel.  Stands
+    in for ``soxr.resample(x, fs, 16000)`` of pesq_metric (:69-70): libsoxr's HQ filter is not reproducible bit-wise
+    (SURVEY 8c), a polyphase low-pass at the same cutoff is what can be restated."""
+    from scipy.signal import firwin
+    require_cuda(x)
+    x = x.contiguous().float()
+    P, L = x.shape
+    g = math.gcd(int(fs_in), int(fs_out))
+    up, down = int(fs_out) // g, int(fs_in) // g
+    key = ("poly", up, down, L, x.device)
+    if key not in _cache:
+        mx = max(up, down)
+        half_len = 10 * mx
+        h = firwin(2 * half_len + 1, 1.0 / mx, window=("kaiser", 5.0)) * up
+        n_pre_pad = down - half_len % down
+        n_pre_remove = (half_len + n_pre_pad) // down
+        n_out = L * up // down + (1 if (L * up) % down else 0)
+        hp = np.concatenate([np.zeros(n_pre_pad), h])
+        _cache[key] = (torch.from_numpy(hp).to(x.device), len(hp), n_pre_remove, n_out)
+    hp, hlen, npr, n_out = _cache[key]
+    y = torch.empty(P, n_out, device=x.device, dtype=torch.float32)
+    call("resample_poly", x, y, hp, hlen, P, L, n_out, up, down, npr, stream_ptr())
+    return y
+
+
+def pesq_batch(ref, inf, fs, mode=None, lens=None, return_trace=False, max_pairs_per_launch=512):
+    """PESQ (MOS-LQO) of P pairs f32 [P, L] -> f32 [P]; NaN where pesq.pesq returns NO_UTTERANCES_DETECTED (pesq_metric maps
+    that to None / nan, :81-88, :160-162).  mode None = the rule of pesq_metric: 'nb' at 8 kHz, 'wb' at 16 kHz, higher rates
+    are resampled to 16 kHz first.  return_trace: also the integer outputs of the alignment stages, int32 [P, 286]."""
+    require_cuda(ref, inf)
+    assert ref.shape == inf.shape and ref.dim() == 2
+    fs = int(fs)
+    if mode is None:
+        if fs == 8000:
+            mode = "nb"
+        elif fs >= 16000:
+            mode = "wb"
+        else:
+            raise ValueError("sample rate must be 8000 or 16000+ for PESQ evaluation, but got %d" % fs)
+    if fs > 16000:
+        ref, inf = _poly_resample(ref, fs, 16000), _poly_resample(inf, fs, 16000)
+        if lens is not None:
+            lens = (torch.as_tensor(lens).long() * 16000 + fs - 1) // fs
+        fs = 16000
+    ref, inf = ref.contiguous().float(), inf.contiguous().float()
+    P, L = ref.shape
+    dev = ref.device
+    if lens is not None:
+        lens = torch.as_tensor(lens).to(device=dev, dtype=torch.int32).contiguous()
+    mos = torch.empty(P, device=dev, dtype=torch.float32)
+    raw = torch.empty(P, device=dev, dtype=torch.float32)
+    trace = torch.zeros(P, PESQ_TRACE, device=dev, dtype=torch.int32)
+    import ctypes
+    nbytes = ctypes.c_int64()
+    chunk = min(P, max_pairs_per_launch)
+    lib = __import__("urgent2026_challenge_track1_amd._lib", fromlist=["load"]).load()
+    if lib.urse_pesq_workspace_bytes(chunk, L, fs, ctypes.addressof(nbytes)) != 0:
+        raise RuntimeError(lib.urse_last_error().decode())
+    key = ("pesq_ws", dev)
+    if key not in _cache or _cache[key].numel() < nbytes.value:
+        _cache[key] = torch.empty(nbytes.value, device=dev, dtype=torch.uint8)
+    ws = _cache[key]
+    for p0 in range(0, P, chunk):
+        n = min(chunk, P - p0)
+        call("pesq_batch", ref[p0:], inf[p0:], ref.stride(0), None if lens is None else lens[p0:], n, L, fs,
+             1 if mode == "wb" else 0, mos[p0:], raw[p0:], trace[p0:], ws, ws.numel(), stream_ptr())
+    return (mos, raw, trace) if return_trace else mos
+
+
 # ---- the reference's per-pair functions ----------------------------------------------------------------------
 def _dev(x, device="cuda"):
     return torch.as_tensor(np.asarray(x, dtype=np.float32)).reshape(1, -1).to(device)
@@ -100,6 +173,13 @@ def _dev(x, device="cuda"):
 
 def estoi_metric(ref, inf, fs=16000):
     return float(estoi_batch(_dev(ref), _dev(inf), fs)[0])
+
+
+def pesq_metric(ref, inf, fs=8000):
+    """-> MOS-LQO, or None when no utterance is detected (calculate_intrusive_se_metrics.py:52-88)."""
+    assert np.shape(ref) == np.shape(inf)
+    v = float(pesq_batch(_dev(ref), _dev(inf), fs)[0])
+    return None if math.isnan(v) else v
 
 
 def sdr_metric(ref, inf):
