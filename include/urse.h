@@ -68,6 +68,7 @@ const char* urse_last_error(void);
 #define URSE_KV_ISTFT_GENERIC 21
 #define URSE_KV_ISTFT960 22
 #define URSE_KV_LSTM_BWD_WS 23     /* weight-stationary cluster BPTT (lstm_bwd_ws.hip) */
+#define URSE_KV_LSTM_FWD_CLUSTER_X 24 /* cluster forward with the input projection fused in */
 #define URSE_KV_COUNT 32
 int urse_launch_count(int variant);
 int urse_launch_counts_reset(void);
@@ -185,6 +186,15 @@ int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan);
 int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                           void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
                           int64_t outer, int64_t stride, int save, void* stream);
+/* The same recurrence with the layer's INPUT PROJECTION fused in (N = 196 / H = 392 geometry: Np = 224, Hp = 416): xin = the
+ * normalised layer input [M, ldx] bf16 (K padded to Np), wihq = urse_lstm_pack_ih_quads(W_ih), bias = b_ih + b_hh in the
+ * gate-interleaved order (urse_lstm_pack's `bias`).  x_t W_ih^T + b is accumulated in f32 together with h_{t-1} W_hh^T, the
+ * [M, 8H] pre-activation matrix is never written or read; `gates` receives the gate activations when save != 0. */
+int urse_lstm_pack_ih_quads(const float* wih, void* out, int N, int Np, int H, void* stream);
+int urse_lstm_cluster_fwd_x(const void* xin, int64_t ldx, const void* wihq, const float* bias, void* gates, int64_t ldg,
+                            const void* whhq, void* hout, int64_t ldh, float* c, void* hx, void* err_flag, int Np, int H,
+                            int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
+                            void* stream);
 /* Generalised cluster forward (csrc/lstm_cluster2.hip): same protocol and arguments, geometry chosen per hidden size
  * (H = 768, the flow model: 24 workgroups per cluster; H = 392: 7).  plan = {C, clusters per direction, rows per cluster,
  * hx bf16 elements}; hx is zeroed by the call; whhq from urse_lstm_pack_quads. */
@@ -385,6 +395,18 @@ int urse_ema_update(float* shadow, const float* params, float one_minus_decay, i
 int urse_pesq_workspace_bytes(int pairs, int L, int fs, int64_t* bytes);
 int urse_pesq_batch(const float* ref, const float* deg, int64_t ld, const int32_t* lens, int pairs, int L, int fs, int wb,
                     float* mos, float* raw, int32_t* trace, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- FLAC decoding (HOST code, HOST pointers) -------------------------------------------------------------------
+ * soundfile.read behind baseline_code/dataset.py:318-322 and simulation/simulate_data_from_param.py:347-349 (libsndfile is
+ * not in the image; URGENT sources are largely FLAC).  info int64 [6] = {fs, channels, bits, total frames | 0, min block,
+ * max block}; urse_flac_decode writes interleaved int32 samples [capacity_frames, channels] and the number of frames. */
+int urse_flac_info(const void* data, int64_t nbytes, int64_t* info);
+int urse_flac_decode(const void* data, int64_t nbytes, int32_t* out, int64_t capacity_frames, int64_t* decoded);
+
+/* ---- diagnostics (not on the product path) ----------------------------------------------------------------------
+ * streams `bytes` of `buf` with `width`-byte (4 | 8 | 16) per-lane reads (write = 0) or writes (write = 1): a known byte
+ * count to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters per access width (scripts/pmc_calibrate.py). */
+int urse_diag_stream(void* buf, float* sink, int64_t bytes, int width, int write, void* stream);
 
 #ifdef __cplusplus
 }

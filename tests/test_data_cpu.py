@@ -125,3 +125,67 @@ def test_mix_oracle_equals_the_reference_simulator():
     stop = early_rir_stop(rir, fs)
     assert np.array_equal(np.where(np.arange(rir.shape[1]) < stop, rir, 0.0), GOLD["early_rir"])
     assert np.array_equal(filter_designs(48000), GOLD["hp_taps_48000"])
+
+
+def _speechy(rng, n, ch, bits):
+    x = np.cumsum(rng.standard_normal((n, ch)), axis=0)
+    x = x / np.abs(x).max() * (0.7 * (1 << (bits - 1)))
+    return np.round(x).astype(np.int64)
+
+
+def test_flac_decoder_reads_every_subframe_and_stereo_mode(tmp_path):
+    """the library's host-side FLAC decoder (csrc/flac.hip) against streams written by tests/flac_writer.py: every subframe
+    type, Rice with 4- / 5-bit parameters, partition orders, an escape partition, wasted bits, all stereo decorrelations,
+    16- and 24-bit, an odd last block.  (No FLAC file or encoder exists in the image: encoder and decoder both follow the
+    published format specification; agreement is self-consistency, not a pin against libFLAC.)"""
+    from tests import flac_writer as fw
+    from urgent2026_challenge_track1_amd.audio_io import audio_frames, read_audio
+    from urgent2026_challenge_track1_amd.flac import decode_flac
+    rng = np.random.default_rng(0)
+    # mono, 16 bit
+    x = _speechy(rng, 4096 + 1152 + 256 + 192 + 100, 1, 16)
+    x[4096 + 1152:4096 + 1152 + 256] = 1234                          # a constant block
+    x[4096 + 1152 + 256:4096 + 1152 + 256 + 192] &= ~0x7                # three wasted bits
+    frames = [(4096, "indep", [("fixed2", dict(method=0, part_order=3))]),
+              (1152, "indep", [("lpc", dict(coefs=[1700, -700], shift=10, prec=12, method=1, part_order=2, escape_part=1))]),
+              (256, "indep", [("constant", {})]),
+              (192, "indep", [("fixed1", dict(wasted=3, method=0, part_order=0))]),
+              (100, "indep", [("verbatim", {})])]
+    data = fw.encode(x, 16000, 16, frames)
+    y, fs = decode_flac(data)
+    assert fs == 16000 and y.shape == (len(x), 1) and np.array_equal(np.round(y[:, 0] * 32768).astype(np.int64), x[:, 0])
+    # stereo, 24 bit, every channel mode and the remaining fixed orders
+    s = _speechy(rng, 4 * 576 + 77, 2, 24)
+    s[:, 1] = s[:, 0] // 2 + _speechy(rng, len(s), 1, 24)[:, 0] // 8
+    frames = [(576, "mid_side", [("fixed4", dict(method=0, part_order=2)), ("fixed3", dict(method=0, part_order=0))]),
+              (576, "left_side", [("fixed0", dict(method=1, part_order=1)), ("fixed2", dict(method=0, part_order=1))]),
+              (576, "right_side", [("fixed1", dict(method=0, part_order=0)), ("verbatim", {})]),
+              (576, "indep", [("fixed3", dict(method=0, part_order=4)), ("lpc", dict(coefs=[900, 60, -100], shift=10, prec=11, method=0,
+                                                                                       part_order=0))]),
+              (77, "mid_side", [("fixed1", dict(method=0, part_order=0)), ("fixed1", dict(method=0, part_order=0))])]
+    data = fw.encode(s, 48000, 24, frames)
+    y, fs = decode_flac(data)
+    assert fs == 48000 and np.array_equal(np.round(y * (1 << 23)).astype(np.int64), s)
+    # through the file API the datasets use
+    p = tmp_path / "a.flac"
+    p.write_bytes(data)
+    z, fs2 = read_audio(str(p))
+    assert fs2 == 48000 and z.shape == (1, len(s)) and np.array_equal(z[0], y[:, 0]) and audio_frames(str(p)) == len(s)
+
+
+def test_wav_reader_agrees_with_scipy(tmp_path):
+    from scipy.io import wavfile
+    from urgent2026_challenge_track1_amd.audio_io import audio_frames, read_audio
+    rng = np.random.default_rng(1)
+    x16 = (rng.standard_normal((3000, 2)) * 8000).astype(np.int16)
+    wavfile.write(str(tmp_path / "s16.wav"), 22050, x16)
+    y, fs = read_audio(str(tmp_path / "s16.wav"))
+    assert fs == 22050 and np.array_equal(y[0], x16[:, 0].astype(np.float32) / 32768.0) and audio_frames(str(tmp_path / "s16.wav")) == 3000
+    xf = rng.standard_normal(2000).astype(np.float32) * 0.1
+    wavfile.write(str(tmp_path / "f32.wav"), 48000, xf)
+    y, fs = read_audio(str(tmp_path / "f32.wav"))
+    assert fs == 48000 and np.array_equal(y[0], xf)
+    x32 = (rng.standard_normal(1000) * 1e8).astype(np.int32)
+    wavfile.write(str(tmp_path / "s32.wav"), 8000, x32)
+    y, fs = read_audio(str(tmp_path / "s32.wav"))
+    assert np.array_equal(y[0], x32.astype(np.float32) / 2147483648.0)
