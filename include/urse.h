@@ -68,7 +68,6 @@ const char* urse_last_error(void);
 #define URSE_KV_ISTFT_GENERIC 21
 #define URSE_KV_ISTFT960 22
 #define URSE_KV_LSTM_BWD_WS 23     /* weight-stationary cluster BPTT (lstm_bwd_ws.hip) */
-#define URSE_KV_LSTM_FWD_CLUSTER_X 24 /* cluster forward with the input projection fused in */
 #define URSE_KV_COUNT 32
 int urse_launch_count(int variant);
 int urse_launch_counts_reset(void);
@@ -186,15 +185,6 @@ int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan);
 int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                           void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
                           int64_t outer, int64_t stride, int save, void* stream);
-/* The same recurrence with the layer's INPUT PROJECTION fused in (N = 196 / H = 392 geometry: Np = 224, Hp = 416): xin = the
- * normalised layer input [M, ldx] bf16 (K padded to Np), wihq = urse_lstm_pack_ih_quads(W_ih), bias = b_ih + b_hh in the
- * gate-interleaved order (urse_lstm_pack's `bias`).  x_t W_ih^T + b is accumulated in f32 together with h_{t-1} W_hh^T, the
- * [M, 8H] pre-activation matrix is never written or read; `gates` receives the gate activations when save != 0. */
-int urse_lstm_pack_ih_quads(const float* wih, void* out, int N, int Np, int H, void* stream);
-int urse_lstm_cluster_fwd_x(const void* xin, int64_t ldx, const void* wihq, const float* bias, void* gates, int64_t ldg,
-                            const void* whhq, void* hout, int64_t ldh, float* c, void* hx, void* err_flag, int Np, int H,
-                            int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
-                            void* stream);
 /* Generalised cluster forward (csrc/lstm_cluster2.hip): same protocol and arguments, geometry chosen per hidden size
  * (H = 768, the flow model: 24 workgroups per cluster; H = 392: 7).  plan = {C, clusters per direction, rows per cluster,
  * hx bf16 elements}; hx is zeroed by the call; whhq from urse_lstm_pack_quads. */

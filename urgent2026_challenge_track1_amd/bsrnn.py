@@ -359,7 +359,6 @@ class BSRNNCore(nn.Module):
                 pk[p + "whh"], pk[p + "whhT"] = lp["whh"], lp["whhT"]
                 pk[p + "whhq"], pk[p + "whhTq"] = lp.get("whhq"), lp.get("whhTq")
                 pk[p + "whhb"] = lp.get("whhb")
-                pk[p + "wihq"] = lp.get("wihq")
         self._packed = pk
         self._packed_version = self.param_version
 
@@ -463,19 +462,8 @@ class BSRNNCore(nn.Module):
         M = B * T * K
         xn, stats = ops.groupnorm_fwd(skip, self._p(p + "gamma", N), self._p(p + "beta", N), B, T, 1, K * N, N,
                                       d["Np"], 0, dt, GN_EPS, add=temb)
-        sm = self._seqmap(path, B, T, K)
-        fuse = (ops.FUSE_CLUSTER_PROJECTION and ops.USE_CLUSTER_LSTM and pk.get(p + "wihq") is not None and
-                pk.get(p + "whhq") is not None and H not in ops.CLUSTER2_H and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
-                ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None)
-        if fuse:
-            # time path at C2: x_t W_ih^T is accumulated inside the recurrence, the [M, 8H] pre-activations never exist
-            hout, c, gx, err = ops.lstm_fwd_cluster_x(xn, pk[p + "wihq"], pk[p + "bias"], pk[p + "whhq"], d["Np"], H, d["Hp"],
-                                                      save=save, **sm)
-            self._cluster_err = err
-            out = torch.empty_like(skip)
-            ops.gemm_nt(hout, pk[p + "wfc"], self._p(p + "bfc", N), resid=skip.view(M, N), out=out.view(M, N))
-            return out, ((stats, xn, gx, c, hout) if save else None)
         gx = ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
+        sm = self._seqmap(path, B, T, K)
         if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H in ops.CLUSTER2_H and \
                 ops.lstm_cluster2_plan(H, d["Hp"], sm["n_seq"]) is not None:
             hout, c, err = ops.lstm_fwd_cluster2(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)

@@ -26,9 +26,6 @@ constexpr int UW = CW * 4;        // hidden units per workgroup (56)
 
 struct ClusterArgs {
   void* gx; long ldg;
-  const void* xin; long ldx;      // fused input projection (XSLAB > 0): layer input [M, ldx] bf16, K padded to 32 * XSLAB
-  const void* wihq;               // [2][nq][XSLAB][64][16 B] quad-ordered W_ih fragments
-  const float* bias;              // [2 * 4H] b_ih + b_hh, gate-interleaved (unit * 4 + gate)
   const void* whhq;               // [2][nq][NSLAB][64][16 B] quad-ordered fragments
   void* hout; long ldh;
   float* c;
@@ -67,11 +64,7 @@ __device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned of
   return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
-// XSLAB > 0 fuses the layer's input projection into the recurrence: the workgroup also keeps its 224 columns of W_ih in
-// registers (XSLAB fragments per wave), the step's 64 input rows are prefetched one step ahead, staged in LDS as a second
-// MFMA A tile, and x_t W_ih^T + b is accumulated in f32 with h_{t-1} W_hh^T.  The [M, 8H] pre-activation matrix (2.74 GB
-// written by a GEMM and read back here at C2) is never formed; the gates buffer is only written (for BPTT).
-template <int NSLAB, int MAXCH, int XSLAB>
+template <int NSLAB, int MAXCH>
 __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
@@ -79,10 +72,8 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   const int cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
   const int H = p.H;
   constexpr int Hp = NSLAB * 32, pitch = lds_frag_pitch(Hp * 2);      // compile-time: the index arithmetic below folds to shifts / multiplies
-  constexpr int XP = XSLAB > 0 ? XSLAB * 32 : 32, xpitch = lds_frag_pitch(XP * 2);
   char* htile = smem;                                    // [CROWS][pitch]
   bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + CROWS * pitch);   // [CROWS][UW]
-  char* xtile = smem + CROWS * pitch + CROWS * UW * 2 + 16;           // [CROWS][xpitch] (XSLAB > 0)
   const int nq = (H + 3) >> 2;
   const int qd = j * CW + w;                             // this wave's unit quad
   const bool qvalid = qd < nq;
@@ -96,15 +87,6 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
     const char* src = reinterpret_cast<const char*>(p.whhq) + (((long)dir * nq + (qvalid ? qd : 0)) * NSLAB) * 1024 + lane * 16;
 #pragma unroll
     for (int ks = 0; ks < NSLAB; ++ks) breg[ks] = *reinterpret_cast<const uint4*>(src + ks * 1024);
-  }
-  uint4 xreg[XSLAB > 0 ? XSLAB : 1];                     // resident W_ih fragments
-  float bq[4] = {0.f, 0.f, 0.f, 0.f};                    // bias of this lane's (unit, gate 0..3) after the quad transpose
-  if constexpr (XSLAB > 0) {
-    const char* src = reinterpret_cast<const char*>(p.wihq) + (((long)dir * nq + (qvalid ? qd : 0)) * XSLAB) * 1024 + lane * 16;
-#pragma unroll
-    for (int ks = 0; ks < XSLAB; ++ks) xreg[ks] = *reinterpret_cast<const uint4*>(src + ks * 1024);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bq[g] = p.bias[dir * 4 * H + uc * 4 + g];
   }
   for (int i = tid; i < CROWS * UW / 2; i += CTHR) reinterpret_cast<unsigned*>(hstage)[i] = 0u;   // pad units stay 0
   float cst[MAXCH][4];
@@ -153,32 +135,8 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
       dst[rt] = *reinterpret_cast<const uint2*>(gx + ((long)(rowb[rt] + toff) * ldg_i + (gcol_i + uc * 4)));
   };
   uint2 gxn[4];                                          // gate pre-activations, prefetched one step ahead
-  // fused projection: the cluster's 64 input rows of a step = CROWS * XP / 8 chunks of 16 B, two per thread
-  constexpr int XCPR = XP * 2 / 16, XL = (CROWS * XCPR + CTHR - 1) / CTHR;
-  const bf16_t* xin = reinterpret_cast<const bf16_t*>(p.xin);
-  const int ldx_i = (int)p.ldx;
-  int xrow[XL], xcc[XL];
-  uint4 xn[XL];
-#pragma unroll
-  for (int i = 0; i < XL; ++i) {
-    const int idx = tid + i * CTHR;
-    const int row = idx / XCPR;
-    xcc[i] = idx - row * XCPR;
-    int seq = seq0 + (row < CROWS ? row : 0);
-    if (seq >= p.n_seq) seq = p.n_seq - 1;
-    xrow[i] = (idx < CROWS * XCPR && row < nrows) ? (int)((seq / p.inner) * p.outer + (seq % p.inner)) : -1;
-    xn[i] = make_uint4(0, 0, 0, 0);
-  }
-  auto load_x = [&](int toff) {
-#pragma unroll
-    for (int i = 0; i < XL; ++i)
-      if (xrow[i] >= 0) xn[i] = *reinterpret_cast<const uint4*>(xin + ((long)(xrow[i] + toff) * ldx_i + xcc[i] * 8));
-  };
-  if constexpr (XSLAB > 0) load_x((dir ? p.seq_len - 1 : 0) * stride_i);
-  else load_gx(0, (dir ? p.seq_len - 1 : 0) * stride_i, gxn);
+  load_gx(0, (dir ? p.seq_len - 1 : 0) * stride_i, gxn);
   unsigned* deadflag = reinterpret_cast<unsigned*>(smem + CROWS * pitch + CROWS * UW * 2);
-  if constexpr (XSLAB > 0)                               // rows beyond the cluster's sequences stay zero
-    for (int i = tid; i < CROWS * xpitch / 16; i += CTHR) reinterpret_cast<uint4*>(xtile)[i] = make_uint4(0, 0, 0, 0);
   if (tid == 0) *deadflag = 0u;
   const int hchunks = H / 8;                             // 16-byte chunks of a row that carry data (H % 8 == 0)
   constexpr unsigned TAGM = 0x40004000u;                 // bit 14 of both bf16 halves: always 0 in |h| <= 1
@@ -246,19 +204,9 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
     uint2 gxc[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) gxc[rt] = gxn[rt];
-    if constexpr (XSLAB > 0) {                             // this step's input rows -> LDS (A tile of the projection)
-#pragma unroll
-      for (int i = 0; i < XL; ++i) {
-        const int idx = tid + i * CTHR;
-        if (idx < CROWS * XCPR) *reinterpret_cast<uint4*>(xtile + (idx / XCPR) * xpitch + xcc[i] * 16) = xn[i];
-      }
-    }
     __syncthreads();
-    // prefetch the gate pre-activations / input rows of the next step (independent of the recurrence)
-    if (step + 1 < p.seq_len) {
-      if constexpr (XSLAB > 0) load_x((dir ? t - 1 : t + 1) * stride_i);
-      else load_gx(0, (dir ? t - 1 : t + 1) * stride_i, gxn);
-    }
+    // prefetch the gate pre-activations of the next step (independent of the recurrence)
+    if (step + 1 < p.seq_len) load_gx(0, (dir ? t - 1 : t + 1) * stride_i, gxn);
     // 2. gates for (64 rows) x (this wave's quad)
     uint2 gsave[4];
     float csave[4];
@@ -272,15 +220,6 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                       __builtin_bit_cast(bf16x8_t, breg[ks]), acc, 0, 0, 0);
       }
-      if constexpr (XSLAB > 0) {
-        const char* xr = xtile + (rt * 16 + lc) * xpitch + 16 * lr;
-#pragma unroll
-        for (int ks = 0; ks < XSLAB; ++ks) {
-          const uint4 a = *reinterpret_cast<const uint4*>(xr + ks * 64);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                        __builtin_bit_cast(bf16x8_t, xreg[ks]), acc, 0, 0, 0);
-        }
-      }
       // acc[r] = gate (lc & 3) of unit (lc >> 2), row rt*16 + lr*4 + r.  4x4 transpose inside the lane quad
       float pre[4];
 #pragma unroll
@@ -289,14 +228,9 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
                     v3 = quad_bcast(acc[3], g);
         pre[g] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
       }
-      float gi, gf, gg, go;
-      if constexpr (XSLAB > 0) {
-        gi = pre[0] + bq[0]; gf = pre[1] + bq[1]; gg = pre[2] + bq[2]; go = pre[3] + bq[3];
-      } else {
-        const uint2 gxv = gxc[rt];
-        gi = pre[0] + __uint_as_float(gxv.x << 16); gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
-        gg = pre[2] + __uint_as_float(gxv.y << 16); go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
-      }
+      const uint2 gxv = gxc[rt];
+      const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
+      const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
       const float iv = sigmoidf_(gi), fv = sigmoidf_(gf), gv = tanhf_(gg), ov = sigmoidf_(go);
       const float cv = fv * cst[ch][rt] + iv * gv;
       cst[ch][rt] = cv;
@@ -571,15 +505,14 @@ __global__ void __launch_bounds__(256) lstm_pack_bwd_quads_kernel(const float* _
   }
 }
 
-template <int NSLAB, int MAXCH, int XSLAB = 0>
+template <int NSLAB, int MAXCH>
 static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH, XSLAB>),
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  size_t lds = (size_t)CROWS * lds_frag_pitch(p.Hp * 2) + (size_t)CROWS * UW * 2 + 16;
-  if (XSLAB > 0) lds += (size_t)CROWS * lds_frag_pitch(XSLAB * 64);
+  const size_t lds = (size_t)CROWS * lds_frag_pitch(p.Hp * 2) + (size_t)CROWS * UW * 2 + 16;
   dim3 grid(p.C * p.ncl, 2);
-  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH, XSLAB>), grid, dim3(CTHR), lds, st, p);
+  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH>), grid, dim3(CTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_cluster_fwd");
   return URSE_OK;
 }
@@ -685,7 +618,6 @@ extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, vo
   URSE_CHECK_ARG(ldg < (1L << 31) && ldh < (1L << 31) && stride * seq_len + (n_seq / inner + 1) * outer < (1L << 31),
                  "urse_lstm_cluster_fwd: row indices must fit 32 bits");
   ClusterArgs p;
-  p.xin = nullptr; p.ldx = 0; p.wihq = nullptr; p.bias = nullptr;
   p.gx = gx; p.ldg = ldg; p.whhq = whhq; p.hout = hout; p.ldh = ldh; p.c = c; p.hx = (bf16_t*)hx;
   p.cnt = (unsigned*)counters; p.err = (unsigned*)err_flag; p.H = H; p.Hp = Hp; p.save = save;
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
@@ -698,59 +630,4 @@ extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, vo
   if (nslab == 13) return launch_cluster<13, 1>(p, st);
   if (nslab == 2) return launch_cluster<2, 1>(p, st);
   return launch_cluster<1, 1>(p, st);
-}
-
-// quad-ordered W_ih fragments for the fused projection: block (dir, quad, slab) = 64 lanes x 16 B; lane (lr, lc): unit
-// quad*4 + (lc >> 2), gate lc & 3, k = slab*32 + 8*lr + j over the Np (zero padded) input features
-namespace urse {
-__global__ void __launch_bounds__(256) lstm_pack_ih_quads_kernel(const float* __restrict__ wih, bf16_t* __restrict__ out, int N,
-                                                                 int Np, int H) {
-  const int nq = (H + 3) >> 2, nslab = Np / 32, G4 = 4 * H;
-  const long total = (long)2 * nq * nslab * 64 * 8;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long r = idx;
-    const int jj = (int)(r % 8); r /= 8;
-    const int lane = (int)(r % 64); r /= 64;
-    const int ks = (int)(r % nslab); r /= nslab;
-    const int qd = (int)(r % nq);
-    const int d = (int)(r / nq);
-    const int lc = lane & 15, lr = lane >> 4;
-    const int u = qd * 4 + (lc >> 2), g = lc & 3, k = ks * 32 + 8 * lr + jj;
-    out[idx] = f32_to_bf16((u < H && k < N) ? wih[((long)d * G4 + g * H + u) * N + k] : 0.f);
-  }
-}
-}  // namespace urse
-
-extern "C" int urse_lstm_pack_ih_quads(const float* wih, void* out, int N, int Np, int H, void* stream) {
-  URSE_CHECK_ARG(wih && out && N > 0 && Np % 32 == 0 && Np >= N && H > 0, "urse_lstm_pack_ih_quads: bad argument");
-  hipLaunchKernelGGL(lstm_pack_ih_quads_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, wih, (bf16_t*)out, N, Np, H);
-  URSE_CHECK_LAUNCH("urse_lstm_pack_ih_quads");
-  return URSE_OK;
-}
-
-extern "C" int urse_lstm_cluster_fwd_x(const void* xin, int64_t ldx, const void* wihq, const float* bias, void* gates, int64_t ldg,
-                                       const void* whhq, void* hout, int64_t ldh, float* c, void* hx, void* err_flag, int Np, int H,
-                                       int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
-                                       void* stream) {
-  URSE_CHECK_ARG(xin && wihq && bias && whhq && hout && hx && err_flag && ((gates && c) || !save),
-                 "urse_lstm_cluster_fwd_x: null pointer");
-  int64_t plan[6];
-  int rc = urse_lstm_cluster_plan(H, Hp, n_seq, plan);
-  if (rc) return rc;
-  URSE_CHECK_ARG(Np == 224 && Hp == 416, "urse_lstm_cluster_fwd_x: built for Np = 224, Hp = 416 (got %d, %d)", Np, Hp);
-  URSE_CHECK_ARG(ldx >= Np && (ldx * 2) % 16 == 0 && ((uintptr_t)xin % 16) == 0 && (!save || (ldg >= 8L * H && ldg % 4 == 0)) &&
-                     ldh >= 2L * H && (ldh * 2) % 16 == 0 && ((uintptr_t)hout % 16) == 0 && ((uintptr_t)hx % 16) == 0,
-                 "urse_lstm_cluster_fwd_x: bad leading dimension / alignment");
-  URSE_CHECK_ARG(ldg < (1L << 31) && ldh < (1L << 31) && ldx < (1L << 31) && stride * seq_len + (n_seq / inner + 1) * outer < (1L << 31),
-                 "urse_lstm_cluster_fwd_x: row indices must fit 32 bits");
-  ClusterArgs p;
-  p.xin = xin; p.ldx = ldx; p.wihq = wihq; p.bias = bias;
-  p.gx = gates; p.ldg = ldg; p.whhq = whhq; p.hout = hout; p.ldh = ldh; p.c = c; p.hx = (bf16_t*)hx;
-  p.cnt = nullptr; p.err = (unsigned*)err_flag; p.H = H; p.Hp = Hp; p.save = save;
-  p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
-  p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2]; p.rows_pad = (int)plan[3];
-  hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(hx, 0, sizeof(bf16_t) * plan[4], st);
-  note_launch(URSE_KV_LSTM_FWD_CLUSTER_X);
-  return launch_cluster<13, 1, 7>(p, st);
 }

@@ -43,7 +43,7 @@ def timed_call(tname, name, *args):
 KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_ring", "nt_grouped_128", "tn_ring", "tn_ring_t",
                    "tn_dual", "tn_128", "tn_grouped", "lstm_fwd_stream", "lstm_fwd_wide", "lstm_fwd_cluster",
                    "lstm_fwd_cluster2", "lstm_bwd_stream16", "lstm_bwd_stream32", "lstm_bwd_cluster", "lstm_bwd_split",
-                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_bwd_ws", "lstm_fwd_cluster_x")
+                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_bwd_ws")
 
 
 def launch_counts(reset=False):
@@ -240,10 +240,6 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
             if "whhb" not in out:
                 out["whhb"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32) * 4 * 512, device=dev, dtype=dtype)
             call("lstm_pack_blocks", whh, out["whhb"], H, Hp, stream_ptr())
-        if Np == 224 and Hp == 416:                  # fused input projection of the cluster forward (N = 196 geometry)
-            if "wihq" not in out:
-                out["wihq"] = torch.empty(2 * ((H + 3) // 4) * (Np // 32) * 512, device=dev, dtype=dtype)
-            call("lstm_pack_ih_quads", wih, out["wihq"], N, Np, H, stream_ptr())
         if H % 8 == 0:
             C = ((H + 3) // 4 + 13) // 14
             if "whhTq" not in out:
@@ -324,29 +320,6 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster_fwd", gx, gx.stride(0), whhq, hout, ldh,
                c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
     return hout, c, err
-
-
-# fuse the input projection into the cluster forward (no [M, 8H] pre-activation matrix): on by default where the kernel exists
-FUSE_CLUSTER_PROJECTION = os.environ.get("URSE_LSTM_FUSE_X", "1") != "0"
-
-
-def lstm_fwd_cluster_x(xn, wihq, bias, whhq, Np, H, Hp, n_seq, seq_len, inner, outer, stride, save=True):
-    """cluster LSTM forward with the input projection fused in: xn [M, Np] bf16 -> (hout, c, gates [M, 8H] | None, err)."""
-    plan = lstm_cluster_plan(H, Hp, n_seq)
-    M, dev = xn.shape[0], xn.device
-    key = (dev, H, Hp, n_seq)
-    if key not in _cluster_ws:
-        _cluster_ws[key] = (torch.zeros(plan[4], device=dev, dtype=torch.bfloat16),
-                            torch.zeros(plan[5], device=dev, dtype=torch.int32),
-                            kernel_error_flag(dev))
-    hx, cnt, err = _cluster_ws[key]
-    ldh = kpad(2 * H, xn.dtype)
-    hout = _hout_buffer(M, ldh, H, xn)
-    c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
-    gates = torch.empty(M, 8 * H, device=dev, dtype=xn.dtype) if save else None
-    timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster_fwd_x", xn, xn.stride(0), wihq, bias, gates,
-               8 * H, whhq, hout, ldh, c, hx, err, Np, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
-    return hout, c, gates, err
 
 
 # which hidden sizes take the generalised cluster kernel: "768" by default (H = 392 keeps lstm_cluster.hip unless asked)
