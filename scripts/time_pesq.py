@@ -1,0 +1,16 @@
+"""PESQ kernel throughput vs pairs per launch (4 s @ 16 kHz wide-band pairs resident in HBM)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from urgent2026_challenge_track1_amd import metrics
+import bench
+dev = torch.device("cuda")
+fs, L = 16000, 64000
+clean, noisy = bench.synth_batch(2048, L, fs, 1, dev)
+metrics.pesq_batch(clean[:64], noisy[:64], fs); torch.cuda.synchronize()
+for n in (64, 256, 768, 1024, 2048):
+    t0 = time.perf_counter()
+    m = metrics.pesq_batch(clean[:n], noisy[:n], fs, max_pairs_per_launch=n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("pairs/launch %5d: %.1f ms  -> %.0f pairs/s   mean MOS %.3f" % (n, dt * 1e3, n / dt, float(torch.nanmean(m))), flush=True)

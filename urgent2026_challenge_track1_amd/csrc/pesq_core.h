@@ -167,6 +167,98 @@ PQ_FN inline float2* fft(const Team& T, float2* a, float2* b, int n, bool invers
   return x;
 }
 
+// batched form for transforms that live in LDS: `batch` independent n-point transforms stored back to back
+PQ_FN inline float2* fft_batched(const Team& T, float2* a, float2* b, int n, int batch, bool inverse, const Params& P) {
+  const int step = P.twn / n, hn = n >> 1;
+  float2 *x = a, *y = b;
+  for (int l = hn, m = 1; l >= 1; l >>= 1, m <<= 1) {
+    for (int id = T.tid; id < hn * batch; id += T.nt) {
+      const int q = id / hn, idx = id - q * hn;
+      const int j = idx / m, k = idx - j * m;
+      float2 w = P.tw[j * m * step];
+      if (inverse) w.y = -w.y;
+      const float2 c0 = x[q * n + k + j * m], c1 = x[q * n + k + j * m + l * m];
+      float2 sm, d, r;
+      sm.x = c0.x + c1.x; sm.y = c0.y + c1.y;
+      d.x = c0.x - c1.x; d.y = c0.y - c1.y;
+      r.x = d.x * w.x - d.y * w.y; r.y = d.x * w.y + d.y * w.x;
+      y[q * n + k + 2 * j * m] = sm;
+      y[q * n + k + 2 * j * m + m] = r;
+    }
+    T.sync();
+    float2* t = x; x = y; y = t;
+  }
+  return x;
+}
+
+// Long transforms (2^13 .. 2^17 points) as N = N1 x 1024 (four-step): N1-point transforms down the columns (1024 / N1 columns
+// per LDS tile), twiddle, 1024-point transforms along the rows - the signal crosses global memory twice instead of once per
+// radix-2 pass.  Forward: natural order in `src`, PERMUTED order out in `dst`: dst[pos(k)] = X[k], pos(k) = (k mod N1) *
+// 1024 + k / N1.  Inverse: permuted order in, natural order out (not scaled).  la / lb: 1024-point LDS buffers.
+PQ_FN inline int big_pos(int k, int n1) { return (k & (n1 - 1)) * 1024 + k / n1; }
+
+PQ_FN inline void fft_big_forward(const Team& T, const Params& P, float2* src, float2* dst, int n, float2* la, float2* lb) {
+  const int n1 = n >> 10, cols = 1024 / n1, tstep = P.twn / n;
+  for (int c0 = 0; c0 < 1024; c0 += cols) {            // columns n2 = c0 .. c0 + cols - 1
+    for (int i = T.tid; i < 1024; i += T.nt) {
+      const int r = i / cols, c = i - r * cols;          // element (n1 index r, column c): coalesced over c
+      la[c * n1 + r] = src[1024 * r + c0 + c];
+    }
+    T.sync();
+    float2* R = fft_batched(T, la, lb, n1, cols, false, P);
+    for (int i = T.tid; i < 1024; i += T.nt) {
+      const int k1 = i / cols, c = i - k1 * cols, n2 = c0 + c;
+      const float2 v = R[c * n1 + k1];
+      const int e = (int)(((long)n2 * k1) % n);
+      float2 w = P.tw[(e < n / 2 ? e : e - n / 2) * tstep];
+      if (e >= n / 2) { w.x = -w.x; w.y = -w.y; }
+      float2 o;
+      o.x = v.x * w.x - v.y * w.y; o.y = v.x * w.y + v.y * w.x;
+      dst[k1 * 1024 + n2] = o;
+    }
+    T.sync();
+  }
+  for (int k1 = 0; k1 < n1; ++k1) {                       // rows: 1024-point transforms in place
+    for (int i = T.tid; i < 1024; i += T.nt) la[i] = dst[k1 * 1024 + i];
+    T.sync();
+    float2* R = fft(T, la, lb, 1024, false, P);
+    for (int i = T.tid; i < 1024; i += T.nt) dst[k1 * 1024 + i] = R[i];
+    T.sync();
+  }
+}
+
+PQ_FN inline void fft_big_inverse(const Team& T, const Params& P, float2* src, float2* dst, int n, float2* la, float2* lb) {
+  const int n1 = n >> 10, cols = 1024 / n1, tstep = P.twn / n;
+  for (int k1 = 0; k1 < n1; ++k1) {
+    for (int i = T.tid; i < 1024; i += T.nt) la[i] = src[k1 * 1024 + i];
+    T.sync();
+    float2* R = fft(T, la, lb, 1024, true, P);
+    for (int n2 = T.tid; n2 < 1024; n2 += T.nt) {
+      const float2 v = R[n2];
+      const int e = (int)(((long)n2 * k1) % n);
+      float2 w = P.tw[(e < n / 2 ? e : e - n / 2) * tstep];
+      if (e >= n / 2) { w.x = -w.x; w.y = -w.y; }
+      float2 o;                                           // times conj(w)
+      o.x = v.x * w.x + v.y * w.y; o.y = v.y * w.x - v.x * w.y;
+      src[k1 * 1024 + n2] = o;
+    }
+    T.sync();
+  }
+  for (int c0 = 0; c0 < 1024; c0 += cols) {
+    for (int i = T.tid; i < 1024; i += T.nt) {
+      const int k1 = i / cols, c = i - k1 * cols;
+      la[c * n1 + k1] = src[k1 * 1024 + c0 + c];
+    }
+    T.sync();
+    float2* R = fft_batched(T, la, lb, n1, cols, true, P);
+    for (int i = T.tid; i < 1024; i += T.nt) {
+      const int r = i / cols, c = i - r * cols;
+      dst[1024 * r + c0 + c] = R[c * n1 + r];
+    }
+    T.sync();
+  }
+}
+
 PQ_FN inline float interpolate(float freq, const float (*curve)[2], int n) {
   int lo, hi;
   if (freq <= curve[0][0]) { lo = 0; hi = 1; }
@@ -181,10 +273,12 @@ PQ_FN inline float interpolate(float freq, const float (*curve)[2], int n) {
 }
 
 // apply_filter: FFT-domain filter of data[sb .. sb + n), gain relative to 1 kHz
-PQ_FN inline void apply_filter(const Team& T, const Params& P, Pair& S, float* data, int nsamples, const float (*curve)[2], int npts) {
+PQ_FN inline void apply_filter(const Team& T, const Params& P, Pair& S, const Lds& L, float* data, int nsamples,
+                               const float (*curve)[2], int npts) {
   const int sb = SEARCHBUFFER * P.ds;
   const int n = nsamples - 2 * sb + P.pad;
-  const int p2 = nextpow2(n);
+  int p2 = nextpow2(n);
+  if (p2 < 2048) p2 = 2048;                               // (four-step form needs N1 >= 2; a longer transform filters the same)
   for (int i = T.tid; i < p2; i += T.nt) {
     float2 v;
     v.x = i < n ? data[sb + i] : 0.f;
@@ -192,20 +286,21 @@ PQ_FN inline void apply_filter(const Team& T, const Params& P, Pair& S, float* d
     S.ca[i] = v;
   }
   T.sync();
-  float2* X = fft(T, S.ca, S.cb, p2, false, P);
-  float2* Y = X == S.ca ? S.cb : S.ca;
+  fft_big_forward(T, P, S.ca, S.cb, p2, L.la, L.lb);
   const float ref_gain = interpolate(1000.f, curve, npts);
   const float res = (float)P.fs / (float)p2;
+  const int n1 = p2 >> 10;
   for (int i = T.tid; i <= p2 / 2; i += T.nt) {
     const float db = interpolate(i * res, curve, npts) - ref_gain;
     const float fac = powf(10.f, db / 20.f);
-    X[i].x *= fac; X[i].y *= fac;
-    if (i > 0 && i < p2 / 2) { X[p2 - i].x *= fac; X[p2 - i].y *= fac; }
+    const int a = big_pos(i, n1);
+    S.cb[a].x *= fac; S.cb[a].y *= fac;
+    if (i > 0 && i < p2 / 2) { const int b = big_pos(p2 - i, n1); S.cb[b].x *= fac; S.cb[b].y *= fac; }
   }
   T.sync();
-  float2* R = fft(T, X, Y, p2, true, P);
+  fft_big_inverse(T, P, S.cb, S.ca, p2, L.la, L.lb);
   const float inv = 1.f / (float)p2;
-  for (int i = T.tid; i < n; i += T.nt) data[sb + i] = R[i].x * inv;
+  for (int i = T.tid; i < n; i += T.nt) data[sb + i] = S.ca[i].x * inv;
   T.sync();
 }
 
@@ -267,12 +362,12 @@ PQ_FN inline void iir_cascade(const Team& T, float* x, int n, const float (*sos)
 #endif
 }
 
-PQ_FN inline void fix_power_level(const Team& T, const Params& P, Pair& S, int sig, int maxn) {
+PQ_FN inline void fix_power_level(const Team& T, const Params& P, Pair& S, const Lds& L, int sig, int maxn) {
   const int sb = SEARCHBUFFER * P.ds, n = S.nsamp[sig];
   float* tmp = S.tweaked;                                  // free at this stage
   for (int i = T.tid; i < n + P.pad; i += T.nt) tmp[i] = S.data[sig][i];
   T.sync();
-  apply_filter(T, P, S, tmp, n, ALIGN_FILTER_DB, 26);
+  apply_filter(T, P, S, L, tmp, n, ALIGN_FILTER_DB, 26);
   const double p = pow_of(T, tmp, sb, n - sb + P.pad, maxn - 2 * sb + P.pad);
   const float g = p > 0.0 ? (float)sqrt(1.0e7 / p) : 1.0f;          // (an all-zero signal is left alone)
   for (int i = T.tid; i < n; i += T.nt) S.data[sig][i] *= g;
@@ -843,9 +938,10 @@ PQ_FN inline int delay_at(const Params& P, const int* st, int sample) {
 }
 
 // compute_delay of the bad-interval realignment: |x| cross-correlation through the long FFT
-PQ_FN inline int compute_delay(const Team& T, const Params& P, Pair& S, const float* s1, const float* s2, int n, int search_range,
-                               float* max_corr) {
-  const int p2 = nextpow2(2 * n);
+PQ_FN inline int compute_delay(const Team& T, const Params& P, Pair& S, const Lds& L, const float* s1, const float* s2, int n,
+                               int search_range, float* max_corr) {
+  int p2 = nextpow2(2 * n);
+  if (p2 < 2048) p2 = 2048;
   const double pw1 = pow_of(T, s1, 0, n, n) * (double)n / p2, pw2 = pow_of(T, s2, 0, n, n) * (double)n / p2;
   if (pw1 <= 1e-6 || pw2 <= 1e-6 || p2 > S.p2max) { *max_corr = 0.f; return 0; }
   const double norm = sqrt(pw1 * pw2);
@@ -856,19 +952,24 @@ PQ_FN inline int compute_delay(const Team& T, const Params& P, Pair& S, const fl
     S.ca[i] = v;
   }
   T.sync();
-  float2* Z = fft(T, S.ca, S.cb, p2, false, P);
-  float2* O = Z == S.ca ? S.cb : S.ca;
+  const int n1 = p2 >> 10;
+  const double pw_unused = 0; (void)pw_unused;
+  fft_big_forward(T, P, S.ca, S.cb, p2, L.la, L.lb);
+  float2* Z = S.cb;                                       // permuted order: Z[big_pos(k)]
+  float2* O = S.ca;
   for (int k = T.tid; k < p2; k += T.nt) {
-    const float2 a = Z[k], b = Z[(p2 - k) & (p2 - 1)];
+    const int pk = big_pos(k, n1);
+    const float2 a = Z[pk], b = Z[big_pos((p2 - k) & (p2 - 1), n1)];
     const float x1r = 0.5f * (a.x + b.x) / p2, x1i = 0.5f * (a.y - b.y) / p2;
     const float x2r = 0.5f * (a.y + b.y), x2i = -0.5f * (a.x - b.x);
     float2 p;
     p.x = x1r * x2r + x1i * x2i;
     p.y = x1r * x2i - x1i * x2r;
-    O[k] = p;
+    O[pk] = p;
   }
   T.sync();
-  float2* R = fft(T, O, Z, p2, true, P);
+  fft_big_inverse(T, P, O, Z, p2, L.la, L.lb);
+  float2* R = Z;
   // candidates in the reference order: -search_range .. -1, then 0 .. search_range - 1; first maximum wins
   float lb = 0.f;
   int li = -1;
@@ -894,10 +995,10 @@ PQ_FN inline float pesq_pair(const Team& T, const Params& P, Pair& S, const Lds&
   for (int i = T.tid; i < F_COUNT; i += T.nt) S.fst[i] = 0.f;
   for (int i = T.tid; i < TRACE_INTS; i += T.nt) trace[i] = 0;
   T.sync();
-  for (int sig = 0; sig < 2; ++sig) fix_power_level(T, P, S, sig, maxn);
+  for (int sig = 0; sig < 2; ++sig) fix_power_level(T, P, S, L, sig, maxn);
   for (int sig = 0; sig < 2; ++sig) {
     if (P.wb) iir_cascade(T, S.data[sig], S.nsamp[sig] + P.pad, P.fs == 16000 ? WB_INIIR_16K : WB_INIIR_8K, 1, L.iir);
-    else apply_filter(T, P, S, S.data[sig], S.nsamp[sig], STANDARD_IRS_FILTER_DB, 26);
+    else apply_filter(T, P, S, L, S.data[sig], S.nsamp[sig], STANDARD_IRS_FILTER_DB, 26);
   }
   for (int sig = 0; sig < 2; ++sig) {
     for (int i = T.tid; i < S.na; i += T.nt) S.adata[sig][i] = S.data[sig][i];
@@ -1085,7 +1186,7 @@ PQ_FN inline float pesq_pair(const Team& T, const Params& P, Pair& S, const Lds&
         }
         T.sync();
         float corr;
-        dly = compute_delay(T, P, S, r, d, len, srange, &corr);
+        dly = compute_delay(T, P, S, L, r, d, len, srange, &corr);
         if (corr < 0.5f) dly = 0;
       }
       if (T.tid == 0) bi[1 + q] = dly;
