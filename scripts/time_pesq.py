@@ -14,3 +14,10 @@ for n in (64, 256, 768, 1024, 2048):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("pairs/launch %5d: %.1f ms  -> %.0f pairs/s   mean MOS %.3f" % (n, dt * 1e3, n / dt, float(torch.nanmean(m))), flush=True)
+
+m, raw, tr = metrics.pesq_batch(clean[:256], noisy[:256], fs, return_trace=True)
+tr = tr.cpu().numpy()
+a, b = (tr[:, 5] & 0xffff) * 0.064, ((tr[:, 5] >> 16) & 0xffff) * 0.064
+c, d = (tr[:, 6] & 0xffff) * 0.064, ((tr[:, 6] >> 16) & 0xffff) * 0.064
+print("per-pair stage times (ms, mean / max over 256 pairs): filters+VAD %.1f / %.1f | alignment %.1f / %.1f | splitting %.1f / %.1f | "
+      "perceptual %.1f / %.1f | utterances mean %.1f" % (a.mean(), a.max(), b.mean(), b.max(), c.mean(), c.max(), d.mean(), d.max(), tr[:, 1].mean()))

@@ -66,7 +66,8 @@ def test_pesq_batch_is_independent_of_batch_composition(lib):
     from urgent2026_challenge_track1_amd import metrics
     a = _gpu([5, 6, 8, 9])
     b = _gpu([8])
-    assert a[8][0] == b[8][0] and np.array_equal(a[8][2], b[8][2])
+    keep = np.r_[0:5, 8:a[8][2].size]                  # (trace[5:8] are stage timers)
+    assert a[8][0] == b[8][0] and np.array_equal(a[8][2][keep], b[8][2][keep])
     fs, mode, ref, deg = pesq_cases.make_case(6)
     R = torch.tensor(np.stack([ref] * 5)).cuda()
     D = torch.tensor(np.stack([deg] * 5)).cuda()

@@ -128,6 +128,15 @@ enum { I_NUTT = 0, I_CRUDE = 1, I_SSTART = 2, I_SEND = I_SSTART + MAXNUTT, I_DES
        I_START = I_DELAY + MAXNUTT, I_END = I_START + MAXNUTT, I_TMP = I_END + MAXNUTT, I_COUNT = I_TMP + 64 };
 enum { F_CONF = 0, F_TMP = MAXNUTT, F_COUNT = F_TMP + 64 };
 
+// stage timer for the trace (microseconds of the 100 MHz wall clock on the device, 0 on the host)
+PQ_FN inline long long stamp() {
+#if PQ_DEVICE
+  return (long long)wall_clock64();
+#else
+  return 0;
+#endif
+}
+
 PQ_FN inline int nextpow2(int x) {
   int n = 1;
   while (n < x) n <<= 1;
@@ -138,7 +147,7 @@ PQ_FN inline int cdiv(int a, int b) { return a / b; }      // C division truncat
 struct Lds {                 // team-shared (LDS) buffers: frame transforms (1024-point max), VAD scan copy, IIR hand-off
   float2 *la, *lb;
   float *x, *h;
-  volatile float* iir;       // 192 floats
+  volatile float* iir;       // 384 floats
   float* w;                  // wcap floats
   int wcap;
 };
@@ -310,52 +319,59 @@ PQ_FN inline double pow_of(const Team& T, const float* x, int start, int stop, i
   return T.sum(p) / divisor;
 }
 
-// cascade of direct-form-II sections {b0, b1, b2, a1, a2} over x[0, n): section s on lane s of wave 0, samples move from
-// lane to lane by shuffle (device); plain loops on the host
-PQ_FN inline void iir_cascade(const Team& T, float* x, int n, const float (*sos)[5], int nsos, volatile float* lds64x3) {
+// cascade of direct-form-II sections {b0, b1, b2, a1, a2} over xa[0, n) and xb[0, n) (the two signals of the pair at once).
+// Device: one wave; signal a lives on lanes 0-15, signal b on lanes 16-31, section s on lane s of its row, and a sample moves
+// from section to section with a one-lane DPP row shift (a few cycles; the generic shuffle is a 100-cycle LDS permute, and the
+// recurrence makes every iteration wait for it).  Inputs are fetched 64 at a time by the whole wave and handed out with
+// v_readlane; the last section's outputs collect in LDS and leave 64 at a time.  Host: plain loops.
+PQ_FN inline void iir_cascade2(const Team& T, float* xa, float* xb, int n, const float (*sos)[5], int nsos, volatile float* obuf) {
 #if PQ_DEVICE
   if (T.tid < 64) {
-    const int lane = T.tid;
+    const int lane = T.tid, row = lane >> 4, sec = lane & 15;
+    const bool mine = row < 2 && sec < nsos;
     float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;
-    if (lane < nsos) { b0 = sos[lane][0]; b1 = sos[lane][1]; b2 = sos[lane][2]; a1 = sos[lane][3]; a2 = sos[lane][4]; }
+    if (mine) { b0 = sos[sec][0]; b1 = sos[sec][1]; b2 = sos[sec][2]; a1 = sos[sec][3]; a2 = sos[sec][4]; }
     float z1 = 0.f, z2 = 0.f, out_prev = 0.f;
-    volatile float* obuf = lds64x3;                      // 192 floats: outputs of the last section, stored 64 at a time
     const int total = n + nsos - 1;
-    float chunk = lane < n ? x[lane] : 0.f;
+    float ca = lane < n ? xa[lane] : 0.f, cb = lane < n ? xb[lane] : 0.f;
     for (int base = 0; base < total; base += 64) {
-      const float next = (base + 64 + lane < n) ? x[base + 64 + lane] : 0.f;     // prefetch under the 64 iterations
+      const float na = (base + 64 + lane < n) ? xa[base + 64 + lane] : 0.f;     // next 64 inputs, in flight under the loop
+      const float nb = (base + 64 + lane < n) ? xb[base + 64 + lane] : 0.f;
+#pragma unroll 4
       for (int k = 0; k < 64; ++k) {
         const int i = base + k;
-        const float up = __shfl_up(out_prev, 1, 64);
-        const float in0 = __shfl(chunk, k, 64);
-        const float in = lane == 0 ? in0 : up;
-        const int si = i - lane;
+        const float ina = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), k));     // (the builtin moves ints: bit casts,
+        const float inb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb), k));     //  not value conversions)
+        const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out_prev), 0x111, 0xf, 0xf, true));  // row_shr:1
+        const float in = sec == 0 ? (row == 0 ? ina : inb) : up;
+        const int si = i - sec;
         float out = 0.f;
-        if (lane < nsos && si >= 0 && si < n) {
+        if (mine && si >= 0 && si < n) {
           const float z0 = in - a1 * z1 - a2 * z2;
           out = b0 * z0 + b1 * z1 + b2 * z2;
           z2 = z1; z1 = z0;
-          if (lane == nsos - 1) obuf[si % 192] = out;
+          if (sec == nsos - 1) obuf[row * 192 + si % 192] = out;
         }
         out_prev = out;
       }
-      // outputs si in [base - (nsos-1), base + 64 - (nsos-1)) are complete now
-      const int o0 = base - (nsos - 1);
-      const int si = o0 + lane;
-      if (si >= 0 && si < n) x[si] = obuf[si % 192];
-      chunk = next;
+      const int si = base - (nsos - 1) + lane;                 // outputs completed during this chunk
+      if (si >= 0 && si < n) { xa[si] = obuf[si % 192]; xb[si] = obuf[192 + si % 192]; }
+      ca = na; cb = nb;
     }
   }
   T.sync();
 #else
-  (void)lds64x3;
-  for (int s = 0; s < nsos; ++s) {
-    const float b0 = sos[s][0], b1 = sos[s][1], b2 = sos[s][2], a1 = sos[s][3], a2 = sos[s][4];
-    float z1 = 0.f, z2 = 0.f;
-    for (int i = 0; i < n; ++i) {
-      const float z0 = x[i] - a1 * z1 - a2 * z2;
-      x[i] = b0 * z0 + b1 * z1 + b2 * z2;
-      z2 = z1; z1 = z0;
+  (void)obuf;
+  for (int q = 0; q < 2; ++q) {
+    float* x = q == 0 ? xa : xb;
+    for (int s = 0; s < nsos; ++s) {
+      const float b0 = sos[s][0], b1 = sos[s][1], b2 = sos[s][2], a1 = sos[s][3], a2 = sos[s][4];
+      float z1 = 0.f, z2 = 0.f;
+      for (int i = 0; i < n; ++i) {
+        const float z0 = x[i] - a1 * z1 - a2 * z2;
+        x[i] = b0 * z0 + b1 * z1 + b2 * z2;
+        z2 = z1; z1 = z0;
+      }
     }
   }
   (void)T;
@@ -995,19 +1011,20 @@ PQ_FN inline float pesq_pair(const Team& T, const Params& P, Pair& S, const Lds&
   for (int i = T.tid; i < F_COUNT; i += T.nt) S.fst[i] = 0.f;
   for (int i = T.tid; i < TRACE_INTS; i += T.nt) trace[i] = 0;
   T.sync();
+  const long long t_begin = stamp();
   for (int sig = 0; sig < 2; ++sig) fix_power_level(T, P, S, L, sig, maxn);
-  for (int sig = 0; sig < 2; ++sig) {
-    if (P.wb) iir_cascade(T, S.data[sig], S.nsamp[sig] + P.pad, P.fs == 16000 ? WB_INIIR_16K : WB_INIIR_8K, 1, L.iir);
-    else apply_filter(T, P, S, L, S.data[sig], S.nsamp[sig], STANDARD_IRS_FILTER_DB, 26);
-  }
+  // (both signals of a pair have the same length here: the batch API pads / crops them to a common `lens[pair]`)
+  if (P.wb) iir_cascade2(T, S.data[0], S.data[1], S.nsamp[0] + P.pad, P.fs == 16000 ? WB_INIIR_16K : WB_INIIR_8K, 1, L.iir);
+  else for (int sig = 0; sig < 2; ++sig) apply_filter(T, P, S, L, S.data[sig], S.nsamp[sig], STANDARD_IRS_FILTER_DB, 26);
   for (int sig = 0; sig < 2; ++sig) {
     for (int i = T.tid; i < S.na; i += T.nt) S.adata[sig][i] = S.data[sig][i];
     T.sync();
     dc_block(T, P, S.adata[sig], S.nsamp[sig]);
-    if (P.fs == 16000) iir_cascade(T, S.adata[sig], S.nsamp[sig] + P.pad, INIIR_16K, 12, L.iir);
-    else iir_cascade(T, S.adata[sig], S.nsamp[sig] + P.pad, INIIR_8K, 8, L.iir);
-    apply_vad(T, P, S.adata[sig], S.nsamp[sig], S.vad[sig], S.logvad[sig], L);
   }
+  if (P.fs == 16000) iir_cascade2(T, S.adata[0], S.adata[1], S.nsamp[0] + P.pad, INIIR_16K, 12, L.iir);
+  else iir_cascade2(T, S.adata[0], S.adata[1], S.nsamp[0] + P.pad, INIIR_8K, 8, L.iir);
+  for (int sig = 0; sig < 2; ++sig) apply_vad(T, P, S.adata[sig], S.nsamp[sig], S.vad[sig], S.logvad[sig], L);
+  const long long t_filtered = stamp();
   crude_align(T, P, S, -1);
   if (T.tid == 0) st[I_NUTT] = utt_scan(P, S, true);
   T.sync();
@@ -1018,10 +1035,12 @@ PQ_FN inline float pesq_pair(const Team& T, const Params& P, Pair& S, const Lds&
     crude_align(T, P, S, u);
     time_align(T, P, S, L, u);
   }
+  const long long t_aligned = stamp();
   if (T.tid == 0) id_utterances(P, S);
   T.sync();
   utterance_split(T, P, S, L);
   T.sync();
+  const long long t_split = stamp();
   const int nutt = st[I_NUTT];
   if (T.tid == 0) {
     trace[1] = nutt;
@@ -1236,6 +1255,13 @@ PQ_FN inline float pesq_pair(const Team& T, const Params& P, Pair& S, const Lds&
     raw = 4.5f - 0.1f * d_ind - 0.0309f * a_ind;
     S.fst[F_TMP] = raw;
     trace[2] = start_frame; trace[3] = stop_frame; trace[4] = nbad;
+    // stage times in 10 ns ticks / 100 = microseconds: level + input filters + VAD | crude + fine alignment | utterance splitting |
+    // perceptual model  (packed two per int: 16 bits each of (us / 64))
+    const long long t_end = stamp();
+    const int a = (int)((t_filtered - t_begin) / 6400), b = (int)((t_aligned - t_filtered) / 6400);
+    const int c = (int)((t_split - t_aligned) / 6400), d = (int)((t_end - t_split) / 6400);
+    trace[5] = (a & 0xffff) | ((b & 0xffff) << 16);
+    trace[6] = (c & 0xffff) | ((d & 0xffff) << 16);
   }
   T.sync();
   return S.fst[F_TMP];
