@@ -366,10 +366,19 @@ def main():
         np.random.seed(2024 + rank)
         state = {"i": 0}
 
-        def feed():          # B recipes + raw sources (host), stacked; the simulator itself runs on the GPU (materialise)
-            items = [ds[(state["i"] + b) % len(ds)] for b in range(B)]
-            state["i"] += B
-            return collate_dynamic(items).materialise(dev, skipped)
+        import queue
+        import threading
+        ready = queue.Queue(maxsize=2)
+
+        def produce():       # what DataLoader workers do in train_se.fit: recipe draw + source reads + stacking, pinned for the copy
+            while True:
+                items = [ds[(state["i"] + b) % len(ds)] for b in range(B)]
+                state["i"] += B
+                ready.put(collate_dynamic(items).pin_memory())
+        threading.Thread(target=produce, daemon=True).start()
+
+        def feed():          # host batches arrive from the producer thread; the simulator itself runs on the GPU, inside the step
+            return ready.get().materialise(dev, skipped)
 
     def step():
         loss = model.training_step(feed() if feed is not None else batch)

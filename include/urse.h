@@ -378,8 +378,8 @@ int urse_ema_update(float* shadow, const float* params, float one_minus_decay, i
  * ITU-T P.862 with the P.862.1 ('nb', fs 8000) / P.862.2 ('wb', fs 16000) MOS-LQO mapping.  One workgroup per pair.
  * ref, deg f32 [pairs, L] (row pitch ld), lens int32 [pairs] or NULL (= L).  mos f32 [pairs]: MOS-LQO, NaN where the
  * reference returns NO_UTTERANCES_DETECTED; raw f32 [pairs] (may be NULL): the raw P.862 score.  trace int32 [pairs, 286]:
- * the integer outputs of the alignment stages {crude delay, utterances, first / last frame, bad intervals, two words of stage
- * timers (four 16-bit counts of 64 us: filters + VAD, alignment, splitting, perceptual model), 0,
+ * the integer outputs of the alignment stages {crude delay, utterances, first / last frame, bad intervals, three words of stage
+ * timers (six 16-bit counts of 64 us: level filters, input filter, DC + alignment IIR, VAD, alignment + splitting, model),
  * utterance start[50], end[50], delay[50], bad-interval (first, last) frame[64]} - what "bit-exact through the integer
  * stage" is checked on.  workspace: urse_pesq_workspace_bytes(pairs, L, fs) bytes of device memory. */
 #define URSE_PESQ_TRACE 286

@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
   std::vector<float> fst(F_COUNT);
   S.st = st.data(); S.fst = fst.data();
   std::vector<float2> la(1024), lb(1024);
-  std::vector<float> x(1024), h(1024), w(4096), iir(384);
+  std::vector<float> x(1024), h(1024), w(4096), iir(512);
   Lds Ld;
   Ld.la = la.data(); Ld.lb = lb.data(); Ld.x = x.data(); Ld.h = h.data(); Ld.w = w.data(); Ld.wcap = 4096; Ld.iir = iir.data();
   double red[4];

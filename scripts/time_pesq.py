@@ -17,7 +17,7 @@ for n in (64, 256, 768, 1024, 2048):
 
 m, raw, tr = metrics.pesq_batch(clean[:256], noisy[:256], fs, return_trace=True)
 tr = tr.cpu().numpy()
-a, b = (tr[:, 5] & 0xffff) * 0.064, ((tr[:, 5] >> 16) & 0xffff) * 0.064
-c, d = (tr[:, 6] & 0xffff) * 0.064, ((tr[:, 6] >> 16) & 0xffff) * 0.064
-print("per-pair stage times (ms, mean / max over 256 pairs): filters+VAD %.1f / %.1f | alignment %.1f / %.1f | splitting %.1f / %.1f | "
-      "perceptual %.1f / %.1f | utterances mean %.1f" % (a.mean(), a.max(), b.mean(), b.max(), c.mean(), c.max(), d.mean(), d.max(), tr[:, 1].mean()))
+names = ("level filters", "input filter", "DC + alignment IIR", "VAD", "alignment + splitting", "perceptual")
+vals = [(tr[:, 5 + i // 2] >> (16 * (i % 2)) & 0xffff) * 0.064 for i in range(6)]
+print("per-pair stage times, ms (mean / max over 256 pairs): " + " | ".join("%s %.1f / %.1f" % (n, v.mean(), v.max()) for n, v in zip(names, vals))
+      + " | utterances mean %.1f" % tr[:, 1].mean())

@@ -175,3 +175,23 @@ def test_simulate_recipes_matches_the_reference_simulator(lib):
         en = np.abs(noisy[i].cpu().numpy() - rn).max()
         # inputs are rounded to f32 on the way in (the reference computes in f64 from f64 files); 0.9-peak signals
         assert es <= 2e-5 and en <= 2e-5, (i, es, en)
+
+
+def test_bandwidth_limitation_polyphase_matches_scipy(lib):
+    """the polyphase branch of the reference's bandwidth limitation (librosa.resample(res_type="polyphase") = scipy.signal
+    .resample_poly + fix_length, down and back up) on the device vs scipy on the CPU."""
+    import math
+    from scipy.signal import resample_poly
+    from urgent2026_challenge_track1_amd import mixing
+    x = _signals(1, 24000, 7)[0]
+    for fs, fs_new in ((48000, 16000), (48000, 22050), (16000, 8000)):
+        g = math.gcd(fs, fs_new)
+        down = resample_poly(x.astype(np.float64), fs_new // g, fs // g)
+        n1 = int(math.ceil(len(x) * fs_new / fs))
+        down = down[:n1] if len(down) >= n1 else np.pad(down, (0, n1 - len(down)))
+        up = resample_poly(down, fs // g, fs_new // g)
+        n2 = int(math.ceil(n1 * fs / fs_new))
+        up = up[:n2] if len(up) >= n2 else np.pad(up, (0, n2 - len(up)))
+        ref = up[:len(x)] if len(up) >= len(x) else np.pad(up, (0, len(x) - len(up)))
+        got = mixing.bandwidth_limitation_polyphase(torch.tensor(x[None]).cuda(), fs, fs_new)[0].cpu().numpy()
+        assert got.shape == x.shape and np.abs(got - ref).max() <= 2e-5, (fs, fs_new, np.abs(got - ref).max())

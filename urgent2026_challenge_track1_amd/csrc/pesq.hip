@@ -28,7 +28,7 @@ __host__ __device__ inline long pesq_align(long v) { return (v + 63) / 64 * 64; 
 __global__ void __launch_bounds__(256) pesq_kernel(PesqArgs a) {
   using namespace pesq;
   __shared__ float2 s_la[1024], s_lb[1024];
-  __shared__ float s_x[1024], s_h[1024], s_w[2048], s_iir[384];
+  __shared__ float s_x[1024], s_h[1024], s_w[2048], s_iir[512];
   __shared__ double s_red[256];
   __shared__ int s_ired[256];
   const int pair = blockIdx.x;

@@ -44,14 +44,12 @@ struct Team {
   }
   PQ_FN double sum(double v) const {
 #if PQ_DEVICE
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     sync();
-    red[tid] = v;
+    if ((tid & 63) == 0) red[tid >> 6] = v;
     sync();
-    for (int s = nt >> 1; s > 0; s >>= 1) {
-      if (tid < s) red[tid] += red[tid + s];
-      sync();
-    }
-    const double r = red[0];
+    double r = 0;
+    for (int w = 0; w < (nt >> 6); ++w) r += red[w];
     sync();
     return r;
 #else
@@ -60,14 +58,12 @@ struct Team {
   }
   PQ_FN float maxf(float v) const {
 #if PQ_DEVICE
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     sync();
-    red[tid] = (double)v;
+    if ((tid & 63) == 0) red[tid >> 6] = (double)v;
     sync();
-    for (int s = nt >> 1; s > 0; s >>= 1) {
-      if (tid < s && red[tid + s] > red[tid]) red[tid] = red[tid + s];
-      sync();
-    }
-    const float r = (float)red[0];
+    float r = (float)red[0];
+    for (int w = 1; w < (nt >> 6); ++w) r = fmaxf(r, (float)red[w]);
     sync();
     return r;
 #else
@@ -147,28 +143,70 @@ PQ_FN inline int cdiv(int a, int b) { return a / b; }      // C division truncat
 struct Lds {                 // team-shared (LDS) buffers: frame transforms (1024-point max), VAD scan copy, IIR hand-off
   float2 *la, *lb;
   float *x, *h;
-  volatile float* iir;       // 384 floats
+  float* iir;                // 512 floats
   float* w;                  // wcap floats
   int wcap;
 };
 
-// ---- FFT (Stockham radix-2, out of place between a and b; returns the buffer holding the result) --------------------
-PQ_FN inline float2* fft(const Team& T, float2* a, float2* b, int n, bool inverse, const Params& P) {
+// ---- FFT: Stockham autosort, radix-4 passes (+ one radix-2 pass when log2 n is odd), out of place between a and b; returns the
+// buffer that holds the result.  `batch` independent n-point transforms stored back to back share the passes (and barriers).
+PQ_FN inline float2 tw_at(const Params& P, int idx) {      // exp(-2 pi i idx / twn), idx < twn
+  const int h = P.twn >> 1;
+  float2 w = P.tw[idx < h ? idx : idx - h];
+  if (idx >= h) { w.x = -w.x; w.y = -w.y; }
+  return w;
+}
+PQ_FN inline float2 cmul(float2 a, float2 w) {
+  float2 r;
+  r.x = a.x * w.x - a.y * w.y; r.y = a.x * w.y + a.y * w.x;
+  return r;
+}
+
+PQ_FN inline float2* fft_batched(const Team& T, float2* a, float2* b, int n, int batch, bool inverse, const Params& P) {
   const int step = P.twn / n;
   float2 *x = a, *y = b;
-  for (int l = n >> 1, m = 1; l >= 1; l >>= 1, m <<= 1) {
-    for (int idx = T.tid; idx < (n >> 1); idx += T.nt) {
-      const int j = idx / m, k = idx - j * m;
-      float2 w = P.tw[j * m * step];
-      if (inverse) w.y = -w.y;
-      const float2 c0 = x[k + j * m], c1 = x[k + j * m + l * m];
-      float2 s, d;
-      s.x = c0.x + c1.x; s.y = c0.y + c1.y;
-      d.x = c0.x - c1.x; d.y = c0.y - c1.y;
-      float2 r;
-      r.x = d.x * w.x - d.y * w.y; r.y = d.x * w.y + d.y * w.x;
-      y[k + 2 * j * m] = s;
-      y[k + 2 * j * m + m] = r;
+  int nc = n, st = 1;                                      // current sub-length, stride
+  while (nc >= 4) {
+    const int n1 = nc >> 2, per = n1 * st;                 // butterflies per transform in this pass = n / 4
+    for (int id = T.tid; id < per * batch; id += T.nt) {
+      const int q0 = id / per, r = id - q0 * per;
+      const int p = r / st, q = r - p * st;
+      float2* xb = x + q0 * n;
+      float2* yb = y + q0 * n;
+      const float2 va = xb[q + st * p], vb = xb[q + st * (p + n1)], vc = xb[q + st * (p + 2 * n1)], vd = xb[q + st * (p + 3 * n1)];
+      float2 apc, amc, bpd, jbmd;
+      apc.x = va.x + vc.x; apc.y = va.y + vc.y;
+      amc.x = va.x - vc.x; amc.y = va.y - vc.y;
+      bpd.x = vb.x + vd.x; bpd.y = vb.y + vd.y;
+      const float dx = vb.x - vd.x, dy = vb.y - vd.y;
+      if (!inverse) { jbmd.x = -dy; jbmd.y = dx; } else { jbmd.x = dy; jbmd.y = -dx; }     // (+-i) (b - d)
+      float2 w1 = tw_at(P, p * st * step), w2 = tw_at(P, 2 * p * st * step), w3 = tw_at(P, 3 * p * st * step);
+      if (inverse) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+      float2 o0, t1, t2, t3;
+      o0.x = apc.x + bpd.x; o0.y = apc.y + bpd.y;
+      t1.x = amc.x - jbmd.x; t1.y = amc.y - jbmd.y;
+      t2.x = apc.x - bpd.x; t2.y = apc.y - bpd.y;
+      t3.x = amc.x + jbmd.x; t3.y = amc.y + jbmd.y;
+      yb[q + st * (4 * p)] = o0;
+      yb[q + st * (4 * p + 1)] = cmul(t1, w1);
+      yb[q + st * (4 * p + 2)] = cmul(t2, w2);
+      yb[q + st * (4 * p + 3)] = cmul(t3, w3);
+    }
+    T.sync();
+    float2* t = x; x = y; y = t;
+    nc >>= 2; st <<= 2;
+  }
+  if (nc == 2) {                                            // last pass of an odd power of two: plain butterflies, stride n / 2
+    const int per = st;
+    for (int id = T.tid; id < per * batch; id += T.nt) {
+      const int q0 = id / per, q = id - q0 * per;
+      float2* xb = x + q0 * n;
+      float2* yb = y + q0 * n;
+      const float2 c0 = xb[q], c1 = xb[q + st];
+      float2 s0, s1;
+      s0.x = c0.x + c1.x; s0.y = c0.y + c1.y;
+      s1.x = c0.x - c1.x; s1.y = c0.y - c1.y;
+      yb[q] = s0; yb[q + st] = s1;
     }
     T.sync();
     float2* t = x; x = y; y = t;
@@ -176,28 +214,8 @@ PQ_FN inline float2* fft(const Team& T, float2* a, float2* b, int n, bool invers
   return x;
 }
 
-// batched form for transforms that live in LDS: `batch` independent n-point transforms stored back to back
-PQ_FN inline float2* fft_batched(const Team& T, float2* a, float2* b, int n, int batch, bool inverse, const Params& P) {
-  const int step = P.twn / n, hn = n >> 1;
-  float2 *x = a, *y = b;
-  for (int l = hn, m = 1; l >= 1; l >>= 1, m <<= 1) {
-    for (int id = T.tid; id < hn * batch; id += T.nt) {
-      const int q = id / hn, idx = id - q * hn;
-      const int j = idx / m, k = idx - j * m;
-      float2 w = P.tw[j * m * step];
-      if (inverse) w.y = -w.y;
-      const float2 c0 = x[q * n + k + j * m], c1 = x[q * n + k + j * m + l * m];
-      float2 sm, d, r;
-      sm.x = c0.x + c1.x; sm.y = c0.y + c1.y;
-      d.x = c0.x - c1.x; d.y = c0.y - c1.y;
-      r.x = d.x * w.x - d.y * w.y; r.y = d.x * w.y + d.y * w.x;
-      y[q * n + k + 2 * j * m] = sm;
-      y[q * n + k + 2 * j * m + m] = r;
-    }
-    T.sync();
-    float2* t = x; x = y; y = t;
-  }
-  return x;
+PQ_FN inline float2* fft(const Team& T, float2* a, float2* b, int n, bool inverse, const Params& P) {
+  return fft_batched(T, a, b, n, 1, inverse, P);
 }
 
 // Long transforms (2^13 .. 2^17 points) as N = N1 x 1024 (four-step): N1-point transforms down the columns (1024 / N1 columns
@@ -218,7 +236,7 @@ PQ_FN inline void fft_big_forward(const Team& T, const Params& P, float2* src, f
     for (int i = T.tid; i < 1024; i += T.nt) {
       const int k1 = i / cols, c = i - k1 * cols, n2 = c0 + c;
       const float2 v = R[c * n1 + k1];
-      const int e = (int)(((long)n2 * k1) % n);
+      const int e = n2 * k1;                              // < 1024 * N1 = n: no reduction needed
       float2 w = P.tw[(e < n / 2 ? e : e - n / 2) * tstep];
       if (e >= n / 2) { w.x = -w.x; w.y = -w.y; }
       float2 o;
@@ -244,7 +262,7 @@ PQ_FN inline void fft_big_inverse(const Team& T, const Params& P, float2* src, f
     float2* R = fft(T, la, lb, 1024, true, P);
     for (int n2 = T.tid; n2 < 1024; n2 += T.nt) {
       const float2 v = R[n2];
-      const int e = (int)(((long)n2 * k1) % n);
+      const int e = n2 * k1;                              // < 1024 * N1 = n: no reduction needed
       float2 w = P.tw[(e < n / 2 ? e : e - n / 2) * tstep];
       if (e >= n / 2) { w.x = -w.x; w.y = -w.y; }
       float2 o;                                           // times conj(w)
@@ -324,38 +342,48 @@ PQ_FN inline double pow_of(const Team& T, const float* x, int start, int stop, i
 // from section to section with a one-lane DPP row shift (a few cycles; the generic shuffle is a 100-cycle LDS permute, and the
 // recurrence makes every iteration wait for it).  Inputs are fetched 64 at a time by the whole wave and handed out with
 // v_readlane; the last section's outputs collect in LDS and leave 64 at a time.  Host: plain loops.
-PQ_FN inline void iir_cascade2(const Team& T, float* xa, float* xb, int n, const float (*sos)[5], int nsos, volatile float* obuf) {
+PQ_FN inline void iir_cascade2(const Team& T, float* xa, float* xb, int n, const float (*sos)[5], int nsos, float* obuf) {
 #if PQ_DEVICE
   if (T.tid < 64) {
     const int lane = T.tid, row = lane >> 4, sec = lane & 15;
     const bool mine = row < 2 && sec < nsos;
+    // sections that do not exist (and the idle rows) carry zero coefficients: their arithmetic runs unconditionally and yields 0
     float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0;
     if (mine) { b0 = sos[sec][0]; b1 = sos[sec][1]; b2 = sos[sec][2]; a1 = sos[sec][3]; a2 = sos[sec][4]; }
+    const bool first = sec == 0, rowa = row == 0, last = mine && sec == nsos - 1;
+    // 256-entry ring of the last section's outputs per signal, in LDS.  (A volatile generic pointer here compiled to a
+    // write-through FLAT store followed by s_waitcnt vmcnt(0) in EVERY iteration: 160 cycles per sample.)  One wave writes and
+    // reads it in program order; the fences below only keep the compiler from moving the accesses.
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float* ring = (lds_float*)obuf + (row & 1) * 256;
+    lds_float* ring_all = (lds_float*)obuf;
     float z1 = 0.f, z2 = 0.f, out_prev = 0.f;
     const int total = n + nsos - 1;
     float ca = lane < n ? xa[lane] : 0.f, cb = lane < n ? xb[lane] : 0.f;
     for (int base = 0; base < total; base += 64) {
       const float na = (base + 64 + lane < n) ? xa[base + 64 + lane] : 0.f;     // next 64 inputs, in flight under the loop
       const float nb = (base + 64 + lane < n) ? xb[base + 64 + lane] : 0.f;
-#pragma unroll 4
+      // Before its first sample a section sees zeros (state stays 0); past the end it computes values nobody reads: no branches.
+#pragma unroll 8
       for (int k = 0; k < 64; ++k) {
-        const int i = base + k;
         const float ina = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), k));     // (the builtin moves ints: bit casts,
         const float inb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb), k));     //  not value conversions)
         const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out_prev), 0x111, 0xf, 0xf, true));  // row_shr:1
-        const float in = sec == 0 ? (row == 0 ? ina : inb) : up;
-        const int si = i - sec;
-        float out = 0.f;
-        if (mine && si >= 0 && si < n) {
-          const float z0 = in - a1 * z1 - a2 * z2;
-          out = b0 * z0 + b1 * z1 + b2 * z2;
-          z2 = z1; z1 = z0;
-          if (sec == nsos - 1) obuf[row * 192 + si % 192] = out;
-        }
+        const float in = first ? (rowa ? ina : inb) : up;
+        // transposed direct form II: one multiply-add between a section's input and its output (the samples' way down the
+        // cascade is the serial chain of this loop); the standard's code uses direct form II - same filter, rounding differs
+        const float out = b0 * in + z1;
+        z1 = b1 * in - a1 * out + z2;
+        z2 = b2 * in - a2 * out;
+        if (last) ring[(base + k - (nsos - 1)) & 255] = out;
         out_prev = out;
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       const int si = base - (nsos - 1) + lane;                 // outputs completed during this chunk
-      if (si >= 0 && si < n) { xa[si] = obuf[si % 192]; xb[si] = obuf[192 + si % 192]; }
+      if (si >= 0 && si < n) { xa[si] = ring_all[si & 255]; xb[si] = ring_all[256 + (si & 255)]; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       ca = na; cb = nb;
     }
   }
@@ -1013,9 +1041,11 @@ PQ_FN inline float pesq_pair(const Team& T, const Params& P, Pair& S, const Lds&
   T.sync();
   const long long t_begin = stamp();
   for (int sig = 0; sig < 2; ++sig) fix_power_level(T, P, S, L, sig, maxn);
+  const long long t_level = stamp();
   // (both signals of a pair have the same length here: the batch API pads / crops them to a common `lens[pair]`)
   if (P.wb) iir_cascade2(T, S.data[0], S.data[1], S.nsamp[0] + P.pad, P.fs == 16000 ? WB_INIIR_16K : WB_INIIR_8K, 1, L.iir);
   else for (int sig = 0; sig < 2; ++sig) apply_filter(T, P, S, L, S.data[sig], S.nsamp[sig], STANDARD_IRS_FILTER_DB, 26);
+  const long long t_input = stamp();
   for (int sig = 0; sig < 2; ++sig) {
     for (int i = T.tid; i < S.na; i += T.nt) S.adata[sig][i] = S.data[sig][i];
     T.sync();
@@ -1023,6 +1053,7 @@ PQ_FN inline float pesq_pair(const Team& T, const Params& P, Pair& S, const Lds&
   }
   if (P.fs == 16000) iir_cascade2(T, S.adata[0], S.adata[1], S.nsamp[0] + P.pad, INIIR_16K, 12, L.iir);
   else iir_cascade2(T, S.adata[0], S.adata[1], S.nsamp[0] + P.pad, INIIR_8K, 8, L.iir);
+  const long long t_iir = stamp();
   for (int sig = 0; sig < 2; ++sig) apply_vad(T, P, S.adata[sig], S.nsamp[sig], S.vad[sig], S.logvad[sig], L);
   const long long t_filtered = stamp();
   crude_align(T, P, S, -1);
@@ -1255,13 +1286,14 @@ PQ_FN inline float pesq_pair(const Team& T, const Params& P, Pair& S, const Lds&
     raw = 4.5f - 0.1f * d_ind - 0.0309f * a_ind;
     S.fst[F_TMP] = raw;
     trace[2] = start_frame; trace[3] = stop_frame; trace[4] = nbad;
-    // stage times in 10 ns ticks / 100 = microseconds: level + input filters + VAD | crude + fine alignment | utterance splitting |
-    // perceptual model  (packed two per int: 16 bits each of (us / 64))
+    // stage timers, 16 bits each in units of 64 us (100 MHz wall clock): trace[5] = level filters | input filter,
+    // trace[6] = DC + alignment IIR | VAD, trace[7] = crude / fine alignment + utterance splitting | perceptual model
     const long long t_end = stamp();
-    const int a = (int)((t_filtered - t_begin) / 6400), b = (int)((t_aligned - t_filtered) / 6400);
-    const int c = (int)((t_split - t_aligned) / 6400), d = (int)((t_end - t_split) / 6400);
-    trace[5] = (a & 0xffff) | ((b & 0xffff) << 16);
-    trace[6] = (c & 0xffff) | ((d & 0xffff) << 16);
+    auto u = [](long long dt) { return (int)(dt / 6400) & 0xffff; };
+    trace[5] = u(t_level - t_begin) | (u(t_input - t_level) << 16);
+    trace[6] = u(t_iir - t_input) | (u(t_filtered - t_iir) << 16);
+    trace[7] = u(t_split - t_filtered) | (u(t_end - t_split) << 16);
+    (void)t_aligned;
   }
   T.sync();
   return S.fst[F_TMP];

@@ -150,16 +150,40 @@ def simulate_batch(speech, lens, noise_raw, noise_lens, fs, snr_db, noise_offset
     return speech, noisy, fs, noise
 
 
+def bandwidth_limitation_polyphase(speech, fs, fs_new):
+    """``bandwidth_limitation(x, fs, fs_new, res_type="polyphase")`` (simulate_data_from_param.py:233-252): librosa's polyphase
+    branch is ``scipy.signal.resample_poly(y, target // gcd, orig // gcd)`` followed by ``fix_length`` to ``ceil(n * ratio)``,
+    applied down and back up, cropped to the input length.  Runs on the batched polyphase kernel (`metrics._poly_resample`:
+    scipy's default Kaiser(5.0) design).  The other three resamplers the reference draws (kaiser_best / kaiser_fast need resampy's
+    filter tables, scipy = one FFT per utterance) have no device implementation."""
+    import math
+    from .metrics import _poly_resample
+    if fs == fs_new:
+        return speech
+    L = speech.shape[1]
+
+    def fix(y, n):
+        if y.shape[1] >= n:
+            return y[:, :n].contiguous()
+        out = torch.zeros(y.shape[0], n, device=y.device, dtype=y.dtype)
+        out[:, :y.shape[1]] = y
+        return out
+    down = fix(_poly_resample(speech, fs, fs_new), int(math.ceil(L * fs_new / fs)))
+    up = fix(_poly_resample(down, fs_new, fs), int(math.ceil(down.shape[1] * fs / fs_new)))
+    return fix(up, L)
+
+
 def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_early_stops, fs, recipes, skipped=None):
     """``process_one_sample(on_the_fly=True)`` (simulate_data_from_param.py:440-590) for a batch of raw sources and the
     recipes ``dataset.draw_recipe`` drew for them (one fs per batch) -> (speech, noisy) f32 [B, L].
 
     Utterances without an RIR convolve with a unit impulse (exact identity).  ``clipping`` / ``packet_loss`` are applied in
     each recipe's own order: pass p handles every utterance's p-th augmentation, the others ride along with identity
-    parameters (quantiles 0 / 1, no packets).  ``bandwidth_limitation`` (librosa resamplers), ``codec`` (ffmpeg) and the
-    wind-noise side-chain compressor (ffmpeg) have no device implementation: the recipe still DRAWS them (so the random
-    stream matches the reference) but they are not applied - wind noise is mixed additively at its drawn SNR - and each
-    omission is counted in ``skipped``."""
+    parameters (quantiles 0 / 1, no packets).  ``bandwidth_limitation`` is applied when the recipe drew the polyphase
+    resampler (one of the four methods); the other resamplers (resampy / FFT), ``codec`` (ffmpeg) and the wind-noise side-chain
+    compressor (ffmpeg) have no device implementation: the recipe still DRAWS them (so the random stream matches the
+    reference) but they are not applied - wind noise is mixed additively at its drawn SNR - and each omission is counted in
+    ``skipped``."""
     ops.require_cuda(speech, noise_raw)
     B, L = speech.shape
     dev = speech.device
@@ -194,10 +218,17 @@ def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_ear
         for a in r.get("order", []):
             if a in ("clipping", "packet_loss"):
                 mine.append(a)
+            elif a == "bandwidth_limitation" and r["params"][a]["res_type"] in ("polyphase", "none"):
+                mine.append(a)
             else:
                 count(a)
         todo.append(mine)
     for p in range(max([len(t) for t in todo] or [0])):
+        for b in range(B):          # bandwidth limitation (polyphase draws only): per utterance, its own rate pair
+            if len(todo[b]) > p and todo[b][p] == "bandwidth_limitation" and recipes[b]["params"]["bandwidth_limitation"]["fs_new"] != fs:
+                n = int(lens[b])
+                noisy[b:b + 1, :n] = bandwidth_limitation_polyphase(noisy[b:b + 1, :n].contiguous(), fs,
+                                                                   recipes[b]["params"]["bandwidth_limitation"]["fs_new"])
         lo = [recipes[b]["params"]["clipping"]["min_quantile"] if len(todo[b]) > p and todo[b][p] == "clipping" else 0.0
               for b in range(B)]
         hi = [recipes[b]["params"]["clipping"]["max_quantile"] if len(todo[b]) > p and todo[b][p] == "clipping" else 1.0
