@@ -414,6 +414,22 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// The same transfer through a BUFFER resource: 64 lanes x 16 B from rsrc.base + voff (per lane) to lds_dst + lane*16; a lane whose
+// offset is >= rsrc.num_records reads zeros (hardware range check), which replaces every "valid ? pointer : zero page" select.
+typedef int rsrc_v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_v4i_t make_rsrc(const char* base, unsigned num_records) {
+  const unsigned long a = (unsigned long)base;
+  return rsrc_v4i_t{(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)num_records, 0x00020000};
+}
+__device__ __forceinline__ void blds16(unsigned voff, rsrc_v4i_t rsrc, unsigned dst) {      // dst: LDS byte address, wave uniform
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst) : "memory");
+}
+#ifndef URSE_TN_LEAN_ISSUE
+#define URSE_TN_LEAN_ISSUE 1   // stage addressing on the scalar unit + buffer range checks instead of per-lane pointer selects
+#endif
+
 // ring depth of the big TN kernel: 5 stages of 32 KB = the whole 160 KB LDS, four stages in flight (measured
 // 0.92 vs 1.01 ms for the 3136 x 196 wgrad against 4 stages); the NT kernel is faster with 4 (short K: longer prologue)
 #ifndef URSE_TN_PIPE
@@ -534,8 +550,64 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
       q.ph -= q.ph >= per_u ? per_u : 0u;
     }
   };
+#if URSE_TN_LEAN_ISSUE
+  // Lean issue path.  The 32 rows of a stage are addressed from a SCALAR stage base (buffer resource rebuilt per stage on the
+  // scalar unit), every lane keeps one constant 32-bit offset per piece, and the hardware range check of the buffer supplies the
+  // zeros: rows past the end of the matrix, shifted rows before its start (the offset wraps past num_records), columns outside
+  // the operand (offset preset out of range).  Slices are multiples of 32 rows, so a computed stage never crosses its slice
+  // end; the stages issued past the last computed one read rows of the next slice into slots nobody reads.  Only the
+  // (row / inner) % period mask of the shifted operand is still tracked per lane.  (The generic path below spent ~50 vector and
+  // ~100 scalar instructions per wave and stage on per-lane pointer selects; this one spends ~6 + ~30.)
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const unsigned lda2 = (unsigned)(p.lda * 2), ldb2 = (unsigned)(ldb_ * 2);
+  unsigned voA[2], voB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rowl = 4 * w + 2 * j + half;
+    voA[j] = aok[j] ? (unsigned)(((long)rowl * p.lda + acol[j]) * 2) : OOB;
+    voB[j] = bok[j] ? (unsigned)(((long)rowl * ldb_ + bcol[j]) * 2) : OOB;
+  }
+  // stage state, all wave-uniform 32-bit quantities (64-bit compares / multiplies made the scalar path longer than the vector
+  // path it replaced): first row of the next stage, its A pointer, and the two resources of the stage being issued
+  int st_row = (int)r_begin;
+  const char* st_pA = p.A + r_begin * (long)lda2;
+  const long stepA = 32L * lda2;
+  const int capA = (int)(0x7FFFFFFFu / lda2), capB = (int)(0x7FFFFFFFu / ldb2);
+  rsrc_v4i_t cur_rA = make_rsrc(p.A, 0), cur_rB = make_rsrc(Bop, 0);
+  unsigned cur_delta = 0;
+  auto stage_begin = [&]() __attribute__((always_inline)) {
+    int remA = R_i - st_row;
+    remA = remA < 0 ? 0 : (remA > capA ? capA : remA);
+    cur_rA = make_rsrc(st_pA, (unsigned)remA * lda2);
+    const int rowB = st_row + shift_i;
+    const int baseRow = rowB < 0 ? 0 : rowB;              // shifted rows before the matrix: base stays at row 0, offsets wrap
+    int remB = R_i - baseRow;
+    remB = remB < 0 ? 0 : (remB > capB ? capB : remB);
+    cur_rB = make_rsrc(Bop + (long)baseRow * ldb2, (unsigned)remB * ldb2);
+    cur_delta = (unsigned)((rowB - baseRow) * (int)ldb2);
+  };
+  const unsigned lds_u = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+  auto issue_lean = [&](Src& q, int j, unsigned dst) __attribute__((always_inline)) {
+    if (j == 0) stage_begin();
+    blds16(voA[j], cur_rA, dst);
+    unsigned vb = voB[j] + cur_delta;
+    if (per_u) {
+      vb = q.ph != inval_u ? vb : OOB;
+      q.rm += step_r;
+      const unsigned c = q.rm >= inner_u ? 1u : 0u;
+      q.rm -= c ? inner_u : 0u;
+      q.ph += step_q + c;
+      q.ph -= q.ph >= per_u ? per_u : 0u;
+    }
+    blds16(vb, cur_rB, dst + 16384);
+    if (j == 1) { st_row += 32; st_pA += stepA; }
+  };
+  auto issue0 = [&](int slot) __attribute__((always_inline)) { issue_lean(q0, 0, lds_u + slot * STAGE + 4 * w * 512); };
+  auto issue1 = [&](int slot) __attribute__((always_inline)) { issue_lean(q1, 1, lds_u + slot * STAGE + 4 * w * 512 + 1024); };
+#else
   auto issue0 = [&](int slot) __attribute__((always_inline)) { issue_one(q0, lds + slot * STAGE + 4 * w * 512); };
   auto issue1 = [&](int slot) __attribute__((always_inline)) { issue_one(q1, lds + slot * STAGE + 4 * w * 512 + 1024); };
+#endif
   auto issue = [&](int slot) __attribute__((always_inline)) {
     issue0(slot);
     issue1(slot);
