@@ -427,7 +427,12 @@ __device__ __forceinline__ void blds16(unsigned voff, rsrc_v4i_t rsrc, unsigned 
                : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst) : "memory");
 }
 #ifndef URSE_TN_LEAN_ISSUE
-#define URSE_TN_LEAN_ISSUE 1   // stage addressing on the scalar unit + buffer range checks instead of per-lane pointer selects
+#define URSE_TN_LEAN_ISSUE 0   // stage addressing on the scalar unit + buffer range checks instead of per-lane pointer selects:
+                               // 103 -> 59 vector and 174 -> 156 scalar instructions per wave and stage, bit-identical gradients,
+                               // dual wgrad alone 1.315 -> 1.283 ms (time path) / 1.198 -> 1.086 ms (band path) at 256 workgroups,
+                               // but the train step is NOT shorter (same-box A/B, scripts/ab_step_tn_issue.sh: 170.7 / 172.0 ms
+                               // against 170.3 / 170.6): like the interleaved-issue variant above, a denser stream in the
+                               // kernel that shares CUs with the BPTT costs that kernel what it saves here.  Off.
 #endif
 
 // ring depth of the big TN kernel: 5 stages of 32 KB = the whole 160 KB LDS, four stages in flight (measured
