@@ -368,13 +368,13 @@ def main():
 
         import queue
         import threading
-        ready = queue.Queue(maxsize=2)
+        ready = queue.Queue(maxsize=3)
 
         def produce():       # what DataLoader workers do in train_se.fit: recipe draw + source reads + stacking, pinned for the copy
             while True:
                 items = [ds[(state["i"] + b) % len(ds)] for b in range(B)]
                 state["i"] += B
-                ready.put(collate_dynamic(items).pin_memory())
+                ready.put(collate_dynamic(items, pinned=True))
         threading.Thread(target=produce, daemon=True).start()
 
         def feed():          # host batches arrive from the producer thread; the simulator itself runs on the GPU, inside the step
@@ -388,6 +388,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.dynamic_mix:     # the page-locked staging buffers of the first batches are allocations, not steady state
+        while not ready.full():
+            time.sleep(0.01)
     names = ["lstm_fwd_time", "lstm_fwd_band", "lstm_bwd_time", "lstm_bwd_band", "stft_fwd"]
     ops.enable_timing(names)
     torch.cuda.synchronize()

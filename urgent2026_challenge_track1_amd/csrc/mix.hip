@@ -135,44 +135,67 @@ __global__ void __launch_bounds__(256) mix_apply_kernel(const float* __restrict_
   }
 }
 
-// y[b, i] = sum_k taps[tb, k] * x[b, i - k], 0 <= i < len: 256 outputs per workgroup, taps staged through LDS in
-// chunks of 1024 together with the 1279 input samples they touch
+// y[b, i] = sum_k taps[tb, k] * x[b, i - k], 0 <= i < len, accumulated in f64 in ascending k.  1024 outputs per workgroup,
+// four consecutive ones per thread; taps go through LDS in chunks of 1024 together with the 2048 input samples they touch.
+// Per block of four taps a thread reads ONE new aligned quad of inputs (the other quad of its 7-sample window is the
+// previous block's) and one broadcast quad of taps for 16 multiply-adds.
+constexpr int FIR_TC = 1024;
+constexpr int FIR_OUT = 1024;
 __global__ void __launch_bounds__(256) fir_full_kernel(const float* __restrict__ x, const int* __restrict__ lens, long ld,
                                                        const float* __restrict__ taps, const int* __restrict__ ntaps,
                                                        long ldt, int taps_per_utt, float* __restrict__ y, int len_add) {
-  constexpr int TC = 1024;
-  __shared__ float st[TC];
-  __shared__ float sx[TC + 256];
+  constexpr int TC = FIR_TC, NO = FIR_OUT;
+  __shared__ __align__(16) float st[TC];
+  __shared__ __align__(16) float sx[TC + NO];       // sx[j] = x[i0 - k0 - TC + j]
   const int b = blockIdx.y;
   const int len = lens[b] + len_add;
-  const long i0 = (long)blockIdx.x * 256;
+  const long i0 = (long)blockIdx.x * NO;
+  float* yb = y + (long)b * ld;
   if (i0 >= len) {
-    for (long i = i0 + threadIdx.x; i < i0 + 256 && i < ld; i += 256) y[(long)b * ld + i] = 0.f;
+    for (long i = i0 + threadIdx.x; i < i0 + NO && i < ld; i += 256) yb[i] = 0.f;
     return;
   }
   const int tb = taps_per_utt ? b : 0;
   int nt = ntaps[tb];
-  if ((long)nt > i0 + 256) nt = (int)(i0 + 256);          // taps beyond the last output index never contribute
+  if ((long)nt > i0 + NO) nt = (int)(i0 + NO);             // taps beyond the last output index never contribute
   const float* xb = x + (long)b * ld;
   const float* tp = taps + (long)tb * ldt;
-  const long i = i0 + threadIdx.x;
-  double acc = 0.0;
+  const int t = threadIdx.x;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int k0 = 0; k0 < nt; k0 += TC) {
+    const int nk = nt - k0 < TC ? nt - k0 : TC;
+    const int nkb = (nk + 3) >> 2;                          // blocks of four taps in this chunk (tail zero-padded)
     __syncthreads();
-    for (int k = threadIdx.x; k < TC; k += 256) st[k] = (k0 + k < nt) ? tp[k0 + k] : 0.f;
-    // inputs i0 - k0 - (TC-1) .. i0 - k0 + 255
-    const long xlo = i0 - k0 - (TC - 1);
-    for (int j = threadIdx.x; j < TC + 256; j += 256) {
+    for (int k = t; k < 4 * nkb; k += 256) st[k] = (k < nk) ? tp[k0 + k] : 0.f;
+    const long xlo = i0 - k0 - TC;
+    for (int j = TC - 4 * nkb + t; j < TC + NO; j += 256) {
       const long p = xlo + j;
       sx[j] = (p >= 0 && p < len) ? xb[p] : 0.f;
     }
     __syncthreads();
-    // x[i - (k0 + k)] = sx[threadIdx.x + TC - 1 - k]
-    const float* px = sx + threadIdx.x + TC - 1;
-#pragma unroll 8
-    for (int k = 0; k < TC; ++k) acc += (double)st[k] * (double)px[-k];
+    // output i0 + 4t + c, tap k0 + 4kb + r reads sx[TC + 4(t - kb) + c - r]
+    const float4* q = reinterpret_cast<const float4*>(sx) + (TC / 4 + t);
+    const float4* tq = reinterpret_cast<const float4*>(st);
+    float4 cf = q[0];
+    double w[8];
+    w[4] = cf.x; w[5] = cf.y; w[6] = cf.z; w[7] = cf.w;
+#pragma unroll 2
+    for (int kb = 0; kb < nkb; ++kb) {
+      const float4 pf = q[-kb - 1];
+      const float4 tf = tq[kb];
+      w[0] = pf.x; w[1] = pf.y; w[2] = pf.z; w[3] = pf.w;
+      const double tk[4] = {(double)tf.x, (double)tf.y, (double)tf.z, (double)tf.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += tk[r] * w[4 + c - r];
+      w[4] = w[0]; w[5] = w[1]; w[6] = w[2]; w[7] = w[3];
+    }
   }
-  if (i < ld) y[(long)b * ld + i] = (i < len) ? (float)acc : 0.f;
+  const long o = i0 + 4 * t;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (o + c < ld) yb[o + c] = (o + c < len) ? (float)acc[c] : 0.f;
 }
 
 // scipy.signal.filtfilt(b, 1.0, x) for an FIR b (high-pass of simulate_data_from_param.py:461): odd extension by
@@ -361,7 +384,7 @@ extern "C" int urse_mix_noise(const float* speech, const float* noise_raw, const
 extern "C" int urse_fir_full(const float* x, const int32_t* lens, int B, int64_t ld, const float* taps, const int32_t* ntaps,
                              int64_t ldt, int taps_per_utt, float* y, void* stream) {
   URSE_CHECK_ARG(x && lens && taps && ntaps && y && x != y && B > 0 && ld > 0 && ldt > 0, "urse_fir_full: bad argument");
-  hipLaunchKernelGGL(fir_full_kernel, dim3((unsigned)((ld + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, lens, (long)ld,
+  hipLaunchKernelGGL(fir_full_kernel, dim3((unsigned)((ld + FIR_OUT - 1) / FIR_OUT), B), dim3(256), 0, (hipStream_t)stream, x, lens, (long)ld,
                      taps, ntaps, (long)ldt, taps_per_utt, y, 0);
   URSE_CHECK_LAUNCH("urse_fir_full");
   return URSE_OK;
@@ -376,7 +399,7 @@ extern "C" int urse_filtfilt_fir(const float* x, const int32_t* lens, int B, int
   float* e = scratch;                       // [B, lds_] extended input of a pass
   float* f = scratch + (long)B * lds_;      // [B, lds_] its causal convolution
   const int gx = (int)((lds_ + 255) / 256 < 1024 ? (lds_ + 255) / 256 : 1024);
-  const dim3 gfir((unsigned)((lds_ + 255) / 256), B);
+  const dim3 gfir((unsigned)((lds_ + FIR_OUT - 1) / FIR_OUT), B);
   hipLaunchKernelGGL(filtfilt_stage_kernel, dim3(gx, B), dim3(256), 0, st, x, lens, (long)ld, e, (long)lds_, P, padlen, 0);
   hipLaunchKernelGGL(fir_full_kernel, gfir, dim3(256), 0, st, (const float*)e, lens, (long)lds_, taps, ntaps_dev, (long)ntaps, 0, f,
                      P + 2 * padlen);

@@ -345,14 +345,16 @@ class RawMixBatch:
     """What ``collate_dynamic`` hands to the trainer: padded raw sources + recipes of one fs.  ``materialise(device)``
     runs the simulator on the GPU and returns the ``collate_fn`` tuple ``(clean[B,1,T], noisy[B,1,T], fs, lengths)``."""
 
-    def __init__(self, items):
+    def __init__(self, items, pinned=False):
+        """pinned: stack straight into page-locked memory (an in-process producer; DataLoader workers cannot, their batches
+        cross a process boundary and the loader's pin thread calls ``pin_memory()`` instead)."""
         assert len({it["fs"] for it in items}) == 1, "mixed sampling rates in one batch"
         self.fs = items[0]["fs"]
         self.recipes = [it["recipe"] for it in items]
         self.lengths = [it["length"] for it in items]
 
         def stack(key, width):
-            out = torch.zeros(len(items), width, dtype=torch.float32)
+            out = torch.zeros(len(items), width, dtype=torch.float32, pin_memory=pinned)
             lens = []
             for b, it in enumerate(items):
                 a = it[key]
@@ -373,7 +375,7 @@ class RawMixBatch:
     def pin_memory(self):
         for k in ("speech", "noise", "rir"):
             t = getattr(self, k)
-            if t is not None:
+            if t is not None and not t.is_pinned():
                 setattr(self, k, t.pin_memory())
         return self
 
@@ -389,8 +391,8 @@ class RawMixBatch:
                 torch.tensor(self.lengths, dtype=torch.int32))
 
 
-def collate_dynamic(items):
-    return RawMixBatch(items)
+def collate_dynamic(items, pinned=False):
+    return RawMixBatch(items, pinned)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -15,12 +15,30 @@ from ._lib import call
 from .ops import stream_ptr
 
 
+def _upload(v, dtype, dev):
+    """small per-batch parameter lists -> device.  Through pinned memory and non-blocking: a pageable `.to(device)` makes the
+    host wait for everything queued on the stream before it, and the train step behind the simulator then starts with an
+    empty queue (20 such waits per batch cost 20 ms of a 200 ms step)."""
+    if torch.is_tensor(v) and v.device.type == "cuda":
+        return v.to(dtype).contiguous()
+    t = torch.as_tensor(v, dtype=dtype).contiguous()
+    if torch.device(dev).type != "cuda":
+        return t
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 def _i32(v, dev):
-    return torch.as_tensor(v, dtype=torch.int32).to(dev).contiguous()
+    return _upload(v, torch.int32, dev)
 
 
 def _f32(v, dev):
-    return torch.as_tensor(v, dtype=torch.float32).to(dev).contiguous()
+    return _upload(v, torch.float32, dev)
+
+
+@functools.lru_cache(maxsize=None)
+def _device_taps(fs, dev):
+    taps = filter_designs(int(fs))
+    return _f32(taps, dev), _i32([len(taps)], dev), len(taps)
 
 
 def nonsilence_power(x, lens):
@@ -73,13 +91,11 @@ def high_pass(speech, lens, fs):
     ops.require_cuda(speech)
     B, L = speech.shape
     dev = speech.device
-    taps = filter_designs(int(fs))
-    nt = len(taps)
+    taps_dev, nt_dev, nt = _device_taps(int(fs), str(dev))
     lds = L + 7 * nt
     scratch = torch.empty(2 * B * lds, dtype=torch.float32, device=dev)
     out = torch.empty_like(speech)
-    call("filtfilt_fir", speech, _i32(lens, dev), B, speech.stride(0), _f32(taps, dev), _i32([nt], dev), nt, out, scratch, lds,
-         stream_ptr())
+    call("filtfilt_fir", speech, _i32(lens, dev), B, speech.stride(0), taps_dev, nt_dev, nt, out, scratch, lds, stream_ptr())
     return out
 
 
@@ -191,20 +207,17 @@ def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_ear
 
     def count(name):
         skipped[name] = skipped.get(name, 0) + 1
+    host_lens = [int(n) for n in lens]
+    lens = _i32(lens, dev)                      # one upload; every stage below takes the device copy
     if recipes[0].get("highpass", True):
         speech = high_pass(speech, lens, fs)
     noisy = speech
     if rir is not None and any(n > 0 for n in rir_lens):
+        full = [int(n) if n > 0 else 1 for n in rir_lens]
+        early = [min(int(n), int(e)) if n > 0 else 1 for n, e in zip(rir_lens, rir_early_stops)]
+        # rows without an RIR are all zero: make them unit impulses
         rir = rir.clone()
-        full, early = [], []
-        for b in range(B):
-            if rir_lens[b] > 0:
-                full.append(int(rir_lens[b]))
-                early.append(min(int(rir_lens[b]), int(rir_early_stops[b])))
-            else:
-                rir[b, 0] = 1.0
-                full.append(1)
-                early.append(1)
+        rir[:, 0].add_(_f32([0.0 if n > 0 else 1.0 for n in rir_lens], dev))
         noisy = add_reverberation(speech, lens, rir, full)
         speech = add_reverberation(speech, lens, rir, early)
     for r in recipes:
@@ -226,7 +239,7 @@ def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_ear
     for p in range(max([len(t) for t in todo] or [0])):
         for b in range(B):          # bandwidth limitation (polyphase draws only): per utterance, its own rate pair
             if len(todo[b]) > p and todo[b][p] == "bandwidth_limitation" and recipes[b]["params"]["bandwidth_limitation"]["fs_new"] != fs:
-                n = int(lens[b])
+                n = host_lens[b]
                 noisy[b:b + 1, :n] = bandwidth_limitation_polyphase(noisy[b:b + 1, :n].contiguous(), fs,
                                                                    recipes[b]["params"]["bandwidth_limitation"]["fs_new"])
         lo = [recipes[b]["params"]["clipping"]["min_quantile"] if len(todo[b]) > p and todo[b][p] == "clipping" else 0.0

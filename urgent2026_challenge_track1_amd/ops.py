@@ -68,7 +68,10 @@ def stft_forward(wav, n_fft, hop, window=WIN_HANN, lens=None):
     T, Fb = L // hop + 1, n_fft // 2 + 1
     spec = torch.empty(B, T, Fb, 2, device=wav.device, dtype=torch.float32)
     if lens is not None:
-        lens = lens.to(device=wav.device, dtype=torch.int32).contiguous()
+        if lens.device.type == "cpu":   # through page-locked memory: a pageable copy makes the host wait for the whole queue
+            lens = lens.to(torch.int32).contiguous().pin_memory().to(wav.device, non_blocking=True)
+        else:
+            lens = lens.to(device=wav.device, dtype=torch.int32).contiguous()
     timed_call("stft_fwd", "stft_fwd", wav, lens, spec, B, L, n_fft, hop, window, stream_ptr())
     return torch.view_as_complex(spec)
 
