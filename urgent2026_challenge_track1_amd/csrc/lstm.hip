@@ -44,6 +44,7 @@ struct LstmBwdArgs {
   const void* whhT;          // fragment-ordered [2][nut][nslabT][64][16 B]
   int H;
   int dbuf;                  // two LDS tiles (set by the launcher when they fit)
+  int xcd;                   // xcd_dir_tile mapping
   SeqMap m;
 };
 
@@ -228,7 +229,9 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   constexpr int ES = sizeof(T), R = 16 * RT;
   typedef typename Vec4<T>::raw V4;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
-  const int dir = blockIdx.y, s0 = blockIdx.x * R;
+  int dir, tile_;
+  xcd_dir_tile(p.xcd, dir, tile_);
+  const int s0 = tile_ * R;
   const int H = HC ? HC : p.H, nut = (H + 15) >> 4, G4 = 4 * H;
   const int pitch = HPC ? lds_frag_pitch(4 * HPC * ES) : lds_frag_pitch(G4 * ES);
   const int nbuf = p.dbuf ? 2 : 1;         // double-buffered dgates tile: one barrier per step
@@ -471,6 +474,7 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
   URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_bwd: H %d with %d rows exceeds LDS", p.H, R);
   LstmBwdArgs pa = p;
   pa.dbuf = (2 * lds <= 150 * 1024) ? 1 : 0;
+  pa.xcd = xcd_dir_env() & 1;
   if (pa.dbuf) lds *= 2;
   dim3 grid(ceil_div(p.m.n_seq, R), 2);
   const int upw = ((p.H + 15) / 16 + NW - 1) / NW;

@@ -40,6 +40,7 @@ struct WideArgs {
   long inner, outer, stride;
   int n_seq, seq_len;
   unsigned m_cpr;                 // fastdiv magic of the 16-B chunks per h row
+  int xcd;                        // xcd_dir_tile mapping
 };
 
 template <int NSLAB, int MAXG, int RT, int WW>
@@ -48,10 +49,11 @@ __global__ void __launch_bounds__(WW * 64, 2) lstm_fwd_wide_kernel(WideArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps block bookkeeping and weight bases in SGPRs
-  const int dir = blockIdx.y;
+  int dir, tile_;
+  xcd_dir_tile(p.xcd, dir, tile_);
   const int H = p.H;
   constexpr int Hp = NSLAB * 32, pitch = lds_frag_pitch(Hp * 2);      // compile-time: LDS offsets of the k loop fold into immediates
-  const int seq0 = blockIdx.x * WROWS;
+  const int seq0 = tile_ * WROWS;
   const int nrows = min(WROWS, p.n_seq - seq0);
   int* rowtab = reinterpret_cast<int*>(smem + 2 * WROWS * pitch);   // row index of (sequence, t = 0)
 
@@ -320,6 +322,7 @@ extern "C" int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void*
   p.gx = gx; p.ldg = ldg; p.whhb = whhb; p.hout = hout; p.ldh = ldh; p.c = c; p.H = H; p.Hp = Hp; p.save = save;
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
   p.m_cpr = fastdiv_magic((unsigned)((H * 2 + 15) / 16));
+  p.xcd = (xcd_dir_env() >> 1) & 1;
   hipStream_t st = (hipStream_t)stream;
   static const int variant = getenv("URSE_WIDE_VARIANT") ? atoi(getenv("URSE_WIDE_VARIANT")) : 0;
   note_launch(URSE_KV_LSTM_FWD_WIDE);

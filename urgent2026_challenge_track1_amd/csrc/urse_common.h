@@ -4,6 +4,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/urse.h"
@@ -87,6 +88,26 @@ __device__ __forceinline__ float tanhf_(float x) {
   // tanh(x) = 1 - 2/(exp(2x)+1); <= 2 ulp f32 and safe for |x| large (e = inf -> rcp = 0 -> 1)
   const float e = __expf(2.0f * x);
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// A recurrence launch is a grid (tiles, 2 directions).  Workgroups are dealt to the 8 XCDs round-robin by linear id; with the
+// plain (blockIdx.x, blockIdx.y) reading every XCD's L2 serves BOTH directions' recurrent weights.  This reading gives XCD x
+// direction x & 1 only (a bijection onto tiles x directions for any tile count).
+__device__ __forceinline__ void xcd_dir_tile(int on, int& dir, int& tile) {
+  if (on) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, r = lin & 7;
+    dir = r & 1;
+    tile = (lin >> 3) * 4 + (r >> 1);
+  } else {
+    dir = blockIdx.y;
+    tile = blockIdx.x;
+  }
+}
+// URSE_LSTM_XCD_DIR: bit 0 = the BPTT kernels (default on: time path 7.49 -> 7.09 ms per launch, step 168.1 -> 166.2 ms, same-box
+// A/B), bit 1 = the wide forward (default off: 3.2 -> 3.3 ms, its activations thrash the L2 either way)
+static inline int xcd_dir_env() {
+  static const int v = getenv("URSE_LSTM_XCD_DIR") ? atoi(getenv("URSE_LSTM_XCD_DIR")) : 1;
+  return v;
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
