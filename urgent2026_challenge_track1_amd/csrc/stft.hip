@@ -439,6 +439,79 @@ __global__ void __launch_bounds__(256) istft_kernel(const float2* __restrict__ s
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 960-point inverse STFT at hop 480 (the C2 back end), on the register FFT of stft960_kernel.  A workgroup owns 15 hops of
+// the padded overlap-add axis and transforms the 16 frames that cover them (one halo frame recomputed); a half-wave
+// turns one frame PAIR into one complex transform: z[k] = conj(Xa[k] + i Xb[k]) over the Hermitian-extended spectra,
+// y = FFT(z), frame a = Re y / n, frame b = -Im y / n.  The generic kernel above walks five radix passes through LDS
+// (96 us at C2); here a transform makes two LDS round trips and the windowed overlap-add reads the complex result in place.
+constexpr int IS960_NFF = 8, IS960_C = 2 * IS960_NFF - 1;
+__global__ void __launch_bounds__(IS960_NFF * 32) istft960_kernel(const float2* __restrict__ spec, float* __restrict__ out, int T,
+                                                                   int L_out, int hann, const float2* __restrict__ tw_g) {
+  constexpr int N = 960, F = 481, HOP = 480, NFF = IS960_NFF, NTH = NFF * 32, ZS = 1000;
+  __shared__ float2 zbuf[NFF][ZS];
+  __shared__ float2 tw[N];
+  const int tid = threadIdx.x, lane = tid & 63, l = lane & 31;
+  const int f = 2 * (tid >> 6) + (lane >> 5);
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * IS960_C;          // first hop of the chunk
+  const int tf = c0 - 1;                        // first frame carried
+  for (int i = tid; i < N; i += NTH) tw[i] = tw_g[i];
+  const int ta = tf + 2 * f, tb = ta + 1;
+  const bool va = ta >= 0 && ta < T, vb = tb >= 0 && tb < T;
+  const float2* sa = spec + ((size_t)b * T + (va ? ta : 0)) * F;
+  const float2* sb = spec + ((size_t)b * T + (vb ? tb : 0)) * F;
+  const float ma = va ? 1.f : 0.f, mb = vb ? 1.f : 0.f;
+  const int lq = l < 30 ? l : 29;
+  float2 v[32];
+#pragma unroll
+  for (int n1 = 0; n1 < 32; ++n1) {
+    const int k = 30 * n1 + lq;
+    const int kk = k <= N / 2 ? k : N - k;
+    const float sg = k <= N / 2 ? 1.f : -1.f;                    // Hermitian extension: conj beyond n/2
+    const float e = (kk == 0 || kk == N / 2) ? 0.f : 1.f;        // the imaginary parts of DC / Nyquist are dropped
+    const float2 xa = sa[kk], xb = sb[kk];
+    const float ax = xa.x * ma, ay = xa.y * (ma * sg * e), bx = xb.x * mb, by = xb.y * (mb * sg * e);
+    v[n1] = make_float2(ax - by, -(ay + bx));
+  }
+  __syncthreads();                                               // twiddle table complete
+  if (l < 30) {
+    dft32_dif(v);
+    constexpr int BREV[32] = {0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30,
+                              1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31};
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) {
+      const float2 a = v[BREV[k1]];
+      const float2 w = tw[l * k1];
+      zbuf[f][k1 * 31 + l] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+    }
+  }
+  {
+    float2 u[30];
+#pragma unroll
+    for (int n2 = 0; n2 < 30; ++n2) u[n2] = zbuf[f][l * 31 + n2];
+    dft30_pfa(u);
+#pragma unroll
+    for (int k2 = 0; k2 < 30; ++k2) zbuf[f][l + 32 * k2] = u[k2];
+  }
+  __syncthreads();
+  // overlap-add: position p of the chunk takes sample 480 + p % 480 of frame s1 = p / 480 and sample p % 480 of frame s1 + 1
+  const float inv_n = 1.0f / (float)N;
+  for (int p = tid; p < IS960_C * HOP; p += NTH) {
+    const int o = c0 * HOP + p - N / 2;
+    if (o < 0 || o >= L_out) continue;
+    const int s1 = p / HOP, i2 = p - s1 * HOP, i1 = i2 + HOP, s2 = s1 + 1;
+    const float w1 = hann ? 0.5f - 0.5f * tw[i1].x : 1.f, w2 = hann ? 0.5f - 0.5f * tw[i2].x : 1.f;
+    const float2 y1 = zbuf[s1 >> 1][i1], y2 = zbuf[s2 >> 1][i2];
+    const float f1 = (s1 & 1) ? -y1.y : y1.x, f2 = (s2 & 1) ? -y2.y : y2.x;
+    const bool ok1 = tf + s1 >= 0 && tf + s1 < T, ok2 = tf + s2 >= 0 && tf + s2 < T;
+    const float acc = (ok1 ? f1 * (w1 * inv_n) : 0.f) + (ok2 ? f2 * (w2 * inv_n) : 0.f);
+    const float env = (ok1 ? w1 * w1 : 0.f) + (ok2 ? w2 * w2 : 0.f);
+    out[(size_t)b * L_out + o] = (env > 1e-11f) ? acc / env : 0.f;
+  }
+}
+
 }  // namespace urse
 
 using namespace urse;
@@ -502,6 +575,15 @@ extern "C" int urse_istft_fwd(const float* spec, float* wav, int B, int T, int n
   init_lds_attrs();
   int rc = get_tables(n_fft, &tb);
   if (rc) return rc;
+  static const bool no960 = getenv("URSE_STFT_GENERIC") != nullptr;
+  if (n_fft == 960 && hop == 480 && (window == URSE_WIN_RECT || window == URSE_WIN_HANN) && !no960) {
+    const long need960 = (long)n_fft / 2 + L_out;
+    note_launch(URSE_KV_ISTFT960);
+    hipLaunchKernelGGL(istft960_kernel, dim3(ceil_div(need960, (long)IS960_C * 480), B), dim3(IS960_NFF * 32), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2*>(spec), wav, T, L_out, window == URSE_WIN_HANN ? 1 : 0, tb.tw);
+    URSE_CHECK_LAUNCH("urse_istft_fwd");
+    return URSE_OK;
+  }
   const int ov = (n_fft + hop - 1) / hop;
   const int NF = pick_nf(n_fft, (ov + 2) / 2);
   const int C = 2 * NF - ov + 1;
