@@ -259,6 +259,9 @@ __device__ __forceinline__ void dft30_pfa(float2 (&u)[30]) {
     }
 }
 
+// MODE 0: STFT (reflect padding).  MODE 1: adjoint of the hop-480 iSTFT (zero padding, input divided by the OLA envelope, bins
+// scaled by c_k / n), as stft_kernel<1>.
+template <int MODE>
 __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
                                                       float2* __restrict__ out, int L, int T, int hop,
                                                       int hann, const float2* __restrict__ tw_g) {
@@ -286,6 +289,35 @@ __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const
   const int lq = l < 30 ? l : 29;
   const int pa0 = tac * hop - N / 2 + lq, pb0 = tbc * hop - N / 2 + lq;
   float xa_[32], xb_[32];
+  if (MODE == 1) {
+    // zero padding; the second frame of the pair shares its first 16 rows with the first one (hop 480 only)
+#pragma unroll
+    for (int n1 = 0; n1 < 32; ++n1) {
+      const int qa = pa0 + 30 * n1;
+      const bool ok = qa >= 0 && qa < L;
+      const float val = xb[ok ? qa : 0];
+      xa_[n1] = ok ? val : 0.f;
+    }
+    if (tbc == tac + 1) {
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) xb_[n1] = xa_[n1 + 16];
+    } else {
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const int qb = pb0 + 30 * n1;
+        const bool ok = qb >= 0 && qb < L;
+        const float val = xb[ok ? qb : 0];
+        xb_[n1] = ok ? val : 0.f;
+      }
+    }
+#pragma unroll
+    for (int n1 = 16; n1 < 32; ++n1) {
+      const int qb = pb0 + 30 * n1;
+      const bool ok = qb >= 0 && qb < L;
+      const float val = xb[ok ? qb : 0];
+      xb_[n1] = ok ? val : 0.f;
+    }
+  } else {
 #pragma unroll
   for (int n1 = 0; n1 < 32; ++n1) {
     int qa = pa0 + 30 * n1;
@@ -311,6 +343,7 @@ __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const
       xb_[n1] = xb[qb];
     }
   }
+  }
   __syncthreads();                                          // twiddle table complete
   if (l < 30) {
     // window: periodic Hann = 0.5 - 0.5 cos(2 pi i / N) = 0.5 - 0.5 Re(W^i) straight from the twiddle table in LDS
@@ -318,6 +351,16 @@ __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const
     for (int n1 = 0; n1 < 32; ++n1) {
       const int i = 30 * n1 + l;
       const float w = hann ? 0.5f - 0.5f * tw[i].x : 1.0f;
+      if (MODE == 1) {
+        // OLA envelope at padded position m = t * 480 + i: frames m / 480 (sample r) and m / 480 - 1 (sample r + 480)
+        const int r = i < 480 ? i : i - 480;
+        const float w0 = hann ? 0.5f - 0.5f * tw[r].x : 1.0f, w1 = hann ? 0.5f - 0.5f * tw[r + 480].x : 1.0f;
+        const int ja = tac + (i >= 480 ? 1 : 0), jb = tbc + (i >= 480 ? 1 : 0);
+        const float ea = (ja < T ? w0 * w0 : 0.f) + (ja >= 1 ? w1 * w1 : 0.f);
+        const float eb = (jb < T ? w0 * w0 : 0.f) + (jb >= 1 ? w1 * w1 : 0.f);
+        xa_[n1] = xa_[n1] != 0.f ? xa_[n1] / ea : 0.f;
+        xb_[n1] = xb_[n1] != 0.f ? xb_[n1] / eb : 0.f;
+      }
       v[n1] = make_float2(xa_[n1] * w * ma, xb_[n1] * w * mb);
     }
 #ifndef STABL_NO_DFT
@@ -350,8 +393,15 @@ __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const
     const int ff = idx / F, k = idx - ff * F;
     const float2 zk = zbuf[ff][k];
     const float2 zc = zbuf[ff][k == 0 ? 0 : N - k];
-    const float2 xa = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-    const float2 xbv = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+    float2 xa = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+    float2 xbv = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+    if (MODE == 1) {
+      const bool edge = k == 0 || k == N / 2;
+      const float sc = edge ? 1.0f / (float)N : 2.0f / (float)N;
+      xa.x *= sc; xbv.x *= sc;
+      xa.y = edge ? 0.f : xa.y * sc;
+      xbv.y = edge ? 0.f : xbv.y * sc;
+    }
     const int t = blockIdx.x * 2 * NFF + 2 * ff;
 #ifdef STABL_NO_STORE
     if (xa.x != 123.456f) continue;
@@ -464,14 +514,36 @@ __global__ void __launch_bounds__(IS960_NFF * 32) istft960_kernel(const float2* 
   const float2* sb = spec + ((size_t)b * T + (vb ? tb : 0)) * F;
   const float ma = va ? 1.f : 0.f, mb = vb ? 1.f : 0.f;
   const int lq = l < 30 ? l : 29;
+  // rows 0..15 (k = 30 n1 + l <= 479) and k = 480 are loaded; the Hermitian half comes from the other lanes' registers:
+  // k' = 960 - (30 n1 + l) = 30 (31 - n1) + (30 - l), i.e. row 31 - n1 of lane 30 - l (lane 0: its own row 32 - n1)
+  float2 da[17], db[17];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    da[n1] = sa[30 * n1 + lq];
+    db[n1] = sb[30 * n1 + lq];
+  }
+  da[16] = sa[N / 2];
+  db[16] = sb[N / 2];
   float2 v[32];
+  const int src = (lane & 32) | (l == 0 ? 0 : (l < 30 ? 30 - l : 1));
 #pragma unroll
   for (int n1 = 0; n1 < 32; ++n1) {
-    const int k = 30 * n1 + lq;
-    const int kk = k <= N / 2 ? k : N - k;
-    const float sg = k <= N / 2 ? 1.f : -1.f;                    // Hermitian extension: conj beyond n/2
-    const float e = (kk == 0 || kk == N / 2) ? 0.f : 1.f;        // the imaginary parts of DC / Nyquist are dropped
-    const float2 xa = sa[kk], xb = sb[kk];
+    float2 xa, xb;
+    float sg = 1.f;
+    if (n1 < 16) {
+      xa = da[n1]; xb = db[n1];
+    } else {
+      const int m = 31 - n1;                                      // 15 .. 0
+      float2 ma_ = make_float2(__shfl(da[m].x, src, 64), __shfl(da[m].y, src, 64));
+      float2 mb_ = make_float2(__shfl(db[m].x, src, 64), __shfl(db[m].y, src, 64));
+      // lane 0 of row n1: k = 30 n1 -> mirrored k' = 30 (32 - n1) is its own row 32 - n1 (row 16 = the Nyquist bin, unmirrored)
+      const float2 oa = da[32 - n1], ob = db[32 - n1];
+      xa = l == 0 ? oa : ma_;
+      xb = l == 0 ? ob : mb_;
+      sg = (n1 == 16 && l == 0) ? 1.f : -1.f;
+    }
+    const bool edge = (n1 == 0 || n1 == 16) && l == 0;            // DC / Nyquist: imaginary parts dropped
+    const float e = edge ? 0.f : 1.f;
     const float ax = xa.x * ma, ay = xa.y * (ma * sg * e), bx = xb.x * mb, by = xb.y * (mb * sg * e);
     v[n1] = make_float2(ax - by, -(ay + bx));
   }
@@ -537,7 +609,7 @@ extern "C" int urse_stft_fwd(const float* wav, const int32_t* lens, float* spec,
   static const bool no960 = getenv("URSE_STFT_GENERIC") != nullptr;
   if (n_fft == 960 && !no960) {
     note_launch(URSE_KV_STFT960);
-    hipLaunchKernelGGL(stft960_kernel, dim3(ceil_div(T, 2 * URSE_STFT960_NFF), B), dim3(URSE_STFT960_NFF_THREADS), 0, (hipStream_t)stream, wav, lens,
+    hipLaunchKernelGGL(stft960_kernel<0>, dim3(ceil_div(T, 2 * URSE_STFT960_NFF), B), dim3(URSE_STFT960_NFF_THREADS), 0, (hipStream_t)stream, wav, lens,
                        reinterpret_cast<float2*>(spec), L, T, hop, window == URSE_WIN_HANN ? 1 : 0, tb.tw);
     URSE_CHECK_LAUNCH("urse_stft_fwd");
     return URSE_OK;
@@ -559,6 +631,15 @@ extern "C" int urse_istft_bwd(const float* grad_wav, float* grad_spec, int B, in
   init_lds_attrs();
   int rc = get_tables(n_fft, &tb);
   if (rc) return rc;
+  static const bool no960 = getenv("URSE_STFT_GENERIC") != nullptr;
+  if (n_fft == 960 && hop == 480 && L_out > 480 && (window == URSE_WIN_RECT || window == URSE_WIN_HANN) && !no960) {
+    note_launch(URSE_KV_STFT960);
+    hipLaunchKernelGGL(stft960_kernel<1>, dim3(ceil_div(T, 2 * URSE_STFT960_NFF), B), dim3(URSE_STFT960_NFF_THREADS), 0, (hipStream_t)stream,
+                       grad_wav, (const int32_t*)nullptr, reinterpret_cast<float2*>(grad_spec), L_out, T, hop,
+                       window == URSE_WIN_HANN ? 1 : 0, tb.tw);
+    URSE_CHECK_LAUNCH("urse_istft_bwd");
+    return URSE_OK;
+  }
   const int NF = pick_nf(n_fft, 1);
   dim3 grid(ceil_div(T, 2 * NF), B);
   hipLaunchKernelGGL(stft_kernel<1>, grid, dim3(stft_threads()), lds_bytes(n_fft, NF), (hipStream_t)stream, grad_wav,
