@@ -168,6 +168,95 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restr
   }
 }
 
+// backward pass 1 for N % 4 == 0: the same sums with one thread per 4 channels of one N-vector (16-byte loads, 256 / (N/4)
+// vectors in flight per pass), per-channel partials of the vector slots combined through LDS before the atomics
+__global__ void __launch_bounds__(256) gn_bwd_reduce4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const double* __restrict__ stats,
+                                                             const float* __restrict__ gamma, double* __restrict__ sums,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             GnShape s, float eps, int rows_per_block) {
+  __shared__ float4 red_g[256], red_b[256];
+  __shared__ double red[8];
+  const int n4 = s.N >> 2, vpb = 256 / n4, wn = s.W / s.N;
+  const int b = blockIdx.z, kg = blockIdx.y;
+  const int slot = threadIdx.x / n4, c = (threadIdx.x - slot * n4) * 4;
+  const int t0 = blockIdx.x * rows_per_block;
+  int t1 = t0 + rows_per_block;
+  if (t1 > s.T) t1 = s.T;
+  float mean, rstd;
+  gn_mean_rstd(stats, (long)b * s.Kg + kg, (double)s.T * s.W, eps, &mean, &rstd);
+  float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+  float a1 = 0.f, a2 = 0.f;
+  if (slot < vpb) {
+    float ga[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ga[j] = gamma[(long)kg * s.gstride + c + j];
+    const int nvec = (t1 - t0) * wn;                   // N-vectors of this block's rows
+    int t = t0 + slot / wn, v = slot - (slot / wn) * wn;
+    const int dt = vpb / wn, dv = vpb - dt * wn;
+    // four vectors in flight per thread: offsets first, then the eight 16-byte loads, then the arithmetic
+    const long rowp = (long)s.Kg * s.W;                                  // elements per (b, t) row
+    const long gbase = ((long)b * s.T * s.Kg + kg) * (long)s.W + c;      // (b, t = 0, kg, v = 0, c)
+    auto acc = [&](const float4& xv, const float4& dv4) {
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (xs[q] - mean) * rstd;
+        dg[q] += ds[q] * xh;
+        db[q] += ds[q];
+        a1 += ds[q] * ga[q];
+        a2 += ds[q] * ga[q] * xh;
+      }
+    };
+    int j = slot;
+    for (; j + 3 * vpb < nvec; j += 4 * vpb) {
+      long off[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        off[u] = gbase + (long)t * rowp + v * s.N;
+        t += dt; v += dv;
+        if (v >= wn) { v -= wn; ++t; }
+      }
+      float4 xv[4], dv4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *reinterpret_cast<const float4*>(x + off[u]);
+        dv4[u] = *reinterpret_cast<const float4*>(dy + off[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc(xv[u], dv4[u]);
+    }
+    for (; j < nvec; j += vpb) {
+      const long off = gbase + (long)t * rowp + v * s.N;
+      acc(*reinterpret_cast<const float4*>(x + off), *reinterpret_cast<const float4*>(dy + off));
+      t += dt; v += dv;
+      if (v >= wn) { v -= wn; ++t; }
+    }
+  }
+  red_g[threadIdx.x] = make_float4(dg[0], dg[1], dg[2], dg[3]);
+  red_b[threadIdx.x] = make_float4(db[0], db[1], db[2], db[3]);
+  double s1 = wave_sum_d((double)a1), s2 = wave_sum_d((double)a2);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[w] = s1; red[4 + w] = s2; }
+  __syncthreads();
+  if (threadIdx.x < n4) {
+    float4 g = red_g[threadIdx.x], bb = red_b[threadIdx.x];
+    for (int q = 1; q < vpb; ++q) {
+      const float4 g2 = red_g[threadIdx.x + q * n4], b2 = red_b[threadIdx.x + q * n4];
+      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+      bb.x += b2.x; bb.y += b2.y; bb.z += b2.z; bb.w += b2.w;
+    }
+    float* pg = dgamma + (long)kg * s.gstride + c;
+    float* pb = dbeta + (long)kg * s.gstride + c;
+    atomicAdd(pg, g.x); atomicAdd(pg + 1, g.y); atomicAdd(pg + 2, g.z); atomicAdd(pg + 3, g.w);
+    atomicAdd(pb, bb.x); atomicAdd(pb + 1, bb.y); atomicAdd(pb + 2, bb.z); atomicAdd(pb + 3, bb.w);
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + ((long)b * s.Kg + kg) * 2, red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(sums + ((long)b * s.Kg + kg) * 2 + 1, red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
 // backward pass 2: dx = rstd * (gamma*dy - s1/n - xhat*s2/n) (+ dres), float4 per thread
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const double* __restrict__ stats,
@@ -287,12 +376,20 @@ extern "C" int urse_groupnorm_bwd(const float* x, const float* dy, const double*
   URSE_CHECK_ARG(x && dy && stats && gamma && dx && dgamma && dbeta && sums, "urse_groupnorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * Kg, st);
-  int nblk = ceil_div((long)T * W, 32768);
+  // elements per workgroup of pass 1.  Every workgroup ends with 2 N f32 atomics on the SAME 2 N addresses (dgamma, dbeta): at
+  // 32768 elements (2,592 workgroups at C2) the kernel was bound by that serialisation, not by its 684 MB of reads
+  // (same-box A/B of the step: 169.8 ms at 32768, 168.6 at 65536, 167.3 at 131072, 167.1 at 262144)
+  static const long red_elems = getenv("URSE_GN_REDUCE_ELEMS") ? atol(getenv("URSE_GN_REDUCE_ELEMS")) : 262144;
+  int nblk = ceil_div((long)T * W, red_elems);
   if (nblk > T) nblk = T;
   const int rpb = ceil_div(T, nblk);
   dim3 grid(ceil_div(T, rpb), Kg, B);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, st, x, dy, stats, gamma, sums, dgamma, dbeta, s, eps,
-                     rpb);
+  static const bool reduce1 = getenv("URSE_GN_REDUCE1") != nullptr;
+  if (N % 4 == 0 && N / 4 <= 256 && W % N == 0 && !reduce1)
+    hipLaunchKernelGGL(gn_bwd_reduce4_kernel, grid, dim3(256), 0, st, x, dy, stats, gamma, sums, dgamma, dbeta, s, eps, rpb);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, st, x, dy, stats, gamma, sums, dgamma, dbeta, s, eps,
+                       rpb);
   URSE_CHECK_ARG(N / 4 <= 256, "urse_groupnorm_bwd: N %d too wide", N);
   const int vpb_b = 256 / (N / 4);
   dim3 grid_a(ceil_div((long)T * (W / N), (long)vpb_b * GN_ITER), Kg, B);

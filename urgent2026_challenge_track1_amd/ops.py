@@ -468,7 +468,7 @@ def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
 # geometry override of the streaming BPTT per path ("t" / "f"): 0 = the library decides from the number of sequences
 # (32-sequence workgroups of 8 waves once there are >= 4096 of them); 2 | 16 forces that geometry - the parity tests of
 # the benchmarked kernel set use it to run the C2 kernels on batches a CPU oracle can follow
-BWD_ROWS16 = {}
+BWD_ROWS16 = {k: int(os.environ[e]) for k, e in (("t", "URSE_BWD_ROWS_T"), ("f", "URSE_BWD_ROWS_F")) if e in os.environ}
 
 
 def lstm_bwd(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride, rows16=0):
