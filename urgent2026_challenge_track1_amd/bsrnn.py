@@ -83,7 +83,7 @@ def nt_grouped(rows, device, in_dt, out_dt, act=0):
     host copy too and picks the kernel / grid (include/urse.h: urse_gemm_nt_grouped_h)."""
     host = np.asarray(rows, dtype=np.int64)
     assert host.ndim == 2 and host.shape[1] == 12
-    call("gemm_nt_grouped_h", torch.from_numpy(host).to(device), host.ctypes.data, host.shape[0], in_dt, out_dt, act,
+    call("gemm_nt_grouped_h", ops.upload(torch.from_numpy(host), device), host.ctypes.data, host.shape[0], in_dt, out_dt, act,
          stream_ptr())
 
 
