@@ -46,11 +46,16 @@ KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_r
                    "stft960", "stft_generic", "istft_generic", "istft960", "lstm_bwd_ws")
 
 
+_PAGEABLE_UPLOADS = os.environ.get("URSE_PAGEABLE_UPLOADS", "0") == "1"
+
+
 def upload(host_tensor, device):
     """small host table -> device through page-locked memory, non-blocking: a pageable `.to(device)` makes the host wait for
     everything queued on the stream (the per-band descriptor tables go up eight times per step)."""
     if torch.device(device).type != "cuda":
         return host_tensor
+    if _PAGEABLE_UPLOADS:          # A/B switch: the blocking copies this replaced
+        return host_tensor.to(device)
     return host_tensor.contiguous().pin_memory().to(device, non_blocking=True)
 
 
@@ -77,7 +82,7 @@ def stft_forward(wav, n_fft, hop, window=WIN_HANN, lens=None):
     spec = torch.empty(B, T, Fb, 2, device=wav.device, dtype=torch.float32)
     if lens is not None:
         if lens.device.type == "cpu":   # through page-locked memory: a pageable copy makes the host wait for the whole queue
-            lens = lens.to(torch.int32).contiguous().pin_memory().to(wav.device, non_blocking=True)
+            lens = upload(lens.to(torch.int32), wav.device)
         else:
             lens = lens.to(device=wav.device, dtype=torch.int32).contiguous()
     timed_call("stft_fwd", "stft_fwd", wav, lens, spec, B, L, n_fft, hop, window, stream_ptr())
