@@ -68,6 +68,26 @@ def test_reverberation_and_high_pass(lib):
     np.testing.assert_allclose(mixing.filter_designs(16000), mix_ref.filter_designs(16000), rtol=0, atol=0)
 
 
+def test_fir_tap_counts_and_ragged_tiles(lib):
+    """the FIR kernel works in blocks of four taps and 1024-tap chunks on 1024-output tiles: tap counts around every boundary,
+    a row pitch that is not a tile multiple, lengths that end inside a tile - against numpy's f64 convolution."""
+    from urgent2026_challenge_track1_amd import mixing
+    rng = np.random.default_rng(11)
+    counts = [1, 2, 3, 5, 1023, 1024, 1025, 2051]
+    B, L = len(counts), 5003
+    sp = rng.standard_normal((B, L)).astype(np.float32)
+    lens = [L, 4097, 1024, 1025, 3000, 17, L, 4999]
+    rir = np.zeros((B, max(counts)), np.float32)
+    for b, n in enumerate(counts):
+        rir[b, :n] = rng.standard_normal(n).astype(np.float32)
+        sp[b, lens[b]:] = 0
+    out = mixing.add_reverberation(torch.tensor(sp).cuda(), lens, torch.tensor(rir).cuda(), counts).cpu().numpy()
+    for b, n in enumerate(counts):
+        ref = np.convolve(sp[b, :lens[b]].astype(np.float64), rir[b, :n].astype(np.float64))[:lens[b]]
+        assert np.abs(out[b, :lens[b]] - ref).max() <= 2e-6 * np.abs(ref).max(), (b, n)
+        assert np.all(out[b, lens[b]:] == 0), b
+
+
 def test_clipping_packet_loss_peak_norm(lib):
     from urgent2026_challenge_track1_amd import mixing
     from oracle import mix_ref

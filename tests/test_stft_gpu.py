@@ -14,6 +14,7 @@ CASES = [  # (n_fft, hop, L, window)
     (1536, 384, 19200, "hann"),    # flow model
     (256, 128, 5000, "rect"), (512, 256, 5000, "rect"), (768, 384, 5000, "rect"), (1024, 512, 5000, "rect"),
     (160, 80, 4001, "hann"), (640, 320, 9999, "hann"), (882, 441, 22050, "hann"), (480, 240, 12000, "hann"),
+    (960, 480, 7700, "rect"),      # the register-FFT kernels' rectangular-window branch, a length that ends inside a workgroup's chunk
 ]
 
 
@@ -54,7 +55,7 @@ def test_istft_matches_oracle_and_roundtrip(lib, n_fft, hop, L, window):
     assert (y - x).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("n_fft,hop,L,window", CASES[:5])
+@pytest.mark.parametrize("n_fft,hop,L,window", CASES[:5] + CASES[-1:])
 def test_istft_backward_is_adjoint(lib, n_fft, hop, L, window):
     from urgent2026_challenge_track1_amd import ops
     g = torch.Generator().manual_seed(7)
@@ -77,6 +78,7 @@ def test_stft_linearity_at_full_size(lib):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(32, 192000, generator=g).cuda()
     y = torch.randn(32, 192000, generator=g).cuda()
+    ops.launch_counts(reset=True)
     a = ops.stft_forward(x, 960, 480)
     b = ops.stft_forward(y, 960, 480)
     c = ops.stft_forward(2.0 * x - 3.0 * y, 960, 480)
@@ -85,3 +87,5 @@ def test_stft_linearity_at_full_size(lib):
     # Parseval on an interior frame-free quantity: round trip at full size
     r = ops.istft_forward(a, 960, 480, 192000)
     assert (r - x).abs().max().item() <= 5e-5
+    n = ops.launch_counts()
+    assert n["stft960"] == 3 and n["istft960"] == 1 and n["stft_generic"] == 0 and n["istft_generic"] == 0, n   # the register-FFT kernels ran
