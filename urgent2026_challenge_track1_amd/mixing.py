@@ -171,7 +171,7 @@ def bandwidth_limitation_polyphase(speech, fs, fs_new):
     branch is ``scipy.signal.resample_poly(y, target // gcd, orig // gcd)`` followed by ``fix_length`` to ``ceil(n * ratio)``,
     applied down and back up, cropped to the input length.  Runs on the batched polyphase kernel (`metrics._poly_resample`:
     scipy's default Kaiser(5.0) design).  The other three resamplers the reference draws (kaiser_best / kaiser_fast need resampy's
-    filter tables, scipy = one FFT per utterance) have no device implementation."""
+    filter tables) have no device implementation; the scipy one is `bandwidth_limitation_fft`."""
     import math
     from .metrics import _poly_resample
     if fs == fs_new:
@@ -189,14 +189,45 @@ def bandwidth_limitation_polyphase(speech, fs, fs_new):
     return fix(up, L)
 
 
+def _fft_resample(x, num):
+    """``scipy.signal.resample(x, num, axis=1)`` for real f32 [P, n]: the spectrum is truncated / zero-padded to ``num`` bins (the
+    Nyquist bin doubled when it is cut, halved when it is introduced) and transformed back.  The two transforms have the
+    utterance's own, arbitrary length: they are plain library FFTs (rocFFT through ``torch.fft``)."""
+    ops.require_cuda(x)
+    P, nx = x.shape
+    X = torch.fft.rfft(x.float(), dim=1)
+    n = min(num, nx)
+    nyq = n // 2 + 1
+    Y = torch.zeros(P, num // 2 + 1, dtype=X.dtype, device=x.device)
+    Y[:, :nyq] = X[:, :nyq]
+    if n % 2 == 0:
+        if num < nx:
+            Y[:, n // 2] *= 2.0
+        elif nx < num:
+            Y[:, n // 2] *= 0.5
+    return torch.fft.irfft(Y, n=num, dim=1) * (float(num) / float(nx))
+
+
+def bandwidth_limitation_fft(speech, fs, fs_new):
+    """``bandwidth_limitation(x, fs, fs_new, res_type="scipy")`` (simulate_data_from_param.py:233-252): librosa's scipy / fft branch is
+    ``scipy.signal.resample(y, ceil(n * ratio))``, applied down and back up, cropped to the input length."""
+    import math
+    if fs == fs_new:
+        return speech
+    L = speech.shape[1]
+    down = _fft_resample(speech, int(math.ceil(L * float(fs_new) / fs)))
+    up = _fft_resample(down, int(math.ceil(down.shape[1] * float(fs) / fs_new)))
+    return up[:, :L].contiguous()
+
+
 def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_early_stops, fs, recipes, skipped=None):
     """``process_one_sample(on_the_fly=True)`` (simulate_data_from_param.py:440-590) for a batch of raw sources and the
     recipes ``dataset.draw_recipe`` drew for them (one fs per batch) -> (speech, noisy) f32 [B, L].
 
     Utterances without an RIR convolve with a unit impulse (exact identity).  ``clipping`` / ``packet_loss`` are applied in
     each recipe's own order: pass p handles every utterance's p-th augmentation, the others ride along with identity
-    parameters (quantiles 0 / 1, no packets).  ``bandwidth_limitation`` is applied when the recipe drew the polyphase
-    resampler (one of the four methods); the other resamplers (resampy / FFT), ``codec`` (ffmpeg) and the wind-noise side-chain
+    parameters (quantiles 0 / 1, no packets).  ``bandwidth_limitation`` is applied when the recipe drew the polyphase or
+    the scipy (FFT) resampler (two of the four methods); the resampy ones (kaiser_best / kaiser_fast), ``codec`` (ffmpeg) and the wind-noise side-chain
     compressor (ffmpeg) have no device implementation: the recipe still DRAWS them (so the random stream matches the
     reference) but they are not applied - wind noise is mixed additively at its drawn SNR - and each omission is counted in
     ``skipped``."""
@@ -231,7 +262,7 @@ def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_ear
         for a in r.get("order", []):
             if a in ("clipping", "packet_loss"):
                 mine.append(a)
-            elif a == "bandwidth_limitation" and r["params"][a]["res_type"] in ("polyphase", "none"):
+            elif a == "bandwidth_limitation" and r["params"][a]["res_type"] in ("polyphase", "scipy", "none"):
                 mine.append(a)
             else:
                 count(a)
@@ -240,8 +271,9 @@ def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_ear
         for b in range(B):          # bandwidth limitation (polyphase draws only): per utterance, its own rate pair
             if len(todo[b]) > p and todo[b][p] == "bandwidth_limitation" and recipes[b]["params"]["bandwidth_limitation"]["fs_new"] != fs:
                 n = host_lens[b]
-                noisy[b:b + 1, :n] = bandwidth_limitation_polyphase(noisy[b:b + 1, :n].contiguous(), fs,
-                                                                   recipes[b]["params"]["bandwidth_limitation"]["fs_new"])
+                bw = recipes[b]["params"]["bandwidth_limitation"]
+                limit = bandwidth_limitation_fft if bw["res_type"] == "scipy" else bandwidth_limitation_polyphase
+                noisy[b:b + 1, :n] = limit(noisy[b:b + 1, :n].contiguous(), fs, bw["fs_new"])
         lo = [recipes[b]["params"]["clipping"]["min_quantile"] if len(todo[b]) > p and todo[b][p] == "clipping" else 0.0
               for b in range(B)]
         hi = [recipes[b]["params"]["clipping"]["max_quantile"] if len(todo[b]) > p and todo[b][p] == "clipping" else 1.0
