@@ -377,8 +377,17 @@ def main():
                 ready.put(collate_dynamic(items, pinned=True))
         threading.Thread(target=produce, daemon=True).start()
 
-        def feed():          # host batches arrive from the producer thread; the simulator itself runs on the GPU, inside the step
-            return ready.get().materialise(dev, skipped)
+        # host batches arrive from the producer thread; the simulator runs on the GPU, one batch ahead on a side stream
+        # (train_se.DevicePrefetcher, as in train_se.fit): one batch is simulated per timed step, beside the previous step
+        from urgent2026_challenge_track1_amd.train_se import DevicePrefetcher
+
+        def host_batches():
+            while True:
+                yield ready.get()
+        staged = iter(DevicePrefetcher(host_batches(), dev, skipped))
+
+        def feed():
+            return next(staged)
 
     def step():
         loss = model.training_step(feed() if feed is not None else batch)

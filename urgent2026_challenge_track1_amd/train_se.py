@@ -79,6 +79,46 @@ def to_device(batch, dev, skipped=None):
     return clean.to(dev, non_blocking=True), noisy.to(dev, non_blocking=True), fs, lens
 
 
+class DevicePrefetcher:
+    """Iterates a loader one batch ahead on a side stream: the host→device copies of batch i+1 and, for a dynamic-mixing batch,
+    its simulator kernels run beside the train step of batch i (whose recurrences leave most issue slots idle) instead of in front
+    of step i+1.  The consumer's stream waits on the batch's event; the tensors are handed over with ``record_stream``."""
+
+    def __init__(self, loader, dev, skipped=None):
+        self.loader, self.dev, self.skipped = loader, dev, skipped
+        self.stream = torch.cuda.Stream(dev) if torch.device(dev).type == "cuda" else None
+
+    def _stage(self, batch):
+        if self.stream is None:
+            return to_device(batch, self.dev, self.skipped), None
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # buffers freed by the consumer are safe to reuse
+        with torch.cuda.stream(self.stream):
+            out = to_device(batch, self.dev, self.skipped)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return out, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            (out, ev), nxt = nxt, None
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                pass
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.dev)
+                cur.wait_event(ev)
+                for t in out:
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)
+            yield out
+
+
 def validate(model, loader, dev):
     tot, n = 0.0, 0
     model.eval()
@@ -152,8 +192,8 @@ def fit(cfg, max_steps=None, log_every=50):
     for epoch in range(epoch0, cfg.num_train_epochs):
         # the reference never advances the sampler epoch (quirk C.3: on_train_epoch_start is not a DataModule hook)
         equalise_batch_counts(dm.train_batch_sampler, world, dev)
-        for batch in train_loader:
-            loss = model.training_step(to_device(batch, dev, skipped))
+        for batch in DevicePrefetcher(train_loader, dev, skipped):
+            loss = model.training_step(batch)
             loss.backward()
             model.optimizer_step(opt, reducer)
             step += 1
