@@ -1,0 +1,12 @@
+#!/bin/bash
+# per-kernel times of the BSRNN-Flow (C4) leg: bash scripts/gpu_profile_flow.sh <tag>
+tag=${1:-flow}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --model flow --steps 4 --pretouch-gib 0 > $O/bench.log 2>&1; echo "rc=$?"
+find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
+find $O -name "*.db" -delete 2>/dev/null; find $O -name "*kernel_trace.csv" -delete 2>/dev/null
+tail -1 $O/bench.log | cut -c1-600

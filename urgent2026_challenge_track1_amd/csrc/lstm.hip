@@ -34,6 +34,7 @@ struct LstmFwdArgs {
   void* hout; long ldh;      // [M, ldh] T: h (dir 0 cols [0,H), dir 1 cols [H,2H))
   float* c;                  // [M, 2H] f32 cell state (saved when `save`)
   int H, Hp, save;
+  int xcd;                   // xcd_dir_tile mapping
   SeqMap m;
 };
 
@@ -95,7 +96,9 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
   constexpr int ES = sizeof(T), R = 16 * RT;
   typedef typename Vec4<T>::raw V4;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
-  const int dir = blockIdx.y, s0 = blockIdx.x * R;
+  int dir, tile_;
+  xcd_dir_tile(p.xcd, dir, tile_);
+  const int s0 = tile_ * R;
   const int H = p.H, Hp = p.Hp, nut = (H + 15) >> 4;
   const int pitch = lds_frag_pitch(Hp * ES);
   for (int i = tid; i < 2 * R * pitch / 4; i += NTHR) reinterpret_cast<unsigned*>(smem)[i] = 0u;
@@ -544,6 +547,7 @@ extern "C" int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void*
   URSE_CHECK_ARG(gx && whh && hout && (c || !save), "urse_lstm_bidir_fwd: null pointer");
   LstmFwdArgs p;
   p.gx = gx; p.ldg = ldg; p.whh = whh; p.hout = hout; p.ldh = ldh; p.c = c; p.H = H; p.Hp = Hp; p.save = save;
+  p.xcd = (xcd_dir_env() >> 2) & 1;
   p.m.inner = inner; p.m.outer = outer; p.m.stride = stride; p.m.n_seq = n_seq; p.m.seq_len = seq_len;
   const int es = dtype == URSE_BF16 ? 2 : 4;
   int rc = check_map(p.m, H, es, "urse_lstm_bidir_fwd");

@@ -104,9 +104,10 @@ __device__ __forceinline__ void xcd_dir_tile(int on, int& dir, int& tile) {
   }
 }
 // URSE_LSTM_XCD_DIR: bit 0 = the BPTT kernels (default on: time path 7.49 -> 7.09 ms per launch, step 168.1 -> 166.2 ms, same-box
-// A/B), bit 1 = the wide forward (default off: 3.2 -> 3.3 ms, its activations thrash the L2 either way)
+// A/B), bit 1 = the wide forward (default off: 3.2 -> 3.3 ms, its activations thrash the L2 either way), bit 2 = the streaming
+// forward (default on; the flow model's band path streams 4.7 MB of recurrent weights per direction: Euler sampler 587 -> 576 ms)
 static inline int xcd_dir_env() {
-  static const int v = getenv("URSE_LSTM_XCD_DIR") ? atoi(getenv("URSE_LSTM_XCD_DIR")) : 1;
+  static const int v = getenv("URSE_LSTM_XCD_DIR") ? atoi(getenv("URSE_LSTM_XCD_DIR")) : 5;
   return v;
 }
 
