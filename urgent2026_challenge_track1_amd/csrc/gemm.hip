@@ -1046,12 +1046,21 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d) {
           }
           if (ACT == 2) {   // tanh backward: aux (= resid slot, TO typed) holds h = tanh(.)
             const long row = m0 + wm * 64 + i * 16 + lc;
+            const TO* hp = reinterpret_cast<const TO*>(d.resid) + row * d.ldr + col;
+            float hv[4] = {0.f, 0.f, 0.f, 0.f};
+            // the lane's four columns are consecutive: one 8-byte load instead of four 2-byte ones (the scalar form made this
+            // epilogue 6x the kernel's byte floor on the mask decoder's backward)
+            if (OS == 2 && row < d.M && col + 3 < d.N && ((reinterpret_cast<uintptr_t>(hp) & 7) == 0)) {
+              const uint2 q = *reinterpret_cast<const uint2*>(hp);
+              hv[0] = __uint_as_float(q.x << 16); hv[1] = __uint_as_float(q.x & 0xffff0000u);
+              hv[2] = __uint_as_float(q.y << 16); hv[3] = __uint_as_float(q.y & 0xffff0000u);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float hv = 0.f;
-              if (row < d.M && col + r < d.N) hv = to_f32<TO>(reinterpret_cast<const TO*>(d.resid)[row * d.ldr + col + r]);
-              v[r] *= (1.f - hv * hv);
+              for (int r = 0; r < 4; ++r)
+                if (row < d.M && col + r < d.N) hv[r] = to_f32<TO>(hp[r]);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= (1.f - hv[r] * hv[r]);
           }
           char* dst = lds + lrow * CP + lcol * OS;
           if (OS == 2) {
