@@ -146,3 +146,15 @@ def test_wav_io_roundtrip(tmp_path):
     write_audio(str(tmp_path / "b.wav"), x, 48000)
     y, fs = read_audio(str(tmp_path / "b.wav"))
     assert fs == 48000 and np.abs(y[0] - x).max() <= 1.0 / 32768
+
+
+def test_device_prefetcher_order_and_end():
+    """the one-batch-ahead iterator hands out every batch once, in order, and ends with the loader (host path: no side stream)."""
+    import torch
+    from urgent2026_challenge_track1_amd.train_se import DevicePrefetcher
+    batches = [(torch.full((2, 1, 8), float(i)), torch.full((2, 1, 8), -float(i)), torch.tensor(16000), torch.tensor([8, 8]))
+               for i in range(5)]
+    got = list(DevicePrefetcher(batches, "cpu"))
+    assert len(got) == 5 and all(float(g[0][0, 0, 0]) == i and float(g[1][0, 0, 0]) == -i for i, g in enumerate(got))
+    assert list(DevicePrefetcher([], "cpu")) == []
+    assert len(list(DevicePrefetcher(batches[:1], "cpu"))) == 1
