@@ -180,6 +180,31 @@ def test_fit_with_dynamic_mixing_feed(lib, tmp_path):
     assert len([f for f in os.listdir(train_se.ckpt_dir(cfg)) if "val_loss" in f]) == 1
 
 
+def test_device_prefetcher_equals_inline_materialise(lib, tmp_path):
+    """staging a dynamic-mixing batch one step ahead on the side stream gives the tensors the inline path gives, while the main
+    stream is busy with other work."""
+    import copy
+    from urgent2026_challenge_track1_amd import train_se
+    from urgent2026_challenge_track1_amd.dataset import DynamicMixingDataset, collate_dynamic
+    _write_source_set(tmp_path / "train", n_speech=8)
+    root = tmp_path / "train"
+    ds = DynamicMixingDataset(*[str(root / (k + ".scp")) for k in ("speech_sources", "noise_scoures", "rirs", "wind_noise_scoures",
+                                                                   "source_length")], max_duration=6000)
+    np.random.seed(9)
+    raws = [collate_dynamic([ds[(4 * k + b) % len(ds)] for b in range(4)]) for k in range(3)]
+    dev = torch.device("cuda")
+    inline = [copy.deepcopy(r).materialise(dev) for r in raws]
+    busy = torch.randn(2048, 2048, device=dev)
+    got = []
+    for out in train_se.DevicePrefetcher([copy.deepcopy(r) for r in raws], dev):
+        for _ in range(20):
+            busy = busy @ busy * 1e-3                    # main-stream work the staged batch overlaps with
+        got.append(out)
+    assert len(got) == 3
+    for a, b in zip(inline, got):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and int(a[2]) == int(b[2])
+
+
 def test_two_rank_fit_mixed_fs_uneven_shards(lib, tmp_path):
     """train_se.fit (not bench.py) with two gloo ranks on one GPU, 16 / 48 kHz utterances of varying length: the ranks see
     different K per step (unused-band zeros through the real model), their shards give different batch counts
