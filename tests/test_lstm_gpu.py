@@ -249,6 +249,36 @@ def test_cluster2_kernel_matches_streaming_kernel(lib, path, B, T, K, N):
     assert (h1.float() - h2.float()).abs().mean().item() <= 1e-4
 
 
+def test_cluster2_chunked_band_path_matches_streaming_kernel(lib):
+    """more sequences than the resident clusters hold (H = 768: 320 per direction) run as several launches over contiguous row
+    blocks of the band path: B x T = 700 sequences of K = 12 steps == the streaming kernel, saved activations and cell state too."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(8)
+    N, B, T, K = 384, 1, 700, 12
+    H, dtype, dev = 2 * N, torch.bfloat16, "cuda"
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    M = B * T * K
+    sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    assert ops.lstm_cluster2_plan(H, pk["Hp"], sm["n_seq"]) is None
+    chunks = ops.lstm_cluster2_chunks(H, pk["Hp"], **sm)
+    assert chunks is not None and len(chunks) == 3 and sum(n for _, n in chunks) == 700
+    assert ops.lstm_cluster2_chunks(H, pk["Hp"], n_seq=700, seq_len=K, inner=K, outer=T * K, stride=K) is None   # not row blocks
+    xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dtype)
+    gx1 = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    gx2 = gx1.clone()
+    h1, c1 = ops.lstm_fwd(gx1, pk["whh"], H, pk["Hp"], **sm)
+    ops.launch_counts(reset=True)
+    h2, c2, err = ops.lstm_fwd_cluster2(gx2, pk["whhq"], H, pk["Hp"], **sm)
+    assert int(err.item()) == 0 and ops.launch_counts()["lstm_fwd_cluster2"] == 3
+    assert (h1.float() - h2.float()).abs().max().item() <= 1e-2
+    assert (c1 - c2).abs().max().item() <= 2e-2
+    assert (gx1.float() - gx2.float()).abs().max().item() <= 2e-2
+    assert (h1.float() - h2.float()).abs().mean().item() <= 1e-4
+
+
 def test_cooperative_kernel_timeout_is_reported(lib):
     """the cluster / split kernels share one device error word; a set word makes the next check raise (fail loudly)."""
     from urgent2026_challenge_track1_amd import ops, _lib

@@ -465,7 +465,7 @@ class BSRNNCore(nn.Module):
         gx = ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
         sm = self._seqmap(path, B, T, K)
         if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H in ops.CLUSTER2_H and \
-                ops.lstm_cluster2_plan(H, d["Hp"], sm["n_seq"]) is not None:
+                ops.lstm_cluster2_chunks(H, d["Hp"], **sm) is not None:
             hout, c, err = ops.lstm_fwd_cluster2(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
             self._cluster_err = err
         elif ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and \

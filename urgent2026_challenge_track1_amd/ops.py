@@ -350,19 +350,51 @@ def lstm_cluster2_plan(H, Hp, n_seq):
     return list(plan)
 
 
+def lstm_cluster2_chunks(H, Hp, n_seq, seq_len, inner, outer, stride):
+    """[(first sequence, count)] launches of the generalised cluster kernel that cover n_seq sequences, or None.  One launch takes
+    what the clusters resident on the chip hold (H = 768: 5 clusters x 64 sequences per direction); more sequences run as
+    several launches when every sequence is a contiguous block of rows (the band path: inner 1, stride 1) - at H = 768 a launch
+    is 48 steps x 7 us against 43 us per step of the streaming kernel, which re-reads 4.7 MB of weights per step and CU."""
+    if lstm_cluster2_plan(H, Hp, n_seq) is not None:
+        return [(0, n_seq)]
+    if not (inner == 1 and stride == 1 and outer == seq_len):
+        return None
+    probe = lstm_cluster2_plan(H, Hp, 1)
+    if probe is None:
+        return None
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    cap = max(1, (cus - 4) // 2 // probe[0]) * 64
+    n = (n_seq + cap - 1) // cap
+    if n > CLUSTER2_MAX_CHUNKS:
+        return None
+    per = (n_seq + n - 1) // n
+    return [(s0, min(per, n_seq - s0)) for s0 in range(0, n_seq, per)]
+
+
+CLUSTER2_MAX_CHUNKS = int(os.environ.get("URSE_LSTM_CLUSTER2_MAX_CHUNKS", "6"))
+
+
 def lstm_fwd_cluster2(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save=True):
     """generalised persistent cluster LSTM forward (bf16): see csrc/lstm_cluster2.hip."""
-    plan = lstm_cluster2_plan(H, Hp, n_seq)
+    chunks = lstm_cluster2_chunks(H, Hp, n_seq, seq_len, inner, outer, stride)
     M, dev = gx.shape[0], gx.device
-    key = ("c2", dev, H, Hp, n_seq)
-    if key not in _cluster_ws:
-        _cluster_ws[key] = (torch.empty(plan[3], device=dev, dtype=torch.bfloat16), kernel_error_flag(dev))
-    hx, err = _cluster_ws[key]
     ldh = kpad(2 * H, gx.dtype)
     hout = _hout_buffer(M, ldh, H, gx)
     c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
-    timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster2_fwd", gx, gx.stride(0), whhq, hout, ldh, c, hx,
-               err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
+    err = None
+    for s0, n in chunks:
+        plan = lstm_cluster2_plan(H, Hp, n)
+        key = ("c2", dev, H, Hp, n)
+        if key not in _cluster_ws:
+            _cluster_ws[key] = (torch.empty(plan[3], device=dev, dtype=torch.bfloat16), kernel_error_flag(dev))
+        hx, err = _cluster_ws[key]
+        if len(chunks) == 1:
+            g_, h_, c_ = gx, hout, c
+        else:                                   # sequence s is rows [s * seq_len, (s + 1) * seq_len)
+            r0, r1 = s0 * seq_len, (s0 + n) * seq_len
+            g_, h_, c_ = gx[r0:r1], hout[r0:r1], (c[r0:r1] if save else None)
+        timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster2_fwd", g_, gx.stride(0), whhq, h_, ldh, c_, hx,
+                   err, H, Hp, n, seq_len, inner, outer, stride, int(save), stream_ptr())
     return hout, c, err
 
 
