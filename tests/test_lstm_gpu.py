@@ -220,6 +220,37 @@ def test_split_bptt_matches_streaming_kernel(lib, B, T, K, N):
     assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, (d.max().item(), d.mean().item(), scale)
 
 
+def test_split_bptt_chunked_band_path_matches_streaming_kernel(lib, monkeypatch):
+    """band path of the flow model (H = 768): 1,002 sequences of 12 steps exceed what one split launch can keep resident; the BPTT
+    runs as row-block launches (opt-in: URSE_LSTM_SPLIT_BWD_MAX_CHUNKS) == the streaming kernel."""
+    from urgent2026_challenge_track1_amd import ops
+    monkeypatch.setattr(ops, "SPLIT_BWD_MAX_CHUNKS", 4)
+    torch.manual_seed(12)
+    N, B, T, K = 384, 2, 501, 12
+    H, dtype, dev = 2 * N, torch.bfloat16, "cuda"
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    M = B * T * K
+    sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+    assert ops.lstm_split_plan(H, sm["n_seq"]) is None
+    chunks = ops.lstm_split_chunks(H, **sm)
+    assert chunks is not None and len(chunks) >= 2 and sum(n for _, n in chunks) == 1002
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dtype)
+    gx = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    hout, c = ops.lstm_fwd(gx, pk["whh"], H, pk["Hp"], **sm)
+    dh = ops.pack2d(torch.randn(M, 2 * H, device=dev), M, hout.shape[1], dtype)
+    g1, g2 = gx.clone(), gx.clone()
+    ops.lstm_bwd(dh, g1, c, pk["whhT"], H, **sm)
+    ops.launch_counts(reset=True)
+    _, err = ops.lstm_bwd_split(dh, g2, c, pk["whhT"], H, **sm)
+    assert int(err.item()) == 0 and ops.launch_counts()["lstm_bwd_split"] == len(chunks)
+    d = (g1.float() - g2.float()).abs()
+    scale = g1.float().abs().max().item()
+    assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, (d.max().item(), d.mean().item(), scale)
+
+
 @pytest.mark.parametrize("path,B,T,K,N", [("time", 2, 21, 48, 384), ("band", 1, 60, 10, 384), ("time", 3, 40, 34, 196), ("time", 1, 9, 5, 196)])
 def test_cluster2_kernel_matches_streaming_kernel(lib, path, B, T, K, N):
     """generalised cluster forward (H = 768: 24 workgroups per cluster; H = 392: two unit quads per wave) == streaming kernel."""

@@ -506,7 +506,7 @@ class BSRNNCore(nn.Module):
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
             dg, self._cluster_err = ops.lstm_bwd_cluster(dh, gates, c, pk[p + "whhTq"], H, d["Hp"], **sm)
         elif (ops.USE_SPLIT_LSTM_BWD or H >= ops.SPLIT_BWD_MIN_H) and dt == torch.bfloat16 and \
-                ops.lstm_split_plan(H, sm["n_seq"]) is not None:
+                ops.lstm_split_chunks(H, **sm) is not None:
             dg, self._cluster_err = ops.lstm_bwd_split(dh, gates, c, pk[p + "whhT"], H, **sm)
         else:
             dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, rows16=ops.BWD_ROWS16.get(path, 0), **sm)   # dgates, gate-interleaved columns

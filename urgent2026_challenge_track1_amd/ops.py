@@ -497,16 +497,43 @@ def lstm_split_plan(H, n_seq):
     return list(plan)
 
 
+# row-block launches of the split BPTT for the flow model's band path: measured neutral against the streaming kernel (train step
+# 114.5 ms either way, profiles/r02_ab_flow_split_chunks_v1.log), so one launch or none by default
+SPLIT_BWD_MAX_CHUNKS = int(os.environ.get("URSE_LSTM_SPLIT_BWD_MAX_CHUNKS", "1"))
+
+
+def lstm_split_chunks(H, n_seq, seq_len, inner, outer, stride):
+    """[(first sequence, count)] launches of the split BPTT that cover n_seq sequences, or None: one launch when all its
+    workgroups fit the chip, else (band path only: every sequence a contiguous block of rows) the fewest equal row blocks that do."""
+    if lstm_split_plan(H, n_seq) is not None:
+        return [(0, n_seq)]
+    if not (inner == 1 and stride == 1 and outer == seq_len):
+        return None
+    for n in range(2, SPLIT_BWD_MAX_CHUNKS + 1):
+        per = (n_seq + n - 1) // n
+        if lstm_split_plan(H, per) is not None:
+            return [(s0, min(per, n_seq - s0)) for s0 in range(0, n_seq, per)]
+    return None
+
+
 def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
-    """split BPTT (bf16, time path): gates (saved activations) is overwritten with d(pre-activations)."""
-    plan = lstm_split_plan(H, n_seq)
+    """split BPTT (bf16): gates (saved activations) is overwritten with d(pre-activations)."""
+    chunks = lstm_split_chunks(H, n_seq, seq_len, inner, outer, stride)
     dev = gates.device
-    key = ("split", dev, H, n_seq)
-    if key not in _cluster_ws:
-        _cluster_ws[key] = (torch.empty(plan[2], device=dev, dtype=torch.float32), kernel_error_flag(dev))
-    xbuf, err = _cluster_ws[key]
-    timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_split_bwd", dh, dh.stride(0), gates, gates.stride(0), c,
-               whhT, xbuf, err, H, n_seq, seq_len, inner, outer, stride, stream_ptr())
+    err = None
+    for s0, n in chunks:
+        plan = lstm_split_plan(H, n)
+        key = ("split", dev, H, n)
+        if key not in _cluster_ws:
+            _cluster_ws[key] = (torch.empty(plan[2], device=dev, dtype=torch.float32), kernel_error_flag(dev))
+        xbuf, err = _cluster_ws[key]
+        if len(chunks) == 1:
+            d_, g_, c_ = dh, gates, c
+        else:                                   # sequence s is rows [s * seq_len, (s + 1) * seq_len)
+            r0, r1 = s0 * seq_len, (s0 + n) * seq_len
+            d_, g_, c_ = dh[r0:r1], gates[r0:r1], c[r0:r1]
+        timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_split_bwd", d_, dh.stride(0), g_, gates.stride(0), c_,
+                   whhT, xbuf, err, H, n, seq_len, inner, outer, stride, stream_ptr())
     return gates, err
 
 
