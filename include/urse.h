@@ -67,7 +67,6 @@ const char* urse_last_error(void);
 #define URSE_KV_STFT_GENERIC 20
 #define URSE_KV_ISTFT_GENERIC 21
 #define URSE_KV_ISTFT960 22
-#define URSE_KV_LSTM_BWD_WS 23     /* weight-stationary cluster BPTT (lstm_bwd_ws.hip) */
 #define URSE_KV_COUNT 32
 int urse_launch_count(int variant);
 int urse_launch_counts_reset(void);

@@ -43,7 +43,7 @@ def timed_call(tname, name, *args):
 KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_ring", "nt_grouped_128", "tn_ring", "tn_ring_t",
                    "tn_dual", "tn_128", "tn_grouped", "lstm_fwd_stream", "lstm_fwd_wide", "lstm_fwd_cluster",
                    "lstm_fwd_cluster2", "lstm_bwd_stream16", "lstm_bwd_stream32", "lstm_bwd_cluster", "lstm_bwd_split",
-                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_bwd_ws")
+                   "stft960", "stft_generic", "istft_generic", "istft960")
 
 
 _PAGEABLE_UPLOADS = os.environ.get("URSE_PAGEABLE_UPLOADS", "0") == "1"
