@@ -78,6 +78,15 @@ def _view(buf, h):
     return buf[off:off + r * c].view(r, c)
 
 
+def _empty_padded(K, M, ld, n, dtype, device):
+    """[K, M, ld] buffer whose first n columns a GEMM will write: zeros only in the padding (the next GEMM reads it as K padding;
+    a full zero fill of the two mask-decoder hidden tensors was 1.4 GB per pass)."""
+    t = torch.empty(K, M, ld, dtype=dtype, device=device)
+    if ld > n:
+        t[:, :, n:].zero_()
+    return t
+
+
 def nt_grouped(rows, device, in_dt, out_dt, act=0):
     """one launch over per-band GEMM records {A, B, C, bias, resid, lda, ldb, ldc, M, N, K, ldr}; the library sees the
     host copy too and picks the kernel / grid (include/urse.h: urse_gemm_nt_grouped_h)."""
@@ -618,7 +627,7 @@ class BSRNNCore(nn.Module):
             p = "md%s." % tag
             xn, st = ops.groupnorm_fwd(skip, self._p(p + "gamma", Kf * N), self._p(p + "beta", Kf * N), B, T, K, N, N,
                                        Np, N, dt, GN_EPS)
-            hid = torch.zeros(K, M, ld4N, dtype=dt, device=dev)
+            hid = _empty_padded(K, M, ld4N, 4 * N, dt, dev)     # the GEMM writes the 4N columns; only the K padding must be zero
             pre = torch.empty(M, P, dtype=torch.float32, device=dev)
             b2_off = 0
             for k in range(K):
@@ -647,7 +656,7 @@ class BSRNNCore(nn.Module):
         dpre = [torch.zeros(M, P, dtype=dt, device=dev) for _ in range(2)]
         call("glu_mask_apply_bwd", pres[0], pres[1], spec, dout, dpre[0], dpre[1], tb["bands"], tb["f2k"], M, F, P,
              ops._dt(dpre[0]), stream_ptr())
-        dhp = [torch.zeros(K, M, ld4N, dtype=dt, device=dev) for _ in range(2)]
+        dhp = [_empty_padded(K, M, ld4N, 4 * N, dt, dev) for _ in range(2)]
         dxn = [torch.empty(M * K, N, dtype=torch.float32, device=dev) for _ in range(2)]
         rows_a, rows_b = [], []
         for i, tag in enumerate("mr"):
