@@ -89,3 +89,64 @@ def test_pesq_metric_surface(lib):
     assert v is not None and 1.0 < v < 4.65
     with pytest.raises(ValueError):
         metrics.pesq_metric(ref, deg, fs=11025)
+
+
+def _random_case(seed):
+    """a seeded pair with random rate, length, SNR, delay and one random impairment (pause / late second part / dropout)."""
+    rng = np.random.default_rng(7000 + seed)
+    fs, mode = ((8000, "nb"), (16000, "wb"))[int(rng.integers(0, 2))]
+    L = int(rng.uniform(2.0, 6.0) * fs)
+    clean = pesq_cases.speech_like(rng, L, fs)
+    variant = ("", "pause", "jump", "dropout")[int(rng.integers(0, 4))]
+    pos = int(rng.uniform(0.35, 0.65) * L)
+    if variant == "pause":
+        w = int(rng.uniform(0.2, 0.5) * fs)
+        clean[pos - w:pos + w] *= 1e-3
+    deg = clean.copy()
+    if variant == "jump":
+        d = int(rng.uniform(0.008, 0.04) * fs)
+        deg = np.concatenate([clean[:pos], np.zeros(d), clean[pos:L - d]])
+    if variant == "dropout":
+        deg[pos:pos + int(rng.uniform(0.05, 0.2) * fs)] = 0.0
+    snr = rng.uniform(0.0, 35.0)
+    deg = deg + rng.standard_normal(L) * np.sqrt((clean ** 2).mean() / 10 ** (snr / 10))
+    delay = int(rng.integers(-400, 401))
+    return fs, mode, clean.astype(np.float32), pesq_cases.shift(deg, delay).astype(np.float32)
+
+
+def test_pesq_random_pairs_match_oracle(lib):
+    """20 random pairs scored by the oracle on the spot (not regression vectors): integer stages equal, MOS within 2e-3."""
+    from oracle import pesq_ref
+    from urgent2026_challenge_track1_amd import metrics
+    cases = [_random_case(s) for s in range(20)]
+    worst, n_split, n_bad = 0.0, 0, 0
+    for cfg in ((8000, "nb"), (16000, "wb")):
+        items = [c for c in cases if (c[0], c[1]) == cfg]
+        if not items:
+            continue
+        Lm = max(len(c[2]) for c in items)
+        R, D = np.zeros((len(items), Lm), np.float32), np.zeros((len(items), Lm), np.float32)
+        for k, c in enumerate(items):
+            R[k, :len(c[2])], D[k, :len(c[3])] = c[2], c[3]
+        mos, raw, trace = metrics.pesq_batch(torch.tensor(R).cuda(), torch.tensor(D).cuda(), cfg[0], cfg[1],
+                                             lens=[len(c[2]) for c in items], return_trace=True)
+        mos, trace = mos.cpu().numpy(), trace.cpu().numpy()
+        for k, c in enumerate(items):
+            want_mos, want = pesq_ref.pesq(c[0], c[2], c[3], c[1], return_trace=True)
+            tr = trace[k]
+            if want.get("n_utterances") is None:
+                assert np.isnan(mos[k]), k
+                continue
+            nu = int(tr[1])
+            assert int(tr[0]) == want["crude_delay"] and nu == want["n_utterances"], (cfg, k, int(tr[0]), nu, want)
+            assert tr[8:8 + nu].tolist() == list(want["utt_start"]) and tr[58:58 + nu].tolist() == list(want["utt_end"]), (cfg, k)
+            assert tr[108:108 + nu].tolist() == list(want["utt_delay"]), (cfg, k, tr[108:108 + nu], want["utt_delay"])
+            assert (int(tr[2]), int(tr[3])) == (want["start_frame"], want["stop_frame"]), (cfg, k)
+            assert int(tr[4]) == len(want["bad_intervals"]), (cfg, k)
+            for q, b in enumerate(want["bad_intervals"]):
+                assert tr[158 + 2 * q:160 + 2 * q].tolist() == list(b[:2]), (cfg, k, q)
+            n_split += nu > 1
+            n_bad += len(want["bad_intervals"]) > 0
+            worst = max(worst, abs(float(mos[k]) - float(want_mos)))
+            assert abs(float(mos[k]) - float(want_mos)) <= 2e-3, (cfg, k, float(mos[k]), float(want_mos))
+    print("PESQ random pairs: 20 scored, %d with several utterances, %d with bad intervals, max |MOS - oracle| = %.2e" % (n_split, n_bad, worst))
