@@ -346,7 +346,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #ifndef URSE_BWD_KB
 #define URSE_BWD_KB 13
 #endif
-        constexpr int KB = (sizeof(T) == 2) ? URSE_BWD_KB : 8;
+#ifndef URSE_BWD_KB2
+#define URSE_BWD_KB2 17   // the 32-sequence geometry (8 waves, 256-VGPR budget): 49 slabs = 17 + 17 + 15, 230 VGPRs; band-path BPTT
+                          // 27.15 -> 26.4 ms per step, step -1.1 ms (same-box A/B, profiles/r02_ab_bptt_kb_v1.log)
+#endif
+        constexpr int KB = (sizeof(T) == 2) ? (RT >= 2 ? URSE_BWD_KB2 : URSE_BWD_KB) : 8;
         #pragma unroll 1
         for (int k0 = 0; k0 < nslab; k0 += KB) {
           uint4 b[KB];
