@@ -198,7 +198,7 @@ class _InMemorySources:
         return self.audio[path].shape[1]
 
 
-def metrics_bench(dev, pairs=1024, batches=1, fs=16000, seconds=4.0):
+def metrics_bench(dev, pairs=2048, batches=1, fs=16000, seconds=4.0):
     """Second metric of BASELINE.json ("PESQ+STOI pairs/sec", config C5: 4 s @ 16 kHz enhanced / reference pairs resident in
     HBM): PESQ (P.862.2 wide-band) + ESTOI + SDR on the HIP kernels, `batches` x `pairs` pairs per run (`--metric-pairs N`
     runs N, e.g. the 10,000 of C5).  CPU baseline = the numpy oracles on a bounded sample of the same pairs, one core each
@@ -222,12 +222,13 @@ def metrics_bench(dev, pairs=1024, batches=1, fs=16000, seconds=4.0):
         noise = torch.randn(pairs, L, device=dev, generator=g)
         noise = noise * (clean.pow(2).mean(1, keepdim=True) / noise.pow(2).mean(1, keepdim=True)).sqrt() * 10 ** (-snr / 20)
         enh = clean + noise
-        # PESQ runs one workgroup per pair, three to a CU: launches of 1,024 pairs keep the chip full; ESTOI / SDR in 256-pair slices
+        # PESQ runs one workgroup per pair, four to a CU; the slowest pair of a launch takes 3-4x the mean (utterance splitting), so
+        # launches of 2,048 pairs (two full rounds) amortise that tail; ESTOI / SDR in 256-pair slices
         metrics.pesq_batch(clean[:64], enh[:64], fs); metrics.estoi_batch(clean[:256], enh[:256], fs); metrics.sdr_batch(clean[:256], enh[:256])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(batches):
-            q = metrics.pesq_batch(clean, enh, fs, max_pairs_per_launch=1024)
+            q = metrics.pesq_batch(clean, enh, fs, max_pairs_per_launch=2048)
         torch.cuda.synchronize()
         t_pesq = time.perf_counter() - t0
         for _ in range(batches):
@@ -297,7 +298,7 @@ def main():
                     help="first-touch this much HBM (or all that is free) before the model is built; 0 = off")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=1.0)
-    ap.add_argument("--metric-pairs", type=int, default=1024, help="pairs the metric leg scores (config C5: 10000)")
+    ap.add_argument("--metric-pairs", type=int, default=2048, help="pairs the metric leg scores (config C5: 10000)")
     ap.add_argument("--no-flow", action="store_true", help="skip the extra BSRNN-Flow (config C4) leg")
     ap.add_argument("--model", default="bsrnn", choices=["bsrnn", "flow"],
                     help="flow: print the BSRNN-Flow (config C4) line instead of the headline one")
@@ -481,7 +482,7 @@ def main():
         torch.cuda.empty_cache()
         out["flow_c4"] = flow_bench(dev)
     if rank == 0 and world == 1 and not args.no_metrics:
-        out["metrics_bench"] = metrics_bench(dev, batches=max(1, args.metric_pairs // 1024))
+        out["metrics_bench"] = metrics_bench(dev, batches=max(1, args.metric_pairs // 2048))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -25,7 +25,12 @@ struct PesqArgs {
 
 __host__ __device__ inline long pesq_align(long v) { return (v + 63) / 64 * 64; }
 
-__global__ void __launch_bounds__(256) pesq_kernel(PesqArgs a) {
+#ifndef URSE_PESQ_WAVES_PER_SIMD
+#define URSE_PESQ_WAVES_PER_SIMD 4      // workgroups per CU the register budget is cut for (one wave of each per SIMD): 120 VGPRs and
+                                        // 37 KB of LDS let four pairs share a CU - 13.1 k pairs/s at 2,048 pairs per launch against 12.0 k
+                                        // with three (132 VGPRs); launches of <= 768 pairs are 7 % slower
+#endif
+__global__ void __launch_bounds__(256, URSE_PESQ_WAVES_PER_SIMD) pesq_kernel(PesqArgs a) {
   using namespace pesq;
   __shared__ float2 s_la[1024], s_lb[1024];
   __shared__ float s_x[1024], s_h[1024], s_w[2048], s_iir[512];

@@ -122,7 +122,7 @@ def _poly_resample(x, fs_in, fs_out):
     return y
 
 
-def pesq_batch(ref, inf, fs, mode=None, lens=None, return_trace=False, max_pairs_per_launch=512):
+def pesq_batch(ref, inf, fs, mode=None, lens=None, return_trace=False, max_pairs_per_launch=2048):
     """PESQ (MOS-LQO) of P pairs f32 [P, L] -> f32 [P]; NaN where pesq.pesq returns NO_UTTERANCES_DETECTED (pesq_metric maps
     that to None / nan, :81-88, :160-162).  mode None = the rule of pesq_metric: 'nb' at 8 kHz, 'wb' at 16 kHz, higher rates
     are resampled to 16 kHz first.  return_trace: also the integer outputs of the alignment stages, int32 [P, 286]."""
