@@ -98,6 +98,13 @@ int urse_istft_bwd(const float* grad_wav, float* grad_spec, int B, int T, int n_
 int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                  const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K, int in_dtype, int out_dtype,
                  int act, void* stream);
+/* urse_gemm_nt with f32 output plus the GroupNorm statistics of that output (what the next layer's normalisation needs:
+ * espnet BSRNN `norm_time / norm_freq`, GroupNorm(1, N) over a whole batch element): stats[g] = (sum, sum of squares) of rows
+ * [g * rows_per_group, (g + 1) * rows_per_group) x N columns; fused into the producing GEMM's epilogue when its ring kernel
+ * takes the shape, a separate pass otherwise.  M % rows_per_group == 0, ldc == N, N % 4 == 0. */
+int urse_gemm_nt_gnstats(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                         const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K, int in_dtype, int act,
+                         double* stats, int64_t rows_per_group, void* stream);
 /* grouped form: `descs` = device array of `groups` records of 12 int64
  * {A, B, C, bias, resid, lda, ldb, ldc, M, N, K, ldr}; grid.x = max_blocks (largest tile count). */
 int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_dtype, int out_dtype, int act,
@@ -138,6 +145,11 @@ int urse_gemm_tn_grouped(const void* descs, int groups, int max_blocks, int dtyp
  * added after the affine (the flow model's time embedding, bsrnn_flowse.py:293-294). */
 int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* add, void* y, double* stats,
                        int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* stream);
+/* the two halves of urse_groupnorm_fwd on their own: statistics only (accumulates into `stats`, zeroed by the caller), and the
+ * normalisation with statistics that exist already (urse_gemm_nt_gnstats) */
+int urse_groupnorm_stats(const float* x, double* stats, int B, int T, int Kg, int W, int N, void* stream);
+int urse_groupnorm_apply(const float* x, const float* gamma, const float* beta, const float* add, void* y, const double* stats,
+                         int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* stream);
 /* dx = GN backward(dy) (+ dres); dgamma / dbeta are accumulated (+=).  dx_packed (may be NULL): bf16 copy of dx as
  * rows [B*T*Kg*(W/N)][ldp] with columns N..ldp-1 zeroed (the A operand of the next dgrad GEMM, saves a pack pass). */
 int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, const float* gamma, const float* dres,

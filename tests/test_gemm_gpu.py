@@ -248,3 +248,28 @@ def test_gemm_nt_grouped_h_ring_kernel_matches_small_kernel(lib, monkeypatch, ac
         assert (a[:, :N].double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
         assert (a[:, :N].double() - b[:, :N].double()).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
         assert torch.count_nonzero(a[:, N:]) == 0          # nothing written past a group's N
+
+
+@pytest.mark.parametrize("M,N,K,rows,resid", [(4096, 196, 800, 1024, True), (4096, 196, 800, 2048, False), (3 * 640, 196, 416, 640, True),
+                                              (512, 20, 64, 128, True)])
+def test_gemm_nt_with_groupnorm_statistics(lib, M, N, K, rows, resid):
+    """urse_gemm_nt_gnstats: the output equals urse_gemm_nt's bit for bit, and the (sum, sum of squares) per group of rows equal
+    the statistics pass on that output - from the ring kernel's epilogue (first three shapes) and from the fallback (last)."""
+    from urgent2026_challenge_track1_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g) if resid else None
+    ref = ops.gemm_nt(A, W, bias, resid=r, out_dtype=torch.float32)
+    out, st = ops.gemm_nt(A, W, bias, resid=r, out_dtype=torch.float32, gn_rows=rows)
+    assert torch.equal(out, ref)
+    x = ref.double().view(M // rows, rows * N)
+    want = torch.stack([x.sum(1), (x * x).sum(1)], 1).reshape(-1)
+    assert (st - want).abs().max().item() <= 1e-6 * want.abs().max().item(), (st, want)
+    # and the normalisation that takes them equals the two-pass one
+    gamma, beta = torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda")
+    Np = (N + 31) // 32 * 32
+    y1, s1 = ops.groupnorm_fwd(ref, gamma, beta, M // rows, rows, 1, N, N, Np, 0, torch.bfloat16)
+    y2, _ = ops.groupnorm_fwd(ref, gamma, beta, M // rows, rows, 1, N, N, Np, 0, torch.bfloat16, stats=st)
+    assert (y1.float() - y2.float()).abs().max().item() <= 1e-2 and (s1 - st).abs().max().item() <= 1e-6 * want.abs().max().item()

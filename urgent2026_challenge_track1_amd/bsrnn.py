@@ -130,6 +130,7 @@ class BSRNNCore(nn.Module):
         self.grad_ready_hook = None     # callable(tag) fired when a parameter group's grads are final
         self._deferred, self._inflight, self._side = [], None, None     # weight-gradient GEMMs parked for the side stream
         self._grad_pack = None          # (data_ptr of a gradient stream tensor, its bf16 K-padded copy)
+        self._gn_stats = None           # (a dual-path output, its GroupNorm statistics from the fc GEMM's epilogue)
 
     # ------------------------------------------------------------------------------------------
     # parameter containers (espnet names) of the parts that differ between the discriminative and the flow DNN
@@ -469,8 +470,12 @@ class BSRNNCore(nn.Module):
         H, dt, pk, d = self.H, self.compute_dtype, self._packed, self._dims
         p = "l%d%s." % (l, path)
         M = B * T * K
+        # the statistics of `skip` came out of the GEMM that produced it (the previous half layer's fc + residual), if one did
+        pre = self._gn_stats[1] if (self._gn_stats is not None and self._gn_stats[0].data_ptr() == skip.data_ptr() and
+                                    self._gn_stats[0].shape == skip.shape) else None
+        self._gn_stats = None
         xn, stats = ops.groupnorm_fwd(skip, self._p(p + "gamma", N), self._p(p + "beta", N), B, T, 1, K * N, N,
-                                      d["Np"], 0, dt, GN_EPS, add=temb)
+                                      d["Np"], 0, dt, GN_EPS, add=temb, stats=pre)
         gx = ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
         sm = self._seqmap(path, B, T, K)
         if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H in ops.CLUSTER2_H and \
@@ -486,7 +491,12 @@ class BSRNNCore(nn.Module):
         else:
             hout, c = ops.lstm_fwd(gx, pk[p + "whh"], H, d["Hp"], save=save, **sm)
         out = torch.empty_like(skip)
-        ops.gemm_nt(hout, pk[p + "wfc"], self._p(p + "bfc", N), resid=skip.view(M, N), out=out.view(M, N))
+        if ops.FUSE_GN_STATS and dt == torch.bfloat16 and N % 4 == 0 and not (path == "f" and l == self.num_layer - 1):
+            # the next half layer normalises `out` over each batch element (T * K rows): its sums ride on this GEMM's epilogue
+            _, st = ops.gemm_nt(hout, pk[p + "wfc"], self._p(p + "bfc", N), resid=skip.view(M, N), out=out.view(M, N), gn_rows=T * K)
+            self._gn_stats = (out, st)      # (holding `out` keeps its storage from being handed to another tensor)
+        else:
+            ops.gemm_nt(hout, pk[p + "wfc"], self._p(p + "bfc", N), resid=skip.view(M, N), out=out.view(M, N))
         return out, ((stats, xn, gx, c, hout) if save else None)
 
     def dualpath_bwd(self, skip, saved, l, path, dout):

@@ -899,7 +899,7 @@ static void launch_tn_dma(int ntw, int csm, dim3 grid, hipStream_t st, const TnA
 // fragment reads, so the 16 rows of a fragment hit 16 different 16-byte bank groups.  Epilogue as gemm_nt_kernel
 // (bias / tanh / tanh-backward / residual, output staged through LDS for 16-byte coalesced stores).
 template <typename TO, int NTW, int ACT, int BMX, int WNC>
-__device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d) {
+__device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gstats = nullptr, long rpg = 0) {
   // tile = BMX rows x (16 * NTW * WNC) columns; waves BMX/64 (m) x WNC (n), each 64 x 16*NTW
   // <256, 2>: 8 waves, 256 x 224/256, 4 stages of 32 KB (long K: least operand traffic per FLOP)
   // <128, 4>: 8 waves, 128 x 448, 4 stages of 36 KB (short K, write-bound outputs: 896-byte row segments reach 5.4 TB/s
@@ -1027,6 +1027,12 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d) {
   const bool vec_ok = ((d.ldc * OS) % 16 == 0) && ((reinterpret_cast<uintptr_t>(d.C) % 16) == 0) &&
                       (!d.resid || ACT == 2 || (((d.ldr * 4) % 16 == 0) && (reinterpret_cast<uintptr_t>(d.resid) % 16) == 0));
   // (storing straight from the accumulators, 8/16 B per lane, measured 2.3x slower than this staged epilogue)
+  // optional GroupNorm statistics of the OUTPUT (f32, after the residual): sum and sum of squares per group of `rpg` consecutive
+  // rows, accumulated from the values the sweep below stores - the separate pass over the tensor (gn_stats_kernel) goes away.
+  // A tile spans at most two groups (rpg >= BMX, checked by the launcher).
+  float gsa = 0.f, gqa = 0.f, gsb = 0.f, gqb = 0.f;
+  const bool gst = OS == 4 && gstats != nullptr;
+  const long gidx = gst ? m0 / rpg : 0, gbound = gst ? (gidx + 1) * rpg : 0;
 #pragma unroll 1
   for (int pass = 0; pass < BMX / RPP; ++pass) {
     if (pass > 0) __syncthreads();
@@ -1090,6 +1096,11 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d) {
             f.x += rr.x; f.y += rr.y; f.z += rr.z; f.w += rr.w;
             v = *reinterpret_cast<uint4*>(&f);
           }
+          if (gst) {
+            const float4 f = *reinterpret_cast<const float4*>(&v);
+            const float sv = (f.x + f.y) + (f.z + f.w), qv = (f.x * f.x + f.y * f.y) + (f.z * f.z + f.w * f.w);
+            if (row < gbound) { gsa += sv; gqa += qv; } else { gsb += sv; gqb += qv; }
+          }
 #ifdef NABL_NO_GST
           if (v.x == 0x12345678u)
 #endif
@@ -1100,6 +1111,9 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d) {
           for (int e = 0; e < EPC && col + e < d.N; ++e) {
             float f = to_f32<TO>(sv[e]);
             if (OS == 4 && d.resid && ACT != 2) f += d.resid[row * d.ldr + col + e];
+            if (gst) {
+              if (row < gbound) { gsa += f; gqa += f * f; } else { gsb += f; gqb += f * f; }
+            }
             C[row * d.ldc + col + e] = from_f32<TO>(f);
           }
         }
@@ -1108,11 +1122,31 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d) {
       if (ch >= CPR) { ch -= CPR; ++lrow; }
     }
   }
+  if (gst) {
+    __syncthreads();                                           // the staging area is free again
+    double* red = reinterpret_cast<double*>(lds);
+    const double r0 = wave_sum_d((double)gsa), r1 = wave_sum_d((double)gqa), r2 = wave_sum_d((double)gsb), r3 = wave_sum_d((double)gqb);
+    if (lane == 0) { red[w * 4] = r0; red[w * 4 + 1] = r1; red[w * 4 + 2] = r2; red[w * 4 + 3] = r3; }
+    __syncthreads();
+    if (tid < 4) {
+      double t = 0.0;
+      for (int i = 0; i < NWV; ++i) t += red[i * 4 + tid];
+      const long g = gidx + (tid >> 1);
+      if (tid < 2 || gbound < m0 + BMX) {                      // the second pair only when the tile reaches into the next group
+        if (g * rpg < d.M) atomicAdd(gstats + g * 2 + (tid & 1), t);
+      }
+    }
+  }
 }
 
+struct NtExtra {       // optional outputs of the ring NT kernel beside C (null / 0 = none)
+  double* gstats;      // GroupNorm statistics of C per group of `rpg` rows: [groups][2] (sum, sum of squares), pre-zeroed
+  long rpg;
+};
+
 template <typename TO, int NTW, int ACT, int BMX, int WNC = 2>
-__global__ void __launch_bounds__(BMX / 64 * WNC * 64) gemm_nt_dma_kernel(GemmDesc d) {
-  gemm_nt_dma_body<TO, NTW, ACT, BMX, WNC>(d);
+__global__ void __launch_bounds__(BMX / 64 * WNC * 64) gemm_nt_dma_kernel(GemmDesc d, NtExtra x) {
+  gemm_nt_dma_body<TO, NTW, ACT, BMX, WNC>(d, x.gstats, x.rpg);
 }
 
 // grouped form (one descriptor per band, blockIdx.y = group): the per-band 1x1 convolutions of the mask decoder /
@@ -1299,9 +1333,10 @@ static int g_nt_bres_wgs = 256;      // persistent workgroups of the weight-stat
 static int g_nt_wide_default = 1;
 static long g_nt_wide_maxk = 256;
 
-extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                            const float* bias, const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K,
-                            int in_dtype, int out_dtype, int act, void* stream) {
+static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                        const float* bias, const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K,
+                        int in_dtype, int out_dtype, int act, void* stream, double* gstats, long rpg, int* fused) {
+  NtExtra xtra{nullptr, 0};
   GemmDesc d;
   d.A = (const char*)A; d.B = (const char*)B; d.C = (char*)C; d.bias = bias; d.resid = resid;
   d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.ldr = ldr;
@@ -1339,10 +1374,15 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
     URSE_CHECK_ARG(tl < (1L << 31), "urse_gemm_nt: too many tiles");
     dim3 grid((unsigned)tl);
     hipStream_t st = (hipStream_t)stream;
+    if (gstats && out_dtype == URSE_F32 && act != 2 && !wide && rpg >= bmx) {   // statistics of C ride on the epilogue sweep
+      xtra.gstats = gstats;
+      xtra.rpg = rpg;
+      if (fused) *fused = 1;
+    }
 #define URSE_NT_DMA(TO_, NTW_, ACT_, BMX_) \
-  hipLaunchKernelGGL((gemm_nt_dma_kernel<TO_, NTW_, ACT_, BMX_>), grid, dim3(BMX_ * 2), 0, st, d)
+  hipLaunchKernelGGL((gemm_nt_dma_kernel<TO_, NTW_, ACT_, BMX_>), grid, dim3(BMX_ * 2), 0, st, d, xtra)
 #define URSE_NT_DMA_W(TO_, ACT_) \
-  hipLaunchKernelGGL((gemm_nt_dma_kernel<TO_, 7, ACT_, 128, 4>), grid, dim3(512), 0, st, d)
+  hipLaunchKernelGGL((gemm_nt_dma_kernel<TO_, 7, ACT_, 128, 4>), grid, dim3(512), 0, st, d, xtra)
 #define URSE_NT_DMA_B(TO_, NTW_, ACT_) do { if (wide) URSE_NT_DMA_W(TO_, ACT_); else if (bmx == 128) URSE_NT_DMA(TO_, NTW_, ACT_, 128); else URSE_NT_DMA(TO_, NTW_, ACT_, 256); } while (0)
 #define URSE_NT_DMA_ACT(TO_, NTW_) \
   do { if (act == 0) URSE_NT_DMA_B(TO_, NTW_, 0); else if (act == 1) URSE_NT_DMA_B(TO_, NTW_, 1); else URSE_NT_DMA_B(TO_, NTW_, 2); } while (0)
@@ -1359,6 +1399,29 @@ extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
   URSE_CHECK_ARG(blocks < (1L << 31), "urse_gemm_nt: too many tiles");
   note_launch(URSE_KV_NT_128);
   return dispatch_nt(nullptr, d, 1, (int)blocks, in_dtype, out_dtype, act, (hipStream_t)stream);
+}
+
+extern "C" int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                            const float* bias, const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K,
+                            int in_dtype, int out_dtype, int act, void* stream) {
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, resid, ldr, M, N, K, in_dtype, out_dtype, act, stream, nullptr, 0, nullptr);
+}
+
+// urse_gemm_nt with f32 output + the GroupNorm statistics of that output: stats[g] = (sum, sum of squares) over rows
+// [g * rows_per_group, (g + 1) * rows_per_group) x all N columns, the layout urse_groupnorm_apply / _bwd read.  Fused into the
+// ring kernel's epilogue when that kernel takes the shape; otherwise the statistics pass runs behind the GEMM.
+extern "C" int urse_gemm_nt_gnstats(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                    const float* bias, const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K,
+                                    int in_dtype, int act, double* stats, int64_t rows_per_group, void* stream) {
+  URSE_CHECK_ARG(stats && rows_per_group > 0 && M % rows_per_group == 0 && ldc == N && N % 4 == 0,
+                 "urse_gemm_nt_gnstats: needs whole groups of rows, a dense output and N %% 4 == 0");
+  const int groups = (int)(M / rows_per_group);
+  (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups, (hipStream_t)stream);
+  int fused = 0;
+  int rc = gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, resid, ldr, M, N, K, in_dtype, URSE_F32, act, stream, stats, rows_per_group,
+                        &fused);
+  if (rc || fused) return rc;
+  return urse_groupnorm_stats(C, stats, groups, (int)rows_per_group, 1, (int)N, (int)N, stream);
 }
 
 extern "C" int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_dtype, int out_dtype,

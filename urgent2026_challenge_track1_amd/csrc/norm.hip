@@ -364,6 +364,39 @@ extern "C" int urse_groupnorm_fwd(const float* x, const float* gamma, const floa
   return URSE_OK;
 }
 
+// the two halves of urse_groupnorm_fwd on their own: statistics only (accumulates into `stats`, which the caller has zeroed),
+// and normalisation with statistics that exist already (e.g. from urse_gemm_nt_gnstats)
+extern "C" int urse_groupnorm_stats(const float* x, double* stats, int B, int T, int Kg, int W, int N, void* stream) {
+  GnShape s;
+  int rc = make_shape(&s, B, T, Kg, W, N, N, 0, "urse_groupnorm_stats");
+  if (rc) return rc;
+  URSE_CHECK_ARG(x && stats, "urse_groupnorm_stats: null pointer");
+  int nblk = ceil_div((long)T * W, 32768);
+  if (nblk > T) nblk = T;
+  const int rpb = ceil_div(T, nblk);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(ceil_div(T, rpb), Kg, B), dim3(256), 0, (hipStream_t)stream, x, stats, s, rpb);
+  URSE_CHECK_LAUNCH("urse_groupnorm_stats");
+  return URSE_OK;
+}
+
+extern "C" int urse_groupnorm_apply(const float* x, const float* gamma, const float* beta, const float* add, void* y,
+                                    const double* stats, int B, int T, int Kg, int W, int N, int Np, int gstride, float eps,
+                                    int out_dtype, void* stream) {
+  GnShape s;
+  int rc = make_shape(&s, B, T, Kg, W, N, Np, gstride, "urse_groupnorm_apply");
+  if (rc) return rc;
+  URSE_CHECK_ARG(x && gamma && beta && y && stats && Np / 4 <= 256, "urse_groupnorm_apply: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int vpb_f = 256 / (Np / 4);
+  dim3 grid_a(ceil_div((long)T * (W / N), (long)vpb_f * GN_ITER), Kg, B);
+  if (out_dtype == URSE_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (bf16_t*)y, s, eps);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (float*)y, s, eps);
+  URSE_CHECK_LAUNCH("urse_groupnorm_apply");
+  return URSE_OK;
+}
+
 extern "C" int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, const float* gamma,
                                   const float* dres, float* dx, float* dgamma, float* dbeta, double* sums, int B,
                                   int T, int Kg, int W, int N, int gstride, float eps, void* dx_packed, int ldp,

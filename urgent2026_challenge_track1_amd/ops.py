@@ -126,8 +126,10 @@ def _dt(t):
     raise TypeError("URSE GEMM operands are bf16 or f32, got %s" % t.dtype)
 
 
-def gemm_nt(A, W, bias=None, resid=None, act=0, out=None, out_dtype=None, N=None):
-    """out[M, N] = act(A[M, K] @ W[N, K]^T + bias) (+ resid).  A, W: 2-D, unit inner stride, same dtype."""
+def gemm_nt(A, W, bias=None, resid=None, act=0, out=None, out_dtype=None, N=None, gn_rows=0):
+    """out[M, N] = act(A[M, K] @ W[N, K]^T + bias) (+ resid).  A, W: 2-D, unit inner stride, same dtype.
+    gn_rows > 0 (f32 dense output): also returns the GroupNorm statistics of `out` per group of gn_rows rows, f64 [M / gn_rows, 2]
+    (sum, sum of squares) as `groupnorm_fwd(..., stats=)` takes them -> (out, stats)."""
     require_cuda(A, W)
     M, K = A.shape
     Nw = W.shape[0] if N is None else N
@@ -135,6 +137,12 @@ def gemm_nt(A, W, bias=None, resid=None, act=0, out=None, out_dtype=None, N=None
     if out is None:
         out = torch.empty(M, Nw, device=A.device, dtype=out_dtype or A.dtype)
     assert out.stride(1) == 1
+    if gn_rows:
+        assert out.dtype == torch.float32 and out.stride(0) == Nw and M % gn_rows == 0
+        stats = torch.empty(M // gn_rows * 2, device=A.device, dtype=torch.float64)
+        call("gemm_nt_gnstats", A, A.stride(0), W, W.stride(0), out, out.stride(0), bias, resid,
+             0 if resid is None else resid.stride(0), M, Nw, K, _dt(A), act, stats, gn_rows, stream_ptr())
+        return out, stats
     call("gemm_nt", A, A.stride(0), W, W.stride(0), out, out.stride(0), bias, resid,
          0 if resid is None else resid.stride(0), M, Nw, K, _dt(A), _dt(out), act, stream_ptr())
     return out
@@ -215,10 +223,15 @@ def pack2d(inp, out_rows, out_cols, dtype, transpose=False, out=None):
     return out
 
 
-def groupnorm_fwd(x, gamma, beta, B, T, Kg, W, N, Np, gstride, dtype, eps=1e-5, add=None):
-    """x f32 [B,T,Kg,W] -> (y [B*T*Kg*(W/N), Np] dtype, stats f64 [B*Kg*2])."""
+def groupnorm_fwd(x, gamma, beta, B, T, Kg, W, N, Np, gstride, dtype, eps=1e-5, add=None, stats=None):
+    """x f32 [B,T,Kg,W] -> (y [B*T*Kg*(W/N), Np] dtype, stats f64 [B*Kg*2]).  stats: the statistics of x where its producer
+    computed them already (`gemm_nt(..., gn_rows=)`): only the normalisation runs."""
     require_cuda(x)
     y = torch.empty(B * T * Kg * (W // N), Np, device=x.device, dtype=dtype)
+    if stats is not None:
+        assert stats.numel() == B * Kg * 2 and stats.dtype == torch.float64
+        call("groupnorm_apply", x, gamma, beta, add, y, stats, B, T, Kg, W, N, Np, gstride, float(eps), _dt(y), stream_ptr())
+        return y, stats
     stats = torch.empty(B * Kg * 2, device=x.device, dtype=torch.float64)
     call("groupnorm_fwd", x, gamma, beta, add, y, stats, B, T, Kg, W, N, Np, gstride, float(eps), _dt(y), stream_ptr())
     return y, stats
@@ -410,6 +423,8 @@ def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, ro
 
 
 USE_WIDE_LSTM = os.environ.get("URSE_LSTM_WIDE", "1") != "0"
+# GroupNorm statistics of a dual-path output from the epilogue of the fc GEMM that produces it (else a separate pass)
+FUSE_GN_STATS = os.environ.get("URSE_FUSE_GN_STATS", "1") != "0"
 # run the dual-path weight-gradient GEMMs on a second stream beside the time path's BPTT kernel (which fills 136 CUs)
 TN_OVERLAP = os.environ.get("URSE_TN_OVERLAP", "1") != "0"
 def low_priority_stream(device):
