@@ -9,7 +9,11 @@ the in-tree twin ``baseline_code/models/bsrnn_flowse.py:16-86,288-307`` (minus
 the ``t_emb`` lines 293-294).  Parameter/attribute names match espnet so that
 ``state_dict`` keys are ``bsrnn.bsrnn.band_split.norm.{i}.weight`` etc.
 Architecture pin: parameter counts of ``conf/models/BSRNN_baseline.yaml:30-31``
-(checked in tests/test_oracle.py).  Numerical parity with espnet: unpinned.
+(checked in tests/test_oracle.py).  Numerical pin (round 3): ``BandSplit`` and ``BSRNN.dual_path``
+are asserted BIT-EQUAL to the reference's own ``bsrnn_flowse.BandSplit`` / ``BSRNN`` loop run in the
+build container (tests/golden/make_golden_bsrnn.py -> ref_bsrnn.npz).  ``MaskDecoder`` and the
+``m*x + r`` tail restate espnet2 (absent; the in-tree twin's GradDecoder is a different head): that
+part stays unpinned against espnet itself.
 
 ``emulate_bf16=True`` restates the rounding points of the bf16 MFMA product
 path (operands of every dense contraction rounded to bf16, f32 accumulate, gate
@@ -149,9 +153,10 @@ class BSRNN(nn.Module):
         self.fc_freq = nn.ModuleList([nn.Linear(2 * hd, N) for _ in range(num_layer)])
         self.mask_decoder = MaskDecoder(input_dim, self.band_split.subbands, channels=N, num_spk=num_spk)
 
-    def forward(self, x, emulate_bf16=False):
+    def dual_path(self, z, emulate_bf16=False):
+        """the L x {time path, band path} loop on z [B, N, T, K] (bsrnn_flowse.py:288-307 without the t_emb lines 293-294);
+        pinned to the reference's own loop by tests/golden/make_golden_bsrnn.py."""
         e = emulate_bf16
-        z = self.band_split(x, e)
         B, N, T, K = z.shape
         skip = z
         for i in range(self.num_layer):
@@ -167,6 +172,11 @@ class BSRNN(nn.Module):
             out = F.linear(_r(out, e), _r(self.fc_freq[i].weight, e), self.fc_freq[i].bias)
             out = out.reshape(B, T, K, N).permute(0, 3, 1, 2).contiguous()
             skip = skip + out
+        return skip
+
+    def forward(self, x, emulate_bf16=False):
+        e = emulate_bf16
+        skip = self.dual_path(self.band_split(x, e), e)
         m, r = self.mask_decoder(skip, e)
         m = torch.view_as_complex(m.contiguous())
         r = torch.view_as_complex(r.contiguous())

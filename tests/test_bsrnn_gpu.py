@@ -103,3 +103,43 @@ def test_against_committed_golden_vectors(lib):
             gr = g[k]
             got = params[k[5:]].grad.cpu().numpy()
             assert np.abs(got - gr).max() <= 2e-3 * np.abs(gr).max() + 1e-7, k
+
+
+def test_dual_path_and_band_split_match_reference_twin_vectors(lib):
+    """HIP path vs outputs of the REFERENCE'S OWN code (tests/golden/ref_bsrnn.npz: bsrnn_flowse.BandSplit(481) at four rates and the
+    dual-path loop of bsrnn_flowse.BSRNN driven with a zero / a folded time embedding), f32 MFMA mode, bound 1e-3 (north_star)."""
+    import os
+    import numpy as np
+    from urgent2026_challenge_track1_amd.bsrnn import BSRNN_SE
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_bsrnn.npz"))
+    worst = 0.0
+    for fold in (False, True):
+        ref = bsrnn_ref.BSRNN_SE(16, 2)
+        inner = ref.bsrnn.bsrnn
+        inner.band_split.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("bsw:")})
+        sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:")}
+        if fold:
+            sd.update({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("wfold:")})
+        inner.load_state_dict(sd, strict=False)
+        mine = BSRNN_SE(16, 2, compute_dtype=torch.float32)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        core = mine.cuda().core
+        core._prepare()
+        with torch.no_grad():
+            if not fold:
+                for fs in (48000, 22050, 16000, 8000):
+                    z, _ = core.bandsplit_fwd(torch.from_numpy(g["bs_x_%d" % fs]).cuda())      # [B, T, K, N]
+                    want = torch.from_numpy(g["bs_z_%d" % fs]).permute(0, 2, 3, 1)             # reference: [B, N, T, K]
+                    assert z.shape == want.shape, (fs, z.shape, want.shape)
+                    e = (z.cpu() - want).abs().max().item() / want.abs().max().item()
+                    worst = max(worst, e)
+                    assert e <= 1e-3, (fs, e)
+            z = torch.from_numpy(g["z"]).permute(0, 2, 3, 1).contiguous().cuda()
+            for l in range(2):
+                z, _ = core.dualpath_fwd(z, l, "t", False)
+                z, _ = core.dualpath_fwd(z, l, "f", False)
+            want = torch.from_numpy(g["skip_folded_temb" if fold else "skip_zero_temb"]).permute(0, 2, 3, 1)
+            e = (z.cpu() - want).abs().max().item() / want.abs().max().item()
+            worst = max(worst, e)
+            assert e <= 1e-3, (fold, e)
+    print("HIP vs reference-twin vectors: worst relative error %.2e" % worst)

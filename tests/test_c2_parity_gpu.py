@@ -106,12 +106,65 @@ def test_bf16_c2_kernel_set_matches_oracle(lib, c2_dispatch, L):
         if r_e > ge:
             ge, worst = r_e, n
         gf = max(gf, r_f)
-    print("C2 kernel set, L=%d: wav vs emulated %.2e / f32 %.2e; loss %.2e / %.2e; worst grad (rel. L2) %.2e (%s) / %.2e"
-          % (L, e_wav_e, e_wav_f, e_loss_e, e_loss_f, ge, worst, gf))
+    l2_e, l2_f = _rel(wav_c, wav_e), _rel(wav_c, wav_f)
+    print("C2 kernel set, L=%d: wav vs emulated %.2e / f32 %.2e (rel. L2 %.2e / %.2e); loss %.2e / %.2e; worst grad (rel. L2) %.2e (%s) / %.2e"
+          % (L, e_wav_e, e_wav_f, l2_e, l2_f, e_loss_e, e_loss_f, ge, worst, gf))
+    # Bounds = 2x what round 2 / 3 observed on the GPU (L=1: 1.4e-3 / 4.0e-3 wav, 6.6e-3 / 1.06e-2 grads; L=6: 2.5e-3 / 4.4e-3,
+    # 4.5e-3 / 1.04e-2; loss <= 7e-6 / 3.1e-5): a regression by 2x fails.  In bf16 the LOSS meets north_star's 1e-3 against the f32
+    # reference arithmetic; waveform samples (4e-3 of the peak) and gradients (1e-2) do NOT - that is what 8-bit operand mantissas
+    # give, stated in DESIGN.md section 4 and in bench.py's line ("parity"); the f32 mode below meets 1e-3 on everything.
     # against the oracle that rounds where the kernels round: only summation order and the exp / rcp approximations differ
-    assert e_wav_e <= 2e-2 and e_loss_e <= 1e-3 and ge <= 3e-2, (e_wav_e, e_loss_e, ge, worst)
-    # against the f32 reference arithmetic: what bf16 operands cost (recorded in DESIGN.md section 4)
-    assert e_wav_f <= 6e-2 and e_loss_f <= 5e-3 and gf <= 1e-1, (e_wav_f, e_loss_f, gf)
+    assert e_wav_e <= 5e-3 and l2_e <= 1e-2 and e_loss_e <= 5e-5 and ge <= 1.3e-2, (e_wav_e, l2_e, e_loss_e, ge, worst)
+    # against the f32 reference arithmetic: what bf16 operands cost
+    assert e_wav_f <= 9e-3 and l2_f <= 2e-2 and e_loss_f <= 1e-4 and gf <= 2.1e-2, (e_wav_f, l2_f, e_loss_f, gf)
+
+
+def test_f32_full_width_matches_oracle_1e3(lib):
+    """north_star's tolerance (1e-3 relative on enhanced waveform, spectrum, loss - and here every gradient) at the REAL width and
+    depth: N = 196, L = 6, compute_dtype f32 (exact-f32 MFMA), default dispatch, B = 6 x 1 s @ 48 kHz with one shorter
+    utterance, against the f32 oracle (whose BandSplit / dual-path loop are pinned to the reference's in-tree twin)."""
+    from urgent2026_challenge_track1_amd import ops
+    from urgent2026_challenge_track1_amd.config import Config
+    from urgent2026_challenge_track1_amd.d_model import SEModel
+    torch.manual_seed(11)
+    ref = bsrnn_ref.BSRNN_SE(N, 6)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    model = SEModel(Config(model_configs={"num_channel": N, "num_layer": 6}, compute_dtype="f32"))
+    model.se_model.load_state_dict(ref.state_dict())
+    model = model.cuda()
+    clean, noisy, lens = _batch(seed=12)
+    ref.zero_grad(set_to_none=True)
+    wav_r, spec_r = ref(noisy[:, 0], lens, FS, False)
+    loss_r = losses_ref.mr_l1_loss(clean[:, 0], wav_r).mean()
+    loss_r.backward()
+    wav, spec = model.se_model(noisy[:, 0].cuda(), lens, FS)
+    loss = ops.mr_l1_loss(clean[:, 0].cuda(), wav).mean()
+    loss.backward()
+    model.se_model.core._flush_deferred_wgrads()
+    torch.cuda.synchronize()
+    ops.poll_kernel_errors(torch.device("cuda", torch.cuda.current_device()), sync=True)
+    wav_c, wav_r = wav.detach().cpu(), wav_r.detach()
+    e_wav = float((wav_c - wav_r).abs().max() / wav_r.abs().max())
+    sp_c, sp_r = torch.view_as_real(spec.detach().cpu()), torch.view_as_real(spec_r.detach())
+    e_spec = float((sp_c - sp_r).abs().max() / sp_r.abs().max())
+    e_loss = abs(float(loss) - float(loss_r)) / abs(float(loss_r))
+    worst, wname = 0.0, None
+    refg = dict(ref.named_parameters())
+    for n, p in model.se_model.named_parameters():
+        gr = refg[n].grad
+        if gr is None:
+            assert torch.all(p.grad == 0), n
+            continue
+        r = max(_rel(p.grad.cpu(), gr), float((p.grad.cpu() - gr).abs().max() / (gr.abs().max() + 1e-30)))
+        if r > worst:
+            worst, wname = r, n
+    print("f32 N=196 L=6: wav %.2e (rel. L2 %.2e), spec %.2e, loss %.2e, worst grad %.2e (%s)"
+          % (e_wav, _rel(wav_c, wav_r), e_spec, e_loss, worst, wname))
+    assert e_wav <= 1e-3 and _rel(wav_c, wav_r) <= 1e-3 and e_spec <= 1e-3 and e_loss <= 1e-3 and worst <= 1e-3, \
+        (e_wav, e_spec, e_loss, worst, wname)
 
 
 def test_bf16_c2_train_step_matches_oracle(lib, c2_dispatch):

@@ -153,3 +153,33 @@ def test_mix_oracle_detect_non_silence_and_scipy_calls():
     assert abs(10 * np.log10(ps / pn) - 7.0) < 1e-9 and np.allclose(noisy, sp + noise)
     assert noise.shape == sp.shape and np.allclose(noise[0, 100:3100] / noise[0, 100], nz[0] / nz[0, 0])
     assert len(mix_ref.filter_designs(48000)) == 1455 and len(mix_ref.filter_designs(8000)) == 243
+
+
+def _twin_models(g, fold=False):
+    """oracle modules loaded with the weights the reference twin ran with (tests/golden/make_golden_bsrnn.py)."""
+    bs = bsrnn_ref.BandSplit(481, 48000, 16)
+    bs.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("bsw:")}, strict=True)
+    net = bsrnn_ref.BSRNN(481, 16, 2, 48000, False, 1)
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:")}
+    if fold:
+        sd.update({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("wfold:")})
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith(("band_split", "mask_decoder")) for m in missing)
+    return bs, net
+
+
+def test_bsrnn_oracle_equals_reference_twin():
+    """ref_bsrnn.npz holds outputs of the REFERENCE'S OWN bsrnn_flowse.BandSplit(481) and BSRNN loop (bsrnn_flowse.py:16-86,
+    288-307), bit-equal to this oracle where it was generated; here (another CPU / BLAS) the bound is 1e-6 relative."""
+    g = np.load(os.path.join(GOLD, "ref_bsrnn.npz"))
+    bs, net = _twin_models(g)
+    with torch.no_grad():
+        for fs in (48000, 22050, 16000, 8000):
+            z = bs(torch.from_numpy(g["bs_x_%d" % fs])).numpy()
+            ref = g["bs_z_%d" % fs]
+            assert z.shape == ref.shape and np.abs(z - ref).max() <= 1e-6 * np.abs(ref).max(), fs
+        skip = net.dual_path(torch.from_numpy(g["z"])).numpy()
+        assert np.abs(skip - g["skip_zero_temb"]).max() <= 1e-6 * np.abs(g["skip_zero_temb"]).max()
+        _, folded = _twin_models(g, fold=True)
+        skip_t = folded.dual_path(torch.from_numpy(g["z"])).numpy()
+        assert np.abs(skip_t - g["skip_folded_temb"]).max() <= 4e-6 * np.abs(g["skip_folded_temb"]).max()
