@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- BSRNN train-step throughput on MI355X (see DESIGN.md "Measurement").
 
-python bench.py --gpus N --steps K --warmup W     (N>1 is launched by torch.distributed.run)
+python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a
+rank; started plainly with --gpus N > 1 it starts the N ranks itself (a child `python -m torch.distributed.run
+--nproc-per-node N bench.py ...`, before this process has touched the GPU), relays rank 0's JSON line and exits with the
+child's status (reference: train_se.py:74-83, `devices=cfg.num_gpu`, strategy ddp).
 
 A "step" = one full SEModel optimisation step (STFT -> band split -> 6 x dual-path BLSTM -> mask decoder
 -> iSTFT -> MR-L1 loss -> backward -> [RCCL all-reduce] -> clip + AdamW) on a per-GPU batch of synthetic
@@ -242,21 +247,49 @@ def metrics_bench(dev, pairs=2048, batches=1, fs=16000, seconds=4.0):
                "mean_pesq": float(torch.nanmean(q)), "mean_estoi": float(e.mean()), "mean_sdr_db": float(d.mean()),
                "pesq_note": "P.862 restated without the pesq package (absent): parity unpinned; the seven Bark bands above 4 kHz of "
                             "the 16 kHz table are reconstructed (oracle/pesq_tables.py)"}
-        from oracle import metrics_ref, pesq_ref
-        n = 4
-        c64, e64 = clean[:n].double().cpu().numpy(), enh[:n].double().cpu().numpy()
-        t0 = time.perf_counter()
-        ref = [(pesq_ref.pesq(fs, c64[i], e64[i], "wb"), metrics_ref.estoi(c64[i], e64[i], fs), metrics_ref.sdr(c64[i], e64[i]))
-               for i in range(n)]
-        cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": n / cdt, "unit": "pairs/s", "cores": 1, "kind": "port",
-                               "sample": "numpy oracles (P.862 / pystoi / fast_bss_eval restatements) on %d of the pairs, one core" % n}
-        out["max_abs_diff_vs_oracle"] = {"pesq_mos": float(max(abs(float(q[i]) - ref[i][0]) for i in range(n))),
+        # CPU baseline as the reference runs it (calculate_intrusive_se_metrics.py:127-132: `process_map(..., max_workers=nj)`, default
+        # nj = 8, one pair per task): 32 of the same pairs scored by the numpy oracles in a pool of 8 worker processes
+        n, nj = 32, 8
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="urse_mcpu_") as td:
+            np.savez(os.path.join(td, "pairs.npz"), clean=clean[:n].double().cpu().numpy(), enh=enh[:n].double().cpu().numpy(), fs=fs, nj=nj)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--metrics-cpu-worker", td], capture_output=True, text=True,
+                               timeout=300)
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+        ref = res["scores"]
+        out["cpu_baseline"] = {"value": n / res["dt"], "unit": "pairs/s", "cores": nj, "kind": "port",
+                               "sample": "numpy oracles (P.862 / pystoi / fast_bss_eval restatements) on %d of the pairs in a pool of %d "
+                                         "worker processes, one pair per task as calculate_intrusive_se_metrics.py:127-132 (nj = 8) "
+                                         "= %.1f s" % (n, nj, res["dt"])}
+        out["max_abs_diff_vs_oracle"] = {"pairs": n, "pesq_mos": float(max(abs(float(q[i]) - ref[i][0]) for i in range(n))),
                                          "estoi": float(max(abs(float(e[i]) - ref[i][1]) for i in range(n))),
                                          "sdr_db": float(max(abs(float(d[i]) - ref[i][2]) for i in range(n)))}
         return out
     except Exception as ex:  # never let the secondary metric break the headline line
         return {"metric": "PESQ + ESTOI + SDR pairs/sec", "value": None, "error": repr(ex)}
+
+
+def _score_pair_cpu(a):
+    from oracle import metrics_ref, pesq_ref
+    c, e, fs = a
+    return (pesq_ref.pesq(fs, c, e, "wb"), metrics_ref.estoi(c, e, fs), metrics_ref.sdr(c, e))
+
+
+def _metrics_cpu_worker(td):
+    """child process of metrics_bench's cpu_baseline: scores pairs.npz with the numpy oracles in a pool of nj processes."""
+    import multiprocessing as mp
+    import numpy as np
+    os.environ["OMP_NUM_THREADS"] = "1"
+    z = np.load(os.path.join(td, "pairs.npz"))
+    fs, nj = int(z["fs"]), int(z["nj"])
+    work = [(z["clean"][i], z["enh"][i], fs) for i in range(z["clean"].shape[0])]
+    with mp.get_context("fork").Pool(nj) as pool:
+        pool.map(_score_pair_cpu, work[:nj])           # workers imported and warm
+        t0 = time.perf_counter()
+        scores = pool.map(_score_pair_cpu, work, chunksize=1)
+        dt = time.perf_counter() - t0
+    print(json.dumps({"dt": dt, "scores": [[float(v) for v in sc] for sc in scores]}))
 
 
 def _pretouch(dev, gib):
@@ -280,6 +313,52 @@ def _pretouch(dev, gib):
     torch.cuda.reset_peak_memory_stats(dev)            # (peak_hbm_gb reports the model's own footprint)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` outside torch.distributed.run: start N ranks as a CHILD process group (never exec: this process
+    may only count devices, it has not initialised the GPU), pass the command line through, relay the ranks' output (rank 0
+    prints the one JSON line) and return the child's exit status."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in js[-1:]:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or not js:
+        print(json.dumps({"error": "launch of %d ranks failed" % n, "returncode": r.returncode, "n_gpus": n}))
+        return r.returncode or 1
+    print(js[-1])
+    return 0
+
+
+def _launcher_selftest(mode):
+    """what a rank does under --launcher-selftest: rendezvous over gloo on the CPU, one all-reduce, rank 0 prints a line (the
+    part of the N > 1 launch that can run on a box without GPUs: tests/test_host_cpu.py)."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if mode == "fail" and rank == world - 1:
+        sys.exit(3)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "sum": t.item(), "backend": "gloo"}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,7 +377,10 @@ def main():
                     help="first-touch this much HBM (or all that is free) before the model is built; 0 = off")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=1.0)
-    ap.add_argument("--metric-pairs", type=int, default=2048, help="pairs the metric leg scores (config C5: 10000)")
+    ap.add_argument("--metrics-cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--metric-pairs", type=int, default=10240,
+                    help="pairs the metric leg scores (BASELINE.json configs[4] / SURVEY C5: 10 k pairs, as five launches of 2,048)")
+    ap.add_argument("--launcher-selftest", default=None, choices=["ok", "fail"], help=argparse.SUPPRESS)
     ap.add_argument("--no-flow", action="store_true", help="skip the extra BSRNN-Flow (config C4) leg")
     ap.add_argument("--model", default="bsrnn", choices=["bsrnn", "flow"],
                     help="flow: print the BSRNN-Flow (config C4) line instead of the headline one")
@@ -309,6 +391,21 @@ def main():
     if args.cpu_baseline_worker:
         _cpu_baseline_worker(args.cpu_baseline_seconds)
         return
+    if args.metrics_cpu_worker:
+        _metrics_cpu_worker(args.metrics_cpu_worker)
+        return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not args.launcher_selftest and args.dist_backend == "nccl" and torch.cuda.device_count() < args.gpus:
+            print(json.dumps({"error": "--gpus %d with %d visible GPU(s); one rank per GPU over RCCL needs %d (use --dist-backend gloo "
+                                       "to put several ranks on one GPU for a functional check)"
+                                       % (args.gpus, torch.cuda.device_count(), args.gpus), "n_gpus": args.gpus}))
+            sys.exit(2)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.launcher_selftest:
+        _launcher_selftest(args.launcher_selftest)
+        return
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s: start one rank per GPU" % (args.gpus, os.environ["WORLD_SIZE"]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -460,7 +557,8 @@ def main():
                                "MR-L1 loss, clip 0.5 + AdamW%s" % (B, args.seconds, args.channels, args.layers,
                                                                    "; fed by DynamicMixingDataset recipes simulated on the GPU inside the step"
                                                                    if args.dynamic_mix else ""),
-                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world},
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "dist_backend": (args.dist_backend if world > 1 else None)},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                      "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
                      "traffic_source": traffic_src, "algorithmic_flops_per_launch": dom_flops,

@@ -158,3 +158,25 @@ def test_device_prefetcher_order_and_end():
     assert len(got) == 5 and all(float(g[0][0, 0, 0]) == i and float(g[1][0, 0, 0]) == -i for i, g in enumerate(got))
     assert list(DevicePrefetcher([], "cpu")) == []
     assert len(list(DevicePrefetcher(batches[:1], "cpu"))) == 1
+
+
+def test_bench_gpus_n_launches_n_ranks_without_torchrun():
+    """bench.py --gpus N outside torch.distributed.run starts N ranks itself, relays rank 0's JSON line and propagates a failing
+    rank as a non-zero exit (the rendezvous / relay part runs here on gloo without a GPU; the real step under -m gpu:
+    tests/test_train_gpu.py::test_bench_gpus_2_starts_its_own_ranks)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest", "ok"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["sum"] == 3.0
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest", "fail"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "error" in json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    # one rank per GPU over RCCL: asking for more ranks than visible GPUs is refused before anything is started
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 64

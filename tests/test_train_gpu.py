@@ -94,3 +94,19 @@ def test_two_ranks_on_one_gpu_hold_identical_weights():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["ranks_hold_identical_weights"] is True
     assert d["config"]["global_batch"] == 4
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun in the command: the parent starts the two ranks itself (child process group),
+    relays rank 0's line, and the line says n_gpus 2 (--gpus was parsed and never read).  gloo lets both ranks share
+    the one GPU of this box; `--dynamic-mix` puts config C3's on-GPU simulator feed into the N > 1 step."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
+           "--pretouch-gib", "0", "--batch", "2", "--seconds", "1", "--channels", "32", "--layers", "2", "--dynamic-mix"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_hold_identical_weights"] is True and d["config"]["dist_backend"] == "gloo"
+    assert d["config"]["global_batch"] == 4 and "dynamic_mix" in d
