@@ -130,3 +130,29 @@ def sdr(ref, est, filter_length=512, clamp_db=50.0):
     eps = e / (1.0 + e)
     coh = min(max(coh, eps), 1.0 - eps)
     return 10.0 * np.log10(coh / (1.0 - coh))
+
+
+# ---- soxr HQ specification resampler (stand-in for soxr.resample / librosa res_type="soxr_hq") -----------------------------------
+def soxr_hq_design(fs_in, fs_out):
+    """One Kaiser-windowed sinc built to the specification of libsoxr's HQ recipe (soxr.c soxr_quality_spec, quality 4: 20-bit =
+    120.4 dB rejection from the lower Nyquist frequency, pass band to 1 - 0.05 / TO_3dB(rej) = 0.9136 of it, linear phase,
+    cutoff mid-transition as lsx_design_lpf places it).  -> (h * up, up, down).  soxr's own cascade is not reproducible
+    bit-wise; what is pinned here is the specification, checked in tests/test_oracle.py."""
+    from math import gcd
+    from scipy.signal import firwin
+    g = gcd(int(fs_in), int(fs_out))
+    up, down = int(fs_out) // g, int(fs_in) // g
+    rej = 20 * 20.0 * np.log10(2.0)
+    to3db = (1.6e-6 * rej - 7.5e-4) * rej + 0.646
+    nyq = 0.5 * min(fs_in, fs_out)
+    f_pass, f_stop = (1.0 - 0.05 / to3db) * nyq, nyq
+    fs_work = float(fs_in) * up
+    dw = 2.0 * np.pi * (f_stop - f_pass) / fs_work
+    half = int(np.ceil((rej - 7.95) / (2.285 * dw) / 2.0))
+    h = firwin(2 * half + 1, (f_pass + f_stop) / fs_work, window=("kaiser", 0.1102 * (rej - 8.7)))
+    return h * up, up, down
+
+
+def resample_soxr_hq_spec(x, fs_in, fs_out):
+    h, up, down = soxr_hq_design(fs_in, fs_out)
+    return resample_poly(np.asarray(x, dtype=np.float64), up, down, window=h)

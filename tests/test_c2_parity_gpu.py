@@ -110,13 +110,13 @@ def test_bf16_c2_kernel_set_matches_oracle(lib, c2_dispatch, L):
     print("C2 kernel set, L=%d: wav vs emulated %.2e / f32 %.2e (rel. L2 %.2e / %.2e); loss %.2e / %.2e; worst grad (rel. L2) %.2e (%s) / %.2e"
           % (L, e_wav_e, e_wav_f, l2_e, l2_f, e_loss_e, e_loss_f, ge, worst, gf))
     # Bounds = 2x what round 2 / 3 observed on the GPU (L=1: 1.4e-3 / 4.0e-3 wav, 6.6e-3 / 1.06e-2 grads; L=6: 2.5e-3 / 4.4e-3,
-    # 4.5e-3 / 1.04e-2; loss <= 7e-6 / 3.1e-5): a regression by 2x fails.  In bf16 the LOSS meets north_star's 1e-3 against the f32
+    # 4.5e-3 / 1.04e-2; rel. L2 of the waveform 1.5e-3 / 4.2e-3 and 2.6e-3 / 4.3e-3; loss <= 8e-6 / 3.1e-5): a regression by 2x fails.  In bf16 the LOSS meets north_star's 1e-3 against the f32
     # reference arithmetic; waveform samples (4e-3 of the peak) and gradients (1e-2) do NOT - that is what 8-bit operand mantissas
     # give, stated in DESIGN.md section 4 and in bench.py's line ("parity"); the f32 mode below meets 1e-3 on everything.
     # against the oracle that rounds where the kernels round: only summation order and the exp / rcp approximations differ
-    assert e_wav_e <= 5e-3 and l2_e <= 1e-2 and e_loss_e <= 5e-5 and ge <= 1.3e-2, (e_wav_e, l2_e, e_loss_e, ge, worst)
+    assert e_wav_e <= 5e-3 and l2_e <= 5.2e-3 and e_loss_e <= 5e-5 and ge <= 1.3e-2, (e_wav_e, l2_e, e_loss_e, ge, worst)
     # against the f32 reference arithmetic: what bf16 operands cost
-    assert e_wav_f <= 9e-3 and l2_f <= 2e-2 and e_loss_f <= 1e-4 and gf <= 2.1e-2, (e_wav_f, l2_f, e_loss_f, gf)
+    assert e_wav_f <= 9e-3 and l2_f <= 8.7e-3 and e_loss_f <= 1e-4 and gf <= 2.1e-2, (e_wav_f, l2_f, e_loss_f, gf)
 
 
 def test_f32_full_width_matches_oracle_1e3(lib):

@@ -189,3 +189,34 @@ def test_wav_reader_agrees_with_scipy(tmp_path):
     wavfile.write(str(tmp_path / "s32.wav"), 8000, x32)
     y, fs = read_audio(str(tmp_path / "s32.wav"))
     assert np.array_equal(y[0], x32.astype(np.float32) / 2147483648.0)
+
+
+def test_sources_at_a_higher_rate_are_served_raw_with_their_rate(tmp_path):
+    """`_pick_source` (the reference's select_sample) falls back to noise / RIR files of a HIGHER rate when none exists at the speech
+    rate - the common case on the real corpus.  The item then carries the raw source, uncropped (the reference's
+    read_audio returns before its max_duration crop on that path, simulate_data_from_param.py:350-352), with its rate; the noise
+    offset is drawn on the length after resampling (ceil(n fs / src))."""
+    from urgent2026_challenge_track1_amd.dataset import DynamicMixingDataset, collate_dynamic
+    rows = {"sp": ["s%d 16000 sp16_%d" % (i, i) for i in range(3)], "nz": ["n%d 48000 nz48_%d" % (i, i) for i in range(2)],
+            "rir": ["r0 48000 rir48_0"], "wn": ["wind_noise0 48000 wn48_0"], "len": ["s%d 20000" % i for i in range(3)]}
+    paths = {}
+    for k, v in rows.items():
+        paths[k] = str(tmp_path / (k + ".scp"))
+        (tmp_path / (k + ".scp")).write_text("\n".join(v) + "\n")
+
+    def reader(path):
+        fs = 48000 if "48" in path else 16000
+        n = {"sp": 20000, "nz": 150001, "ri": 9001, "wn": 150001}[path[:2]]
+        return np.random.default_rng(len(path)).standard_normal((1, n)).astype(np.float32), fs
+    ds = DynamicMixingDataset(paths["sp"], paths["nz"], paths["rir"], paths["wn"], paths["len"], max_duration=40000, reader=reader,
+                              frames=lambda p: reader(p)[0].shape[1])
+    np.random.seed(5)
+    items = [ds[i] for i in range(3)]
+    for it in items:
+        assert it["fs"] == 16000 and it["noise_fs"] == 48000 and it["noise"].shape[1] == 150001     # raw: no crop on this path
+        assert DynamicMixingDataset.resampled_length(150001, 48000, 16000) == 50001
+        assert 0 <= it["recipe"]["noise_offset"] < 50001 - it["length"]
+        if it["rir"] is not None:
+            assert it["rir_fs"] == 48000 and it["rir"].shape[1] == 9001
+    batch = collate_dynamic(items)
+    assert batch.noise_fs == [48000] * 3 and batch.noise.shape == (3, 150001)

@@ -119,6 +119,36 @@ def test_flow_fit_checkpoint_ema_and_inference_fallback(lib, tmp_path):
     assert fs2 == fs and y.shape[1] == L and abs(abs(y).max() - 0.9) < 1e-3
 
 
+def test_flow_init_from_and_resume_keep_the_ema_on_the_device(lib, tmp_path):
+    """every flow checkpoint carries 'ema'; `init_from` used to create the EMA shadow on the host (before .to(dev)) and
+    the first optimizer_step then handed a host pointer to urse_ema_update.  init_from = plain weight load (reference
+    train_se.py:55-59), EMA starts from the loaded weights; resume restores checkpoint['ema']; both fine-tune on the GPU."""
+    from urgent2026_challenge_track1_amd import train_se
+    os.chdir(tmp_path)
+    cfg = _flow_cfg(train_tag="a")
+    model, _ = train_se.fit(cfg, max_steps=2, log_every=1)
+    ck_dir = train_se.ckpt_dir(cfg)
+    ck_path = os.path.join(ck_dir, [f for f in os.listdir(ck_dir) if "val_loss" in f][0])
+    ck = torch.load(ck_path, map_location="cpu", weights_only=False)
+    # warm start of a NEW run from that checkpoint
+    cfg2 = _flow_cfg(train_tag="b", init_from=ck_path)
+    m2, steps = train_se.fit(cfg2, max_steps=2, log_every=1)
+    assert steps == 2 and m2.ema.shadow.is_cuda and m2.ema.num_updates == 2
+    assert torch.isfinite(m2.ema.shadow).all() and torch.isfinite(m2.dnn.flat_params).all()
+    # resume of the first run: EMA state restored from the checkpoint, on the device, and training continues
+    cfg3 = _flow_cfg(train_tag="a", resume=True)
+    m3, steps3 = train_se.fit(cfg3, max_steps=ck["global_step"] + 1, log_every=1)
+    assert m3.ema.shadow.is_cuda and m3.ema.num_updates == ck["ema"]["num_updates"] + 1 and steps3 == ck["global_step"] + 1
+    # an EMA created on the host follows the model to the device
+    from urgent2026_challenge_track1_amd.flow_model import FlowSEModel
+    m4 = FlowSEModel(cfg)
+    m4.init_ema()
+    assert not m4.ema.shadow.is_cuda
+    m4 = m4.cuda()
+    m4.ema.update()
+    assert m4.ema.shadow.is_cuda
+
+
 def _write_source_set(root, fs_list=(16000,), n_speech=6):
     """a tiny dynamic-mixing corpus on disk in the reference's layout (dataset.py:453-460)."""
     from urgent2026_challenge_track1_amd.dataset import SyntheticPairDataset, write_audio

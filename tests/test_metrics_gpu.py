@@ -100,3 +100,16 @@ def test_metrics_driver_files(lib, tmp_path):
     for m in ("PESQ", "ESTOI"):
         assert (tmp_path / "out2" / ("%s.scp" % m)).read_text() == (tmp_path / "out" / ("%s.scp" % m)).read_text()
     assert "SDR: " in (tmp_path / "out2" / "RESULTS.txt").read_text()
+
+
+@pytest.mark.parametrize("fs_in,fs_out", [(48000, 16000), (44100, 16000), (32000, 16000), (22050, 16000)])
+def test_soxr_hq_spec_resampler_matches_oracle(lib, fs_in, fs_out):
+    """the stand-in for soxr.resample(x, fs, 16000) in pesq_metric (calculate_intrusive_se_metrics.py:69-70): a filter built to
+    libsoxr's HQ specification (oracle/metrics_ref.soxr_hq_design, its specification asserted in tests/test_oracle.py), evaluated
+    by the polyphase kernel with f64 accumulation -> equal to the f64 oracle to f32 rounding."""
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 30011)).astype(np.float32)
+    got = metrics.resample_soxr_hq(torch.from_numpy(x).cuda(), fs_in, fs_out).cpu().numpy()
+    for p in range(2):
+        exp = metrics_ref.resample_soxr_hq_spec(x[p], fs_in, fs_out)
+        assert got[p].shape == exp.shape and np.abs(got[p] - exp).max() <= 2e-6 * np.abs(exp).max()

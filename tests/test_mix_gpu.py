@@ -230,3 +230,38 @@ def test_bandwidth_limitation_fft_matches_scipy(lib):
         up = resample(down, int(math.ceil(n1 * float(fs) / fs_new)))[:L]
         got = mixing.bandwidth_limitation_fft(torch.tensor(x[None]).cuda(), fs, fs_new)[0].cpu().numpy()
         assert got.shape == x.shape and np.abs(got - up).max() <= 2e-5, (L, fs, fs_new, np.abs(got - up).max())
+
+
+def test_sources_at_another_rate_are_resampled_on_the_device(lib):
+    """RawMixBatch.materialise with noise / RIR rows recorded at 48 kHz in a 16 kHz batch (`_load` used to raise):
+    the rows are resampled with the soxr-HQ-specification filter on the device and the mix equals the oracle chain run on
+    oracle-resampled sources (oracle/metrics_ref.resample_soxr_hq_spec + oracle/mix_ref)."""
+    from oracle import metrics_ref, mix_ref
+    from urgent2026_challenge_track1_amd.dataset import RawMixBatch
+    from urgent2026_challenge_track1_amd.mixing import early_rir_stop
+    fs, L = 16000, 12000
+    sp = _signals(2, L, 21)
+    nz48 = _signals(2, 60001, 22, silent=False)
+    rng = np.random.default_rng(23)
+    rir48 = (rng.standard_normal(4801) * np.exp(-np.arange(4801) / 900.0)).astype(np.float32)[None]
+    rir16 = (rng.standard_normal(1500) * np.exp(-np.arange(1500) / 300.0)).astype(np.float32)[None]
+    rec = lambda snr, off, rir: dict(snr=snr, noise_offset=off, order=[], params={}, highpass=True, rir_uid=rir, wind=False)
+    items = [dict(speech=sp[0:1], noise=nz48[0:1], rir=rir48, recipe=rec(5.0, 1000, "r48"), fs=fs, length=L, noise_fs=48000, rir_fs=48000),
+             dict(speech=sp[1:2], noise=nz48[1:2, :30000], rir=rir16, recipe=rec(-2.0, 0, "r16"), fs=fs, length=L, noise_fs=16000, rir_fs=16000)]
+    clean, noisy, fs_t, lens = RawMixBatch(items).materialise("cuda")
+    assert int(fs_t) == fs and lens.tolist() == [L, L]
+    for b, it in enumerate(items):
+        n64 = it["noise"][0].astype(np.float64)
+        r64 = it["rir"][0].astype(np.float64)
+        if it["noise_fs"] != fs:
+            n64 = metrics_ref.resample_soxr_hq_spec(n64, it["noise_fs"], fs)[:-(-len(n64) * fs // it["noise_fs"])]
+            r64 = metrics_ref.resample_soxr_hq_spec(r64, it["rir_fs"], fs)[:-(-len(r64) * fs // it["rir_fs"])]
+        s = mix_ref.high_pass(it["speech"].astype(np.float64), fs)
+        early = r64.copy()
+        early[early_rir_stop(r64, fs):] = 0
+        rev, s_early = mix_ref.add_reverberation(s, r64[None]), mix_ref.add_reverberation(s, early[None])
+        mixed, noise = mix_ref.mix_noise(rev, n64[None], it["recipe"]["snr"], it["recipe"]["noise_offset"])
+        s_early, mixed, _ = mix_ref.joint_peak_normalise(s_early, mixed, noise)
+        e_n = np.abs(noisy[b, 0].cpu().numpy() - mixed[0]).max()
+        e_c = np.abs(clean[b, 0].cpu().numpy() - s_early[0]).max()
+        assert e_n <= 5e-5 and e_c <= 5e-5, (b, e_n, e_c)

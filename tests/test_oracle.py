@@ -183,3 +183,22 @@ def test_bsrnn_oracle_equals_reference_twin():
         _, folded = _twin_models(g, fold=True)
         skip_t = folded.dual_path(torch.from_numpy(g["z"])).numpy()
         assert np.abs(skip_t - g["skip_folded_temb"]).max() <= 4e-6 * np.abs(g["skip_folded_temb"]).max()
+
+
+def test_soxr_hq_specification_of_the_resampling_filter():
+    """the 48 -> 16 kHz (and 44.1 / 32 / 22.05 -> 16) filter standing in for soxr HQ meets soxr HQ's own specification
+    (soxr.c soxr_quality_spec quality 4): pass band to 0.9136 x Nyquist flat within 2^-20, stop band from the Nyquist frequency
+    of the lower rate down >= 120.4 dB, linear phase (symmetric taps), unity DC gain.  That - not bit equality with libsoxr, which
+    is not reproducible - is the tolerance the stand-in is held to."""
+    from oracle import metrics_ref
+    for fs_in, fs_out in ((48000, 16000), (32000, 16000), (48000, 8000)):
+        h, up, down = metrics_ref.soxr_hq_design(fs_in, fs_out)
+        assert np.allclose(h, h[::-1]) and len(h) % 2 == 1
+        fsw, n, nyq = fs_in * up, len(h), 0.5 * min(fs_in, fs_out)
+        t = np.arange(n) - (n - 1) / 2
+        resp = lambda f: abs(np.sum(h / up * np.exp(-2j * np.pi * f / fsw * t)))
+        assert abs(resp(0.0) - 1.0) <= 2.0 ** -20
+        for f in np.linspace(0, 0.9136 * nyq, 60):
+            assert abs(resp(f) - 1.0) <= 2.0 ** -20, (fs_in, f)
+        for f in np.linspace(nyq, 0.5 * fsw, 200):
+            assert 20 * np.log10(resp(f) + 1e-30) <= -120.4, (fs_in, f)

@@ -2,7 +2,8 @@
 
 Mirrors ``baseline_code/config.py:6-72``: defaults (``:8-38``), yaml values override CLI flags and may add
 new keys, ``train_tag`` := basename of the yaml (``:41-52``), one ``--flag`` per attribute with bools parsed
-by ``str2bool`` (``:54-72``).  Extra key: ``compute_dtype`` ("bf16" | "f32") selects the MFMA operand type.
+by ``str2bool`` (``:54-72``).  Extra keys: ``compute_dtype`` ("bf16" | "f32") selects the MFMA operand type;
+``unsupported_augmentation`` ("warn" | "raise" | "count") - see below.
 """
 import argparse
 import os
@@ -40,6 +41,10 @@ class Config:
         self.config_file = "none"
         self.model_configs = None
         self.compute_dtype = "bf16"
+        # what the trainer does when a dynamic-mixing recipe draws an augmentation the device simulator cannot apply (codec and the
+        # wind-noise side-chain compressor need ffmpeg): "warn" = apply the rest, warn at the first one, report counters
+        # with every log line; "raise" = stop at the first one; "count" = counters only
+        self.unsupported_augmentation = "warn"
         for k, v in kwargs.items():
             setattr(self, k, v)
 

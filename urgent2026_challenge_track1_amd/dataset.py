@@ -318,12 +318,19 @@ class DynamicMixingDataset(torch.utils.data.Dataset):
         return wav
 
     def _load(self, path, fs):
+        """-> (mono wav [1, n], sampling rate of the file).  A file at the recipe's rate gets the simulator's random crop; a file at
+        ANOTHER rate (`_pick_source` falls back to noise / wind / RIR files of a higher rate by design, as the reference's
+        select_sample does) is handed on raw with its rate: the reference resamples it to fs with soxr_hq and returns BEFORE the
+        crop (simulate_data_from_param.py:350-352); here that resampling runs on the device in ``RawMixBatch.materialise``."""
         wav, got = self._read(path)
         if got != fs:
-            raise ValueError("%s is sampled at %d Hz, the recipe needs %d Hz: the reference resamples with soxr here "
-                             "(simulate_data_from_param.py:350-352), which this build does not restate - list sources "
-                             "per sampling rate" % (path, got, fs))
-        return self._crop(wav[:1])
+            return wav[:1], int(got)
+        return self._crop(wav[:1]), int(fs)
+
+    @staticmethod
+    def resampled_length(n, src_fs, fs):
+        """length of n samples at src_fs after resampling to fs (librosa.resample: ceil(n * fs / src_fs))."""
+        return n if src_fs == fs else -((-n * fs) // src_fs)
 
     def __getitem__(self, index):
         fs, j = self._index[index]
@@ -332,13 +339,17 @@ class DynamicMixingDataset(torch.utils.data.Dataset):
         length = min(self.max_duration, self._frames(path))
         recipe = draw_recipe(length, fs, self.noise_source, self.rirs, self.wind_noises)
         recipe.update(speech_uid=uid, id=uid, snr_dB=recipe["snr"], highpass=self.use_high_pass)
-        speech = self._load(path, fs)
-        noise = self._load(self.all_noise_flt[recipe["noise_uid"]], fs)
-        rir = self._load(self.rirs_flt[recipe["rir_uid"]], fs) if recipe["rir_uid"] != "none" else None
-        # the offset of mix_noise's wrap / crop (:108-119) comes from an unseeded default_rng() when mixing on the fly (:471)
-        ls, ln = speech.shape[1], noise.shape[1]
+        speech, speech_fs = self._load(path, fs)
+        if speech_fs != fs:
+            raise ValueError("%s is sampled at %d Hz but listed at %d Hz in the speech scp" % (path, speech_fs, fs))
+        noise, noise_fs = self._load(self.all_noise_flt[recipe["noise_uid"]], fs)
+        rir, rir_fs = self._load(self.rirs_flt[recipe["rir_uid"]], fs) if recipe["rir_uid"] != "none" else (None, fs)
+        # the offset of mix_noise's wrap / crop (:108-119) comes from an unseeded default_rng() when mixing on the fly (:471);
+        # it is drawn on the noise length AFTER the resampling to fs
+        ls, ln = speech.shape[1], self.resampled_length(noise.shape[1], noise_fs, fs)
         recipe["noise_offset"] = int(np.random.default_rng().integers(0, abs(ls - ln))) if ls != ln else 0
-        return dict(speech=speech, noise=noise, rir=rir, recipe=recipe, fs=fs, length=speech.shape[1])
+        return dict(speech=speech, noise=noise, rir=rir, recipe=recipe, fs=fs, length=speech.shape[1], noise_fs=noise_fs,
+                    rir_fs=rir_fs)
 
 
 class RawMixBatch:
@@ -367,10 +378,14 @@ class RawMixBatch:
         self.noise, self.noise_lens = stack("noise", max(it["noise"].shape[1] for it in items))
         rmax = max([it["rir"].shape[1] for it in items if it["rir"] is not None] or [0])
         self.rir, self.rir_lens = stack("rir", rmax) if rmax else (None, [0] * len(items))
+        self.noise_fs = [it.get("noise_fs", self.fs) for it in items]
+        self.rir_fs = [it.get("rir_fs", self.fs) for it in items]
         self.rir_early = [0] * len(items)
         if rmax:
             from .mixing import early_rir_stop
-            self.rir_early = [early_rir_stop(it["rir"], self.fs) if it["rir"] is not None else 0 for it in items]
+            # (a RIR at another rate: its direct-path / early-part boundary is found after the resampling, on the device copy)
+            self.rir_early = [early_rir_stop(it["rir"], self.fs) if it["rir"] is not None and self.rir_fs[b] == self.fs else 0
+                              for b, it in enumerate(items)]
 
     def pin_memory(self):
         for k in ("speech", "noise", "rir"):
@@ -379,12 +394,39 @@ class RawMixBatch:
                 setattr(self, k, t.pin_memory())
         return self
 
+    def _to_batch_rate(self, x, lens, src_fs):
+        """rows of x [B, W] recorded at another rate than the batch's -> resampled to it on the device (soxr-HQ-specification
+        polyphase filter, metrics.resample_soxr_hq), one launch per distinct source rate; -> (x', lens')."""
+        if x is None or all(f == self.fs for f in src_fs):
+            return x, lens
+        from .metrics import resample_soxr_hq
+        new_lens = [DynamicMixingDataset.resampled_length(n, f, self.fs) for n, f in zip(lens, src_fs)]
+        out = torch.zeros(x.shape[0], max(max(new_lens), 1), dtype=x.dtype, device=x.device)
+        for f in sorted(set(src_fs)):
+            rows = [b for b, g in enumerate(src_fs) if g == f and lens[b] > 0]
+            if not rows:
+                continue
+            if f == self.fs:
+                w = max(lens[b] for b in rows)
+                out[rows, :w] = x[rows, :w]
+                continue
+            w = max(lens[b] for b in rows)
+            y = resample_soxr_hq(x[rows, :w], f, self.fs)           # zero padding behind a row resamples to zeros
+            for i, b in enumerate(rows):
+                out[b, :new_lens[b]] = y[i, :new_lens[b]]
+        return out, new_lens
+
     def materialise(self, device, skipped=None):
         from . import mixing
-        out = mixing.simulate_recipes(self.speech.to(device, non_blocking=True), self.lengths,
-                                      self.noise.to(device, non_blocking=True), self.noise_lens,
-                                      None if self.rir is None else self.rir.to(device, non_blocking=True), self.rir_lens,
-                                      self.rir_early, self.fs, self.recipes, skipped)
+        noise, noise_lens = self._to_batch_rate(self.noise.to(device, non_blocking=True), self.noise_lens, self.noise_fs)
+        rir = None if self.rir is None else self.rir.to(device, non_blocking=True)
+        rir, rir_lens = self._to_batch_rate(rir, self.rir_lens, self.rir_fs)
+        rir_early = list(self.rir_early)
+        for b, f in enumerate(self.rir_fs):
+            if rir is not None and f != self.fs and rir_lens[b] > 0:
+                rir_early[b] = mixing.early_rir_stop(rir[b:b + 1, :rir_lens[b]].cpu().numpy(), self.fs)
+        out = mixing.simulate_recipes(self.speech.to(device, non_blocking=True), self.lengths, noise, noise_lens,
+                                      rir, rir_lens, rir_early, self.fs, self.recipes, skipped)
         clean, noisy = out
         B, T = clean.shape
         return (clean.view(B, 1, T), noisy.view(B, 1, T), torch.tensor(self.fs, dtype=torch.int32),

@@ -292,20 +292,34 @@ class FlowEMA:
         self.shadow = core.flat_params.clone()
         self.collected = None
 
+    def _home(self):
+        """the shadow lives where the flat parameters live: a model moved with ``.to(device)`` after the EMA was created (or loaded
+        from a checkpoint on the host) takes its shadow along instead of handing a host pointer to the kernel."""
+        flat = self.core.flat_params
+        if self.shadow.device != flat.device:
+            self.shadow = self.shadow.to(flat.device)
+            if self.collected is not None:
+                self.collected = self.collected.to(flat.device)
+        return flat
+
     def update(self):
+        flat = self._home()
+        require_cuda(self.shadow)
         self.num_updates += 1
         d = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
-        call("ema_update", self.shadow, self.core.flat_params, float(1.0 - d), self.shadow.numel(), stream_ptr())
+        call("ema_update", self.shadow, flat, float(1.0 - d), self.shadow.numel(), stream_ptr())
 
     def store(self):
-        self.collected = self.core.flat_params.clone()
+        self.collected = self._home().clone()
 
     def copy_to(self):
+        self._home()
         self.core.flat_params.copy_(self.shadow)
         self.core.param_version += 1
 
     def restore(self):
         if self.collected is not None:
+            self._home()
             self.core.flat_params.copy_(self.collected)
             self.core.param_version += 1
             self.collected = None
@@ -328,6 +342,7 @@ class FlowEMA:
 
     def load_state_dict(self, sd, model=None):
         self.decay, self.num_updates = sd["decay"], sd["num_updates"]
+        self._home()
         if "shadow_flat" in sd:
             self.shadow.copy_(sd["shadow_flat"])
         elif model is not None and "shadow_params" in sd:       # a checkpoint written by torch_ema itself

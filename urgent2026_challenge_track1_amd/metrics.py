@@ -96,30 +96,65 @@ def sdr_batch(ref, inf, clamp_db=50.0):
 PESQ_TRACE = 286      # include/urse.h URSE_PESQ_TRACE
 
 
-def _poly_resample(x, fs_in, fs_out):
-    """scipy.signal.resample_poly(x, up, down) with its default Kaiser(5.0) design, on the batched polyphase kernel.  Stands
-    in for ``soxr.resample(x, fs, 16000)`` of pesq_metric (:69-70): libsoxr's HQ filter is not reproducible bit-wise
-    (SURVEY 8c), a polyphase low-pass at the same cutoff is what can be restated."""
+SOXR_HQ_BITS = 20        # soxr.h: SOXR_HQ = "20-bit" quality
+
+
+def soxr_hq_spec(fs_in, fs_out):
+    """The low-pass SPECIFICATION libsoxr's HQ recipe asks of its filters (soxr.c `soxr_quality_spec`, quality 4): stop-band
+    rejection 20 bits x 6.0206 dB = 120.4 dB, stop band from the Nyquist frequency of the lower rate, pass band up to
+    1 - 0.05 / TO_3dB(rej) = 0.9136 of it (TO_3dB(a) = (1.6e-6 a - 7.5e-4) a + 0.646), linear phase.  -> (f_pass, f_stop, att_dB) in Hz."""
+    rej = SOXR_HQ_BITS * 20.0 * math.log10(2.0)
+    to3db = (1.6e-6 * rej - 7.5e-4) * rej + 0.646
+    nyq = 0.5 * min(fs_in, fs_out)
+    return (1.0 - 0.05 / to3db) * nyq, nyq, rej
+
+
+def _design(kind, up, down, fs_in):
+    """host filter design -> (taps f64 scaled by `up`, half length); the polyphase kernel evaluates it exactly (f64 accumulate)."""
     from scipy.signal import firwin
+    mx = max(up, down)
+    if kind == "scipy":         # scipy.signal.resample_poly's default: Kaiser(5.0), 20 * max(up, down) + 1 taps, cutoff at the lower Nyquist
+        half = 10 * mx
+        return firwin(2 * half + 1, 1.0 / mx, window=("kaiser", 5.0)) * up, half
+    # "soxr_hq": ONE Kaiser-windowed sinc meeting soxr HQ's specification (cutoff in the middle of the transition band, as soxr's
+    # lsx_design_lpf places it); soxr itself cascades several stages designed to the same total specification, so the two agree to
+    # the specification's own ripple (2^-20) below f_pass and both reject >= 120 dB above f_stop; they may differ inside the
+    # 0.9136-1.0 x Nyquist transition band.  Not bit-equal to libsoxr (SURVEY 8c: not reproducible).
+    fs_work = float(fs_in) * up
+    f_pass, f_stop, att = soxr_hq_spec(fs_in, fs_in * up / down)
+    dw = 2.0 * math.pi * (f_stop - f_pass) / fs_work
+    half = int(math.ceil((att - 7.95) / (2.285 * dw) / 2.0))
+    h = firwin(2 * half + 1, (f_pass + f_stop) / fs_work, window=("kaiser", 0.1102 * (att - 8.7)))
+    return h * up, half
+
+
+def _poly_resample(x, fs_in, fs_out, design="scipy"):
+    """``scipy.signal.resample_poly(x, up, down, window=h)`` on the batched polyphase kernel, f32 [P, L] -> f32 [P, ceil(L up / down)].
+    design "scipy": its default Kaiser(5.0) filter (librosa's res_type="polyphase", the bandwidth-limitation augmentation);
+    design "soxr_hq": a filter built to libsoxr's HQ specification (`_design`), the stand-in for ``soxr.resample`` in
+    pesq_metric (:69-70) and for ``librosa.resample(res_type="soxr_hq")`` in the simulator's read_audio
+    (simulate_data_from_param.py:350-352)."""
     require_cuda(x)
     x = x.contiguous().float()
     P, L = x.shape
     g = math.gcd(int(fs_in), int(fs_out))
     up, down = int(fs_out) // g, int(fs_in) // g
-    key = ("poly", up, down, L, x.device)
+    key = ("poly", design, up, down, int(fs_in) if design != "scipy" else 0, x.device)     # (not L: the filter does not depend on it)
     if key not in _cache:
-        mx = max(up, down)
-        half_len = 10 * mx
-        h = firwin(2 * half_len + 1, 1.0 / mx, window=("kaiser", 5.0)) * up
-        n_pre_pad = down - half_len % down
-        n_pre_remove = (half_len + n_pre_pad) // down
-        n_out = L * up // down + (1 if (L * up) % down else 0)
+        from . import ops
+        h, half = _design(design, up, down, int(fs_in))
+        n_pre_pad = down - half % down
         hp = np.concatenate([np.zeros(n_pre_pad), h])
-        _cache[key] = (torch.from_numpy(hp).to(x.device), len(hp), n_pre_remove, n_out)
-    hp, hlen, npr, n_out = _cache[key]
+        _cache[key] = (ops.upload(torch.from_numpy(hp), x.device), len(hp), (half + n_pre_pad) // down)
+    hp, hlen, npr = _cache[key]
+    n_out = L * up // down + (1 if (L * up) % down else 0)
     y = torch.empty(P, n_out, device=x.device, dtype=torch.float32)
     call("resample_poly", x, y, hp, hlen, P, L, n_out, up, down, npr, stream_ptr())
     return y
+
+
+def resample_soxr_hq(x, fs_in, fs_out):
+    return _poly_resample(x, fs_in, fs_out, design="soxr_hq")
 
 
 def pesq_batch(ref, inf, fs, mode=None, lens=None, return_trace=False, max_pairs_per_launch=2048):
@@ -137,7 +172,7 @@ def pesq_batch(ref, inf, fs, mode=None, lens=None, return_trace=False, max_pairs
         else:
             raise ValueError("sample rate must be 8000 or 16000+ for PESQ evaluation, but got %d" % fs)
     if fs > 16000:
-        ref, inf = _poly_resample(ref, fs, 16000), _poly_resample(inf, fs, 16000)
+        ref, inf = resample_soxr_hq(ref, fs, 16000), resample_soxr_hq(inf, fs, 16000)
         if lens is not None:
             lens = (torch.as_tensor(lens).long() * 16000 + fs - 1) // fs
         fs = 16000

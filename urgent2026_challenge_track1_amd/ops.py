@@ -427,12 +427,13 @@ USE_WIDE_LSTM = os.environ.get("URSE_LSTM_WIDE", "1") != "0"
 FUSE_GN_STATS = os.environ.get("URSE_FUSE_GN_STATS", "1") != "0"
 # run the dual-path weight-gradient GEMMs on a second stream beside the time path's BPTT kernel (which fills 136 CUs)
 TN_OVERLAP = os.environ.get("URSE_TN_OVERLAP", "1") != "0"
-def low_priority_stream(device):
-    """The stream of the deferred weight-gradient GEMMs.  URSE_SIDE_STREAM_PRIORITY=low makes it a HIP stream of the LOWEST
+def low_priority_stream(device, force=False):
+    """The stream of the deferred weight-gradient GEMMs (and, with force=True, of the dynamic-mixing prefetcher: its simulator
+    workgroups must never keep a cooperative recurrence workgroup off its CU).  URSE_SIDE_STREAM_PRIORITY=low makes it a HIP stream of the LOWEST
     priority (torch only offers normal / high), so that its work only takes CUs the compute stream leaves idle; measured
     WORSE than equal priority (196 vs 189 ms/step): the band path's BPTT runs alone (30 -> 25 ms/step) but all the GEMM work
     then piles up beside the time path's BPTT (48 -> 58 ms/step).  Default: normal priority."""
-    if os.environ.get("URSE_SIDE_STREAM_PRIORITY", "normal") != "low":
+    if not force and os.environ.get("URSE_SIDE_STREAM_PRIORITY", "normal") != "low":
         return torch.cuda.Stream(device=device)
     import ctypes
     try:

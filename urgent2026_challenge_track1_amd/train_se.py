@@ -17,7 +17,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 from .config import Config, config_parser
 from .d_model import SEModel
 from .dataset import AudioDataModule, RawMixBatch
@@ -58,13 +58,16 @@ def save_checkpoint(path, model, opt, sched, epoch, step, val_loss):
     torch.save(ck, path)
 
 
-def load_model_state(model, state_dict):
+def load_model_state(model, state_dict, with_ema=True):
+    """weights of a checkpoint into the model.  with_ema=False is `init_from` (reference train_se.py:55-59: a plain
+    ``model.load_state_dict`` - Lightning's on_load_checkpoint hook does not run there, the EMA starts from the loaded weights);
+    with_ema=True is the resume path (Lightning restores checkpoint['ema'] through the hook, flow_model.py:98-113)."""
     ck = state_dict
     if "state_dict" in state_dict:
         state_dict = state_dict["state_dict"]
     if isinstance(model, FlowSEModel):
         model.load_state_dict({k: v for k, v in state_dict.items() if k.startswith("dnn.")})
-        if "ema" in ck:
+        if with_ema and "ema" in ck:
             model.on_load_checkpoint(ck)
         return
     sd = {k[len("se_model."):] if k.startswith("se_model.") else k: v for k, v in state_dict.items()}
@@ -86,7 +89,9 @@ class DevicePrefetcher:
 
     def __init__(self, loader, dev, skipped=None):
         self.loader, self.dev, self.skipped = loader, dev, skipped
-        self.stream = torch.cuda.Stream(dev) if torch.device(dev).type == "cuda" else None
+        # lowest HIP priority: the simulator's thousands of small workgroups only take CUs the train step leaves idle, so they cannot
+        # keep a workgroup of a cooperative recurrence kernel (which spins on its peers) off its CU
+        self.stream = ops.low_priority_stream(dev, force=True) if torch.device(dev).type == "cuda" else None
 
     def _stage(self, batch):
         if self.stream is None:
@@ -141,6 +146,16 @@ def equalise_batch_counts(sampler, world, dev):
     return sampler.max_batches
 
 
+def raise_kernel_errors_on_all_ranks(dev, world):
+    """the cooperative kernels' error flag, OR-ed over the ranks: a timed-out hand-off on one rank raises on ALL of them (rank 0
+    alone reading it in save_checkpoint would leave the others waiting in the next all-reduce)."""
+    flag = ops.kernel_error_flag(dev).to(torch.int32).clone()
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) != 0:
+        raise _lib.UrseError("a cooperative LSTM kernel timed out on some rank: the last optimisation steps are invalid")
+
+
 def fit(cfg, max_steps=None, log_every=50):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,7 +174,7 @@ def fit(cfg, max_steps=None, log_every=50):
 
     model = build_model(cfg)
     if cfg.init_from != "none":
-        load_model_state(model, torch.load(cfg.init_from, map_location="cpu", weights_only=False))
+        load_model_state(model, torch.load(cfg.init_from, map_location="cpu", weights_only=False), with_ema=False)
         if rank == 0:
             print("Init param loaded from %s" % cfg.init_from)
     model = model.to(dev)
@@ -189,6 +204,7 @@ def fit(cfg, max_steps=None, log_every=50):
     best = []   # [(val_loss, path)]
     t0 = time.time()
     skipped = {}                                # augmentations the recipes drew but the device path cannot apply
+    policy, warned = getattr(cfg, "unsupported_augmentation", "warn"), False
     for epoch in range(epoch0, cfg.num_train_epochs):
         # the reference never advances the sampler epoch (quirk C.3: on_train_epoch_start is not a DataModule hook)
         equalise_batch_counts(dm.train_batch_sampler, world, dev)
@@ -197,12 +213,22 @@ def fit(cfg, max_steps=None, log_every=50):
             loss.backward()
             model.optimizer_step(opt, reducer)
             step += 1
+            if skipped and not warned and policy != "count":
+                warned = True
+                msg = ("dynamic mixing drew an augmentation the device simulator does not apply (%s): it is skipped for that "
+                       "utterance (wind noise is mixed additively); counters follow in every log line "
+                       "(cfg.unsupported_augmentation = warn | raise | count)" % sorted(skipped))
+                if policy == "raise":
+                    raise NotImplementedError(msg)
+                print("WARNING: " + msg, flush=True)
             if rank == 0 and step % log_every == 0:
                 lg = {k: float(v) for k, v in model.logged.items()}
-                print("epoch %d step %d %s  (%.2f s/step)" % (epoch, step, lg, (time.time() - t0) / log_every), flush=True)
+                print("epoch %d step %d %s  (%.2f s/step)%s" % (epoch, step, lg, (time.time() - t0) / log_every,
+                                                               "  not applied: %s" % dict(skipped) if skipped else ""), flush=True)
                 t0 = time.time()
             if step % cfg.val_check_interval == 0:
                 vl = validate(model, val_loader, dev)
+                raise_kernel_errors_on_all_ranks(dev, world)      # every rank fails together, none is left in an all-reduce
                 if rank == 0:
                     path = "%s/best_epoch=%02d-step=%06d-val_loss=%.3f.ckpt" % (ckpt_dir(cfg), epoch, step, vl)
                     save_checkpoint(path, model, opt, sched, epoch, step, vl)
