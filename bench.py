@@ -203,6 +203,22 @@ class _InMemorySources:
         return self.audio[path].shape[1]
 
 
+def _pesq_note():
+    """what a wide-band PESQ number of this build is worth: the measured sensitivity of the score to the reconstructed part of
+    the 16 kHz Bark table (scripts/pesq_band_sweep.py -> profiles/r03_pesq_band_sweep.json)."""
+    note = ("P.862 restated without the pesq package (absent): parity with the package unpinned; integer alignment stages equal to "
+            "the oracle in float64 and with float32 buffers; bands 41-48 of the 16 kHz Bark table are reconstructed (oracle/pesq_tables.py)")
+    try:
+        sw = json.load(open(os.path.join(ROOT, "profiles", "r03_pesq_band_sweep.json")))
+        note += ("; sweeping their free Hz edges over the bin interval the bin counts admit and their Bark widths by +-3 %% moves "
+                 "the wide-band MOS-LQO of 8 test pairs by at most %.3f (edges alone %.3f)"
+                 % (sw["max_abs_delta_mos"], max(sw["max_abs_delta_mos_per_variant"]["edges_low"],
+                                                 sw["max_abs_delta_mos_per_variant"]["edges_high"])))
+    except Exception:
+        pass
+    return note
+
+
 def metrics_bench(dev, pairs=2048, batches=1, fs=16000, seconds=4.0):
     """Second metric of BASELINE.json ("PESQ+STOI pairs/sec", config C5: 4 s @ 16 kHz enhanced / reference pairs resident in
     HBM): PESQ (P.862.2 wide-band) + ESTOI + SDR on the HIP kernels, `batches` x `pairs` pairs per run (`--metric-pairs N`
@@ -245,8 +261,7 @@ def metrics_bench(dev, pairs=2048, batches=1, fs=16000, seconds=4.0):
                "value": pairs * batches / dt, "unit": "pairs/s", "pairs_per_batch": pairs, "batches": batches,
                "pesq_pairs_per_s": pairs * batches / t_pesq, "estoi_sdr_pairs_per_s": pairs * batches / (dt - t_pesq),
                "mean_pesq": float(torch.nanmean(q)), "mean_estoi": float(e.mean()), "mean_sdr_db": float(d.mean()),
-               "pesq_note": "P.862 restated without the pesq package (absent): parity unpinned; the seven Bark bands above 4 kHz of "
-                            "the 16 kHz table are reconstructed (oracle/pesq_tables.py)"}
+               "pesq_note": _pesq_note()}
         # CPU baseline as the reference runs it (calculate_intrusive_se_metrics.py:127-132: `process_map(..., max_workers=nj)`, default
         # nj = 8, one pair per task): 32 of the same pairs scored by the numpy oracles in a pool of 8 worker processes
         n, nj = 32, 8

@@ -9,7 +9,8 @@ lives in ``pesq==0.0.4`` (Cython over the ITU-T P.862 reference C code), which i
 code: ``fix_power_level``, ``apply_filter``, ``input_filter``, ``apply_VAD``, ``crude_align``, ``id_searchwindows``,
 ``time_align``, ``id_utterances``, ``utterance_split`` / ``split_align``, ``pesq_psychoacoustic_model``); the tables and what
 could not be restated digit for digit are in ``pesq_tables.py`` (8 kHz tables: verified by their internal redundancy; 16 kHz:
-the seven bands above 4 kHz reconstructed).  Arithmetic is float64 where the C code is float32: the INTEGER outputs of the
+the seven bands above 4 kHz reconstructed).  Arithmetic is float64 where the C code is float32 (``precision="f32"`` rounds every
+stored buffer to float32 as the C code's `float` arrays do, see `q`): the INTEGER outputs of the
 alignment stages (crude delay, utterance boundaries, per-utterance delays, bad intervals, frame counts) are what the GPU
 path must reproduce exactly (``trace`` returns them), the MOS to floating-point tolerance.
 
@@ -38,12 +39,32 @@ THRESHOLD_BAD_FRAMES = 30.0
 ZWICKER_POWER = 0.23
 NO_UTTERANCES_DETECTED = -1
 
+# Storage precision.  The ITU-T reference code keeps every buffer (signals, VAD, correlations, histograms, Bark densities,
+# loudness, frame disturbances) in C `float`.  `q` rounds an array or scalar to float32 (kept in a float64 container) at
+# every point where that code stores into such a buffer when PRECISION == "f32"; with "f64" (default) it is the identity.
+# Expression-level arithmetic stays float64 in both: the f32 variant restates the code's STORAGE rounding - 1e-7 relative
+# perturbations at ~25 points per pair - which is what can move an integer decision (an argmax, a threshold crossing).
+# tests/test_pesq_cpu.py requires both variants to give the same integers on every seeded pair, tests/test_pesq_gpu.py
+# requires the kernels to equal both.
+PRECISION = "f64"
+
+
+def q(a):
+    if PRECISION == "f64":
+        return a
+    if np.isscalar(a):
+        return float(np.float32(a))
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
 
 def nextpow2(x):
     n = 1
     while n < x:
         n *= 2
     return n
+
+
+TABLE_VARIANT = {}        # scripts/pesq_band_sweep.py: parameters of the reconstructed part of the 16 kHz Bark table
 
 
 class Ctx:
@@ -55,7 +76,7 @@ class Ctx:
         self.pad = DATAPADDING_MSECS * (fs // 1000)
         self.iir = T.INIIR_HSOS_8K if fs == 8000 else T.INIIR_HSOS_16K
         self.wb_iir = T.WB_INIIR_HSOS_8K if fs == 8000 else T.WB_INIIR_HSOS_16K
-        self.tb = T.tables(fs)
+        self.tb = T.tables(fs, **TABLE_VARIANT) if (TABLE_VARIANT and fs == 16000) else T.tables(fs)
 
 
 def interpolate(freq, curve):
@@ -85,14 +106,14 @@ def apply_filter(c, data, nsamples, curve):
     res = c.fs / p2
     fac = np.array([10.0 ** ((interpolate(i * res, curve) - ref_gain) / 20.0) for i in range(p2 // 2 + 1)])
     y = np.fft.irfft(X * fac, p2)
-    data[sb:sb + n] = y[:n]
+    data[sb:sb + n] = q(y[:n])
 
 
 def iir_sos(x, sos):
     """cascade of direct-form-II biquads {b0, b1, b2, a1, a2}, in place."""
     from scipy.signal import lfilter
     for b0, b1, b2, a1, a2 in sos:
-        x[:] = lfilter([b0, b1, b2], [1.0, a1, a2], x)
+        x[:] = q(lfilter([b0, b1, b2], [1.0, a1, a2], x))
 
 
 def pow_of(x, start, stop, divisor):
@@ -106,7 +127,7 @@ def fix_power_level(c, data, nsamples, max_nsamples):
     apply_filter(c, tmp, nsamples, T.ALIGN_FILTER_DB)
     p = pow_of(tmp, sb, nsamples - sb + c.pad, max_nsamples - 2 * sb + c.pad)
     if p > 0.0:                      # (an all-zero signal: the C code scales by inf; here it is left alone)
-        data[:nsamples] *= np.sqrt(TARGET_AVG_POWER / p)
+        data[:nsamples] = q(data[:nsamples] * q(np.sqrt(TARGET_AVG_POWER / p)))
 
 
 def dc_block(c, data, nsamples):
@@ -116,12 +137,13 @@ def dc_block(c, data, nsamples):
     ramp = (0.5 + np.arange(c.ds)) / c.ds
     data[ofs:ofs + c.ds] *= ramp
     data[nsamples - ofs - c.ds:nsamples - ofs] *= ramp[::-1]
+    data[:] = q(data)
 
 
 def apply_vad(c, data, nsamples):
     ds = c.ds
     nw = nsamples // ds
-    vad = (data[:nw * ds].reshape(nw, ds) ** 2).sum(1) / ds
+    vad = q((data[:nw * ds].reshape(nw, ds) ** 2).sum(1) / ds)
     level_thresh = vad.sum() / nw
     level_min = vad.max()
     level_min = level_min * 1.0e-4 if level_min > 0.0 else 1.0
@@ -187,7 +209,7 @@ def apply_vad(c, data, nsamples):
     if level_thresh <= 0.0:
         level_thresh = level_min
     logvad = np.where(vad <= level_thresh, 0.0, np.log(np.maximum(vad, 1e-300) / level_thresh))
-    return vad, logvad
+    return q(vad), q(logvad)
 
 
 def fftn_xcorr(x1, x2):
@@ -196,7 +218,7 @@ def fftn_xcorr(x1, x2):
     nx = nextpow2(max(n1, n2))
     a = np.fft.rfft(x1[::-1], 2 * nx)
     b = np.fft.rfft(x2, 2 * nx)
-    return np.fft.irfft(a * b, 2 * nx)[:n1 + n2 - 1]
+    return q(np.fft.irfft(a * b, 2 * nx)[:n1 + n2 - 1])
 
 
 class Err:
@@ -287,8 +309,8 @@ def _frame_xcorr_hist(c, ref, deg, startr, startd, window):
     n = c.align_nfft
     x1 = np.fft.rfft(ref["data"][startr:startr + n] * window)
     x2 = np.fft.rfft(deg["data"][startd:startd + n] * window)
-    x = np.abs(np.fft.irfft(np.conj(x1) * x2, n))
-    v_max = x.max() * 0.99
+    x = q(np.abs(np.fft.irfft(np.conj(x1) * x2, n)))
+    v_max = q(x.max() * 0.99)
     return x, v_max
 
 
@@ -303,7 +325,7 @@ def time_align(c, ref, deg, e, utt_id):
         startr, startd = -est, 0
     while startd + n <= deg["n"] and startr + n // 4 <= e.search_end[utt_id] * ds:
         x, v_max = _frame_xcorr_hist(c, ref, deg, startr, startd, window)
-        h[x > v_max] += v_max ** 0.125
+        h[x > v_max] = q(h[x > v_max] + q(v_max ** 0.125))
         startr += n // 4
         startd += n // 4
     hsum = h.sum()
@@ -313,7 +335,7 @@ def time_align(c, ref, deg, e, utt_id):
     for k in range(1, kernel):
         x2[k] = x2[n - k] = 1.0 - k / kernel
     sm = np.abs(np.fft.irfft(np.fft.rfft(h) * np.fft.rfft(x2), n))
-    hh = sm / hsum if hsum > 0.0 else np.zeros(n)
+    hh = q(sm / hsum) if hsum > 0.0 else np.zeros(n)
     i_max = int(np.argmax(hh))
     v_max = hh[i_max]
     if v_max <= 0.0:
@@ -385,12 +407,13 @@ def split_align(c, ref, deg, e, utt_start, speech_start, speech_end, utt_end, de
 
     def accumulate(h, startr, startd):
         x, v_max = _frame_xcorr_hist(c, ref, deg, startr, startd, window)
-        n_max = v_max ** 0.125 / kernel
+        n_max = q(v_max ** 0.125 / kernel)
         add = 0.0
         for cnt in np.nonzero(x > v_max)[0]:
             add += n_max * kernel
             idx = (cnt + np.arange(1 - kernel, kernel) + n) % n
             np.add.at(h, idx, n_max * tri)
+            h[idx] = q(h[idx])
         return add
 
     def peak(h, hsum, est):
@@ -508,8 +531,8 @@ def _pitch_pow_dens(c, data, start, whanning):
     spec = np.abs(np.fft.rfft(data[start:start + nf] * whanning)[:nf // 2]) ** 2
     spec[0] = 0.0
     edges = np.concatenate([[0], np.cumsum(tb["nr"])])
-    out = np.add.reduceat(spec, edges[:-1])
-    return out * tb["pow_corr"] * tb["sp"]
+    out = np.add.reduceat(q(spec), edges[:-1])
+    return q(out * tb["pow_corr"] * tb["sp"])
 
 
 def _total_audible(c, ppd, factor):
@@ -526,7 +549,7 @@ def _loudness(c, ppd):
     zp = ZWICKER_POWER * h
     th = tb["abs_thresh"]
     ld = np.where(ppd > th, (th / 0.5) ** zp * ((0.5 + 0.5 * ppd / th) ** zp - 1.0), 0.0)
-    return ld * tb["sl"]
+    return q(ld * tb["sl"])
 
 
 def _pseudo_lp(c, x, p):
@@ -546,7 +569,7 @@ def _disturbances(c, ppd_ref, ppd_deg):
     h = ratio ** 1.2
     h = np.where(h > 12.0, 12.0, h)
     h = np.where(h < 3.0, 0.0, h)
-    return fd, _pseudo_lp(c, d * h, A_POW_F)
+    return q(fd), q(_pseudo_lp(c, q(d * h), A_POW_F))
 
 
 def _lpq_weight(start_frame, stop_frame, p_syl, p_time, fd, tw):
@@ -571,7 +594,7 @@ def compute_delay(start, stop, search_range, s1, s2):
     norm = np.sqrt(pw1 * pw2)
     x1 = np.fft.rfft(np.abs(s1[start:stop]), p2) / p2
     x2 = np.fft.rfft(np.abs(s2[start:stop]), p2)
-    y = np.fft.irfft(np.conj(x1) * x2, p2)
+    y = q(np.fft.irfft(np.conj(x1) * x2, p2))
     best, mx = 0, 0.0
     for i in list(range(-search_range, 0)) + list(range(0, search_range)):
         h = abs(y[i % p2]) / norm
@@ -628,7 +651,7 @@ def psychoacoustic_model(c, ref, deg, e, trace):
     avg_ref = np.where(ppd_ref[act] > th100, ppd_ref[act], 0.0).sum(0) / total_frames
     avg_deg = np.where(ppd_deg[act] > th100, ppd_deg[act], 0.0).sum(0) / total_frames
     x = np.clip((avg_deg + 1000.0) / (avg_ref + 1000.0), 0.01, 100.0)
-    ppd_ref *= x[None, :]
+    ppd_ref[:] = q(ppd_ref * q(x)[None, :])
     fd, fda = np.zeros(nfr), np.zeros(nfr)
     total_power_ref = np.zeros(nfr)
 
@@ -643,7 +666,7 @@ def psychoacoustic_model(c, ref, deg, e, trace):
                 sc = 0.2 * old + 0.8 * sc
             old = sc
             sc = min(max(sc, 3e-4), 5.0)
-            ppd_deg[f] *= sc
+            ppd_deg[f] = q(ppd_deg[f] * q(sc))
             a, b = _disturbances(c, ppd_ref[f], ppd_deg[f])
             if first_pass:
                 fd[f], fda[f] = a, b
@@ -715,8 +738,8 @@ def psychoacoustic_model(c, ref, deg, e, trace):
         twf = min((n - 1000.0) / 5500.0, 0.5)
         tw = (1.0 - twf) + twf * np.arange(nfr) / n
     h = ((total_power_ref + 1e5) / 1e7) ** 0.04
-    fd = np.minimum(fd / h, 45.0)
-    fda = np.minimum(fda / h, 45.0)
+    fd = q(np.minimum(fd / h, 45.0))
+    fda = q(np.minimum(fda / h, 45.0))
     d_ind = _lpq_weight(start_frame, stop_frame, D_POW_S, D_POW_T, fd, tw)
     a_ind = _lpq_weight(start_frame, stop_frame, A_POW_S, A_POW_T, fda, tw)
     trace.update(start_frame=start_frame, stop_frame=stop_frame, bad_intervals=[list(map(int, b)) for b in bad_intervals],
@@ -730,13 +753,22 @@ def _load(c, x, scale):
     sb = SEARCHBUFFER * c.ds
     n = len(x) + 2 * sb
     data = np.zeros(n + c.pad + 4 * c.align_nfft)
-    data[sb:sb + len(x)] = np.asarray(x, dtype=np.float64) * scale
+    data[sb:sb + len(x)] = q(np.asarray(x, dtype=np.float64) * scale)
     return dict(data=data, n=n)
 
 
-def pesq(fs, ref, deg, mode="wb", return_trace=False):
+def pesq(fs, ref, deg, mode="wb", return_trace=False, precision="f64"):
     """-> MOS-LQO (P.862.1 for 'nb', P.862.2 for 'wb'), or NO_UTTERANCES_DETECTED; with return_trace also the integer
-    outputs of the alignment stages."""
+    outputs of the alignment stages.  precision "f32": buffers rounded to float32 where the ITU code stores C floats (`q`)."""
+    global PRECISION
+    old, PRECISION = PRECISION, precision
+    try:
+        return _pesq(fs, ref, deg, mode, return_trace)
+    finally:
+        PRECISION = old
+
+
+def _pesq(fs, ref, deg, mode, return_trace):
     c = Ctx(fs, mode)
     peak = max(float(np.max(np.abs(ref))), float(np.max(np.abs(deg))), 1.0)
     r, d = _load(c, ref, 32768.0 / peak), _load(c, deg, 32768.0 / peak)

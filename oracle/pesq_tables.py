@@ -118,14 +118,17 @@ def check_redundancy():
     return True
 
 
-def _tables_16k():
-    """49-band table: bands 0..40 of the 8 kHz table, bands 41..48 reconstructed (module docstring)."""
+def _tables_16k(edge_pos=None, bark_scale=1.0):
+    """49-band table: bands 0..40 of the 8 kHz table, bands 41..48 reconstructed (module docstring).
+    edge_pos / bark_scale parametrise the RECONSTRUCTED part for the sensitivity sweep (scripts/pesq_band_sweep.py): edge_pos
+    in (0, 1) puts every free Hz edge at that position inside the one-bin interval the bin counts admit (None = the default
+    Bark->Hz continuation); bark_scale scales the reconstructed Bark widths of bands 42-48."""
     wb8, wh8 = np.array(WIDTH_OF_BAND_BARK_8K), np.array(WIDTH_OF_BAND_HZ_8K)
     nr = NR_OF_HZ_BANDS_8K[:41] + NR_OF_HZ_BANDS_16K_TAIL
     assert sum(nr) == 256
     k = np.arange(20, 42)
     wfit = np.polyfit(k, wb8[20:42], 3)
-    wb = np.concatenate([wb8[:42], np.polyval(wfit, np.arange(42, 49))])
+    wb = np.concatenate([wb8[:42], bark_scale * np.polyval(wfit, np.arange(42, 49))])
     eb8 = np.concatenate([[0.0], np.cumsum(wb8)])[:42]          # lower Bark edges of bands 0..41
     eh8 = np.concatenate([[0.0], np.cumsum(wh8)])[:42]          # lower Hz edges of bands 0..41
     # Bark -> Hz of the band edges above 2 kHz: log f is close to quadratic in z there; continue it
@@ -150,6 +153,8 @@ def _tables_16k():
             hz = f_of_z(zb)
             if not lo < hz < hi:
                 hz = 0.5 * (lo + hi)
+            if edge_pos is not None:
+                hz = lo + edge_pos * (hi - lo)
         edges_hz.append(hz)
         edges_bark.append(zb)
     wh = np.concatenate([wh8[:41], np.diff(edges_hz)])
@@ -162,8 +167,11 @@ def _tables_16k():
                 sp=SP_16K, sl=SL_16K)
 
 
-def tables(fs):
+def tables(fs, **variant):
     check_redundancy()
+    if variant:
+        assert fs == 16000
+        return _tables_16k(**variant)
     if fs == 8000:
         return dict(nb=42, nr=np.array(NR_OF_HZ_BANDS_8K), centre_bark=np.array(CENTRE_OF_BAND_BARK_8K),
                     width_bark=np.array(WIDTH_OF_BAND_BARK_8K), width_hz=np.array(WIDTH_OF_BAND_HZ_8K),

@@ -107,6 +107,7 @@ def test_soxr_hq_spec_resampler_matches_oracle(lib, fs_in, fs_out):
     """the stand-in for soxr.resample(x, fs, 16000) in pesq_metric (calculate_intrusive_se_metrics.py:69-70): a filter built to
     libsoxr's HQ specification (oracle/metrics_ref.soxr_hq_design, its specification asserted in tests/test_oracle.py), evaluated
     by the polyphase kernel with f64 accumulation -> equal to the f64 oracle to f32 rounding."""
+    from urgent2026_challenge_track1_amd import metrics
     rng = np.random.default_rng(4)
     x = rng.standard_normal((2, 30011)).astype(np.float32)
     got = metrics.resample_soxr_hq(torch.from_numpy(x).cuda(), fs_in, fs_out).cpu().numpy()

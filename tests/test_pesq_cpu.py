@@ -62,3 +62,16 @@ def test_delay_is_recovered_and_score_falls_with_noise():
     _, tr = pesq_ref.pesq(fs, ref, deg, mode, return_trace=True)
     assert tr["n_utterances"] == 2 and tr["utt_delay"] == [0, 320]
     assert float(GOLD["mos"][1]) > float(GOLD["mos"][2]) and float(GOLD["mos"][5]) > float(GOLD["mos"][6])
+
+
+@pytest.mark.parametrize("i", [3, 7, 8, 9])
+def test_f32_storage_variant_makes_the_same_integer_decisions(i):
+    """the ITU code keeps its buffers in C floats; the oracle computes in float64.  With every stored buffer rounded to float32
+    (pesq_ref.q) the integer outputs of the alignment stages stay the same (pause, negative delay, utterance split, bad
+    interval) and the MOS moves by < 1e-6: the integer-stage parity claim does not hinge on the oracle's precision."""
+    fs, mode, ref, deg = pesq_cases.make_case(i)
+    mos, tr = pesq_ref.pesq(fs, ref, deg, mode, return_trace=True, precision="f32")
+    want = json.loads(str(GOLD["trace_f32"][i]))
+    got = json.loads(json.dumps({k: tr.get(k) for k in pesq_cases.TRACE_KEYS}, default=lambda o: o.tolist() if hasattr(o, "tolist") else float(o)))
+    assert got == want == json.loads(str(GOLD["trace"][i]))
+    assert abs(mos - float(GOLD["mos"][i])) <= 1e-6 and abs(mos - float(GOLD["mos_f32"][i])) <= 1e-9

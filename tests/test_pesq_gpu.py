@@ -42,6 +42,7 @@ def test_pesq_matches_oracle_integer_stages_exactly_and_mos_closely(lib):
     worst = 0.0
     for i in idx:
         want = json.loads(str(GOLD["trace"][i]))
+        assert want == json.loads(str(GOLD["trace_f32"][i]))     # f64 oracle and its f32-storage variant: same integers
         mos, raw, tr = got[i]
         if want.get("n_utterances") is None:                 # NO_UTTERANCES_DETECTED
             assert np.isnan(mos), i
@@ -133,6 +134,9 @@ def test_pesq_random_pairs_match_oracle(lib):
         mos, trace = mos.cpu().numpy(), trace.cpu().numpy()
         for k, c in enumerate(items):
             want_mos, want = pesq_ref.pesq(c[0], c[2], c[3], c[1], return_trace=True)
+            if k % 3 == 0:      # every third pair also through the f32-storage variant of the oracle (the ITU code's C floats)
+                m32, w32 = pesq_ref.pesq(c[0], c[2], c[3], c[1], return_trace=True, precision="f32")
+                assert all(w32.get(key) == want.get(key) for key in pesq_cases.TRACE_KEYS), (cfg, k)
             tr = trace[k]
             if want.get("n_utterances") is None:
                 assert np.isnan(mos[k]), k
