@@ -16,6 +16,16 @@
  *  - `stream` is a hipStream_t passed as void*; calls are asynchronous w.r.t. the host.
  *  - dtype codes: URSE_F32 / URSE_BF16 select the operand type of the dense contractions
  *    (accumulation is always f32).  Complex tensors are interleaved (re, im) float pairs.
+ *  - no tuning or mode state lives in the library: everything that shapes a launch is an argument of the call
+ *    (e.g. target_workgroups of urse_gemm_tn, reserved_cus of the cooperative recurrences).  The only process-wide
+ *    mutable data are the read-only-for-results diagnostics below (urse_launch_count) and the caches of immutable tables.
+ *  - collectives are NOT part of this ABI (SURVEY 8b lists an `urse_allreduce_bucket`): the gradient all-reduce of
+ *    train_se.py:74-83 (Lightning DDP over NCCL) is RCCL reached through the host framework - torch.distributed, backend
+ *    "nccl" = RCCL on ROCm - on the contiguous buckets of the flat gradient buffer this library fills (ddp.GradBucketReducer);
+ *    wrapping rccl's ncclAllReduce behind a C symbol here would add a communicator-lifetime API and no kernel.
+ *  - workspaces: every scratch buffer is an explicit argument whose size follows from the documented shapes (hx / xbuf /
+ *    counters from the urse_lstm_*_plan queries, the PESQ slice from urse_pesq_workspace_bytes); kernels that need none
+ *    beyond their outputs have no query.
  */
 #ifndef URSE_H_
 #define URSE_H_
@@ -118,18 +128,18 @@ int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_descs, int gro
  * (the h_{t-1} operand of the recurrent weight gradient).  perm_h > 0: the columns of A are in the LSTM
  * kernels' gate-interleaved order (dir, unit, gate) and C rows / colsum are written back in nn.LSTM's
  * (dir, gate, unit) order with H = perm_h.  perm_h < 0: flow grad decoder, A columns (bin, 16 sub-channels) ->
- * weight rows (sub-channel, bin) with sb = -perm_h. */
+ * weight rows (sub-channel, bin) with sb = -perm_h.
+ * target_workgroups: workgroups the large-shape kernels aim for (0 = 256, one per CU); a caller that launches beside
+ * another kernel passes the CUs that are free.  A per-call argument: the library keeps no tuning state between calls. */
 int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
                  int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner, int64_t period,
-                 int64_t invalid_step, int64_t perm_h, int dtype, void* stream);
+                 int64_t invalid_step, int64_t perm_h, int dtype, int target_workgroups, void* stream);
 /* Two weight gradients that share their A operand in one pass over A (the two wgrads of one LSTM direction):
  * C[Mo,No] += A^T B (+ colsum) and C2[Mo,No2] += A^T B2', B2' = B2 shifted / masked as in urse_gemm_tn. */
 int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
                       const void* B2, int64_t ldb2, float* C2, int64_t ldc2, int64_t R, int64_t Mo, int64_t No, int64_t No2,
                       int64_t shift, int64_t inner, int64_t period, int64_t invalid_step, int64_t perm_h, int dtype,
-                      void* stream);
-/* Number of workgroups the large-shape urse_gemm_tn kernels aim for (default 256 = one per CU; process-wide). */
-int urse_gemm_tn_set_target(int workgroups);
+                      int target_workgroups, void* stream);
 /* `groups` independent urse_gemm_tn problems in one launch (per-band weight gradients).  descs = device int64
  * [groups, 24]: {A, B, C, colsum, lda, ldb, ldc, R, Mo, No, shift, inner (>= 1), period, invalid_step,
  * rows_per_slice (multiple of 32; the row range is cut into ceil(R / rows_per_slice) split-R slices), perm_h, 8 x 0};
@@ -192,23 +202,28 @@ int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int6
  *  rows per cluster, padded rows, hx elements (bf16), counters (uint32, used by the BPTT variant only)};
  *  err_flag: uint32 set to 1 if a hand-off timed out (results are then invalid). */
 int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, void* stream);
-int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan);
+/* reserved_cus (all cooperative kernels: cluster, cluster2, split): CUs the caller has promised to OTHER work that is resident at
+ *  the same time (workgroups of launches on other streams).  The kernels' workgroups wait for each other, so every one of
+ *  them must be resident: the plan sizes the grid to device CUs - reserved_cus - margin and the call is REFUSED
+ *  (URSE_ERR_UNSUPPORTED, urse_last_error says why) when the sequences do not fit that many co-resident workgroups - the
+ *  caller then takes the streaming kernel (urse_lstm_bidir_fwd / _bwd), which has no such requirement. */
+int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int reserved_cus, int64_t* plan);
 int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                           void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
-                          int64_t outer, int64_t stride, int save, void* stream);
+                          int64_t outer, int64_t stride, int save, int reserved_cus, void* stream);
 /* Generalised cluster forward (csrc/lstm_cluster2.hip): same protocol and arguments, geometry chosen per hidden size
  * (H = 768, the flow model: 24 workgroups per cluster; H = 392: 7).  plan = {C, clusters per direction, rows per cluster,
  * hx bf16 elements}; hx is zeroed by the call; whhq from urse_lstm_pack_quads. */
-int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int64_t* plan);
+int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int reserved_cus, int64_t* plan);
 int urse_lstm_cluster2_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx, void* err_flag,
                            int H, int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
-                           void* stream);
+                           int reserved_cus, void* stream);
 /* Cluster BPTT (bf16), same protocol: whhTq from urse_lstm_pack_bwd_quads(whh, out [2*C*4*(H/8)*512 bf16], H, C);
  * dgx = exchange buffer of 2*2*ncl*64*4H bf16 elements. */
 int urse_lstm_pack_bwd_quads(const float* whh, void* out, int H, int C, void* stream);
 int urse_lstm_cluster_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhTq,
                           void* dgx, void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
-                          int64_t outer, int64_t stride, void* stream);
+                          int64_t outer, int64_t stride, int reserved_cus, void* stream);
 /* "Wide" streaming variant of urse_lstm_bidir_fwd (bf16): 64 sequences per workgroup so every streamed weight byte
  * feeds four MFMA row tiles (the band path's 12,832 short sequences).  whhb = block-ordered fragments from
  * urse_lstm_pack_blocks (2*ceil(H/16)*(Hp/32)*4*512 bf16).  `c` [M, 2H] f32 is REQUIRED (it carries c_{t-1} between
@@ -222,10 +237,10 @@ int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int6
  * hand-off (step parity in the mantissa LSB).  Arguments as urse_lstm_bidir_bwd (whhT from urse_lstm_pack).
  * urse_lstm_split_plan -> {nsplit, clusters per direction, xbuf f32 elements, sequences per cluster (32 | 16)}, < 0 if unsupported (too many sequences
  * for all workgroups to be co-resident, H % 8 != 0, ...).  err_flag: uint32 set to 1 if a hand-off timed out. */
-int urse_lstm_split_plan(int H, int n_seq, int64_t* plan);
+int urse_lstm_split_plan(int H, int n_seq, int reserved_cus, int64_t* plan);
 int urse_lstm_split_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT, void* xbuf,
                         void* err_flag, int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride,
-                        void* stream);
+                        int reserved_cus, void* stream);
 /* Backward through time.  dh [M, ldd>=2H] = gradient w.r.t. hout; gates: in = saved activations,
  * out = gradient w.r.t. the gate pre-activations (same interleaved layout); whhT = fragment-ordered
  * transposed recurrent weights from urse_lstm_pack. */

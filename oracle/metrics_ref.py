@@ -57,9 +57,17 @@ def thirdoct(fs, nfft, num_bands, min_freq):
     return obm, cf, lo, hi
 
 
+# pystoi's frame loops are ``range(0, len(x) - framelen, hop)`` (which records the package's code: "last full frame
+# excluded - keep the off-by-one"): a signal of exactly framelen + k * hop samples has k frames, not k + 1.  That is the reading this
+# oracle and the kernels implement.  LAST_FRAME_INCLUSIVE = True switches the oracle to the other reading (``len - framelen + 1``)
+# so that tests/test_metrics_gpu.py::test_estoi_frame_range_at_the_boundary_length can show, on a length = 256 mod 128 fixture,
+# which one the kernels follow and what the difference is worth (one frame; a few 1e-4 of ESTOI on a 2.6 s signal).
+LAST_FRAME_INCLUSIVE = False
+
+
 def _frames(x, framelen, hop):
     w = np.hanning(framelen + 2)[1:-1]
-    idx = list(range(0, len(x) - framelen, hop))
+    idx = list(range(0, len(x) - framelen + (1 if LAST_FRAME_INCLUSIVE else 0), hop))
     return np.array([w * x[i:i + framelen] for i in idx]).reshape(len(idx), framelen)
 
 

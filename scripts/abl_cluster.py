@@ -21,7 +21,7 @@ c = torch.empty(M, 2 * H, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 P = ctypes.c_void_p
 plan = (ctypes.c_int64 * 6)()
-assert libs["base"].urse_lstm_cluster_plan(H, Hp, B * K, plan) == 0
+assert libs["base"].urse_lstm_cluster_plan(H, Hp, B * K, 0, plan) == 0
 print("plan", list(plan))
 hx = torch.zeros(plan[4], device=dev, dtype=torch.bfloat16)
 cnt = torch.zeros(plan[5], device=dev, dtype=torch.int32)
@@ -29,7 +29,7 @@ err = torch.zeros(1, device=dev, dtype=torch.int32)
 def fwd(lib):
     return lib.urse_lstm_cluster_fwd(P(gx.data_ptr()), ctypes.c_int64(8 * H), P(whhq.data_ptr()), P(hout.data_ptr()), ctypes.c_int64(800),
         P(c.data_ptr()), P(hx.data_ptr()), P(cnt.data_ptr()), P(err.data_ptr()), H, Hp, B * K, T, ctypes.c_int64(K), ctypes.c_int64(T * K),
-        ctypes.c_int64(K), 1, P(st))
+        ctypes.c_int64(K), 1, 0, P(st))
 res = []
 for name, lib in libs.items():
     assert fwd(lib) == 0

@@ -42,14 +42,14 @@ def fwd_wide(lib, path, rt):
     return lib.urse_lstm_wide_fwd(P(gx.data_ptr()), ctypes.c_int64(8 * H), P(whhb.data_ptr()), P(hout.data_ptr()), ctypes.c_int64(800),
         P(c.data_ptr()), H, Hp, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 1, P(st))
 plan = (ctypes.c_int64 * 4)()
-assert libs["base"].urse_lstm_split_plan(H, B * K, plan) == 0
+assert libs["base"].urse_lstm_split_plan(H, B * K, 0, plan) == 0
 print("split plan", list(plan))
 xbuf = torch.empty(plan[2], device=dev, dtype=torch.float32)
 errf = torch.zeros(1, device=dev, dtype=torch.int32)
 def bwd_split(lib, path, rt):
     a = (B * K, T, K, T * K, K)
     return lib.urse_lstm_split_bwd(P(dh.data_ptr()), ctypes.c_int64(800), P(gx.data_ptr()), ctypes.c_int64(8 * H), P(c.data_ptr()),
-        P(whhT.data_ptr()), P(xbuf.data_ptr()), P(errf.data_ptr()), H, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), P(st))
+        P(whhT.data_ptr()), P(xbuf.data_ptr()), P(errf.data_ptr()), H, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 0, P(st))
 for fn, fname in ((bwd, "bwd"),):
     for path in ("time",):
         for rt in (0,):

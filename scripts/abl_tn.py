@@ -1,6 +1,7 @@
 """A/B of the TN ring depth (diagnostic build)."""
 import ctypes, os, subprocess, sys, time
 import torch
+TN_TARGET = [0]      # urse_gemm_tn's per-call target_workgroups (0 = one per CU)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
 variants = {"nst4": [], "nst5": ["-DURSE_TN_NST=5"]}
@@ -19,7 +20,7 @@ st = torch.cuda.current_stream().cuda_stream
 P, L = ctypes.c_void_p, ctypes.c_int64
 def run(lib):
     return lib.urse_gemm_tn(P(dg.data_ptr()), L(8 * H), P(xn.data_ptr()), L(224), P(gw.data_ptr()), L(N), P(0), L(M), L(8 * H), L(N),
-                            L(0), L(1), L(0), L(0), L(H), 1, P(st))
+                            L(0), L(1), L(0), L(0), L(H), 1, TN_TARGET[0], P(st))
 res = []
 for name, lib in libs.items():
     assert run(lib) == 0, name

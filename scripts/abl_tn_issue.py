@@ -3,6 +3,7 @@ at C2 (dW_ih + bias + dW_hh from one pass over the [M, 4H] dgates), time-path an
 give the same gradients."""
 import ctypes, os, subprocess, sys, time
 import torch
+TN_TARGET = [0]      # urse_gemm_tn's per-call target_workgroups (0 = one per CU)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
 variants = {"generic": ["-DURSE_TN_LEAN_ISSUE=0"], "lean": ["-DURSE_TN_LEAN_ISSUE=1"]}
@@ -30,7 +31,7 @@ def run(lib, dr, path, outs):
     h = hout[:, dr * H:(dr + 1) * H]
     return lib.urse_gemm_tn_dual(P(a.data_ptr()), L(8 * H), P(xn.data_ptr()), L(224), P(gwih.data_ptr()), L(N), P(gb.data_ptr()),
                                  P(h.data_ptr()), L(800), P(gwhh.data_ptr()), L(H), L(M), L(4 * H), L(N), L(H), L(sh), L(stride),
-                                 L(seq), L(inv), L(H), 1, P(st))
+                                 L(seq), L(inv), L(H), 1, TN_TARGET[0], P(st))
 ref = {}
 for path in ("t", "f"):
     res = []

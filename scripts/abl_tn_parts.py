@@ -2,6 +2,7 @@
 DMA / fragment reads / MFMA / barrier sets the 1 us k-step?"""
 import ctypes, os, subprocess, sys, time
 import torch
+TN_TARGET = [0]      # urse_gemm_tn's per-call target_workgroups (0 = one per CU)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
 variants = {"base": [], "no_mfma": ["-DTABL_NO_MFMA"], "no_read": ["-DTABL_NO_READ"], "no_dma": ["-DTABL_NO_DMA"],
@@ -29,10 +30,10 @@ def run(lib):
     A = dg[:, :4 * H]; B2 = hout[:, :H]
     rc = lib.urse_gemm_tn_dual(P(A.data_ptr()), L(A.stride(0)), P(xn.data_ptr()), L(224), P(g[0].data_ptr()), L(N), P(g[1].data_ptr()),
                                P(B2.data_ptr()), L(B2.stride(0)), P(g[2].data_ptr()), L(H), L(M), L(4 * H), L(N), L(H),
-                               L(-K), L(K), L(T), L(0), L(H), 1, P(st))
+                               L(-K), L(K), L(T), L(0), L(H), 1, TN_TARGET[0], P(st))
     assert rc == 0
 for name, lib in libs.items():
-    lib.urse_gemm_tn_set_target(105)
+    TN_TARGET[0] = 105
     run(lib); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5): run(lib)
     torch.cuda.synchronize()

@@ -2,6 +2,7 @@
 one LSTM direction's dual wgrad at C2; also checks the two builds agree bit for bit on a fixed input."""
 import ctypes, os, subprocess, sys, time
 import torch
+TN_TARGET = [0]      # urse_gemm_tn's per-call target_workgroups (0 = one per CU)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
 libs = {}
@@ -23,13 +24,13 @@ def run(lib, gwih, gb, gwhh):
     B2 = hout[:, :H]
     rc = lib.urse_gemm_tn_dual(P(A.data_ptr()), L(A.stride(0)), P(xn.data_ptr()), L(224), P(gwih.data_ptr()), L(N), P(gb.data_ptr()),
                                P(B2.data_ptr()), L(B2.stride(0)), P(gwhh.data_ptr()), L(H), L(M), L(4 * H), L(N), L(H),
-                               L(-K), L(K), L(T), L(0), L(H), 1, P(st))
+                               L(-K), L(K), L(T), L(0), L(H), 1, TN_TARGET[0], P(st))
     assert rc == 0
 outs = {}
 for target in (105, 252):
     res = []
     for name, lib in libs.items():
-        lib.urse_gemm_tn_set_target(target)
+        TN_TARGET[0] = target
         g = [torch.zeros(4 * H, N, device=dev), torch.zeros(4 * H, device=dev), torch.zeros(4 * H, H, device=dev)]
         run(lib, *g); torch.cuda.synchronize()
         outs[name] = [x.clone() for x in g]

@@ -12,12 +12,11 @@ dg = (torch.randn(M, 8 * H, device=dev) * 0.1).to(bf)
 xn = torch.zeros(M, 224, device=dev, dtype=bf); xn[:, :N] = (torch.randn(M, N, device=dev) * 0.1).to(bf)
 hout = (torch.randn(M, 2 * H, device=dev) * 0.1).to(bf)
 gwih = torch.zeros(4 * H, N, device=dev); gb = torch.zeros(4 * H, device=dev); gwhh = torch.zeros(4 * H, H, device=dev)
-def run():
-    ops.gemm_tn_dual(dg[:, :4 * H], xn, gwih, gb, hout[:, :H], gwhh, 4 * H, N, H, -K, K, T, 0, perm_h=H)
+def run(target=0):
+    ops.gemm_tn_dual(dg[:, :4 * H], xn, gwih, gb, hout[:, :H], gwhh, 4 * H, N, H, -K, K, T, 0, perm_h=H, target_wgs=target)
 for target in [int(a) for a in sys.argv[1:]] or [105, 126, 147, 168, 210, 252, 336]:
-    call("gemm_tn_set_target", target)
-    run(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(5): run()
+    run(target); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): run(target)
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
     slices = target // 21
     wg_mb = M / slices * 480 * 2 / 1e6

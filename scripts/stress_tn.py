@@ -24,12 +24,10 @@ for (B, T, K, H, N) in ((32, 401, 34, 392, 196), (4, 401, 34, 392, 196), (3, 97,
     R1 = torch.zeros_like(r1); R2 = torch.zeros_like(r2); R1[dst] = r1; R2[dst] = r2
     scale = max(R1.abs().max().item(), R2.abs().max().item())
     for target in (84, 105, 120, 256):
-        call("gemm_tn_set_target", target)
         for it in range(40):
             g1 = torch.zeros(4 * H, N, device=dev); gb = torch.zeros(4 * H, device=dev); g2 = torch.zeros(4 * H, H, device=dev)
-            ops.gemm_tn_dual(dg, xn, g1, gb, hout, g2, 4 * H, N, H, -K, K, T, 0, perm_h=H)
+            ops.gemm_tn_dual(dg, xn, g1, gb, hout, g2, 4 * H, N, H, -K, K, T, 0, perm_h=H, target_wgs=target)
             e = max((g1.double() - R1).abs().max().item(), (g2.double() - R2).abs().max().item()) / scale
             worst = max(worst, e)
             assert e < 2e-3, ("outlier", B, target, it, e)
     print("B=%d: ok, worst relative deviation so far %.2e" % (B, worst), flush=True)
-call("gemm_tn_set_target", 256)

@@ -114,3 +114,25 @@ def test_soxr_hq_spec_resampler_matches_oracle(lib, fs_in, fs_out):
     for p in range(2):
         exp = metrics_ref.resample_soxr_hq_spec(x[p], fs_in, fs_out)
         assert got[p].shape == exp.shape and np.abs(got[p] - exp).max() <= 2e-6 * np.abs(exp).max()
+
+
+def test_estoi_frame_range_at_the_boundary_length(lib):
+    """pystoi frames with ``range(0, len - 256, 128)``: at len = 256 + 128 k exactly the last full frame is NOT taken.
+    Fixture: 10 kHz signals (no resampling in front) of 256 + 128 * 200 samples whose last frame is loud speech.  The kernels
+    follow the pystoi reading to 1e-4 and differ from the inclusive reading by what that one frame is worth."""
+    from urgent2026_challenge_track1_amd import metrics
+    L = 256 + 128 * 200
+    ref, inf = _pairs(3, L, 10000, 31)
+    ref[:, -int(0.08 * L):] = ref[:, int(0.3 * L):int(0.3 * L) + int(0.08 * L)]       # loud to the very end: the last frame counts
+    inf[:, -int(0.08 * L):] = inf[:, int(0.3 * L):int(0.3 * L) + int(0.08 * L)]
+    got = metrics.estoi_batch(torch.from_numpy(ref).cuda(), torch.from_numpy(inf).cuda(), 10000).cpu().numpy()
+    a = np.array([metrics_ref.estoi(ref[p], inf[p], 10000) for p in range(3)])
+    metrics_ref.LAST_FRAME_INCLUSIVE = True
+    try:
+        b = np.array([metrics_ref.estoi(ref[p], inf[p], 10000) for p in range(3)])
+    finally:
+        metrics_ref.LAST_FRAME_INCLUSIVE = False
+    assert np.abs(got - a).max() <= 1e-4, (got, a)
+    assert np.abs(a - b).max() > 1e-6                      # the two readings are distinguishable on this fixture
+    assert np.abs(got - a).max() < 0.2 * np.abs(a - b).max()
+    print("ESTOI at len = 256 mod 128: kernels vs pystoi reading %.1e; pystoi vs inclusive reading %.1e" % (np.abs(got - a).max(), np.abs(a - b).max()))

@@ -536,13 +536,14 @@ class BSRNNCore(nn.Module):
 
         # three launches per half layer, deferred separately (the band path's BPTT gets only the first ops.TN_BAND_PARTS of
         # them for company, see _run_deferred_wgrads); the half layer's gradients are final with the last one
-        def wg_fc():
+        def wg_fc(target_wgs=0):
             if _DIAG_SKIP_WGRADS:                       # timing diagnostic only (gradients wrong): bound on what the TN GEMMs cost
                 return
-            ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N, No=2 * H)
+            ops.gemm_tn(doT, hout, self._g(p + "wfc", N * 2 * H).view(N, 2 * H), colsum=self._g(p + "bfc", N), Mo=N, No=2 * H,
+                        target_wgs=target_wgs)
 
         def wg_dir(dr, sh, inv, last):
-            def run():
+            def run(target_wgs=0):
                 if _DIAG_SKIP_WGRADS:
                     return
                 gb = self._g(p + "bih", 8 * H)
@@ -551,7 +552,7 @@ class BSRNNCore(nn.Module):
                 ops.gemm_tn_dual(dg[:, dr * 4 * H:(dr + 1) * 4 * H], xn, gwih[dr * 4 * H:(dr + 1) * 4 * H],
                                  gb[dr * 4 * H:(dr + 1) * 4 * H], hout[:, dr * H:(dr + 1) * H],
                                  self._g(p + "whh", 4 * H * H, dr * 4 * H * H).view(4 * H, H), 4 * H, N, H, sh, st, L, inv,
-                                 perm_h=H)
+                                 perm_h=H, target_wgs=target_wgs)
                 if last:
                     call("axpby", gb, self._g(p + "bhh", 8 * H), 1.0, 1.0, 8 * H, stream_ptr())
             return run
@@ -587,14 +588,13 @@ class BSRNNCore(nn.Module):
         start.record(torch.cuda.current_stream())
         self._side.wait_event(start)
         with torch.cuda.stream(self._side):
-            call("gemm_tn_set_target", target_wgs)            # they share the chip with a BPTT kernel
             for fn, _ in now:
-                fn()
-            call("gemm_tn_set_target", 256)
+                fn(target_wgs)                                # they share the chip with a BPTT kernel
             done = torch.cuda.Event()
             done.record(self._side)
         self._inflight = (self._inflight or []) + [(done, now)]
         self._deferred = later
+        ops.CO_RESIDENT_WGS = target_wgs          # a cooperative recurrence launched from here on shares the chip with these
 
     def _join_deferred_wgrads(self, keep=0):
         """wait (on the compute stream) for the side stream's batches, except the `keep` most recent ones."""
@@ -605,6 +605,8 @@ class BSRNNCore(nn.Module):
             return
         batches, rest = self._inflight[:n], self._inflight[n:]
         self._inflight = rest or None
+        if not rest:
+            ops.CO_RESIDENT_WGS = 0                      # (the compute stream waits below: nothing of the second queue is resident after)
         for done, items in batches:
             torch.cuda.current_stream().wait_event(done)
             for _, tag in items:                         # gradients final: tell the reducer (and drop the closures)

@@ -1472,19 +1472,16 @@ extern "C" int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_des
   return URSE_OK;
 }
 
-// workgroups the big TN kernels aim for (one per CU).  A caller that runs them beside another kernel on part of the
-// chip (bsrnn.py: deferred wgrads next to the time path's BPTT) lowers it to the CUs that are actually free, so the
-// launch is one round of long workgroups instead of two-and-a-bit rounds.
-static int g_tn_target_wgs = 256;
-extern "C" int urse_gemm_tn_set_target(int workgroups) {
-  g_tn_target_wgs = workgroups > 0 ? workgroups : 256;
-  return URSE_OK;
-}
+// target_workgroups: workgroups the big TN kernels aim for (0 = 256, one per CU).  A caller that runs them beside another
+// kernel on part of the chip (bsrnn.py: deferred wgrads next to the time path's BPTT) passes the CUs that are actually free,
+// so the launch is one round of long workgroups instead of two-and-a-bit rounds.  Per call: the library keeps no tuning state.
 
 extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                             float* colsum, int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner,
-                            int64_t period, int64_t invalid_step, int64_t perm_h, int dtype, void* stream) {
-  URSE_CHECK_ARG(A && B && C && R > 0 && Mo > 0 && No > 0, "urse_gemm_tn: bad argument");
+                            int64_t period, int64_t invalid_step, int64_t perm_h, int dtype, int target_workgroups,
+                            void* stream) {
+  URSE_CHECK_ARG(A && B && C && R > 0 && Mo > 0 && No > 0 && target_workgroups >= 0, "urse_gemm_tn: bad argument");
+  const long g_tn_target_wgs = target_workgroups > 0 ? target_workgroups : 256;
   const int es = dtype == URSE_BF16 ? 2 : 4;
   URSE_CHECK_ARG((lda * es) % 16 == 0 && (ldb * es) % 16 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
                  "urse_gemm_tn: operands must be 16-byte aligned with 16-byte-multiple row pitch");
@@ -1577,16 +1574,19 @@ extern "C" int urse_gemm_tn_grouped(const void* descs, int groups, int max_block
 extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
                                  const void* B2, int64_t ldb2, float* C2, int64_t ldc2, int64_t R, int64_t Mo, int64_t No,
                                  int64_t No2, int64_t shift, int64_t inner, int64_t period, int64_t invalid_step,
-                                 int64_t perm_h, int dtype, void* stream) {
-  URSE_CHECK_ARG(A && B && C && B2 && C2 && R > 0 && Mo > 0 && No > 0 && No2 > 0, "urse_gemm_tn_dual: bad argument");
+                                 int64_t perm_h, int dtype, int target_workgroups, void* stream) {
+  URSE_CHECK_ARG(A && B && C && B2 && C2 && R > 0 && Mo > 0 && No > 0 && No2 > 0 && target_workgroups >= 0,
+                 "urse_gemm_tn_dual: bad argument");
+  const long g_tn_target_wgs = target_workgroups > 0 ? target_workgroups : 256;
   static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr;
   const bool big = dtype == URSE_BF16 && !no_dma && Mo >= 512 && R >= 16384 && R < (1L << 30) && shift > -(1L << 30) && shift < (1L << 30) && period < (1L << 31) && inner < (1L << 31) &&
                    (lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && (ldb2 * 2) % 16 == 0 && ((uintptr_t)A % 16) == 0 &&
                    ((uintptr_t)B % 16) == 0 && ((uintptr_t)B2 % 16) == 0;
   if (!big) {
-    int rc = urse_gemm_tn(A, lda, B, ldb, C, ldc, colsum, R, Mo, No, 0, 1, 0, 0, perm_h, dtype, stream);
+    int rc = urse_gemm_tn(A, lda, B, ldb, C, ldc, colsum, R, Mo, No, 0, 1, 0, 0, perm_h, dtype, target_workgroups, stream);
     if (rc) return rc;
-    return urse_gemm_tn(A, lda, B2, ldb2, C2, ldc2, nullptr, R, Mo, No2, shift, inner, period, invalid_step, perm_h, dtype, stream);
+    return urse_gemm_tn(A, lda, B2, ldb2, C2, ldc2, nullptr, R, Mo, No2, shift, inner, period, invalid_step, perm_h, dtype,
+                        target_workgroups, stream);
   }
   URSE_CHECK_ARG(lda >= Mo && ldb >= No && ldc >= No && ldb2 >= No2 && ldc2 >= No2, "urse_gemm_tn_dual: leading dimension too small");
   TnArgs p;

@@ -552,10 +552,11 @@ static int launch_cluster_bwd(const ClusterBwdArgs& p, hipStream_t st) {
 
 extern "C" int urse_lstm_cluster_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c,
                                      const void* whhTq, void* dgx, void* counters, void* err_flag, int H, int Hp,
-                                     int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, void* stream) {
+                                     int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int reserved_cus,
+                                     void* stream) {
   URSE_CHECK_ARG(dh && gates && c && whhTq && dgx && counters && err_flag, "urse_lstm_cluster_bwd: null pointer");
   int64_t plan[6];
-  int rc = urse_lstm_cluster_plan(H, Hp, n_seq, plan);
+  int rc = urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus, plan);
   if (rc) return rc;
   URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldd >= 2L * H && ((uintptr_t)dgx % 16) == 0,
                  "urse_lstm_cluster_bwd: bad leading dimension / alignment");
@@ -576,8 +577,8 @@ extern "C" int urse_lstm_cluster_bwd(const void* dh, int64_t ldd, void* gates, i
 }
 
 // workspace query: {C, ncl, rows_per_cluster, rows_pad, hx_elems, n_counters}; returns < 0 if the shape is unsupported
-extern "C" int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan) {
-  URSE_CHECK_ARG(plan && H > 0 && n_seq > 0, "urse_lstm_cluster_plan: bad argument");
+extern "C" int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int reserved_cus, int64_t* plan) {
+  URSE_CHECK_ARG(plan && H > 0 && n_seq > 0 && reserved_cus >= 0, "urse_lstm_cluster_plan: bad argument");
   const int nslab = Hp / 32;
   if (Hp % 32 != 0 || !(nslab == 1 || nslab == 2 || nslab == 13) || H % 8 != 0) {
     set_error("urse_lstm_cluster_plan: unsupported H=%d Hp=%d", H, Hp);
@@ -585,16 +586,18 @@ extern "C" int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan) {
   }
   const int nq = (H + 3) / 4;
   const int C = (nq + CW - 1) / CW;
-  int ncl = (device_cu_count() - 4) / 2 / C;   // 2 directions * ncl * C workgroups, one per CU with a small margin: all co-resident
+  // 2 directions * ncl * C workgroups, one per CU with a small margin, on the CUs the caller has not promised to other
+  // resident work (reserved_cus: workgroups of launches on other streams that run at the same time): all co-resident, or refused
+  int ncl = (device_cu_count() - reserved_cus - 4) / 2 / C;
   if (ncl < 1) {
-    set_error("urse_lstm_cluster_plan: %d workgroups per cluster do not fit this device", C);
+    set_error("urse_lstm_cluster_plan: %d workgroups per cluster do not fit this device (%d CUs reserved)", C, reserved_cus);
     return URSE_ERR_UNSUPPORTED;
   }
   int rpc = (n_seq + ncl - 1) / ncl;
   if (rpc < 1) rpc = 1;
   const int max_rows = CROWS;              // one 64-row chunk per cluster (long-sequence / few-sequence regime)
   if (rpc > max_rows) {
-    set_error("urse_lstm_cluster_plan: %d sequences exceed the cluster capacity", n_seq);
+    set_error("urse_lstm_cluster_plan: %d sequences exceed the capacity of the co-resident clusters (%d CUs reserved)", n_seq, reserved_cus);
     return URSE_ERR_UNSUPPORTED;
   }
   ncl = (n_seq + rpc - 1) / rpc;
@@ -607,10 +610,10 @@ extern "C" int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int64_t* plan) {
 
 extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                                      void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len,
-                                     int64_t inner, int64_t outer, int64_t stride, int save, void* stream) {
+                                     int64_t inner, int64_t outer, int64_t stride, int save, int reserved_cus, void* stream) {
   URSE_CHECK_ARG(gx && whhq && hout && hx && counters && err_flag && (c || !save), "urse_lstm_cluster_fwd: null pointer");
   int64_t plan[6];
-  int rc = urse_lstm_cluster_plan(H, Hp, n_seq, plan);
+  int rc = urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus, plan);
   if (rc) return rc;
   URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldh >= 2L * H && (ldh * 2) % 16 == 0 &&
                      ((uintptr_t)hout % 16) == 0 && ((uintptr_t)hx % 16) == 0,

@@ -287,8 +287,8 @@ static bool cluster2_geometry(int H, int Hp, int* nw, int* qpw) {
 using namespace urse;
 
 // workspace query: {C, clusters per direction, rows per cluster, hx bf16 elements}; < 0 if the shape is unsupported
-extern "C" int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int64_t* plan) {
-  URSE_CHECK_ARG(plan && H > 0 && n_seq > 0, "urse_lstm_cluster2_plan: bad argument");
+extern "C" int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int reserved_cus, int64_t* plan) {
+  URSE_CHECK_ARG(plan && H > 0 && n_seq > 0 && reserved_cus >= 0, "urse_lstm_cluster2_plan: bad argument");
   int nw, qpw;
   if (!cluster2_geometry(H, Hp, &nw, &qpw)) {
     set_error("urse_lstm_cluster2_plan: unsupported H=%d Hp=%d", H, Hp);
@@ -296,7 +296,7 @@ extern "C" int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int64_t* plan) 
   }
   const int nq = (H + 3) / 4;
   const int C = (nq + nw * qpw - 1) / (nw * qpw);
-  int ncl = (device_cu_count() - 4) / 2 / C;   // 2 directions * ncl * C workgroups, one per CU with a small margin: all co-resident
+  int ncl = (device_cu_count() - reserved_cus - 4) / 2 / C;   // 2 directions * ncl * C workgroups, one per free CU with a small margin: all co-resident, or refused
   if (ncl < 1) { set_error("urse_lstm_cluster2_plan: H=%d needs %d workgroups per cluster", H, C); return URSE_ERR_UNSUPPORTED; }
   int rpc = (n_seq + ncl - 1) / ncl;
   if (rpc > C2ROWS) {
@@ -310,10 +310,10 @@ extern "C" int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int64_t* plan) 
 
 extern "C" int urse_lstm_cluster2_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                                       void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer,
-                                      int64_t stride, int save, void* stream) {
+                                      int64_t stride, int save, int reserved_cus, void* stream) {
   URSE_CHECK_ARG(gx && whhq && hout && hx && err_flag && (c || !save), "urse_lstm_cluster2_fwd: null pointer");
   int64_t plan[4];
-  int rc = urse_lstm_cluster2_plan(H, Hp, n_seq, plan);
+  int rc = urse_lstm_cluster2_plan(H, Hp, n_seq, reserved_cus, plan);
   if (rc) return rc;
   URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldh >= 2L * H && (ldh * 2) % 16 == 0 && ((uintptr_t)hout % 16) == 0 &&
                      ((uintptr_t)hx % 16) == 0 && seq_len > 0 && inner > 0,

@@ -331,8 +331,8 @@ static size_t split_lds(int nut, int ns, int rows) {
 }
 
 // workspace query: {nsplit, clusters per direction, xbuf f32 elements, rows per cluster}; < 0 if the shape has no split kernel
-extern "C" int urse_lstm_split_plan(int H, int n_seq, int64_t* plan) {
-  URSE_CHECK_ARG(plan && H > 0 && n_seq > 0, "urse_lstm_split_plan: bad argument");
+extern "C" int urse_lstm_split_plan(int H, int n_seq, int reserved_cus, int64_t* plan) {
+  URSE_CHECK_ARG(plan && H > 0 && n_seq > 0 && reserved_cus >= 0, "urse_lstm_split_plan: bad argument");
   const int nut = (H + 15) / 16;
   if (H % 8 != 0 || nut > 3 * SW) {
     set_error("urse_lstm_split_plan: unsupported H=%d", H);
@@ -344,13 +344,13 @@ extern "C" int urse_lstm_split_plan(int H, int n_seq, int64_t* plan) {
     const int ncl = (n_seq + rows - 1) / rows;
     for (int ns = rows == 32 ? 3 : 6; ns >= 2; --ns) {
       const int tmax = (nut + ns - 1) / ns;
-      if (2L * ncl * ns > device_cu_count() - 6 || nut < 2 * ns || tmax > SMAXO * SW) continue;   // all workgroups resident
+      if (2L * ncl * ns > device_cu_count() - reserved_cus - 6 || nut < 2 * ns || tmax > SMAXO * SW) continue;   // all workgroups resident
       if (split_lds(nut, ns, rows) > 160 * 1024) continue;
       plan[0] = ns; plan[1] = ncl; plan[2] = (int64_t)2 * 2 * ncl * ns * rows * nut * 16; plan[3] = rows;
       return URSE_OK;
     }
   }
-  set_error("urse_lstm_split_plan: unsupported H=%d n_seq=%d", H, n_seq);
+  set_error("urse_lstm_split_plan: unsupported H=%d n_seq=%d (%d CUs reserved)", H, n_seq, reserved_cus);
   return URSE_ERR_UNSUPPORTED;
 }
 
@@ -366,10 +366,10 @@ static int launch_split(const SplitBwdArgs& p, size_t lds, hipStream_t st) {
 
 extern "C" int urse_lstm_split_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT,
                                    void* xbuf, void* err_flag, int H, int n_seq, int seq_len, int64_t inner, int64_t outer,
-                                   int64_t stride, void* stream) {
+                                   int64_t stride, int reserved_cus, void* stream) {
   URSE_CHECK_ARG(dh && gates && c && whhT && xbuf && err_flag, "urse_lstm_split_bwd: null pointer");
   int64_t plan[4];
-  int rc = urse_lstm_split_plan(H, n_seq, plan);
+  int rc = urse_lstm_split_plan(H, n_seq, reserved_cus, plan);
   if (rc) return rc;
   URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldd >= 2L * H && ((uintptr_t)xbuf % 16) == 0 && seq_len > 0 && inner > 0,
                  "urse_lstm_split_bwd: bad leading dimension / alignment");

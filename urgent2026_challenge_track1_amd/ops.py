@@ -148,8 +148,9 @@ def gemm_nt(A, W, bias=None, resid=None, act=0, out=None, out_dtype=None, N=None
     return out
 
 
-def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=0, invalid_step=0, perm_h=0):
-    """out[Mo, No] (f32) += A[R, Mo]^T @ B'[R, No]; optional colsum[Mo] += sum_r A[r]."""
+def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=0, invalid_step=0, perm_h=0, target_wgs=0):
+    """out[Mo, No] (f32) += A[R, Mo]^T @ B'[R, No]; optional colsum[Mo] += sum_r A[r].  target_wgs: workgroups to aim for when
+    the launch shares the chip with another kernel (0 = one per CU)."""
     require_cuda(A, Bm, out)
     R = A.shape[0]
     Mo = A.shape[1] if Mo is None else Mo
@@ -157,18 +158,18 @@ def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=
     assert Bm.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and A.dtype == Bm.dtype
     assert out.dtype == torch.float32 and out.stride(-1) == 1
     call("gemm_tn", A, A.stride(0), Bm, Bm.stride(0), out, out.stride(0), colsum, R, Mo, No, shift, inner, period,
-         invalid_step, perm_h, _dt(A), stream_ptr())
+         invalid_step, perm_h, _dt(A), int(target_wgs), stream_ptr())
     return out
 
 
-def gemm_tn_dual(A, Bm, out, colsum, B2, out2, Mo, No, No2, shift, inner, period, invalid_step, perm_h=0):
+def gemm_tn_dual(A, Bm, out, colsum, B2, out2, Mo, No, No2, shift, inner, period, invalid_step, perm_h=0, target_wgs=0):
     """out[Mo, No] += A^T Bm (+ colsum) and out2[Mo, No2] += A^T B2' (shifted / masked) in one pass over A."""
     require_cuda(A, Bm, B2, out, out2)
     R = A.shape[0]
     assert Bm.shape[0] == R and B2.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and B2.stride(1) == 1
     assert out.dtype == torch.float32 and out2.dtype == torch.float32 and A.dtype == Bm.dtype == B2.dtype
     call("gemm_tn_dual", A, A.stride(0), Bm, Bm.stride(0), out, out.stride(0), colsum, B2, B2.stride(0), out2, out2.stride(0), R,
-         Mo, No, No2, shift, inner, period, invalid_step, perm_h, _dt(A), stream_ptr())
+         Mo, No, No2, shift, inner, period, invalid_step, perm_h, _dt(A), int(target_wgs), stream_ptr())
 
 
 def tn_desc(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=0, invalid_step=0, perm_h=0):
@@ -323,12 +324,18 @@ USE_CLUSTER_LSTM = os.environ.get("URSE_LSTM_CLUSTER", "1") != "0"
 USE_CLUSTER_LSTM_BWD = os.environ.get("URSE_LSTM_CLUSTER_BWD", "0") == "1"
 
 
+# CUs promised to work that is resident beside a cooperative recurrence kernel (bsrnn sets it to the workgroup target of the
+# deferred weight-gradient launches while they are in flight on the second stream): the cooperative kernels' plans leave
+# that many CUs alone and REFUSE a grid that would not be co-resident on the rest (-> streaming kernel) instead of spinning
+CO_RESIDENT_WGS = 0
+
+
 def lstm_cluster_plan(H, Hp, n_seq):
     """None if the persistent cluster kernel does not support this shape."""
     import ctypes
     plan = (ctypes.c_int64 * 6)()
     lib = _lib.load()
-    if lib.urse_lstm_cluster_plan(H, Hp, n_seq, plan) != 0:
+    if lib.urse_lstm_cluster_plan(H, Hp, n_seq, int(CO_RESIDENT_WGS), plan) != 0:
         return None
     return list(plan)
 
@@ -347,7 +354,7 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
     hout = _hout_buffer(M, ldh, H, gx)
     c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster_fwd", gx, gx.stride(0), whhq, hout, ldh,
-               c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
+               c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), int(CO_RESIDENT_WGS), stream_ptr())
     return hout, c, err
 
 
@@ -358,7 +365,7 @@ CLUSTER2_H = tuple(int(v) for v in os.environ.get("URSE_LSTM_CLUSTER2_H", "768")
 def lstm_cluster2_plan(H, Hp, n_seq):
     import ctypes
     plan = (ctypes.c_int64 * 4)()
-    if _lib.load().urse_lstm_cluster2_plan(H, Hp, n_seq, plan) != 0:
+    if _lib.load().urse_lstm_cluster2_plan(H, Hp, n_seq, int(CO_RESIDENT_WGS), plan) != 0:
         return None
     return list(plan)
 
@@ -376,7 +383,7 @@ def lstm_cluster2_chunks(H, Hp, n_seq, seq_len, inner, outer, stride):
     if probe is None:
         return None
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    cap = max(1, (cus - 4) // 2 // probe[0]) * 64
+    cap = max(1, (cus - int(CO_RESIDENT_WGS) - 4) // 2 // probe[0]) * 64
     n = (n_seq + cap - 1) // cap
     if n > CLUSTER2_MAX_CHUNKS:
         return None
@@ -407,7 +414,7 @@ def lstm_fwd_cluster2(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, sav
             r0, r1 = s0 * seq_len, (s0 + n) * seq_len
             g_, h_, c_ = gx[r0:r1], hout[r0:r1], (c[r0:r1] if save else None)
         timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster2_fwd", g_, gx.stride(0), whhq, h_, ldh, c_, hx,
-                   err, H, Hp, n, seq_len, inner, outer, stride, int(save), stream_ptr())
+                   err, H, Hp, n, seq_len, inner, outer, stride, int(save), int(CO_RESIDENT_WGS), stream_ptr())
     return hout, c, err
 
 
@@ -491,7 +498,7 @@ def lstm_bwd_cluster(dh, gates, c, whhTq, H, Hp, n_seq, seq_len, inner, outer, s
                             kernel_error_flag(dev))
     dgx, cnt, err = _cluster_ws[key]
     timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_cluster_bwd", dh, dh.stride(0), gates,
-               gates.stride(0), c, whhTq, dgx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, stream_ptr())
+               gates.stride(0), c, whhTq, dgx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(CO_RESIDENT_WGS), stream_ptr())
     return gates, err
 
 
@@ -508,7 +515,7 @@ def lstm_split_plan(H, n_seq):
     """None if the split BPTT kernel does not support this shape."""
     import ctypes
     plan = (ctypes.c_int64 * 4)()
-    if _lib.load().urse_lstm_split_plan(H, n_seq, plan) != 0:
+    if _lib.load().urse_lstm_split_plan(H, n_seq, int(CO_RESIDENT_WGS), plan) != 0:
         return None
     return list(plan)
 
@@ -549,7 +556,7 @@ def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
             r0, r1 = s0 * seq_len, (s0 + n) * seq_len
             d_, g_, c_ = dh[r0:r1], gates[r0:r1], c[r0:r1]
         timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_split_bwd", d_, dh.stride(0), g_, gates.stride(0), c_,
-                   whhT, xbuf, err, H, n, seq_len, inner, outer, stride, stream_ptr())
+                   whhT, xbuf, err, H, n, seq_len, inner, outer, stride, int(CO_RESIDENT_WGS), stream_ptr())
     return gates, err
 
 
