@@ -223,7 +223,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
 #endif
 // HC: hidden size known at compile time (0 = run-time p.H): tile pitch, slab count and unit-tile count fold into constants
 // HPC: only the LDS tile pitch is folded (the 32-row variant spills when its loop bounds become constants too)
-template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0>
+// PF: software pipeline over the steps.  The step's inputs (saved gates, c_{t-1}, dh: 14 bytes per (row, unit), from HBM) do not
+// depend on the recurrence.  PF = 0 loads them at the top of the step, one unit tile at a time (registers: the 16-wave
+// geometry is capped at 128), i.e. MAXUT dependent round trips to HBM per step in front of the weight pass.  PF = 1 issues the
+// loads of step t + 1 for ALL the wave's unit tiles right after the cell update of step t, in front of the step's weight pass:
+// they are older than every weight fragment in the wave's in-order vmcnt queue, so they have landed when the first fragment
+// has, and the next step starts on registers.  Same arithmetic in the same order: bit-identical results.
+template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0, int PF = 0>
 __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #if URSE_BWD_PRIO
   __builtin_amdgcn_s_setprio(URSE_BWD_PRIO);   // the BPTT is on the step's critical path; the wgrad GEMMs it shares CUs with are not
@@ -257,7 +263,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   T* gates = reinterpret_cast<T*>(p.gates);
   // 32-bit row indices / leading dimensions (checked on the host): an address costs one v_mad_i64_i32
   const int ldg_i = (int)p.ldg, ldd_i = (int)p.ldd, ldc_i = 2 * H, stride_i = (int)p.m.stride;
+#ifdef BABL_ALIGNED    // timing diagnostic (wrong results): both directions read / write direction 0's columns, whose rows are 128-byte aligned
+  const int gcol_i = 0, hcol_i = 0, prev_i = dir ? stride_i : -stride_i;
+#else
   const int gcol_i = dir * G4, hcol_i = dir * H, prev_i = dir ? stride_i : -stride_i;
+#endif
 
   {
     const long toff0 = (long)(dir ? 0 : p.m.seq_len - 1) * p.m.stride;
@@ -275,32 +285,59 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
         }
     }
   }
+  constexpr int PU = PF ? MAXUT : 1;
+  V4 gpf[PU][RT][4];
+  float cpf[PU][RT][4];
+  T dhpf[PU][RT][4];
+  auto load_step = [&](int ui, int slot, int tt) {
+    const int u = (w + NW * ui) * 16 + lc;
+    const bool first_ = dir ? (tt == p.m.seq_len - 1) : (tt == 0);   // first step of the forward recurrence: c_{-1} = 0
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (int)rowb(rt, r) + tt * stride_i;
+#ifdef BABL_NO_P1LOAD
+        gpf[slot][rt][r] = V4{}; cpf[slot][rt][r] = (float)row; dhpf[slot][rt][r] = T(row & 1);
+#else
+#ifdef BABL_NO_G
+        gpf[slot][rt][r] = V4{};
+#else
+        gpf[slot][rt][r] = *reinterpret_cast<const V4*>(gates + ((long)row * ldg_i + (gcol_i + u * 4)));
+#endif
+#ifdef BABL_NO_C
+        cpf[slot][rt][r] = (float)row;
+#else
+        cpf[slot][rt][r] = first_ ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + u)];
+#endif
+#ifdef BABL_NO_DH
+        dhpf[slot][rt][r] = T(row & 1);
+#else
+        dhpf[slot][rt][r] = dh[(long)row * ldd_i + (hcol_i + u)];
+#endif
+#endif
+      }
+  };
+  auto load_all = [&](int tt) {
+#pragma unroll
+    for (int ui = 0; ui < MAXUT; ++ui)
+      if ((w + NW * ui) * 16 + lc < H) load_step(ui, PF ? ui : 0, tt);
+  };
+  if constexpr (PF == 1) load_all(dir ? 0 : p.m.seq_len - 1);
   for (int step = 0; step < p.m.seq_len; ++step) {
     const int t = dir ? step : (p.m.seq_len - 1 - step);
-    const bool first = dir ? (t == p.m.seq_len - 1) : (t == 0);   // first step of the forward recurrence: c_{-1} = 0
     char* tile = smem + (step % nbuf) * R * pitch;
+    if constexpr (PF == 2) load_all(t);                 // all unit tiles' inputs in ONE round trip, still inside the step
 #pragma unroll
     for (int ui = 0; ui < MAXUT; ++ui) {
       const int ut = w + NW * ui;
       if (ut < nut) {
         const int u = ut * 16 + lc;
         if (u < H) {
-          V4 gpre[RT][4];
-          float cpre[RT][4];
-          T dhpre[RT][4];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = (int)rowb(rt, r) + t * stride_i;
-#ifdef BABL_NO_P1LOAD
-              gpre[rt][r] = V4{}; cpre[rt][r] = (float)row; dhpre[rt][r] = T(row & 1);
-#else
-              gpre[rt][r] = *reinterpret_cast<const V4*>(gates + ((long)row * ldg_i + (gcol_i + u * 4)));
-              cpre[rt][r] = first ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + u)];
-              dhpre[rt][r] = dh[(long)row * ldd_i + (hcol_i + u)];
-#endif
-            }
+          if constexpr (!PF) load_step(ui, 0, t);
+          V4 (&gpre)[RT][4] = gpf[PF ? ui : 0];
+          float (&cpre)[RT][4] = cpf[PF ? ui : 0];
+          T (&dhpre)[RT][4] = dhpf[PF ? ui : 0];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -329,6 +366,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
       }
     }
     if (step + 1 == p.m.seq_len) break;
+    if constexpr (PF == 1) load_all(dir ? t + 1 : t - 1);     // next step's inputs: in flight under the weight pass
     __syncthreads();
 #ifdef BABL_NO_MM
     if (p.m.seq_len > 0) continue;
@@ -350,7 +388,16 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #define URSE_BWD_KB2 17   // the 32-sequence geometry (8 waves, 256-VGPR budget): 49 slabs = 17 + 17 + 15, 230 VGPRs; band-path BPTT
                           // 27.15 -> 26.4 ms per step, step -1.1 ms (same-box A/B, profiles/r02_ab_bptt_kb_v1.log)
 #endif
-        constexpr int KB = (sizeof(T) == 2) ? (RT >= 2 ? URSE_BWD_KB2 : URSE_BWD_KB) : 8;
+#ifndef URSE_BWD_KB8
+#define URSE_BWD_KB8 17   // 16 sequences on 8 waves (256-VGPR budget, room for the prefetched inputs of 4 unit tiles): 49 = 17 + 17 + 15
+#endif
+#ifndef URSE_BWD_KBPF16
+#define URSE_BWD_KBPF16 8   // 16 / 13 waves with prefetched inputs: what the 128-VGPR cap leaves for fragments in flight
+#endif
+#ifndef URSE_BWD_KBPF12
+#define URSE_BWD_KBPF12 14
+#endif
+        constexpr int KB = (sizeof(T) == 2) ? (RT >= 2 ? URSE_BWD_KB2 : (NW == 8 ? URSE_BWD_KB8 : (PF == 1 ? (NW == 12 ? URSE_BWD_KBPF12 : URSE_BWD_KBPF16) : URSE_BWD_KB))) : 8;
         #pragma unroll 1
         for (int k0 = 0; k0 < nslab; k0 += KB) {
           uint4 b[KB];
@@ -371,6 +418,182 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
               for (int rt = 0; rt < RT; ++rt)
                 a[rt] = *reinterpret_cast<const uint4*>(ar + rt * 16 * pitch + (k0 + i) * 64);
               mma_slab<T, RT>(a, b[i], acc);
+            }
+          }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dhr[ui][rt][r] = acc[rt][r];
+      }
+    }
+    if (nbuf == 1) __syncthreads();
+  }
+}
+
+// ---- BPTT, transposed accumulator layout (bf16) -------------------------------------------------------------------------------
+// lstm_bwd_kernel multiplies dgates (A operand, rows = sequences) with W_hh fragments (B operand, columns = units): the MFMA C
+// layout then gives a lane ONE unit and FOUR sequences, and every per-(sequence, unit) input of the cell update - saved gates
+// (8 bytes), c_{t-1} (4), dh (2) - is a separate load per sequence: 48 narrow load instructions per lane and step at four unit
+// tiles per wave, 16 narrow stores.  Measured (profiles/r03_exp_bptt_*.log): with the recurrent product switched off the step
+// still costs 5.7 us, and each of the three input arrays costs about the same whatever its width - the vector memory pipe is
+// bound by wave-INSTRUCTIONS (~28 cycles each for these 4-row scatter patterns), not by bytes or lines.
+// Here the operands swap roles: A = the W_hh fragment (rows = units of the tile), B = the dgates fragment (columns = sequences).
+// The fragments' register contents are the same as before (both MFMA operand layouts index "row l % 16 / 8 k's by l / 16"), only
+// the accumulator changes: lane (lr = l / 16, lc = l % 16) holds units 4 lr .. 4 lr + 3 of ONE sequence lc.  Four consecutive
+// units are contiguous in every array, so a lane loads c_{t-1} with one 16-byte load, dh with one 8-byte load, the saved gates
+// with two 16-byte loads, and stores its 16 gate gradients with two 16-byte stores: 16 + 8 instead of 48 + 16 instructions.
+// The next step's inputs are prefetched in front of the weight pass (PF of lstm_bwd_kernel).  H % 4 == 0.
+template <int RT, int MAXUT, int NW, int HC>
+__global__ void __launch_bounds__(NW * 64) lstm_bwd_tr_kernel(LstmBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = 16 * RT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
+  int dir, tile_;
+  xcd_dir_tile(p.xcd, dir, tile_);
+  const int s0 = tile_ * R;
+  const int H = HC ? HC : p.H, nut = (H + 15) >> 4, G4 = 4 * H;
+  const int pitch = lds_frag_pitch(G4 * 2);
+  const int nbuf = p.dbuf ? 2 : 1;
+  float dcs[MAXUT][RT][4], dhr[MAXUT][RT][4], ccur[MAXUT][RT][4];
+  int rowbase[RT];                         // this lane's sequence per row tile; negative: beyond n_seq (clamped, never stored)
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int seq = s0 + rt * 16 + lc;
+    const bool ok = seq < p.m.n_seq;
+    if (!ok) seq = p.m.n_seq - 1;
+    const int rb = (int)((seq / p.m.inner) * p.m.outer + (seq % p.m.inner));
+    rowbase[rt] = ok ? rb : -rb - 1;
+  }
+  auto rowb = [&](int rt) -> int { return rowbase[rt] >= 0 ? rowbase[rt] : -(rowbase[rt] + 1); };
+  const int nslab = G4 * 2 / 64;
+  const char* whhT = reinterpret_cast<const char*>(p.whhT) + ((long)dir * nut * nslab) * 1024 + lane * 16;
+  const bf16_t* dh = reinterpret_cast<const bf16_t*>(p.dh);
+  bf16_t* gates = reinterpret_cast<bf16_t*>(p.gates);
+  const int ldg_i = (int)p.ldg, ldd_i = (int)p.ldd, ldc_i = 2 * H, stride_i = (int)p.m.stride;
+  const int gcol_i = dir * G4, hcol_i = dir * H, prev_i = dir ? stride_i : -stride_i;
+  auto quad = [&](int ui) -> int { return (w + NW * ui) * 16 + lr * 4; };     // first of this lane's four units in tile ui
+
+  {
+    const int t0 = dir ? 0 : p.m.seq_len - 1;
+#pragma unroll
+    for (int ui = 0; ui < MAXUT; ++ui) {
+      const int u0 = quad(ui) < H ? quad(ui) : H - 4;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float4 cv = *reinterpret_cast<const float4*>(p.c + (long)(rowb(rt) + t0 * stride_i) * ldc_i + (hcol_i + u0));
+        const float c4[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dcs[ui][rt][r] = 0.f;
+          dhr[ui][rt][r] = 0.f;
+          ccur[ui][rt][r] = c4[r];
+        }
+      }
+    }
+  }
+  uint4 gpf[MAXUT][RT][2];
+  float4 cpf[MAXUT][RT];
+  uint2 dpf[MAXUT][RT];
+  auto load_all = [&](int tt) {
+    const bool first_ = dir ? (tt == p.m.seq_len - 1) : (tt == 0);   // first step of the forward recurrence: c_{-1} = 0
+#pragma unroll
+    for (int ui = 0; ui < MAXUT; ++ui) {
+      const int u0 = quad(ui);
+      if (u0 < H) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = rowb(rt) + tt * stride_i;
+          const bf16_t* gp = gates + ((long)row * ldg_i + (gcol_i + u0 * 4));
+          gpf[ui][rt][0] = *reinterpret_cast<const uint4*>(gp);
+          gpf[ui][rt][1] = *reinterpret_cast<const uint4*>(gp + 8);
+          cpf[ui][rt] = first_ ? make_float4(0.f, 0.f, 0.f, 0.f)
+                               : *reinterpret_cast<const float4*>(p.c + (long)(row + prev_i) * ldc_i + (hcol_i + u0));
+          dpf[ui][rt] = *reinterpret_cast<const uint2*>(dh + (long)row * ldd_i + (hcol_i + u0));
+        }
+      }
+    }
+  };
+  load_all(dir ? 0 : p.m.seq_len - 1);
+  for (int step = 0; step < p.m.seq_len; ++step) {
+    const int t = dir ? step : (p.m.seq_len - 1 - step);
+    char* tile = smem + (step % nbuf) * R * pitch;
+#pragma unroll
+    for (int ui = 0; ui < MAXUT; ++ui) {
+      const int u0 = quad(ui);
+      if (u0 < H) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const unsigned gw[8] = {gpf[ui][rt][0].x, gpf[ui][rt][0].y, gpf[ui][rt][0].z, gpf[ui][rt][0].w,
+                                  gpf[ui][rt][1].x, gpf[ui][rt][1].y, gpf[ui][rt][1].z, gpf[ui][rt][1].w};
+          const float c4[4] = {cpf[ui][rt].x, cpf[ui][rt].y, cpf[ui][rt].z, cpf[ui][rt].w};
+          const unsigned dw[2] = {dpf[ui][rt].x, dpf[ui][rt].y};
+          unsigned ow[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float iv = __uint_as_float(gw[2 * r] << 16), fv = __uint_as_float(gw[2 * r] & 0xffff0000u);
+            const float gv = __uint_as_float(gw[2 * r + 1] << 16), ov = __uint_as_float(gw[2 * r + 1] & 0xffff0000u);
+            const float dhv = __uint_as_float((r & 1) ? (dw[r >> 1] & 0xffff0000u) : (dw[r >> 1] << 16));
+            const float dht = dhv + dhr[ui][rt][r];
+            const float tc = tanhf_(ccur[ui][rt][r]);
+            const float dct = dcs[ui][rt][r] + dht * ov * (1.f - tc * tc);
+            const float d0 = dct * gv * iv * (1.f - iv);
+            const float d1 = dct * c4[r] * fv * (1.f - fv);
+            const float d2 = dct * iv * (1.f - gv * gv);
+            const float d3 = dht * tc * ov * (1.f - ov);
+            dcs[ui][rt][r] = dct * fv;
+            ccur[ui][rt][r] = c4[r];                 // c_{t-1} is the next processed step's c_t
+            ow[2 * r] = (unsigned)f32_to_bf16(d0) | ((unsigned)f32_to_bf16(d1) << 16);
+            ow[2 * r + 1] = (unsigned)f32_to_bf16(d2) | ((unsigned)f32_to_bf16(d3) << 16);
+          }
+          const uint4 o0 = make_uint4(ow[0], ow[1], ow[2], ow[3]), o1 = make_uint4(ow[4], ow[5], ow[6], ow[7]);
+          char* tp = tile + (rt * 16 + lc) * pitch + (u0 * 4) * 2;
+          *reinterpret_cast<uint4*>(tp) = o0;
+          *reinterpret_cast<uint4*>(tp + 16) = o1;
+#ifndef BABL_NO_STORE
+          if (rowbase[rt] >= 0) {
+            bf16_t* gp = gates + ((long)(rowbase[rt] + t * stride_i) * ldg_i + (gcol_i + u0 * 4));
+            *reinterpret_cast<uint4*>(gp) = o0;
+            *reinterpret_cast<uint4*>(gp + 8) = o1;
+          }
+#endif
+        }
+      }
+    }
+    if (step + 1 == p.m.seq_len) break;
+    load_all(dir ? t + 1 : t - 1);               // next step's inputs: older than every weight fragment of this step's pass
+    __syncthreads();
+#pragma unroll
+    for (int ui = 0; ui < MAXUT; ++ui) {
+      const int ut = w + NW * ui;
+      if (ut < nut) {
+        f32x4_t acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const char* wr = whhT + ((long)ut * nslab) * 1024;
+        const char* ar = tile + lc * pitch + 16 * lr;
+#ifndef URSE_BWD_TR_KB
+#define URSE_BWD_TR_KB 17
+#endif
+        constexpr int KB = URSE_BWD_TR_KB;
+        #pragma unroll 1
+        for (int k0 = 0; k0 < nslab; k0 += KB) {
+          uint4 b[KB];
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int ks = (k0 + i < nslab) ? k0 + i : nslab - 1;
+            b[i] = *reinterpret_cast<const uint4*>(wr + ks * 1024);
+          }
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            if (k0 + i < nslab) {
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt) {
+                const uint4 a = *reinterpret_cast<const uint4*>(ar + rt * 16 * pitch + (k0 + i) * 64);
+                // A = weight fragment (rows = units), B = dgates fragment (columns = sequences): C[unit 4 lr + r][sequence lc]
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[i]),
+                                                                  __builtin_bit_cast(bf16x8_t, a), acc[rt], 0, 0, 0);
+              }
             }
           }
         }
@@ -474,6 +697,12 @@ static int launch_fwd(const LstmFwdArgs& p, hipStream_t st) {
   return URSE_OK;
 }
 
+// URSE_BWD_VARIANT (experiments): 0 = default dispatch, 1 = 16 waves + prefetch, 2 = 8 waves + prefetch on the time path
+static int bwd_variant() {
+  const char* e = getenv("URSE_BWD_VARIANT");
+  return e ? atoi(e) : 0;
+}
+
 template <typename T, int RT, int NW>
 static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
   constexpr int R = 16 * RT;
@@ -500,7 +729,51 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
       return URSE_OK;
     }
   }
+  if constexpr (sizeof(T) == 2 && NW == 8 && RT == 1) {
+    if (p.H == 392 && bwd_variant() == 6) {     // transposed accumulator layout: wide loads / stores
+      static bool once = (allow_big_lds(lstm_bwd_tr_kernel<1, 4, 8, 392>), true);
+      (void)once;
+      hipLaunchKernelGGL((lstm_bwd_tr_kernel<1, 4, 8, 392>), grid, dim3(NW * 64), lds, st, pa);
+      URSE_CHECK_LAUNCH("urse_lstm_bwd");
+      return URSE_OK;
+    }
+    if (p.H == 392) {     // 16 sequences on 8 waves with the next step's inputs prefetched (PF = 1)
+      static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 4, 8, 392, 0, 1>), true);
+      (void)once;
+      hipLaunchKernelGGL((lstm_bwd_kernel<T, 1, 4, 8, 392, 0, 1>), grid, dim3(NW * 64), lds, st, pa);
+      URSE_CHECK_LAUNCH("urse_lstm_bwd");
+      return URSE_OK;
+    }
+  }
   if constexpr (sizeof(T) == 2 && NW == 16 && RT == 1) {
+    if (p.H == 392 && (bwd_variant() == 4 || bwd_variant() == 5)) {     // experiments: 13 x 2 / 12 x 3 unit tiles, prefetched inputs
+      const int nw = bwd_variant() == 4 ? 13 : 12;
+      if (nw == 13) {
+        static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 2, 13, 392, 0, 1>), true);
+        (void)once;
+        hipLaunchKernelGGL((lstm_bwd_kernel<T, 1, 2, 13, 392, 0, 1>), grid, dim3(nw * 64), lds, st, pa);
+      } else {
+        static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 3, 12, 392, 0, 1>), true);
+        (void)once;
+        hipLaunchKernelGGL((lstm_bwd_kernel<T, 1, 3, 12, 392, 0, 1>), grid, dim3(nw * 64), lds, st, pa);
+      }
+      URSE_CHECK_LAUNCH("urse_lstm_bwd");
+      return URSE_OK;
+    }
+    if (p.H == 392 && bwd_variant() == 3) {     // experiment: both unit tiles' inputs in one round trip at the top of the step
+      static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 2, 16, 392, 0, 2>), true);
+      (void)once;
+      hipLaunchKernelGGL((lstm_bwd_kernel<T, 1, 2, 16, 392, 0, 2>), grid, dim3(NW * 64), lds, st, pa);
+      URSE_CHECK_LAUNCH("urse_lstm_bwd");
+      return URSE_OK;
+    }
+    if (p.H == 392 && bwd_variant() == 1) {     // experiment: prefetch at 16 waves (128-VGPR cap)
+      static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 2, 16, 392, 0, 1>), true);
+      (void)once;
+      hipLaunchKernelGGL((lstm_bwd_kernel<T, 1, 2, 16, 392, 0, 1>), grid, dim3(NW * 64), lds, st, pa);
+      URSE_CHECK_LAUNCH("urse_lstm_bwd");
+      return URSE_OK;
+    }
     if (p.H == 392) {     // the model's size on the time path: compile-time geometry (7.2 -> 7.0 ms; the 32-row variant spills with it)
       static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 2, 16, 392>), true);
       (void)once;
@@ -600,6 +873,7 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
     rt = (many && fits2) ? 2 : 1;
     nw8 = many && fits2;
   }
+  if (rt == 1 && (bwd_variant() == 2 || bwd_variant() == 6)) nw8 = true;
   note_launch(dtype == URSE_BF16 && rt >= 2 && fits2 ? URSE_KV_LSTM_BWD_STREAM32 : URSE_KV_LSTM_BWD_STREAM16);
   if (dtype == URSE_BF16) {
     if (nw8) return (rt >= 2 && fits2) ? launch_bwd<bf16_t, 2, 8>(p, st) : launch_bwd<bf16_t, 1, 8>(p, st);
