@@ -144,7 +144,7 @@ def sdr(ref, est, filter_length=512, clamp_db=50.0):
 def soxr_hq_design(fs_in, fs_out):
     """One Kaiser-windowed sinc built to the specification of libsoxr's HQ recipe (soxr.c soxr_quality_spec, quality 4: 20-bit =
     120.4 dB rejection from the lower Nyquist frequency, pass band to 1 - 0.05 / TO_3dB(rej) = 0.9136 of it, linear phase,
-    cutoff mid-transition as lsx_design_lpf places it).  -> (h * up, up, down).  soxr's own cascade is not reproducible
+    cutoff mid-transition as lsx_design_lpf places it).  -> (h with unity DC gain, up, down).  soxr's own cascade is not reproducible
     bit-wise; what is pinned here is the specification, checked in tests/test_oracle.py."""
     from math import gcd
     from scipy.signal import firwin
@@ -156,11 +156,12 @@ def soxr_hq_design(fs_in, fs_out):
     f_pass, f_stop = (1.0 - 0.05 / to3db) * nyq, nyq
     fs_work = float(fs_in) * up
     dw = 2.0 * np.pi * (f_stop - f_pass) / fs_work
-    half = int(np.ceil((rej - 7.95) / (2.285 * dw) / 2.0))
-    h = firwin(2 * half + 1, (f_pass + f_stop) / fs_work, window=("kaiser", 0.1102 * (rej - 8.7)))
-    return h * up, up, down
+    att = rej + 2.0          # design margin: Kaiser's length estimate lands 1.3 dB short at the very band edges for the 80 k-tap filters
+    half = int(np.ceil((att - 7.95) / (2.285 * dw) / 2.0))
+    h = firwin(2 * half + 1, (f_pass + f_stop) / fs_work, window=("kaiser", 0.1102 * (att - 8.7)))
+    return h, up, down
 
 
 def resample_soxr_hq_spec(x, fs_in, fs_out):
     h, up, down = soxr_hq_design(fs_in, fs_out)
-    return resample_poly(np.asarray(x, dtype=np.float64), up, down, window=h)
+    return resample_poly(np.asarray(x, dtype=np.float64), up, down, window=h)     # (scipy scales the taps by `up` itself)
