@@ -307,6 +307,31 @@ def _metrics_cpu_worker(td):
     print(json.dumps({"dt": dt, "scores": [[float(v) for v in sc] for sc in scores]}))
 
 
+def cold_stream_reference(dev, nbytes):
+    """What a plain float4 elementwise pass (half the bytes read, half written) reaches on `nbytes` from COLD caches - the state the
+    STFT launch of a train step finds after 160 ms of other traffic - timed like the step's kernels (one HIP-event pair per launch,
+    a 2 GiB fill in front of every launch).  Context for `stft_roofline`: the 8 TB/s peak is not what a 74 MB launch can see."""
+    try:
+        n = int(nbytes // 8)
+        a = torch.randn(n, device=dev)
+        b = torch.empty_like(a)
+        junk = torch.empty(1 << 29, device=dev)
+        torch.mul(a, 2.0, out=b)
+        ts = []
+        for it in range(7):
+            junk.fill_(float(it))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); torch.mul(a, 2.0, out=b); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        del a, b, junk
+        torch.cuda.empty_cache()
+        return ts[len(ts) // 2]
+    except Exception:
+        return None
+
+
 def _pretouch(dev, gib):
     """The first process that uses a fresh box's HBM gets its memory in a state that keeps every kernel ~6 % slower for the
     life of the process (measured: 193-195 ms/step in the first process however many warm-up steps it runs, 181-183 in any
@@ -586,6 +611,14 @@ def main():
         "final_loss": float(loss.detach()),
         "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
     }
+    if rank == 0 and world == 1:
+        ref_ms = cold_stream_reference(dev, stft_bytes)
+        if ref_ms:
+            out["stft_roofline"].update({
+                "cold_stream_reference_GBs": stft_bytes / (ref_ms * 1e-3) / 1e9,
+                "frac_of_cold_stream_reference": ref_ms / kt["stft_fwd"][0],
+                "note": "the launch runs from cold caches inside the step; a plain float4 elementwise pass over the same number of bytes, "
+                        "timed the same way (one event pair per launch, caches evicted in front), is the cold_stream_reference"})
     if sync_ok is not None:
         out["ranks_hold_identical_weights"] = sync_ok
     if args.dynamic_mix:
