@@ -352,6 +352,18 @@ int urse_fill_used_flags(float* used, int n_slot, int n_used, void* stream);
 /* ---- batched intrusive metrics ----------------------------------------------------------------------
  * evaluation_metrics/calculate_intrusive_se_metrics.py: estoi_metric (:37-48) -> pystoi.stoi(extended=True),
  * sdr_metric (:90-109) -> fast_bss_eval.bss_eval_sources(compute_permutation=False, clamp_db=50). */
+/* Fourier resampling of whole utterances: y = scipy.signal.resample(x, num) for real f32 rows of arbitrary length n - the
+ * `res_type="scipy"` branch of the bandwidth-limitation augmentation (simulate_data_from_param.py:233-252 -> librosa.resample ->
+ * scipy.signal.resample: rfft, spectrum cut / zero-padded to num // 2 + 1 bins with the Nyquist rule, irfft, x num / n).
+ * Arbitrary lengths run as Bluestein transforms on power-of-two four-step FFTs (csrc/fft_any.hip), one workgroup per row.
+ *  plan: per transform length L (n and num each need one): urse_fft_resample_plan_elems(L) -> float2 elements of the plan and of a
+ *  scratch buffer; urse_fft_resample_plan(plan, scratch, L) fills it (chirp + transformed conjugate chirp) - build once, reuse.
+ *  workspace: urse_fft_resample_workspace_bytes(P, n, num).  2 <= n, num <= 2^19. */
+int urse_fft_resample_plan_elems(int n, int64_t* elems, int64_t* tmp_elems);
+int urse_fft_resample_plan(void* plan, void* tmp, int n, void* stream);
+int urse_fft_resample_workspace_bytes(int P, int n, int num, int64_t* bytes);
+int urse_fft_resample(const float* x, int64_t ldx, float* y, int64_t ldy, const void* plan_n, const void* plan_num,
+                      void* workspace, int64_t workspace_bytes, int P, int n, int num, void* stream);
 /* scipy.signal.resample_poly(x, up, down, window=h) (pystoi.utils.resample_oct): x f32 [P,L] -> y f32 [P,Lout];
  * h_padded (f64, device) = zeros(n_pre_pad) ++ up*h as scipy builds it; n_pre_remove as scipy computes it. */
 int urse_resample_poly(const float* x, float* y, const double* h_padded, int hlen, int P, int L, int Lout, int up,

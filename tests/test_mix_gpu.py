@@ -223,13 +223,20 @@ def test_bandwidth_limitation_fft_matches_scipy(lib):
     import math
     from scipy.signal import resample
     from urgent2026_challenge_track1_amd import mixing
-    for L, fs, fs_new in ((24000, 48000, 16000), (24001, 48000, 22050), (9973, 16000, 8000), (12000, 44100, 32000)):
+    for L, fs, fs_new in ((24000, 48000, 16000), (24001, 48000, 22050), (9973, 16000, 8000), (12000, 44100, 32000), (192000, 48000, 16000),
+                          (131071, 48000, 44100)):
         x = _signals(1, L, 9)[0]
         n1 = int(math.ceil(L * float(fs_new) / fs))
         down = resample(x.astype(np.float64), n1)
         up = resample(down, int(math.ceil(n1 * float(fs) / fs_new)))[:L]
         got = mixing.bandwidth_limitation_fft(torch.tensor(x[None]).cuda(), fs, fs_new)[0].cpu().numpy()
         assert got.shape == x.shape and np.abs(got - up).max() <= 2e-5, (L, fs, fs_new, np.abs(got - up).max())
+    # a batch of rows through one launch, and the single transform against scipy (up- and down-sampling, odd / even / prime lengths)
+    xs = _signals(3, 9973, 10)
+    for num in (4987, 9973, 12001, 19946):
+        got = mixing._fft_resample(torch.tensor(xs).cuda(), num).cpu().numpy()
+        ref = resample(xs.astype(np.float64), num, axis=1)
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-5, (num, np.abs(got - ref).max())
 
 
 def test_sources_at_another_rate_are_resampled_on_the_device(lib):

@@ -62,11 +62,15 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
   const int t0 = j * tb + min(j, trem), tcnt = tb + (j < trem ? 1 : 0), t1 = t0 + tcnt;
   const int ks0 = 2 * t0, ks1 = min(2 * t1, nslab);
   const int ownw = tcnt * 64;                            // gate columns in the LDS tile
-  const int tpitch = ownw * 2 + 16;
+  const int tpitch = ownw * 2 + 32;                       // 32 mod 64 bytes: the ds_read_b128 fragment reads of 16 rows spread over all banks
   char* tile = smem;                                     // [32][tpitch] dgates of the owned units (MFMA A operand)
-  float* stage = reinterpret_cast<float*>(smem + SROWS * tpitch);          // [32][UP] partials to publish
-  float* inbuf = stage + SROWS * UP;                     // [ns-1][32][tcnt*16] partials received
-  unsigned* deadflag = reinterpret_cast<unsigned*>(inbuf + (ns - 1) * SROWS * tcnt * 16);
+  // row pitches of the two f32 tiles: + 4 floats, so that the four 4-row groups of a wave (lanes l / 16) fall on different banks
+  // (UP and tcnt * 16 are multiples of 64 floats at H = 768: every stage write / inbuf read was a 4-way bank conflict,
+  // 45 % of the kernel's LDS cycles in profiles/r02_sq_counters_v2.json)
+  const int SP = UP + 4, IP = tcnt * 16 + 4;
+  float* stage = reinterpret_cast<float*>(smem + SROWS * tpitch);          // [32][SP] partials to publish
+  float* inbuf = stage + SROWS * SP;                     // [ns-1][32][IP] partials received
+  unsigned* deadflag = reinterpret_cast<unsigned*>(inbuf + (ns - 1) * SROWS * IP);
   if (tid == 0) *deadflag = 0u;
 
   // this wave's tiles in the product: w, w + 8, ...; of the owned range [t0, t1) it owns those congruent to w
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
           const int row = rem / in_cpr, cc = rem - row * in_cpr;
           const int js = s < j ? s : s + 1;
           offs[i] = pprev * plane_bytes + cl_bytes + (unsigned)js * src_bytes + (unsigned)((row * UP + t0 * 16 + cc * 4) * 4);
-          dsts[i] = (s * SROWS + row) * tcnt * 16 + cc * 4;
+          dsts[i] = (s * SROWS + row) * IP + cc * 4;
           pend |= 1u << i;
         }
       }
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
             const float gv = __uint_as_float(gv2.y << 16), ov = __uint_as_float(gv2.y & 0xffff0000u);
             float rec = dhr[o][rt][r];
             if (step > 0) {
-              for (int s = 0; s < ns - 1; ++s) rec += inbuf[(s * SROWS + lrow) * tcnt * 16 + (ut - t0) * 16 + lc];
+              for (int s = 0; s < ns - 1; ++s) rec += inbuf[(s * SROWS + lrow) * IP + (ut - t0) * 16 + lc];
             }
             const float dht = bf16_to_f32(dnx[o][rt][r]) + rec;
             const float tc = tanhf_(ccur[o][rt][r]);
@@ -295,7 +299,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
 #pragma unroll
           for (int rt = 0; rt < SRT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(rt * 16 + lr * 4 + r) * UP + ut * 16 + lc] = acc[rt][r];
+            for (int r = 0; r < 4; ++r) stage[(rt * 16 + lr * 4 + r) * SP + ut * 16 + lc] = acc[rt][r];
         }
       }
     }
@@ -309,7 +313,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
         const int row = idx / cpr, cc = idx - row * cpr;
         const int ut = cc >> 2;
         if (ut >= t0 && ut < t1) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(stage + row * UP + cc * 4);
+        uint4 v = *reinterpret_cast<const uint4*>(stage + row * SP + cc * 4);
         v.x = (v.x & ~1u) | tagv; v.y = (v.y & ~1u) | tagv; v.z = (v.z & ~1u) | tagv; v.w = (v.w & ~1u) | tagv;
 #ifndef SABL_NO_PUB
         split_store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)j * src_bytes + (unsigned)((row * UP + cc * 4) * 4), v);
@@ -327,7 +331,7 @@ using namespace urse;
 
 static size_t split_lds(int nut, int ns, int rows) {
   const int tmax = (nut + ns - 1) / ns;
-  return (size_t)rows * (tmax * 128 + 16) + (size_t)rows * nut * 16 * 4 + (size_t)(ns - 1) * rows * tmax * 16 * 4 + 16;
+  return (size_t)rows * (tmax * 128 + 32) + (size_t)rows * (nut * 16 + 4) * 4 + (size_t)(ns - 1) * rows * (tmax * 16 + 4) * 4 + 16;
 }
 
 // workspace query: {nsplit, clusters per direction, xbuf f32 elements, rows per cluster}; < 0 if the shape has no split kernel

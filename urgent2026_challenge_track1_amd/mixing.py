@@ -10,7 +10,7 @@ import functools
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import call
 from .ops import stream_ptr
 
@@ -189,23 +189,56 @@ def bandwidth_limitation_polyphase(speech, fs, fs_new):
     return fix(up, L)
 
 
+_fft_plans = {}        # (device, length) -> plan tensor (chirp + transformed conjugate chirp); a handful of MB each, LRU of 16
+_fft_ws = {}
+
+
+def _fft_plan(n, dev):
+    import ctypes
+    key = (dev, int(n))
+    if key in _fft_plans:
+        _fft_plans[key] = _fft_plans.pop(key)          # (most recently used last)
+        return _fft_plans[key]
+    lib = _lib.load()
+    ne, nt = ctypes.c_int64(), ctypes.c_int64()
+    if lib.urse_fft_resample_plan_elems(int(n), ctypes.addressof(ne), ctypes.addressof(nt)) != 0:
+        raise _lib.UrseError(lib.urse_last_error().decode())
+    plan = torch.empty(ne.value, 2, device=dev, dtype=torch.float32)
+    tmp = torch.empty(nt.value, 2, device=dev, dtype=torch.float32)
+    call("fft_resample_plan", plan, tmp, int(n), stream_ptr())
+    tmp.record_stream(torch.cuda.current_stream(dev))
+    _fft_plans[key] = plan
+    while len(_fft_plans) > 16:
+        _fft_plans.pop(next(iter(_fft_plans)))
+    return plan
+
+
+FFT_RESAMPLE_MAX = 1 << 19
+
+
 def _fft_resample(x, num):
     """``scipy.signal.resample(x, num, axis=1)`` for real f32 [P, n]: the spectrum is truncated / zero-padded to ``num`` bins (the
     Nyquist bin doubled when it is cut, halved when it is introduced) and transformed back.  The two transforms have the
-    utterance's own, arbitrary length: they are plain library FFTs (rocFFT through ``torch.fft``)."""
+    utterance's own, arbitrary length: Bluestein transforms on the library's power-of-two FFTs (csrc/fft_any.hip,
+    ``urse_fft_resample``; no rocFFT / torch.fft on the product path)."""
+    import ctypes
     ops.require_cuda(x)
+    x = x.contiguous().float()
     P, nx = x.shape
-    X = torch.fft.rfft(x.float(), dim=1)
-    n = min(num, nx)
-    nyq = n // 2 + 1
-    Y = torch.zeros(P, num // 2 + 1, dtype=X.dtype, device=x.device)
-    Y[:, :nyq] = X[:, :nyq]
-    if n % 2 == 0:
-        if num < nx:
-            Y[:, n // 2] *= 2.0
-        elif nx < num:
-            Y[:, n // 2] *= 0.5
-    return torch.fft.irfft(Y, n=num, dim=1) * (float(num) / float(nx))
+    num = int(num)
+    dev = x.device
+    pa, pb = _fft_plan(nx, dev), _fft_plan(num, dev)
+    lib = _lib.load()
+    nb = ctypes.c_int64()
+    if lib.urse_fft_resample_workspace_bytes(P, nx, num, ctypes.addressof(nb)) != 0:
+        raise _lib.UrseError(lib.urse_last_error().decode())
+    ws = _fft_ws.get(dev)
+    if ws is None or ws.numel() < nb.value:
+        ws = _fft_ws[dev] = torch.empty(nb.value, device=dev, dtype=torch.uint8)
+    y = torch.empty(P, num, device=dev, dtype=torch.float32)
+    call("fft_resample", x, x.stride(0) if P > 1 else nx, y, num, pa, pb, ws, ws.numel(), P, nx, num, stream_ptr())   # (a size-1 dim may carry stride 0)
+    ws.record_stream(torch.cuda.current_stream(dev))
+    return y
 
 
 def bandwidth_limitation_fft(speech, fs, fs_new):
@@ -262,7 +295,8 @@ def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_ear
         for a in r.get("order", []):
             if a in ("clipping", "packet_loss"):
                 mine.append(a)
-            elif a == "bandwidth_limitation" and r["params"][a]["res_type"] in ("polyphase", "scipy", "none"):
+            elif a == "bandwidth_limitation" and r["params"][a]["res_type"] in ("polyphase", "scipy", "none") and not (
+                    r["params"][a]["res_type"] == "scipy" and int(r["length"]) > FFT_RESAMPLE_MAX):      # (> 10.9 s at 48 kHz)
                 mine.append(a)
             else:
                 count(a)
