@@ -297,6 +297,12 @@ int urse_filtfilt_fir(const float* x, const int32_t* lens, int B, int64_t ld, co
 int urse_quantile_clip(float* x, const int32_t* lens, int B, int64_t ld, const float* qmin, const float* qmax, float* bounds,
                        void* stream);
 int urse_zero_segments(float* x, int64_t ld, const int32_t* segments, int nseg, void* stream);
+/* resampy.resample (librosa res_type "kaiser_best" / "kaiser_fast" of the bandwidth limitation, :233-252): y[t] = sum of x around
+ * t * time_increment weighted by the filter table `win` (right wing, num_table samples per zero crossing, already scaled by the
+ * ratio when downsampling) linearly interpolated with `delta` = its first differences; scale = min(1, ratio), index_step =
+ * int(scale * num_table); all the index arithmetic in float64 as the package does it.  x [P, ldx] f32 -> y [P, ldy] f32. */
+int urse_resample_table(const float* x, int64_t ldx, float* y, int64_t ldy, const double* win, const double* delta, int nwin, int P,
+                        int n_orig, int n_out, double time_increment, double scale, int num_table, int index_step, void* stream);
 int urse_joint_peak_scale(float* speech, float* noisy, float* noise, int B, int64_t ld, float target, void* peak_scratch,
                           void* stream);
 /* y = a*x + b*y (f32). */

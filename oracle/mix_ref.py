@@ -94,3 +94,75 @@ def packet_loss(speech, fs, indices, packet_duration_ms=20):
 def joint_peak_normalise(speech, noisy, noise, target=0.9):
     scale = target / max(np.max(np.abs(noisy)), np.max(np.abs(speech)), np.max(np.abs(noise)), 1e-6)
     return speech * scale, noisy * scale, noise * scale
+
+
+# ---- resampy (librosa res_type "kaiser_best" / "kaiser_fast") ---------------------------------------------------------------------
+# librosa.resample(y, orig_sr, target_sr, res_type="kaiser_best" | "kaiser_fast") = resampy.resample(y, orig_sr, target_sr, filter=res_type)
+# followed by fix_length to ceil(n * ratio) (simulate_data_from_param.py:233-252, the two resampy branches of the bandwidth limitation).
+# resampy is NOT in the image and ships its two filters as pre-computed tables; they are the output of its own
+# `filters.sinc_window(num_zeros, precision, window=kaiser(beta), rolloff)` with the parameters its documentation states:
+#   kaiser_best: 64 zero crossings, 2^9 table samples per crossing, beta 14.769656459379492, roll-off 0.9475937167399596
+#   kaiser_fast: 16 zero crossings, 2^9 table samples per crossing, beta 8.555504641634386,  roll-off 0.85
+# Restated from the published algorithm (Smith's band-limited interpolation with a linearly interpolated filter table,
+# resampy/interpn.py `_resample_loop`); PARITY UNPINNED against the package.
+RESAMPY_FILTERS = {"kaiser_best": (64, 9, 14.769656459379492, 0.9475937167399596),
+                   "kaiser_fast": (16, 9, 8.555504641634386, 0.85)}
+
+
+def resampy_filter(name):
+    """resampy.filters.sinc_window: the right wing of the windowed sinc on 2^precision samples per zero crossing."""
+    num_zeros, precision, beta, rolloff = RESAMPY_FILTERS[name]
+    num_bits = 2 ** precision
+    n = num_bits * num_zeros
+    sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+    taper = np.kaiser(2 * n + 1, beta)[n:]
+    return taper * sinc_win, num_bits
+
+
+def resampy_resample(x, sr_orig, sr_new, name):
+    """resampy.resample(x, sr_orig, sr_new, filter=name) for a 1-D float64 signal (vectorised restatement of _resample_loop)."""
+    x = np.asarray(x, dtype=np.float64)
+    sample_ratio = float(sr_new) / sr_orig
+    n_out = int(x.shape[0] * sample_ratio)
+    interp_win, num_table = resampy_filter(name)
+    if sample_ratio < 1:
+        interp_win = sample_ratio * interp_win
+    interp_delta = np.diff(interp_win, append=interp_win[-1])
+    scale = min(1.0, sample_ratio)
+    t_out = np.arange(n_out) * (1.0 / sample_ratio)
+    index_step = int(scale * num_table)
+    nwin, n_orig = interp_win.shape[0], x.shape[0]
+    y = np.zeros(n_out)
+    taps = nwin // index_step + 2
+    for c0 in range(0, n_out, 4096):
+        tr = t_out[c0:c0 + 4096]
+        n = tr.astype(np.int64)
+        frac = scale * (tr - n)
+        for wing in (0, 1):
+            if wing:
+                frac = scale - frac
+            index_frac = frac * num_table
+            offset = index_frac.astype(np.int64)
+            eta = index_frac - offset
+            cnt = np.minimum(n + 1 if wing == 0 else n_orig - n - 1, (nwin - offset) // index_step)
+            i = np.arange(taps)[None, :]
+            ok = i < cnt[:, None]
+            idx = np.where(ok, offset[:, None] + i * index_step, 0)
+            w = interp_win[idx] + eta[:, None] * interp_delta[idx]
+            xi = np.where(ok, (n[:, None] - i) if wing == 0 else (n[:, None] + i + 1), 0)
+            y[c0:c0 + 4096] += np.where(ok, w * x[xi], 0.0).sum(1)
+    return y
+
+
+def bandwidth_limitation_resampy(x, fs, fs_new, name):
+    """bandwidth_limitation(x[None], fs, fs_new, res_type=name)[0] (simulate_data_from_param.py:233-252)."""
+    import math
+    x = np.asarray(x, dtype=np.float64)
+
+    def librosa_resample(y, orig, target):
+        out = resampy_resample(y, orig, target, name)
+        n = int(math.ceil(len(y) * float(target) / orig))
+        return out[:n] if len(out) >= n else np.pad(out, (0, n - len(out)))
+    down = librosa_resample(x, fs, fs_new)
+    up = librosa_resample(down, fs_new, fs)
+    return up[:len(x)] if len(up) >= len(x) else np.pad(up, (0, len(x) - len(up)))

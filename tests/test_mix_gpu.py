@@ -272,3 +272,28 @@ def test_sources_at_another_rate_are_resampled_on_the_device(lib):
         e_n = np.abs(noisy[b, 0].cpu().numpy() - mixed[0]).max()
         e_c = np.abs(clean[b, 0].cpu().numpy() - s_early[0]).max()
         assert e_n <= 5e-5 and e_c <= 5e-5, (b, e_n, e_c)
+
+
+def test_bandwidth_limitation_resampy_matches_oracle(lib):
+    """the kaiser_best / kaiser_fast branches of the bandwidth limitation (librosa -> resampy.resample, table-interpolated windowed
+    sinc; resampy itself is absent: oracle/mix_ref.resampy_resample restates its loop, unpinned) on the device vs the float64 oracle,
+    down and back up for the rate pairs the recipes draw, odd and even lengths."""
+    from oracle import mix_ref
+    from urgent2026_challenge_track1_amd import mixing
+    for L, fs, fs_new, name in ((24000, 48000, 16000, "kaiser_best"), (24001, 48000, 22050, "kaiser_fast"), (9973, 16000, 8000, "kaiser_best"),
+                                (12000, 44100, 32000, "kaiser_fast"), (30001, 48000, 8000, "kaiser_fast"), (20000, 22050, 16000, "kaiser_best")):
+        x = _signals(1, L, 11)[0]
+        ref = mix_ref.bandwidth_limitation_resampy(x, fs, fs_new, name)
+        got = mixing.bandwidth_limitation_resampy(torch.tensor(x[None]).cuda(), fs, fs_new, name)[0].cpu().numpy()
+        assert got.shape == x.shape and np.abs(got - ref).max() <= 2e-6, (L, fs, fs_new, name, np.abs(got - ref).max())
+    # a recipe that draws it is now applied, not counted as skipped
+    sp = _signals(2, 16000, 12)
+    nz = _signals(2, 20000, 13, silent=False)
+    rec = lambda rt: dict(snr=10.0, noise_offset=100, order=["bandwidth_limitation"], highpass=True, rir_uid="none", wind=False, length=16000,
+                          params={"bandwidth_limitation": dict(res_type=rt, fs_new=8000)})
+    skipped = {}
+    clean, noisy = mixing.simulate_recipes(torch.tensor(sp).cuda(), [16000, 16000], torch.tensor(nz).cuda(), [20000, 20000], None, [0, 0],
+                                           [0, 0], 16000, [rec("kaiser_best"), rec("kaiser_fast")], skipped)
+    assert not skipped and torch.isfinite(noisy).all()
+    X = torch.fft.rfft(noisy.cpu().double(), dim=1).abs()          # (test-side check only) nothing left above 4.2 kHz
+    assert float(X[:, 4300:].max()) <= 1e-3 * float(X.max())

@@ -347,6 +347,59 @@ __global__ void __launch_bounds__(256) scale3_kernel(float* __restrict__ a, floa
 
 using namespace urse;
 
+namespace urse {
+// resampy.resample (librosa res_type "kaiser_best" / "kaiser_fast": two of the four resamplers of the bandwidth-limitation
+// augmentation, simulate_data_from_param.py:233-252): Smith's band-limited interpolation with a linearly interpolated filter
+// table, resampy/interpn.py `_resample_loop` restated.  One thread per output sample, float64 index arithmetic and accumulation
+// as numpy's (the truncations int(time), int(index_frac) must come out the same), table + its first differences in float64.
+__global__ void __launch_bounds__(256) resample_table_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy,
+                                                             const double* __restrict__ win, const double* __restrict__ delta,
+                                                             int nwin, int n_orig, int n_out, double time_increment, double scale,
+                                                             int num_table, int index_step) {
+  const float* xp = x + (long)blockIdx.y * ldx;
+  float* yp = y + (long)blockIdx.y * ldy;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_out; t += gridDim.x * blockDim.x) {
+    const double time_register = (double)t * time_increment;
+    const int n = (int)time_register;
+    double frac = scale * (time_register - (double)n);
+    double index_frac = frac * (double)num_table;
+    int offset = (int)index_frac;
+    double eta = index_frac - (double)offset;
+    double acc = 0.0;
+    int i_max = (nwin - offset) / index_step;
+    if (i_max > n + 1) i_max = n + 1;
+    for (int i = 0; i < i_max; ++i) {
+      const int q = offset + i * index_step;
+      acc += (win[q] + eta * delta[q]) * (double)xp[n - i];
+    }
+    frac = scale - frac;
+    index_frac = frac * (double)num_table;
+    offset = (int)index_frac;
+    eta = index_frac - (double)offset;
+    int k_max = (nwin - offset) / index_step;
+    if (k_max > n_orig - n - 1) k_max = n_orig - n - 1;
+    for (int k = 0; k < k_max; ++k) {
+      const int q = offset + k * index_step;
+      acc += (win[q] + eta * delta[q]) * (double)xp[n + k + 1];
+    }
+    yp[t] = (float)acc;
+  }
+}
+}  // namespace urse
+
+extern "C" int urse_resample_table(const float* x, int64_t ldx, float* y, int64_t ldy, const double* win, const double* delta,
+                                   int nwin, int P, int n_orig, int n_out, double time_increment, double scale, int num_table,
+                                   int index_step, void* stream) {
+  URSE_CHECK_ARG(x && y && win && delta && nwin > 0 && P > 0 && n_orig > 0 && n_out > 0 && ldx >= n_orig && ldy >= n_out &&
+                     time_increment > 0.0 && scale > 0.0 && scale <= 1.0 && num_table > 0 && index_step > 0,
+                 "urse_resample_table: bad argument");
+  URSE_CHECK_ARG((double)(n_out - 1) * time_increment < (double)n_orig, "urse_resample_table: the output grid runs past the input");
+  hipLaunchKernelGGL(urse::resample_table_kernel, dim3(ceil_div(n_out, 256), P), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, y,
+                     (long)ldy, win, delta, nwin, n_orig, n_out, time_increment, scale, num_table, index_step);
+  URSE_CHECK_LAUNCH("urse_resample_table");
+  return URSE_OK;
+}
+
 extern "C" int urse_nonsilence_power(const float* x, const int32_t* lens, int B, int64_t ld, double threshold,
                                      double* hop_scratch, double* power, void* stream) {
   URSE_CHECK_ARG(x && lens && hop_scratch && power && B > 0 && ld > 0, "urse_nonsilence_power: bad argument");

@@ -170,8 +170,8 @@ def bandwidth_limitation_polyphase(speech, fs, fs_new):
     """``bandwidth_limitation(x, fs, fs_new, res_type="polyphase")`` (simulate_data_from_param.py:233-252): librosa's polyphase
     branch is ``scipy.signal.resample_poly(y, target // gcd, orig // gcd)`` followed by ``fix_length`` to ``ceil(n * ratio)``,
     applied down and back up, cropped to the input length.  Runs on the batched polyphase kernel (`metrics._poly_resample`:
-    scipy's default Kaiser(5.0) design).  The other three resamplers the reference draws (kaiser_best / kaiser_fast need resampy's
-    filter tables) have no device implementation; the scipy one is `bandwidth_limitation_fft`."""
+    scipy's default Kaiser(5.0) design).  The other three resamplers the reference draws: `bandwidth_limitation_fft` (scipy),
+    `bandwidth_limitation_resampy` (kaiser_best / kaiser_fast)."""
     import math
     from .metrics import _poly_resample
     if fs == fs_new:
@@ -253,17 +253,74 @@ def bandwidth_limitation_fft(speech, fs, fs_new):
     return up[:, :L].contiguous()
 
 
+# resampy's two filters (absent package: the tables are rebuilt from the parameters its documentation states; unpinned)
+RESAMPY_FILTERS = {"kaiser_best": (64, 9, 14.769656459379492, 0.9475937167399596), "kaiser_fast": (16, 9, 8.555504641634386, 0.85)}
+_resampy_tables = {}
+
+
+def _resampy_table(name, sample_ratio, dev):
+    """(win, delta, nwin, num_table) on the device: resampy.filters.sinc_window(num_zeros, precision, kaiser(beta), rolloff), scaled by
+    the ratio when downsampling, and its first differences (interp_delta of resampy.resample)."""
+    import numpy as np
+    key = (name, float(sample_ratio) if sample_ratio < 1 else 1.0, dev)
+    if key not in _resampy_tables:
+        num_zeros, precision, beta, rolloff = RESAMPY_FILTERS[name]
+        num_bits = 2 ** precision
+        n = num_bits * num_zeros
+        win = np.kaiser(2 * n + 1, beta)[n:] * (rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True)))
+        if sample_ratio < 1:
+            win = sample_ratio * win
+        delta = np.diff(win, append=win[-1])
+        _resampy_tables[key] = (ops.upload(torch.from_numpy(win), dev), ops.upload(torch.from_numpy(delta), dev), len(win), num_bits)
+    return _resampy_tables[key]
+
+
+def _resampy_resample(x, sr_orig, sr_new, name):
+    """``resampy.resample(x, sr_orig, sr_new, filter=name, axis=1)`` for f32 [P, n] (``urse_resample_table``)."""
+    ops.require_cuda(x)
+    x = x.contiguous().float()
+    P, n = x.shape
+    sample_ratio = float(sr_new) / sr_orig
+    n_out = int(n * sample_ratio)
+    win, delta, nwin, num_table = _resampy_table(name, sample_ratio, x.device)
+    scale = min(1.0, sample_ratio)
+    y = torch.empty(P, max(n_out, 1), device=x.device, dtype=torch.float32)
+    if n_out > 0:
+        call("resample_table", x, x.stride(0) if P > 1 else n, y, y.shape[1], win, delta, nwin, P, n, n_out, 1.0 / sample_ratio, scale,
+             num_table, int(scale * num_table), stream_ptr())
+    return y[:, :n_out]
+
+
+def bandwidth_limitation_resampy(speech, fs, fs_new, res_type):
+    """``bandwidth_limitation(x, fs, fs_new, res_type="kaiser_best" | "kaiser_fast")`` (simulate_data_from_param.py:233-252):
+    librosa.resample = resampy.resample + fix_length to ceil(n * ratio), down and back up, cropped to the input length."""
+    import math
+    if fs == fs_new:
+        return speech
+    L = speech.shape[1]
+
+    def fix(y, n):
+        if y.shape[1] >= n:
+            return y[:, :n].contiguous()
+        out = torch.zeros(y.shape[0], n, device=y.device, dtype=y.dtype)
+        out[:, :y.shape[1]] = y
+        return out
+    down = fix(_resampy_resample(speech, fs, fs_new, res_type), int(math.ceil(L * float(fs_new) / fs)))
+    up = fix(_resampy_resample(down, fs_new, fs, res_type), int(math.ceil(down.shape[1] * float(fs) / fs_new)))
+    return fix(up, L)
+
+
 def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_early_stops, fs, recipes, skipped=None):
     """``process_one_sample(on_the_fly=True)`` (simulate_data_from_param.py:440-590) for a batch of raw sources and the
     recipes ``dataset.draw_recipe`` drew for them (one fs per batch) -> (speech, noisy) f32 [B, L].
 
     Utterances without an RIR convolve with a unit impulse (exact identity).  ``clipping`` / ``packet_loss`` are applied in
     each recipe's own order: pass p handles every utterance's p-th augmentation, the others ride along with identity
-    parameters (quantiles 0 / 1, no packets).  ``bandwidth_limitation`` is applied when the recipe drew the polyphase or
-    the scipy (FFT) resampler (two of the four methods); the resampy ones (kaiser_best / kaiser_fast), ``codec`` (ffmpeg) and the wind-noise side-chain
-    compressor (ffmpeg) have no device implementation: the recipe still DRAWS them (so the random stream matches the
-    reference) but they are not applied - wind noise is mixed additively at its drawn SNR - and each omission is counted in
-    ``skipped``."""
+    parameters (quantiles 0 / 1, no packets).  ``bandwidth_limitation`` is applied with all four resamplers the reference draws
+    (polyphase, scipy / FFT, and - round 3 - resampy's kaiser_best / kaiser_fast, restated without the package); ``codec``
+    (ffmpeg) and the wind-noise side-chain compressor (ffmpeg) have no device implementation: the recipe still DRAWS them (so the
+    random stream matches the reference) but they are not applied - wind noise is mixed additively at its drawn SNR - and each
+    omission is counted in ``skipped``."""
     ops.require_cuda(speech, noise_raw)
     B, L = speech.shape
     dev = speech.device
@@ -295,17 +352,20 @@ def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_ear
         for a in r.get("order", []):
             if a in ("clipping", "packet_loss"):
                 mine.append(a)
-            elif a == "bandwidth_limitation" and r["params"][a]["res_type"] in ("polyphase", "scipy", "none") and not (
+            elif a == "bandwidth_limitation" and r["params"][a]["res_type"] in ("polyphase", "scipy", "kaiser_best", "kaiser_fast", "none") and not (
                     r["params"][a]["res_type"] == "scipy" and int(r["length"]) > FFT_RESAMPLE_MAX):      # (> 10.9 s at 48 kHz)
                 mine.append(a)
             else:
                 count(a)
         todo.append(mine)
     for p in range(max([len(t) for t in todo] or [0])):
-        for b in range(B):          # bandwidth limitation (polyphase draws only): per utterance, its own rate pair
+        for b in range(B):          # bandwidth limitation: per utterance, its own rate pair and resampler
             if len(todo[b]) > p and todo[b][p] == "bandwidth_limitation" and recipes[b]["params"]["bandwidth_limitation"]["fs_new"] != fs:
                 n = host_lens[b]
                 bw = recipes[b]["params"]["bandwidth_limitation"]
+                if bw["res_type"] in RESAMPY_FILTERS:
+                    noisy[b:b + 1, :n] = bandwidth_limitation_resampy(noisy[b:b + 1, :n].contiguous(), fs, bw["fs_new"], bw["res_type"])
+                    continue
                 limit = bandwidth_limitation_fft if bw["res_type"] == "scipy" else bandwidth_limitation_polyphase
                 noisy[b:b + 1, :n] = limit(noisy[b:b + 1, :n].contiguous(), fs, bw["fs_new"])
         lo = [recipes[b]["params"]["clipping"]["min_quantile"] if len(todo[b]) > p and todo[b][p] == "clipping" else 0.0
