@@ -136,3 +136,18 @@ def test_estoi_frame_range_at_the_boundary_length(lib):
     assert np.abs(a - b).max() > 1e-6                      # the two readings are distinguishable on this fixture
     assert np.abs(got - a).max() < 0.2 * np.abs(a - b).max()
     print("ESTOI at len = 256 mod 128: kernels vs pystoi reading %.1e; pystoi vs inclusive reading %.1e" % (np.abs(got - a).max(), np.abs(a - b).max()))
+
+
+def test_score_batch_on_two_streams_equals_the_separate_calls(lib):
+    """metrics.score_batch runs PESQ on the caller's stream and ESTOI / SDR beside it on a second one: same numbers as the three
+    entry points called one after the other, whatever the slicing."""
+    from urgent2026_challenge_track1_amd import metrics
+    ref, inf = _pairs(37, 24000, 16000, 41)
+    r, e = torch.from_numpy(ref).cuda(), torch.from_numpy(inf).cuda()
+    a = metrics.score_batch(r, e, 16000, ("PESQ", "ESTOI", "SDR"), slice_pairs=16, pesq_pairs_per_launch=20)
+    torch.cuda.synchronize()
+    assert torch.equal(a["ESTOI"], metrics.estoi_batch(r, e, 16000)) and torch.equal(a["SDR"], metrics.sdr_batch(r, e))
+    p = metrics.pesq_batch(r, e, 16000)
+    assert torch.equal(torch.nan_to_num(a["PESQ"], nan=-1.0), torch.nan_to_num(p, nan=-1.0))
+    b = metrics.score_batch(r, e, 16000, ("ESTOI",))
+    assert set(b) == {"ESTOI"} and torch.equal(b["ESTOI"], a["ESTOI"])
