@@ -4,6 +4,8 @@ recipe draw of DynamicMixingDataset, and the CPU oracle of the simulator DSP (or
 import ast
 import os
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -193,9 +195,10 @@ def test_wav_reader_agrees_with_scipy(tmp_path):
 
 def test_sources_at_a_higher_rate_are_served_raw_with_their_rate(tmp_path):
     """`_pick_source` (the reference's select_sample) falls back to noise / RIR files of a HIGHER rate when none exists at the speech
-    rate - the common case on the real corpus.  The item then carries the raw source, uncropped (the reference's
-    read_audio returns before its max_duration crop on that path, simulate_data_from_param.py:350-352), with its rate; the noise
-    offset is drawn on the length after resampling (ceil(n fs / src))."""
+    rate - the common case on the real corpus.  The item then carries the source at ITS rate (no max_duration crop: the
+    reference's read_audio returns before it on that path, simulate_data_from_param.py:350-352); the noise offset is drawn on the
+    length after resampling (ceil(n fs / src)) and the source is cut to the window that offset selects plus filter margins
+    (crop_for_resampling: bit-identical samples inside the window)."""
     from urgent2026_challenge_track1_amd.dataset import DynamicMixingDataset, collate_dynamic
     rows = {"sp": ["s%d 16000 sp16_%d" % (i, i) for i in range(3)], "nz": ["n%d 48000 nz48_%d" % (i, i) for i in range(2)],
             "rir": ["r0 48000 rir48_0"], "wn": ["wind_noise0 48000 wn48_0"], "len": ["s%d 20000" % i for i in range(3)]}
@@ -213,10 +216,30 @@ def test_sources_at_a_higher_rate_are_served_raw_with_their_rate(tmp_path):
     np.random.seed(5)
     items = [ds[i] for i in range(3)]
     for it in items:
-        assert it["fs"] == 16000 and it["noise_fs"] == 48000 and it["noise"].shape[1] == 150001     # raw: no crop on this path
+        assert it["fs"] == 16000 and it["noise_fs"] == 48000
         assert DynamicMixingDataset.resampled_length(150001, 48000, 16000) == 50001
-        assert 0 <= it["recipe"]["noise_offset"] < 50001 - it["length"]
+        n_src = it["noise"].shape[1]                       # 20,000 output samples need 60,000 source samples + margins
+        assert 60000 <= n_src <= min(150001, 60000 + 2 * 4096 + 8)
+        assert 0 <= it["recipe"]["noise_offset"] and it["recipe"]["noise_offset"] + it["length"] <= DynamicMixingDataset.resampled_length(n_src, 48000, 16000)
         if it["rir"] is not None:
             assert it["rir_fs"] == 48000 and it["rir"].shape[1] == 9001
     batch = collate_dynamic(items)
-    assert batch.noise_fs == [48000] * 3 and batch.noise.shape == (3, 150001)
+    assert batch.noise_fs == [48000] * 3 and batch.noise.shape[0] == 3 and batch.noise.shape[1] <= 60000 + 2 * 4096 + 8
+
+
+def test_cropping_a_source_before_resampling_changes_nothing_inside_the_window():
+    """DynamicMixingDataset.crop_for_resampling: resample(whole file)[offset : offset + L] == resample(cropped file)[offset' : offset' + L]
+    for the polyphase resampler (checked on the float64 oracle filter; the device kernel evaluates the same taps)."""
+    from oracle import metrics_ref
+    from urgent2026_challenge_track1_amd.dataset import DynamicMixingDataset
+    rng = np.random.default_rng(8)
+    for src_fs, fs, n, off, L in ((48000, 16000, 600001, 150000, 20000), (44100, 16000, 400000, 91234, 16000), (48000, 16000, 90000, 5, 20000),
+                                  (22050, 16000, 300000, 190000, 24000)):
+        x = rng.standard_normal((1, n))
+        full = metrics_ref.resample_soxr_hq_spec(x[0], src_fs, fs)
+        assert off + L <= len(full)
+        xc, off2 = DynamicMixingDataset.crop_for_resampling(x, src_fs, fs, off, L)
+        part = metrics_ref.resample_soxr_hq_spec(xc[0], src_fs, fs)
+        assert xc.shape[1] < n or (off2 == off and xc.shape[1] == n)
+        assert np.abs(part[off2:off2 + L] - full[off:off + L]).max() <= 1e-12, (src_fs, fs, np.abs(part[off2:off2 + L] - full[off:off + L]).max())
+        assert xc.shape[1] <= (L * src_fs) // fs + 2 * 4096 + 2 * (src_fs // math.gcd(src_fs, fs)) + 2

@@ -15,6 +15,8 @@ What must agree with the reference for identical shards is the order of RNG call
 import random
 from collections import defaultdict
 
+import math
+
 import numpy as np
 import torch
 from torch.utils.data import BatchSampler, DataLoader
@@ -332,6 +334,23 @@ class DynamicMixingDataset(torch.utils.data.Dataset):
         """length of n samples at src_fs after resampling to fs (librosa.resample: ceil(n * fs / src_fs))."""
         return n if src_fs == fs else -((-n * fs) // src_fs)
 
+    @staticmethod
+    def crop_for_resampling(x, src_fs, fs, offset, length, margin=4096):
+        """A noise file at a higher rate is resampled as a whole by the reference and then cropped to [offset, offset + length)
+        (read_audio + mix_noise); minutes of 48 kHz noise for a 4 s utterance need not travel to the device for that.  The polyphase
+        resampler's output sample n depends on the input only through n * down - j * up, so cutting the SOURCE at a multiple of
+        `down` (s0 = q * down <-> output index q * up) and `margin` source samples around the window (the soxr-HQ-specification filter
+        reaches < 300 source samples) gives bit-identical samples inside the window.  -> (cropped source, offset inside its resampling)."""
+        g = math.gcd(int(fs), int(src_fs))
+        up, down = int(fs) // g, int(src_fs) // g
+        n_src = x.shape[1]
+        q = max(0, (offset * down // up - margin) // down)                 # source start s0 = q * down, output start o0 = q * up
+        s0, o0 = q * down, q * up
+        s1 = min(n_src, -((-(offset + length) * down) // up) + margin)
+        if s0 == 0 and s1 == n_src:
+            return x, offset
+        return x[:, s0:s1], offset - o0
+
     def __getitem__(self, index):
         fs, j = self._index[index]
         uid = self.speech_uids[fs][j]
@@ -348,6 +367,8 @@ class DynamicMixingDataset(torch.utils.data.Dataset):
         # it is drawn on the noise length AFTER the resampling to fs
         ls, ln = speech.shape[1], self.resampled_length(noise.shape[1], noise_fs, fs)
         recipe["noise_offset"] = int(np.random.default_rng().integers(0, abs(ls - ln))) if ls != ln else 0
+        if noise_fs != fs and ln > ls:
+            noise, recipe["noise_offset"] = self.crop_for_resampling(noise, noise_fs, fs, recipe["noise_offset"], ls)
         return dict(speech=speech, noise=noise, rir=rir, recipe=recipe, fs=fs, length=speech.shape[1], noise_fs=noise_fs,
                     rir_fs=rir_fs)
 
