@@ -418,6 +418,136 @@ __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 960-point forward STFT, "slim" variant of stft960_kernel<0>: the same 32 x 30 register FFT per half-wave, but every trip through
+// LDS carries the real and the imaginary parts one after the other through ONE 992-float slice per half-wave (4 KB instead of 8),
+// and the half-wave also splits its own spectrum into the two real frames' spectra and stores them: no workgroup barrier after the
+// twiddle table is in place, 39 KB of LDS per workgroup -> four workgroups (16 waves) per CU instead of two (round 3: the kernel
+// was bound by two resident workgroups per CU running load -> DFT -> LDS -> DFT -> LDS -> store back to back).
+__global__ void __launch_bounds__(256, 3) stft960s_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
+                                                          float2* __restrict__ out, int L, int T, int hann,
+                                                          const float2* __restrict__ tw_g) {
+  constexpr int N = 960, F = 481, NFF = 8, NTH = 256, HOP = 480;
+  constexpr int ZS = 992;                                   // 32 rows of pitch 31 (pass 1 -> 2), 960 natural-order bins (pass 2 -> split)
+  __shared__ float zf[NFF][ZS];
+  __shared__ float2 tw[N];
+  const int tid = threadIdx.x, lane = tid & 63, l = lane & 31;
+  const int f = 2 * (tid >> 6) + (lane >> 5);
+  const int b = blockIdx.y;
+  const int ta = blockIdx.x * 2 * NFF + 2 * f;
+  for (int i = tid; i < N; i += NTH) tw[i] = tw_g[i];
+  const float* xb = x + (size_t)b * L;
+  const int tac = ta < T ? ta : T - 1, tbc = ta + 1 < T ? ta + 1 : T - 1;
+  const float ma = ta < T ? 1.f : 0.f, mb = ta + 1 < T ? 1.f : 0.f;
+  const int lq = l < 30 ? l : 29;
+  const int pa0 = tac * HOP - N / 2 + lq, pb0 = tbc * HOP - N / 2 + lq;
+  // samples straight into the FFT's registers: v[n1].x = frame a row n1, v[n1].y = frame b row n1; with hop 480 = 16 rows, frame
+  // b's rows 0..15 are frame a's rows 16..31 (copied below, before the window touches them)
+  float2 v[32];
+  const bool shared_rows = tbc == tac + 1;
+#pragma unroll
+  for (int n1 = 0; n1 < 32; ++n1) {
+    int qa = pa0 + 30 * n1;
+    qa = qa < 0 ? -qa : qa;
+    qa = qa >= L ? 2 * (L - 1) - qa : qa;
+    v[n1].x = xb[qa];
+  }
+#pragma unroll
+  for (int n1 = 16; n1 < 32; ++n1) {
+    int qb = pb0 + 30 * n1;
+    qb = qb < 0 ? -qb : qb;
+    qb = qb >= L ? 2 * (L - 1) - qb : qb;
+    v[n1].y = xb[qb];
+  }
+  if (!shared_rows) {
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      int qb = pb0 + 30 * n1;
+      qb = qb < 0 ? -qb : qb;
+      qb = qb >= L ? 2 * (L - 1) - qb : qb;
+      v[n1].y = xb[qb];
+    }
+  }
+  __syncthreads();                                          // twiddle table complete (the only workgroup barrier)
+  float* z = zf[f];
+  float2 u[30];
+  {
+    constexpr int BREV[32] = {0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30,
+                              1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31};
+    if (l < 30) {
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const float w = hann ? 0.5f - 0.5f * tw[30 * n1 + l].x : 1.0f;
+        const float rawb = shared_rows ? v[n1 + 16].x : v[n1].y;
+        v[n1] = make_float2(v[n1].x * w * ma, rawb * w * mb);
+      }
+#pragma unroll
+      for (int n1 = 16; n1 < 32; ++n1) {
+        const float w = hann ? 0.5f - 0.5f * tw[30 * n1 + l].x : 1.0f;
+        v[n1] = make_float2(v[n1].x * w * ma, v[n1].y * w * mb);
+      }
+      dft32_dif(v);
+#pragma unroll
+      for (int k1 = 0; k1 < 32; ++k1) {
+        const float2 a = v[BREV[k1]];
+        const float2 w = tw[l * k1];
+        v[BREV[k1]] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+      }
+#pragma unroll
+      for (int k1 = 0; k1 < 32; ++k1) z[k1 * 31 + l] = v[BREV[k1]].x;
+    }
+    // a wave's LDS accesses execute in order, so the half-wave may read what its other lanes wrote without a workgroup barrier -
+    // but only if the wave IS converged between the two: lanes 30 / 31 skip the `if` above, and without a convergent operation
+    // here the compiler threads the two identical `l < 30` tests into one branch whose other side reads before this side wrote.
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n2 = 0; n2 < 30; ++n2) u[n2].x = z[l * 31 + n2];
+    __builtin_amdgcn_wave_barrier();
+    if (l < 30) {
+#pragma unroll
+      for (int k1 = 0; k1 < 32; ++k1) z[k1 * 31 + l] = v[BREV[k1]].y;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n2 = 0; n2 < 30; ++n2) u[n2].y = z[l * 31 + n2];
+    __builtin_amdgcn_wave_barrier();
+  }
+  dft30_pfa(u);
+  // split: Xa[k] = (Z[k] + conj Z[N - k]) / 2, Xb[k] = -i (Z[k] - conj Z[N - k]) / 2, k = l + 32 j (16 bins per lane, 481 in all)
+  float zr[16], zcr[16];
+#pragma unroll
+  for (int k2 = 0; k2 < 30; ++k2) z[l + 32 * k2] = u[k2].x;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = l + 32 * j;
+    const int kc = k == 0 ? 0 : N - k;
+    zr[j] = k < F ? z[k] : 0.f;
+    zcr[j] = k < F ? z[kc] : 0.f;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k2 = 0; k2 < 30; ++k2) z[l + 32 * k2] = u[k2].y;
+  __builtin_amdgcn_wave_barrier();
+  int olen = T;
+  if (lens != nullptr) olen = lens[b] / HOP + 1;
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  float2* oa = out + ((size_t)b * T + ta) * F;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = l + 32 * j;
+    if (k < F) {
+      const int kc = k == 0 ? 0 : N - k;
+      const float zi = z[k], zci = z[kc];
+      const f32x2_t va = {0.5f * (zr[j] + zcr[j]), 0.5f * (zi - zci)};
+      const f32x2_t vb = {0.5f * (zi + zci), -0.5f * (zr[j] - zcr[j])};
+      const f32x2_t zero = {0.f, 0.f};
+      if (ta < T) __builtin_nontemporal_store(ta < olen ? va : zero, reinterpret_cast<f32x2_t*>(oa + k));
+      if (ta + 1 < T) __builtin_nontemporal_store(ta + 1 < olen ? vb : zero, reinterpret_cast<f32x2_t*>(oa + F + k));
+    }
+  }
+}
+
 // iSTFT: each workgroup owns C*hop consecutive positions of the padded OLA axis and transforms
 // the 2*NF frames that cover them (halo frames are recomputed, nothing is accumulated in HBM).
 __global__ void __launch_bounds__(256) istft_kernel(const float2* __restrict__ spec, float* __restrict__ out, int T,
@@ -609,6 +739,11 @@ extern "C" int urse_stft_fwd(const float* wav, const int32_t* lens, float* spec,
   static const bool no960 = getenv("URSE_STFT_GENERIC") != nullptr;
   if (n_fft == 960 && !no960) {
     note_launch(URSE_KV_STFT960);
+    static const bool slim = getenv("URSE_STFT960_SLIM") == nullptr || atoi(getenv("URSE_STFT960_SLIM")) != 0;
+    if (slim && hop == 480)
+      hipLaunchKernelGGL(stft960s_kernel, dim3(ceil_div(T, 16), B), dim3(256), 0, (hipStream_t)stream, wav, lens,
+                         reinterpret_cast<float2*>(spec), L, T, window == URSE_WIN_HANN ? 1 : 0, tb.tw);
+    else
     hipLaunchKernelGGL(stft960_kernel<0>, dim3(ceil_div(T, 2 * URSE_STFT960_NFF), B), dim3(URSE_STFT960_NFF_THREADS), 0, (hipStream_t)stream, wav, lens,
                        reinterpret_cast<float2*>(spec), L, T, hop, window == URSE_WIN_HANN ? 1 : 0, tb.tw);
     URSE_CHECK_LAUNCH("urse_stft_fwd");
