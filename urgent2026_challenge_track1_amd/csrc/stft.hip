@@ -375,7 +375,10 @@ __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const
       zbuf[f][k1 * 31 + l] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);   // row pitch 31: conflict-free reads
     }
   }
-  // pass 1 and pass 2 of an FFT run in the same half-wave: LDS executes a wave's accesses in order, no barrier needed
+  // pass 1 and pass 2 of an FFT run in the same half-wave: LDS executes a wave's accesses in order, no workgroup barrier needed -
+  // but the wave must be converged between the writes (lanes 0..29) and the reads (lanes 0..31): a convergent no-op pins that
+  // (round 3: a kernel with two `l < 30` blocks around such reads was compiled into branches that read before the other side wrote)
+  __builtin_amdgcn_wave_barrier();
   {
     float2 u[30];
 #pragma unroll
@@ -689,6 +692,7 @@ __global__ void __launch_bounds__(IS960_NFF * 32) istft960_kernel(const float2* 
       zbuf[f][k1 * 31 + l] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
     }
   }
+  __builtin_amdgcn_wave_barrier();        // converged between the half-wave's LDS writes and reads (see stft960_kernel)
   {
     float2 u[30];
 #pragma unroll
