@@ -328,6 +328,15 @@ USE_CLUSTER_LSTM_BWD = os.environ.get("URSE_LSTM_CLUSTER_BWD", "0") == "1"
 # deferred weight-gradient launches while they are in flight on the second stream): the cooperative kernels' plans leave
 # that many CUs alone and REFUSE a grid that would not be co-resident on the rest (-> streaming kernel) instead of spinning
 CO_RESIDENT_WGS = 0
+# ... and CUs left to the dynamic-mixing prefetcher's simulator kernels, which run on a low-priority stream beside the WHOLE step,
+# forward included (train_se.DevicePrefetcher sets it to 8 while it stages simulated batches): at C2 the time path's cluster forward
+# then forms 17 clusters of 64 sequences instead of 18 of 61 - same row tiles, same speed - and 14 CUs stay free, so that its
+# workgroups never wait for a simulator workgroup to leave a CU (a 60 ms single-workgroup FFT launch once cost 15 ms per step that way)
+PREFETCH_RESERVED_CUS = 0
+
+
+def reserved_cus():
+    return int(CO_RESIDENT_WGS) + int(PREFETCH_RESERVED_CUS)
 
 
 def lstm_cluster_plan(H, Hp, n_seq):
@@ -335,7 +344,7 @@ def lstm_cluster_plan(H, Hp, n_seq):
     import ctypes
     plan = (ctypes.c_int64 * 6)()
     lib = _lib.load()
-    if lib.urse_lstm_cluster_plan(H, Hp, n_seq, int(CO_RESIDENT_WGS), plan) != 0:
+    if lib.urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus(), plan) != 0:
         return None
     return list(plan)
 
@@ -344,7 +353,7 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
     """persistent cluster LSTM forward (bf16): see csrc/lstm_cluster.hip."""
     plan = lstm_cluster_plan(H, Hp, n_seq)
     M, dev = gx.shape[0], gx.device
-    key = (dev, H, Hp, n_seq)
+    key = (dev, H, Hp, n_seq, plan[4], plan[5])
     if key not in _cluster_ws:
         _cluster_ws[key] = (torch.zeros(plan[4], device=dev, dtype=torch.bfloat16),
                             torch.zeros(plan[5], device=dev, dtype=torch.int32),
@@ -354,7 +363,7 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
     hout = _hout_buffer(M, ldh, H, gx)
     c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster_fwd", gx, gx.stride(0), whhq, hout, ldh,
-               c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), int(CO_RESIDENT_WGS), stream_ptr())
+               c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), reserved_cus(), stream_ptr())
     return hout, c, err
 
 
@@ -365,7 +374,7 @@ CLUSTER2_H = tuple(int(v) for v in os.environ.get("URSE_LSTM_CLUSTER2_H", "768")
 def lstm_cluster2_plan(H, Hp, n_seq):
     import ctypes
     plan = (ctypes.c_int64 * 4)()
-    if _lib.load().urse_lstm_cluster2_plan(H, Hp, n_seq, int(CO_RESIDENT_WGS), plan) != 0:
+    if _lib.load().urse_lstm_cluster2_plan(H, Hp, n_seq, reserved_cus(), plan) != 0:
         return None
     return list(plan)
 
@@ -383,7 +392,7 @@ def lstm_cluster2_chunks(H, Hp, n_seq, seq_len, inner, outer, stride):
     if probe is None:
         return None
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    cap = max(1, (cus - int(CO_RESIDENT_WGS) - 4) // 2 // probe[0]) * 64
+    cap = max(1, (cus - reserved_cus() - 4) // 2 // probe[0]) * 64
     n = (n_seq + cap - 1) // cap
     if n > CLUSTER2_MAX_CHUNKS:
         return None
@@ -404,7 +413,7 @@ def lstm_fwd_cluster2(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, sav
     err = None
     for s0, n in chunks:
         plan = lstm_cluster2_plan(H, Hp, n)
-        key = ("c2", dev, H, Hp, n)
+        key = ("c2", dev, H, Hp, n, plan[3])
         if key not in _cluster_ws:
             _cluster_ws[key] = (torch.empty(plan[3], device=dev, dtype=torch.bfloat16), kernel_error_flag(dev))
         hx, err = _cluster_ws[key]
@@ -414,7 +423,7 @@ def lstm_fwd_cluster2(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, sav
             r0, r1 = s0 * seq_len, (s0 + n) * seq_len
             g_, h_, c_ = gx[r0:r1], hout[r0:r1], (c[r0:r1] if save else None)
         timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster2_fwd", g_, gx.stride(0), whhq, h_, ldh, c_, hx,
-                   err, H, Hp, n, seq_len, inner, outer, stride, int(save), int(CO_RESIDENT_WGS), stream_ptr())
+                   err, H, Hp, n, seq_len, inner, outer, stride, int(save), reserved_cus(), stream_ptr())
     return hout, c, err
 
 
@@ -491,14 +500,14 @@ def lstm_bwd_cluster(dh, gates, c, whhTq, H, Hp, n_seq, seq_len, inner, outer, s
     """persistent cluster BPTT (bf16): gates (saved activations) is overwritten with d(pre-activations)."""
     plan = lstm_cluster_plan(H, Hp, n_seq)
     dev = gates.device
-    key = ("bwd", dev, H, Hp, n_seq)
+    key = ("bwd", dev, H, Hp, n_seq, plan[1], plan[5])
     if key not in _cluster_ws:
         _cluster_ws[key] = (torch.zeros(2 * 2 * plan[1] * 64 * 4 * H, device=dev, dtype=torch.bfloat16),
                             torch.zeros(plan[5], device=dev, dtype=torch.int32),
                             kernel_error_flag(dev))
     dgx, cnt, err = _cluster_ws[key]
     timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_cluster_bwd", dh, dh.stride(0), gates,
-               gates.stride(0), c, whhTq, dgx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(CO_RESIDENT_WGS), stream_ptr())
+               gates.stride(0), c, whhTq, dgx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, reserved_cus(), stream_ptr())
     return gates, err
 
 
@@ -515,7 +524,7 @@ def lstm_split_plan(H, n_seq):
     """None if the split BPTT kernel does not support this shape."""
     import ctypes
     plan = (ctypes.c_int64 * 4)()
-    if _lib.load().urse_lstm_split_plan(H, n_seq, int(CO_RESIDENT_WGS), plan) != 0:
+    if _lib.load().urse_lstm_split_plan(H, n_seq, reserved_cus(), plan) != 0:
         return None
     return list(plan)
 
@@ -546,7 +555,7 @@ def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
     err = None
     for s0, n in chunks:
         plan = lstm_split_plan(H, n)
-        key = ("split", dev, H, n)
+        key = ("split", dev, H, n, plan[2])
         if key not in _cluster_ws:
             _cluster_ws[key] = (torch.empty(plan[2], device=dev, dtype=torch.float32), kernel_error_flag(dev))
         xbuf, err = _cluster_ws[key]
@@ -556,7 +565,7 @@ def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
             r0, r1 = s0 * seq_len, (s0 + n) * seq_len
             d_, g_, c_ = dh[r0:r1], gates[r0:r1], c[r0:r1]
         timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_split_bwd", d_, dh.stride(0), g_, gates.stride(0), c_,
-                   whhT, xbuf, err, H, n, seq_len, inner, outer, stride, int(CO_RESIDENT_WGS), stream_ptr())
+                   whhT, xbuf, err, H, n, seq_len, inner, outer, stride, reserved_cus(), stream_ptr())
     return gates, err
 
 

@@ -94,6 +94,8 @@ class DevicePrefetcher:
         self.stream = ops.low_priority_stream(dev, force=True) if torch.device(dev).type == "cuda" else None
 
     def _stage(self, batch):
+        if isinstance(batch, RawMixBatch):
+            ops.PREFETCH_RESERVED_CUS = 8          # simulator kernels beside the step: the cooperative forward leaves them CUs (ops.py)
         if self.stream is None:
             return to_device(batch, self.dev, self.skipped), None
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # buffers freed by the consumer are safe to reuse
