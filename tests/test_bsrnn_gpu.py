@@ -143,3 +143,28 @@ def test_dual_path_and_band_split_match_reference_twin_vectors(lib):
             worst = max(worst, e)
             assert e <= 1e-3, (fold, e)
     print("HIP vs reference-twin vectors: worst relative error %.2e" % worst)
+
+
+@pytest.mark.parametrize("fs,nsamp", [(24000, 4800), (32000, 6400), (44100, 8820)])
+def test_forward_f32_at_the_other_corpus_rates(lib, fs, nsamp):
+    """URGENT-2026 speech comes at 8 / 16 / 22.05 / 24 / 32 / 44.1 / 48 kHz: the remaining three rates (n_fft 480 / 640 /
+    882, K = 29 / 31 / 34 bands) through the whole model, forward and input gradient, f32 mode vs the oracle at 1e-3."""
+    ref, mine = _pair(16, 1, torch.float32, seed=fs)
+    g = torch.Generator().manual_seed(fs)
+    x = 0.3 * torch.randn(2, nsamp, generator=g)
+    lens = torch.tensor([nsamp, nsamp - 500])
+    wav_r, spec_r = ref(x, lens, fs)
+    wav_m, spec_m = mine(x.cuda(), lens, fs)
+    assert spec_m.shape == spec_r.shape
+    assert (wav_m.detach().cpu() - wav_r.detach()).abs().max().item() <= 1e-3 * wav_r.abs().max().item()
+    assert (spec_m.detach().cpu() - spec_r.detach()).abs().max().item() <= 1e-3 * spec_r.abs().max().item()
+    gw = torch.randn(wav_r.shape, generator=g)
+    wav_r.backward(gw)
+    wav_m.backward(gw.cuda())
+    refg = dict(ref.named_parameters())
+    for n, p in mine.named_parameters():
+        gr = refg[n].grad
+        if gr is None:
+            assert torch.all(p.grad == 0), n
+        else:
+            assert (p.grad.cpu() - gr).abs().max().item() <= 1e-3 * gr.abs().max().item() + 1e-6, n
