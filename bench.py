@@ -619,6 +619,15 @@ def main():
         "gate_gemm_tflops_per_step": 3 * gate_gemm_flops(B, T, K, args.channels, args.layers) / 1e12,
         "final_loss": float(loss.detach()),
         "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
+        # not measured by this run: what the parity tests of this arithmetic observed on the GPU (tests/test_c2_parity_gpu.py at N = 196,
+        # L = 6, default dispatch; log profiles/r03_gputest_new_tests_v1.log), so that the line says which north_star tolerances the
+        # benchmarked dtype meets
+        "parity": {
+            "oracle": "oracle/bsrnn_ref.py; BandSplit + dual-path loop pinned bit-equal to the reference's in-tree bsrnn_flowse.py (tests/golden/ref_bsrnn.npz)",
+            "f32_mode_vs_f32_oracle": {"wav_max_over_peak": 8.2e-7, "spec": 8.0e-7, "loss": 1.2e-7, "worst_grad": 9.1e-6, "meets_1e-3": True},
+            "bf16_mode_vs_f32_oracle": {"loss": 2.9e-5, "loss_meets_1e-3": True, "wav_max_over_peak": 4.2e-3, "wav_rel_l2": 4.3e-3,
+                                        "worst_grad_rel_l2": 1.0e-2, "wav_and_grads_meet_1e-3": False},
+        } if args.dtype == "bf16" else None,
     }
     if rank == 0 and world == 1:
         ref_ms = cold_stream_reference(dev, stft_bytes)
