@@ -433,6 +433,10 @@ def main():
     ap.add_argument("--no-flow", action="store_true", help="skip the extra BSRNN-Flow (config C4) leg")
     ap.add_argument("--model", default="bsrnn", choices=["bsrnn", "flow"],
                     help="flow: print the BSRNN-Flow (config C4) line instead of the headline one")
+    ap.add_argument("--single-rank-collectives", action="store_true",
+                    help="with one rank: still create the process group on --dist-backend (nccl = RCCL) and send every gradient bucket, "
+                         "the weight broadcast, the barriers and the checksum reductions through it - the N > 1 code path with a "
+                         "communicator of size 1 (a 1-GPU box cannot hold two RCCL ranks)")
     ap.add_argument("--dynamic-mix", action="store_true",
                     help="config C3's feed: every step draws B recipes (DynamicMixingDataset) and simulates the batch on the GPU "
                          "inside the timed region")
@@ -465,8 +469,11 @@ def main():
     dev = torch.device("cuda", local)
     if args.pretouch_gib > 0:
         _pretouch(dev, args.pretouch_gib)
-    if world > 1:
+    use_dist = world > 1 or args.single_rank_collectives
+    if use_dist:
         import torch.distributed as dist
+        if world == 1 and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -494,9 +501,9 @@ def main():
     model = SEModel(cfg).to(dev)
     core = model.se_model.core
     (opt,), _ = model.configure_optimizers()
-    if world > 1:   # identical initial weights on every rank
+    if use_dist:   # identical initial weights on every rank
         dist.broadcast(core.flat_params, 0)
-    reducer = GradBucketReducer(core) if world > 1 else None
+    reducer = GradBucketReducer(core, force=args.single_rank_collectives) if use_dist else None
     clean, noisy = synth_batch(B, L, fs, 2024 + rank, dev)
     lens = torch.full((B,), L, dtype=torch.int32)
     fs_t = torch.tensor(fs, dtype=torch.int32)
@@ -550,18 +557,18 @@ def main():
     names = ["lstm_fwd_time", "lstm_fwd_band", "lstm_bwd_time", "lstm_bwd_band", "stft_fwd"]
     ops.enable_timing(names)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     timing = ops.disable_timing()
     sync_ok = None
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -607,7 +614,7 @@ def main():
                                                                    "; fed by DynamicMixingDataset recipes simulated on the GPU inside the step"
                                                                    if args.dynamic_mix else ""),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "dist_backend": (args.dist_backend if world > 1 else None)},
+                   "dist_backend": (args.dist_backend if use_dist else None)},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                      "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
                      "traffic_source": traffic_src, "algorithmic_flops_per_launch": dom_flops,
@@ -639,6 +646,9 @@ def main():
                         "timed the same way (one event pair per launch, caches evicted in front), is the cold_stream_reference"})
     if sync_ok is not None:
         out["ranks_hold_identical_weights"] = sync_ok
+    if reducer is not None:
+        out["gradient_buckets"] = {"buckets": len(reducer.buckets), "collectives_issued": reducer.launched,
+                                   "bucket_MB": [round((hi - lo) * 4 / 1e6, 1) for _, lo, hi in reducer.buckets]}
     if args.dynamic_mix:
         out["dynamic_mix"] = {"augmentations_drawn_but_not_applied": skipped}
     if rank == 0 and world == 1 and not args.no_flow:
@@ -651,7 +661,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

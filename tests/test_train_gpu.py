@@ -110,3 +110,30 @@ def test_bench_gpus_2_starts_its_own_ranks():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["ranks_hold_identical_weights"] is True and d["config"]["dist_backend"] == "gloo"
     assert d["config"]["global_batch"] == 4 and "dynamic_mix" in d
+
+
+@pytest.mark.gpu
+def test_single_rank_rccl_carries_the_gradient_buckets():
+    """The RCCL leg of the N > 1 step on a 1-GPU box: `--single-rank-collectives` creates the `nccl` (= RCCL) process group with one
+    rank and sends the weight broadcast, every gradient bucket (async, on the reducer's stream, beside the backward's kernels), the
+    barriers and the checksum reductions through it.  The step must issue one collective per bucket and step, end with the loss
+    the plain one-GPU run ends with, and the line must say backend nccl.  (Two RCCL ranks cannot share a device; the two-rank
+    arithmetic is covered over gloo above.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--pretouch-gib", "0",
+            "--batch", "2", "--seconds", "1", "--channels", "32", "--layers", "2", "--no-flow", "--no-metrics", "--no-cpu-baseline"]
+    lines = []
+    for extra in ([], ["--single-rank-collectives", "--dist-backend", "nccl"]):
+        r = subprocess.run(base + extra, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+        lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    plain, rccl = lines
+    assert plain["config"]["dist_backend"] is None and "gradient_buckets" not in plain
+    assert rccl["config"]["dist_backend"] == "nccl" and rccl["n_gpus"] == 1 and rccl["ranks_hold_identical_weights"] is True
+    gb = rccl["gradient_buckets"]
+    assert gb["buckets"] >= 1 and gb["collectives_issued"] == gb["buckets"] * 4          # 1 warm-up + 3 timed steps
+    # (the weight-gradient GEMMs sum their K slices with f32 atomics, so two runs agree to rounding, not bit for bit)
+    assert abs(rccl["final_loss"] - plain["final_loss"]) <= 1e-3 * abs(plain["final_loss"]), (rccl["final_loss"], plain["final_loss"])

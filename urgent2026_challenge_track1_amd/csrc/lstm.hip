@@ -296,7 +296,15 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+#ifdef BABL_HOT_INPUTS   // timing diagnostic (wrong results): every workgroup and step reads the same 16 * RT rows, i.e. the inputs are L2 hits
+#if BABL_HOT_INPUTS >= 2   // ... its own rows of ONE step (12 MB over the chip); 3: the gradient store goes to those rows too
+        const int row = (int)rowb(rt, r) + (p.m.seq_len / 2) * stride_i + 0 * tt;
+#else
+        const int row = rt * 16 + lr * 4 + r + 0 * tt;
+#endif
+#else
         const int row = (int)rowb(rt, r) + tt * stride_i;
+#endif
 #ifdef BABL_NO_P1LOAD
         gpf[slot][rt][r] = V4{}; cpf[slot][rt][r] = (float)row; dhpf[slot][rt][r] = T(row & 1);
 #else
@@ -308,7 +316,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #ifdef BABL_NO_C
         cpf[slot][rt][r] = (float)row;
 #else
+#ifdef BABL_HOT_INPUTS
+        cpf[slot][rt][r] = first_ ? 0.f : p.c[(long)row * ldc_i + (hcol_i + u)];
+#else
         cpf[slot][rt][r] = first_ ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + u)];
+#endif
 #endif
 #ifdef BABL_NO_DH
         dhpf[slot][rt][r] = T(row & 1);
@@ -358,8 +370,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
               const V4 pk = Vec4<T>::pack(dg);
               *reinterpret_cast<V4*>(tile + (rt * 16 + lr * 4 + r) * pitch + (u * 4) * ES) = pk;
 #ifndef BABL_NO_STORE
+#if defined(BABL_HOT_INPUTS) && BABL_HOT_INPUTS == 3
+              if (rowbase[rt][r] >= 0)
+                *reinterpret_cast<V4*>(gates + ((long)(rowbase[rt][r] + (p.m.seq_len / 2) * stride_i) * ldg_i + (gcol_i + u * 4))) = pk;
+#else
               if (rowbase[rt][r] >= 0)
                 *reinterpret_cast<V4*>(gates + ((long)(rowbase[rt][r] + t * stride_i) * ldg_i + (gcol_i + u * 4))) = pk;
+#endif
 #endif
             }
         }

@@ -12,10 +12,13 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, core, bucket_bytes=25 * 1024 * 1024, group=None):
+    def __init__(self, core, bucket_bytes=25 * 1024 * 1024, group=None, force=False):
+        """``force``: issue the collectives even on a communicator of size 1 (functional check of the RCCL path on a 1-GPU box)."""
         self.core = core
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        self.launched = 0                      # collectives issued since construction
         self.flat = core.flat_grads
         self.on_gpu = self.flat.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
@@ -37,8 +40,9 @@ class GradBucketReducer:
 
     def _launch(self, lo, hi):
         view = self.flat[lo:hi]
-        if self.world == 1:
+        if not self.active:
             return
+        self.launched += 1
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -59,13 +63,13 @@ class GradBucketReducer:
         """Block the compute stream until every bucket is reduced; returns the 1/world scale for the optimizer."""
         for w in self._works:
             w.wait()
-        if self.on_gpu and self.world > 1:
+        if self.on_gpu and self.active:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works = []
         # every bucket must have been reduced by now: a bucket with tags still pending means this rank would step on
         # local, un-averaged gradients while its peers wait in an all-reduce - fail loudly instead
         for i, (tags, lo, hi) in enumerate(self.buckets):
-            if self._pending[i] and self.world > 1:
+            if self._pending[i] and self.active:
                 raise RuntimeError("backward finished without reducing bucket %d (pending parameter groups: %s)"
                                    % (i, sorted(self._pending[i])))
             self._pending[i] = set(tags)
