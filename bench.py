@@ -57,6 +57,24 @@ def synth_batch(B, L, fs, seed, device):
     return (clean * sc).to(device), (noisy * sc).to(device)
 
 
+def l2_port_roofline(kernel, ms, B, T, K, H):
+    """L2 -> CU bytes of the recurrent weights per launch of a streaming BPTT kernel against the CUs' L2 ports (None for the
+    forward kernels, which keep W_hh in registers / stream it with other geometry)."""
+    geo = {"lstm_bwd_time": (B * K, T, 16), "lstm_bwd_band": (B * T, K, 32)}.get(kernel)
+    if geo is None:
+        return None
+    n_seq, steps, rows = geo
+    wgs = 2 * -(-n_seq // rows)                                  # both directions
+    per_step = 4 * H * H * 2                                      # one direction's W_hh^T, bf16
+    total = wgs * (steps - 1) * per_step
+    cus = min(wgs, 256)
+    per_cu = total / cus / (ms * 1e-3) / 1e9                     # average over the CUs that hold workgroups
+    return {"bound": "l2-port", "kernel": kernel, "workgroups": wgs, "bytes_per_launch": total, "GBs_per_cu": per_cu,
+            "peak_GBs_per_cu": 34500.0 / 256, "frac": per_cu / (34500.0 / 256), "cus": cus,
+            "note": "whole-launch average; the weight pass itself runs at ~120 GB/s per CU, the rest of a step (inputs, cell update, "
+                    "gradient store) uses the same vector memory path one after the other"}
+
+
 def gate_gemm_flops(B, T, K, N, layers):
     """BLSTM gate GEMM FLOPs of one forward: 24 directional LSTMs x 4H(I+H) MAC x T*K rows."""
     H = 2 * N
@@ -619,6 +637,10 @@ def main():
                      "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
                      "traffic_source": traffic_src, "algorithmic_flops_per_launch": dom_flops,
                      "kernel_ms": kt[dom][0], "launches_per_step": kt[dom][1] / args.steps},
+        # what actually binds the streaming BPTT: every workgroup streams its direction's W_hh^T from the XCD's L2
+        # once per time step through ONE CU's vector memory path; peak per CU = 34.5 TB/s / 256 (MI355X_MICROARCH.md, L2), measured
+        # ceiling 136 GB/s (scripts/diag/l2warm.py).  Supplementary to `roofline` (whose bound must be hbm or mfma).
+        "recurrent_weight_stream": l2_port_roofline(dom, kt[dom][0], B, T, K, H),
         "kernels_ms_per_step": {n: tot_ms[n] / args.steps for n in tot_ms},
         "stft_roofline": {"bound": "hbm", "achieved": stft_bytes / (kt["stft_fwd"][0] * 1e-3) / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
