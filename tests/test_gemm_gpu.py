@@ -192,6 +192,11 @@ def test_gemm_tn_grouped_matches_single_calls(lib, dtype):
 
 @pytest.mark.parametrize("dtype,R,H,N,inner,period,rev", [(torch.bfloat16, 34 * 20 * 25, 392, 196, 34, 25, False),
                                                           (torch.bfloat16, 34 * 20 * 25, 392, 196, 34, 25, True),
+                                                          # whole 32-row stages and whole (inner x period) blocks: the 224 x 320 tile kernel
+                                                          (torch.bfloat16, 34 * 32 * 16, 392, 196, 34, 32, False),
+                                                          (torch.bfloat16, 34 * 32 * 16, 392, 196, 34, 32, True),
+                                                          (torch.bfloat16, 34 * 544, 392, 196, 1, 34, False),
+                                                          (torch.bfloat16, 34 * 544, 392, 196, 1, 34, True),
                                                           (torch.float32, 600, 24, 16, 5, 12, False)])
 def test_gemm_tn_dual_matches_two_calls(lib, dtype, R, H, N, inner, period, rev):
     """both weight gradients of one LSTM direction in one pass over the dgates == the two separate contractions

@@ -886,6 +886,251 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// TN, dual operand, 224 x 320 output tile (bf16).  The dual weight gradient of one LSTM direction is [Mo = 4H] x [No | No2] =
+// 1568 x (196 | 392): on the 256 x 224 tiles of gemm_tn_dma_kernel that is 7 x 3 tiles of which 23 % is padding (1792 x 672 computed
+// for 1568 x 588).  Here the two right-hand operands form ONE virtual matrix [B (No rounded up to 8 columns) | B2 | ones column],
+// 200 + 392 + 1 = 593 columns, cut into two 320-column tiles, and the rows into seven 224-row tiles: 14 tiles per row slice, 8 %
+// padding.  The ones column turns the bias gradient (column sums of A) into one more output column instead of extra accumulators.
+// Workgroup: 8 waves = 2 (m) x 4 (n), 7 x 5 MFMA tiles per wave (140 accumulator registers).  Stage = 32 rows: A image 32 x 512 B
+// (224 of 256 columns used), B image columns 0..255 (32 x 512 B) and columns 256..319 (32 x 128 B, its own swizzle key), 36 KB;
+// 4-stage LDS-DMA ring, one barrier per stage.  Per lane a DMA source is fixed for the whole slice: B rows, B2 rows (shifted, step
+// mask), the ones page or the zero page.
+#define URSE_O4 0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u
+#define URSE_O16 URSE_O4, URSE_O4, URSE_O4, URSE_O4
+#define URSE_O64 URSE_O16, URSE_O16, URSE_O16, URSE_O16
+__device__ __attribute__((aligned(1024))) unsigned g_tn_ones_page[256] = {URSE_O64, URSE_O64, URSE_O64, URSE_O64};
+#undef URSE_O4
+#undef URSE_O16
+#undef URSE_O64
+// swizzle key of the 128-byte-pitch image (four 32-byte segments per row): the eight rows of a 32-lane read group (q, 8 + q) alternate
+// between the two bank halves by row parity, so rows of equal parity must differ in the key: bit 1 and bit 3 of the row
+__device__ __forceinline__ int tn_swz4(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+// One LDS-DMA wave-instruction with the LDS destination given as a byte address in an SGPR (no generic -> LDS pointer cast with its null
+// check on the scalar unit, no save / restore of m0: the compiler is told that m0 is clobbered).
+__device__ __forceinline__ void glds16u(const char* gsrc, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(dst) : "memory", "m0");
+}
+
+__global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
+  constexpr int BMX = 224, BNX = 320, NST = 4, STAGE = 36864, MT = 7, NT = 5;
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
+  const long No8 = (p.No + 7) & ~7L;
+  const long V = No8 + p.No2;                               // virtual columns [0, No8) from B, [No8, V) from B2, V = ones (colsum)
+  const long vones = p.colsum ? V : -1;
+  const int tn = (int)((V + (p.colsum ? 1 : 0) + BNX - 1) / BNX);
+  const int tiles = tn * (int)(p.Mo / BMX);
+  const int lid = xcd_remap(blockIdx.x, (int)gridDim.x);
+  const int slice = lid / tiles, tile = lid - slice * tiles;
+  const int tile_m = tile / tn, tile_n = tile - tile_m * tn;
+  const long m0 = (long)tile_m * BMX, n0 = (long)tile_n * BNX;
+  const long r_begin = (long)slice * p.rows_per_slice;
+  long r_end = r_begin + p.rows_per_slice;
+  if (r_end > p.R) r_end = p.R;
+  if (r_begin >= r_end) return;
+  const int nk = (int)((r_end - r_begin) / 32);            // the host guarantees whole 32-row stages (R and the slices are multiples of 32)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 2, wn = w & 3;
+
+  // ---- DMA sources.  The issue path is what bounds a ring kernel of this shape (two waves per SIMD, in-order issue): every lane keeps
+  // a 64-bit source pointer and a 32-bit step per DMA; a lane without data (padding columns) points at the zero page with step 0, the
+  // ones column at the ones page; the only run-time predicate is the step mask of the shifted operand: (row / inner) % period ==
+  // invalid_step, tracked per row group.  Rows outside the matrix only occur on masked rows (checked on the host: shift = -/+ inner
+  // with the first / last step masked), stages past the slice end are issued from the zero page by a wave-uniform branch.
+  const char* zsrc = reinterpret_cast<const char*>(g_tn_zero_page) + lane * 16;
+  const char* osrc = reinterpret_cast<const char*>(g_tn_ones_page) + lane * 16;
+  const unsigned inner_u = (unsigned)p.inner, per_u = (unsigned)p.period, inval_u = (unsigned)p.invalid_step;
+  const unsigned step_q = (32u / inner_u) % per_u, step_r = 32u % inner_u;
+  struct Row { unsigned ph, rm; };                         // (row / inner) % period, row % inner of a DMA row group
+  auto init_row = [&](Row& q, int rowl) __attribute__((always_inline)) {
+    const unsigned rr = (unsigned)((int)r_begin + rowl);
+    q.ph = (rr / inner_u) % per_u;
+    q.rm = rr % inner_u;
+  };
+  auto next_row = [&](Row& q) __attribute__((always_inline)) {
+    q.rm += step_r;
+    const unsigned c = q.rm >= inner_u ? 1u : 0u;
+    q.rm -= c ? inner_u : 0u;
+    q.ph += step_q + c;
+    q.ph -= q.ph >= per_u ? per_u : 0u;
+  };
+  struct Src { const char* ptr; unsigned step, bad; };     // bad: the step phase on which the lane reads zeros (~0: never)
+  auto init_b = [&](Src& b, long v, int rr0) __attribute__((always_inline)) {
+    b.ptr = zsrc; b.step = 0u; b.bad = ~0u;
+    if (v < No8) {
+      if (v < p.ldb) { b.ptr = p.B + ((long)rr0 * p.ldb + v) * 2; b.step = (unsigned)(64 * p.ldb); }
+    } else if (v < V) {
+      b.ptr = p.B2 + (((long)rr0 + p.shift) * p.ldb2 + (v - No8)) * 2; b.step = (unsigned)(64 * p.ldb2); b.bad = inval_u;
+    } else if (v == (vones & ~7L)) {                       // the 8-column chunk that holds the ones column (the other 7 are dropped)
+      b.ptr = osrc;
+    }
+  };
+  const unsigned lds_u = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+  const int half = lane >> 5, chunk = lane & 31;
+  Row rw0, rw1, rw2;
+  Src sa0, sa1, sb0, sb1, sb2;
+  {
+    const int rowl0 = 4 * w + half, rowl1 = 4 * w + 2 + half;
+    init_row(rw0, rowl0);
+    init_row(rw1, rowl1);
+    const int cel0 = (((chunk >> 1) ^ tn_swz(rowl0)) << 4) + (chunk & 1) * 8;
+    const int cel1 = (((chunk >> 1) ^ tn_swz(rowl1)) << 4) + (chunk & 1) * 8;
+    const bool aok0 = cel0 < BMX && m0 + cel0 < p.lda, aok1 = cel1 < BMX && m0 + cel1 < p.lda;
+    sa0.ptr = aok0 ? p.A + ((long)((int)r_begin + rowl0) * p.lda + m0 + cel0) * 2 : zsrc;
+    sa1.ptr = aok1 ? p.A + ((long)((int)r_begin + rowl1) * p.lda + m0 + cel1) * 2 : zsrc;
+    sa0.step = aok0 ? (unsigned)(64 * p.lda) : 0u;
+    sa1.step = aok1 ? (unsigned)(64 * p.lda) : 0u;
+    sa0.bad = sa1.bad = ~0u;
+    init_b(sb0, n0 + cel0, (int)r_begin + rowl0);
+    init_b(sb1, n0 + cel1, (int)r_begin + rowl1);
+    const int rowl2 = 8 * (w & 3) + (lane >> 3), c16 = lane & 7;
+    init_row(rw2, rowl2);
+    const int cel2 = 256 + (((c16 >> 1) ^ tn_swz4(rowl2)) << 4) + (c16 & 1) * 8;
+    init_b(sb2, n0 + cel2, (int)r_begin + rowl2);
+  }
+  int issued = 0;                                           // stages issued so far (wave-uniform)
+  auto issue = [&](int slot) __attribute__((always_inline)) {
+    const unsigned st = lds_u + (unsigned)slot * STAGE + (unsigned)w * 2048;
+    if (issued < nk) {
+#if defined(T224_ZERO_DMA)
+      glds16u(zsrc, st); glds16u(zsrc, st + 1024); glds16u(zsrc, st + 16384); glds16u(zsrc, st + 16384 + 1024);
+#elif defined(T224_NO_DMA)
+      asm volatile("" :: "v"(sa0.ptr), "v"(sa1.ptr), "v"(rw0.ph != sb0.bad ? sb0.ptr : zsrc), "v"(rw1.ph != sb1.bad ? sb1.ptr : zsrc));
+#else
+      glds16u(sa0.ptr, st);
+      glds16u(sa1.ptr, st + 1024);
+      glds16u(rw0.ph != sb0.bad ? sb0.ptr : zsrc, st + 16384);
+      glds16u(rw1.ph != sb1.bad ? sb1.ptr : zsrc, st + 16384 + 1024);
+#endif
+      sa0.ptr += sa0.step; sa1.ptr += sa1.step; sb0.ptr += sb0.step; sb1.ptr += sb1.step;
+      next_row(rw0);
+      next_row(rw1);
+      if (w < 4) {
+#if defined(T224_ZERO_DMA)
+        glds16u(zsrc, lds_u + (unsigned)slot * STAGE + 32768 + (unsigned)w * 1024);
+#elif defined(T224_NO_DMA)
+        asm volatile("" :: "v"(rw2.ph != sb2.bad ? sb2.ptr : zsrc));
+#else
+        glds16u(rw2.ph != sb2.bad ? sb2.ptr : zsrc, lds_u + (unsigned)slot * STAGE + 32768 + (unsigned)w * 1024);
+#endif
+        sb2.ptr += sb2.step;
+        next_row(rw2);
+      }
+    } else {                                                // past the slice: keep the DMA count per stage, read nothing
+      glds16u(zsrc, st); glds16u(zsrc, st + 1024); glds16u(zsrc, st + 16384); glds16u(zsrc, st + 16384 + 1024);
+      if (w < 4) glds16u(zsrc, lds_u + (unsigned)slot * STAGE + 32768 + (unsigned)w * 1024);
+    }
+    ++issued;
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads (ds_read_b64_tr_b16): rows row0 and row0 + 4 of the image, 8 bytes at pp * 8 of the 32-byte segment S ^ key(row).
+  // The segment field (bits 5..8, bits 5..6 in the 128-byte-pitch image) is disjoint from the row / pp bits, so the address is
+  // (per-lane constant) ^ (S << 5): one xor-add per read.
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int row0 = 8 * g + q;
+  const unsigned ba0 = (unsigned)(row0 * 512 + pp * 8) ^ ((unsigned)tn_swz(row0) << 5);
+  const unsigned ba1 = (unsigned)((row0 + 4) * 512 + pp * 8) ^ ((unsigned)tn_swz(row0 + 4) << 5);
+  const unsigned bb0 = (unsigned)(32768 + row0 * 128 + pp * 8) ^ ((unsigned)tn_swz4(row0) << 5);
+  const unsigned bb1 = (unsigned)(32768 + (row0 + 4) * 128 + pp * 8) ^ ((unsigned)tn_swz4(row0 + 4) << 5);
+  auto frag = [&](unsigned a0, unsigned a1) __attribute__((always_inline)) -> short8_t {
+    short4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(size_t)a0);
+    short4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(size_t)a1);
+    return short8_t{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  };
+  const short8_t ones8 = short8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  (void)ones8;
+  const unsigned sA = (unsigned)(wm * MT) << 5, sB = (unsigned)(wn * NT) << 5;
+  auto compute = [&](int sl) __attribute__((always_inline)) {
+    const unsigned st = lds_u + (unsigned)sl * STAGE;
+    short8_t a[MT], b[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#ifdef T224_NO_READ
+      a[i] = ones8; asm volatile("" : "+v"(a[i]));
+#else
+      a[i] = frag((ba0 ^ (sA + (i << 5))) + st, (ba1 ^ (sA + (i << 5))) + st);
+#endif
+    }
+    if (wn < 3) {                                           // segments 0..14: all in the 256-column image
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#ifdef T224_NO_READ
+        b[j] = ones8; asm volatile("" : "+v"(b[j]));
+#else
+        b[j] = frag((ba0 ^ (sB + (j << 5))) + st + 16384, (ba1 ^ (sB + (j << 5))) + st + 16384);
+#endif
+      }
+    } else {                                                // segment 15, then the four segments of the 64-column image
+#ifdef T224_NO_READ
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { b[j] = ones8; asm volatile("" : "+v"(b[j])); }
+#else
+      b[0] = frag((ba0 ^ (15u << 5)) + st + 16384, (ba1 ^ (15u << 5)) + st + 16384);
+#pragma unroll
+      for (int j = 1; j < NT; ++j) b[j] = frag((bb0 ^ ((unsigned)(j - 1) << 5)) + st, (bb1 ^ ((unsigned)(j - 1) << 5)) + st);
+#endif
+    }
+#ifdef T224_NO_MFMA
+#pragma unroll
+    for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(b[j]));
+#pragma unroll
+    for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(a[i]));
+#else
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
+  };
+  // two stages per barrier on four slots: at the wait of iteration kt the stages kt, kt + 1 were issued a whole iteration ago; after
+  // the barrier the slots of stages kt - 2, kt - 1 are free and take kt + 2, kt + 3, which have two stage times to land
+  issue(0);
+  issue(1);
+  int slot = 0;
+  for (int kt = 0; kt < nk; kt += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(slot ^ 2);
+    issue((slot ^ 2) + 1);
+    const int nh = kt + 1 < nk ? 2 : 1;
+#pragma unroll 1
+    for (int h = 0; h < nh; ++h) compute(slot + h);
+    slot ^= 2;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (zero page) DMAs must not outlive the workgroup
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const long v = n0 + (wn * NT + j) * 16 + (lane & 15);
+    float* dst = nullptr;
+    long ld = 0, col = 0;
+    if (v < p.No) { dst = p.C; ld = p.ldc; col = v; }
+    else if (v >= No8 && v < V) { dst = p.C2; ld = p.ldc2; col = v - No8; }
+    else if (v == vones) { dst = p.colsum; ld = 1; col = 0; }
+    if (dst == nullptr) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * (MT * 16) + i * 16 + (lane >> 4) * 4 + r;
+        atomicAdd(dst + tn_perm(row, p.perm_h) * ld + col, acc[i][j][r]);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 static void launch_tn_dma(int ntw, int csm, dim3 grid, hipStream_t st, const TnArgs& p) {
 #define URSE_TN_L(N_, C_) hipLaunchKernelGGL((gemm_tn_dma_kernel<N_, C_>), grid, dim3(512), 0, st, p)
   if (ntw == 7) { if (csm == 0) URSE_TN_L(7, 0); else if (csm == 1) URSE_TN_L(7, 1); else URSE_TN_L(7, 2); }
@@ -1595,6 +1840,27 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
   p.shift = shift; p.inner = inner > 0 ? inner : 1; p.period = period; p.invalid_step = invalid_step;
   p.perm_h = perm_h;
   p.B2 = (const char*)B2; p.C2 = C2; p.ldb2 = ldb2; p.ldc2 = ldc2; p.No2 = No2; p.pad_[0] = p.pad_[1] = 0;
+  {
+    // 224 x 320 tiles over the virtual operand [B | B2 | ones] when the rows are whole 224-row tiles and the columns fit two tiles
+    static const bool no224 = getenv("URSE_TN_NO_224") != nullptr;
+    const long No8 = (No + 7) & ~7L, V = No8 + No2 + (colsum ? 1 : 0);
+    const bool mask_covers_range = period > 0 && R % ((inner > 0 ? inner : 1) * period) == 0 &&
+                                   ((shift == -(inner > 0 ? inner : 1) && invalid_step == 0) || (shift == (inner > 0 ? inner : 1) && invalid_step == period - 1));
+    if (!no224 && Mo % 224 == 0 && No2 % 8 == 0 && ldb2 >= No2 && R % 32 == 0 && mask_covers_range && V <= 640 && ldb >= No8 && perm_h >= 0 && lda >= Mo && ((Mo / 224) * ((V + 319) / 320)) <= g_tn_target_wgs) {
+      const long tl = (Mo / 224) * ((V + 319) / 320);
+      long slices = g_tn_target_wgs / tl;
+      if (slices < 1) slices = 1;
+      long rps = (R + slices - 1) / slices;
+      rps = (rps + 31) / 32 * 32;
+      slices = (R + rps - 1) / rps;
+      p.rows_per_slice = rps;
+      p.nt1 = 0;
+      note_launch(URSE_KV_TN_DUAL);
+      hipLaunchKernelGGL(gemm_tn_dual224_kernel, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+      URSE_CHECK_LAUNCH("urse_gemm_tn_dual");
+      return URSE_OK;
+    }
+  }
   const long bnx = 224;                                   // 7 column tiles per wave: 196 -> 224, 392 -> 448
   p.nt1 = (No + bnx - 1) / bnx;
   const long tl = ((Mo + 255) / 256) * (p.nt1 + (No2 + bnx - 1) / bnx);
