@@ -406,13 +406,17 @@ constexpr long TN_TRANSPOSED = -(1L << 40);
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to lds_dst + lane*16.  Issued as inline
 // asm on purpose: hipcc (ROCm 7.2) drains every outstanding DMA (vmcnt(0)) in front of the next LDS read it can see,
 // which serialises the ring; the kernel orders DMA -> read itself with a counted vmcnt and a raw barrier.
+// (m0 on a clobber list: clang warns that reserved registers "may not be preserved" - these kernels have no other user of m0)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
-  const unsigned dst = __builtin_amdgcn_readfirstlane(
-      (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+  // the low half of a generic pointer into LDS is the LDS byte address (the aperture sits in the high half): no address-space cast
+  // with its null check; m0 is declared clobbered instead of being saved and restored (each cost scalar instructions per DMA, and the
+  // scalar unit is shared by the CU's waves)
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(dst) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // The same transfer through a BUFFER resource: 64 lanes x 16 B from rsrc.base + voff (per lane) to lds_dst + lane*16; a lane whose
 // offset is >= rsrc.num_records reads zeros (hardware range check), which replaces every "valid ? pointer : zero page" select.
@@ -534,14 +538,14 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   auto issue_one = [&](Src& q, char* dst) __attribute__((always_inline)) {
     const bool rin = q.rr < r_end_i;                     // (also false for every stage past the slice's last one)
     const int rs = q.rr + shift_i;
-    const bool ok = rin && q.bok && (per_u == 0 || q.ph != inval_u) && rs >= 0 && rs < R_i;
+    const bool ok = rin & q.bok & ((per_u == 0) | (q.ph != inval_u)) & (rs >= 0) & (rs < R_i);     // (bitwise: no exec-mask branches)
 #ifdef TABL_NO_DMA
     asm volatile("" :: "v"(rin && q.aok ? q.pa : zsrc), "v"(ok ? q.pb : zsrc));
 #elif defined(TABL_ZERO_DMA)
     glds16(zsrc, dst);
     glds16(zsrc, dst + 16384);
 #else
-    glds16((rin && q.aok) ? q.pa : zsrc, dst);
+    glds16((rin & q.aok) ? q.pa : zsrc, dst);
     glds16(ok ? q.pb : zsrc, dst + 16384);
 #endif
     q.rr += 32;
@@ -908,9 +912,12 @@ __device__ __forceinline__ int tn_swz4(int row) { return ((row >> 1) & 1) | (((r
 
 // One LDS-DMA wave-instruction with the LDS destination given as a byte address in an SGPR (no generic -> LDS pointer cast with its null
 // check on the scalar unit, no save / restore of m0: the compiler is told that m0 is clobbered).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void glds16u(const char* gsrc, unsigned dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(dst) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
   constexpr int BMX = 224, BNX = 320, NST = 4, STAGE = 36864, MT = 7, NT = 5;
