@@ -77,7 +77,12 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   const int nq = (H + 3) >> 2;
   const int qd = j * CW + w;                             // this wave's unit quad
   const bool qvalid = qd < nq;
-  const int ul = lc >> 2, q = lc & 3;                    // unit within quad / quad lane
+  // The recurrent product runs with the operands swapped: A = the resident W_hh fragment (rows = the quad's 16 gate columns), B = the
+  // h fragment (columns = sequences).  The register contents are the same either way (both operand layouts are "index lane % 16, 8 k's
+  // by lane / 16"), but the accumulator then holds, in lane (lr, lc), the FOUR GATES acc[0..3] of unit lr of the quad for sequence lc
+  // of the row tile - the cell update needs no cross-lane traffic (it used to start with a 4 x 4 transpose inside each lane quad:
+  // 16 DPP moves + 12 selects per row tile, 112 of the ~500 vector instructions of a wave's step).
+  const int ul = lr, rl = lc;                            // unit within the quad / sequence within the row tile
   const int u = qd * 4 + ul;
   const bool uvalid = qvalid && u < H;
   const int uc = uvalid ? u : H - 1;
@@ -107,13 +112,13 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   constexpr int cpr = Hp * 2 / 16;                       // 16-B chunks per h row
   constexpr int HL = (CROWS * 52 + CTHR - 1) / CTHR;     // h-tile chunks per thread (Hp <= 416)
 
-  // row bookkeeping of this lane (row tile rt: sequence rt*16 + lr*4 + q), hoisted out of the time loop: the run-time
+  // row bookkeeping of this lane (row tile rt: sequence rt*16 + rl), hoisted out of the time loop: the run-time
   // divisions by `inner` cost more than the cell math of a step
   int rowb[4];                                            // 32-bit row indices: one v_mad_i64_i32 per address
   bool rowv[4];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
-    const int lrow = rt * 16 + lr * 4 + q;
+    const int lrow = rt * 16 + rl;
     rowv[rt] = lrow < nrows;
     int seq = seq0 + lrow;
     if (seq >= p.n_seq) seq = p.n_seq - 1;
@@ -217,17 +222,11 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
 #pragma unroll
       for (int ks = 0; ks < NSLAB; ++ks) {
         const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                      __builtin_bit_cast(bf16x8_t, breg[ks]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, breg[ks]),
+                                                      __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
       }
-      // acc[r] = gate (lc & 3) of unit (lc >> 2), row rt*16 + lr*4 + r.  4x4 transpose inside the lane quad
-      float pre[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float v0 = quad_bcast(acc[0], g), v1 = quad_bcast(acc[1], g), v2 = quad_bcast(acc[2], g),
-                    v3 = quad_bcast(acc[3], g);
-        pre[g] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
-      }
+      // acc[g] = gate g of unit ul, sequence rt*16 + rl
+      const float pre[4] = {acc[0], acc[1], acc[2], acc[3]};
       const uint2 gxv = gxc[rt];
       const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
       const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
@@ -235,7 +234,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
       const float cv = fv * cst[ch][rt] + iv * gv;
       cst[ch][rt] = cv;
       const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
-      if (qvalid) hstage[(rt * 16 + lr * 4 + q) * UW + w * 4 + ul] = f32_to_bf16(hv);
+      if (qvalid) hstage[(rt * 16 + rl) * UW + w * 4 + ul] = f32_to_bf16(hv);
       gsave[rt].x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
       gsave[rt].y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
       csave[rt] = cv;

@@ -73,7 +73,9 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
   bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + C2ROWS * pitch);         // [64][UW]
   unsigned* deadflag = reinterpret_cast<unsigned*>(smem + C2ROWS * pitch + C2ROWS * UW * 2);
   const int nq = (H + 3) >> 2;
-  const int ul = lc >> 2, q = lc & 3;                                        // unit within quad / quad lane
+  // operands of the recurrent product swapped as in lstm_cluster.hip (A = resident W_hh fragment, B = h fragment: same register contents):
+  // lane (lr, lc) gets the four gates acc[0..3] of unit lr of a quad for sequence lc of the row tile, no transpose inside the lane quads
+  const int ul = lr, rl = lc;                                                // unit within quad / sequence within the row tile
   const int qd0 = (j * NW + w) * QPW;                                        // first unit quad of this wave
 
   uint4 breg[QPW][NSLAB];                                                    // resident B fragments
@@ -98,65 +100,91 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
   const int nrows = seq1 - seq0;
   bf16_t* gx = reinterpret_cast<bf16_t*>(p.gx);
   bf16_t* hout = reinterpret_cast<bf16_t*>(p.hout);
-  const long gcol0 = (long)dir * 4 * H;
   const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * C2ROWS * HPB);
   const unsigned cl_bytes = (unsigned)(((long)dir * p.ncl + cl) * C2ROWS * HPB);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2u * plane_bytes), 0x00020000);
   const int hchunks = H / 8;
   constexpr unsigned TAGM = 0x40004000u;
 
-  // row of this lane for row tile rt (sequence lrow = rt*16 + lr*4 + q)
-  long rowb[4];
+  // row of this lane for row tile rt (sequence lrow = rt*16 + rl)
+  // 32-bit row indices / leading dimensions (checked on the host): an address costs one v_mad_i64_i32.  Row tiles past the cluster's
+  // last row (the sampler's 48 sequences fill three of the four) are skipped altogether: nrt is wave-uniform.
+  int rowb[4];
   bool rvalid[4];
+  const int nrt = (nrows + 15) >> 4;
+  const int ldg_i = (int)p.ldg, ldh_i = (int)p.ldh, stride_i = (int)p.stride, gcol_i = dir * 4 * H, hcol_i = dir * H, ldc_i = 2 * H;
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
-    const int lrow = rt * 16 + lr * 4 + q;
+    const int lrow = rt * 16 + rl;
     rvalid[rt] = lrow < nrows;
     int seq = seq0 + lrow;
     if (seq >= p.n_seq) seq = p.n_seq - 1;
-    rowb[rt] = (seq / p.inner) * p.outer + (seq % p.inner);
+    rowb[rt] = (int)((seq / p.inner) * p.outer + (seq % p.inner));
   }
-  auto load_gx = [&](long toff, uint2 (&dst)[QPW][4]) {
+  auto load_gx = [&](int toff, uint2 (&dst)[QPW][4]) {
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
       int u = (qd0 + qi) * 4 + ul;
       if (u >= H) u = H - 1;
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) dst[qi][rt] = *reinterpret_cast<const uint2*>(gx + (rowb[rt] + toff) * p.ldg + gcol0 + u * 4);
+      for (int rt = 0; rt < 4; ++rt)
+        if (rt < nrt) dst[qi][rt] = *reinterpret_cast<const uint2*>(gx + ((long)(rowb[rt] + toff) * ldg_i + (gcol_i + u * 4)));
     }
   };
   uint2 gxn[QPW][4];
-  load_gx((long)(dir ? p.seq_len - 1 : 0) * p.stride, gxn);
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) gxn[qi][rt] = make_uint2(0u, 0u);
+  load_gx((dir ? p.seq_len - 1 : 0) * stride_i, gxn);
+  // the pieces of the staged h tile this thread publishes / stores per step (row, 16-byte chunk), with their rows in hout
+  constexpr int SC = UW * 2 / 16, SI = (C2ROWS * SC + NTHR - 1) / NTHR;
+  int st_lds[SI], st_x[SI], st_grow[SI], st_u[SI];        // byte offset in hstage (-1: nothing) / in the exchange rows, row in hout, first unit
+#pragma unroll
+  for (int i = 0; i < SI; ++i) {
+    const int idx = tid + i * NTHR;
+    const int row = idx / SC, cc = idx - row * SC;
+    const int ucol = j * UW + cc * 8;
+    const bool ok = idx < C2ROWS * SC && row < nrows && ucol < H;
+    int seq = seq0 + (row < nrows ? row : 0);
+    if (seq >= p.n_seq) seq = p.n_seq - 1;
+    st_lds[i] = ok ? row * (UW * 2) + cc * 16 : -1;
+    st_x[i] = row * HPB + ucol * 2;
+    st_u[i] = ucol;
+    st_grow[i] = (int)((seq / p.inner) * p.outer + (seq % p.inner));
+  }
+  int h_off[HL];                                          // LDS byte offset of this thread's piece i of the h tile (-1: outside the tile)
+  unsigned h_valid = 0u;                                  // pieces that carry data of a live row (polled from step 1 on)
+#pragma unroll
+  for (int i = 0; i < HL; ++i) {
+    const int idx = tid + i * NTHR;
+    const int row = idx / CPR, cc = idx - row * CPR;
+    h_off[i] = idx < C2ROWS * CPR ? row * pitch + cc * 16 : -1;
+    if (idx < C2ROWS * CPR && row < nrows && cc < hchunks) h_valid |= 1u << i;
+  }
   __syncthreads();
 
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? (p.seq_len - 1 - step) : step;
-    const long toff = (long)t * p.stride;
+    const int toff = t * stride_i;
     const unsigned pprev = (unsigned)((step + 1) & 1), pcur = (unsigned)(step & 1);
     const unsigned tag_cur = (((unsigned)step >> 1) & 1u) ^ 1u;
     const unsigned tag_prev = (((unsigned)(step - 1) >> 1) & 1u) ^ 1u;
-    // 1. h_{t-1} rows -> LDS, every 16-byte piece polled until its tags are current
+    // 1. h_{t-1} rows -> LDS, every 16-byte piece polled until its tags are current (piece i of this thread: chunk tid + i * NTHR of
+    // the cluster's [64][HPB] exchange rows; its validity and its place in the padded LDS tile are hoisted out of the time loop)
     {
       uint4 hn[HL];
-      unsigned pend = 0u;
 #pragma unroll
-      for (int i = 0; i < HL; ++i) {
-        hn[i] = make_uint4(0, 0, 0, 0);
-        const int idx = tid + i * NTHR;
-        const int row = idx / CPR, cc = idx - row * CPR;
-        if (step > 0 && idx < C2ROWS * CPR && row < nrows && cc < hchunks) pend |= 1u << i;
-      }
+      for (int i = 0; i < HL; ++i) hn[i] = make_uint4(0, 0, 0, 0);
+      unsigned pend = step > 0 ? h_valid : 0u;
       if (pend && __hip_atomic_load(deadflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) pend = 0u;
       const unsigned want = tag_prev ? TAGM : 0u;
+      const unsigned xbase = pprev * plane_bytes + cl_bytes + (unsigned)tid * 16u;
       unsigned spins = 0;
       while (pend) {
 #pragma unroll
-        for (int i = 0; i < HL; ++i) {
-          if (pend & (1u << i)) {
-            const int idx = tid + i * NTHR;
-            hn[i] = load_sc1(rs, pprev * plane_bytes + cl_bytes + (unsigned)(idx * 16));
-          }
-        }
+        for (int i = 0; i < HL; ++i)
+          if (pend & (1u << i)) hn[i] = load_sc1(rs, xbase + (unsigned)(i * NTHR * 16));
 #pragma unroll
         for (int i = 0; i < HL; ++i) {
           if (pend & (1u << i)) {
@@ -171,11 +199,9 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
       }
 #pragma unroll
       for (int i = 0; i < HL; ++i) {
-        const int idx = tid + i * NTHR;
-        const int row = idx / CPR, cc = idx - row * CPR;
         uint4 v = hn[i];
         v.x &= ~TAGM; v.y &= ~TAGM; v.z &= ~TAGM; v.w &= ~TAGM;
-        if (idx < C2ROWS * CPR) *reinterpret_cast<uint4*>(htile + row * pitch + cc * 16) = v;
+        if (h_off[i] >= 0) *reinterpret_cast<uint4*>(htile + h_off[i]) = v;
       }
     }
     uint2 gxc[QPW][4];
@@ -184,12 +210,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) gxc[qi][rt] = gxn[qi][rt];
     __syncthreads();
-    if (step + 1 < p.seq_len) load_gx((long)(dir ? t - 1 : t + 1) * p.stride, gxn);
+    if (step + 1 < p.seq_len) load_gx((dir ? t - 1 : t + 1) * stride_i, gxn);
     // 2. gates of the wave's quads for the 64 rows
     uint2 gsave[QPW][4];
     float csave[QPW][4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
+      if (rt >= nrt) continue;
       f32x4_t acc[QPW];
 #pragma unroll
       for (int qi = 0; qi < QPW; ++qi) acc[qi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -199,22 +226,16 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
         const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi)
-          acc[qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                            __builtin_bit_cast(bf16x8_t, breg[qi][ks]), acc[qi], 0, 0, 0);
+          acc[qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, breg[qi][ks]),
+                                                            __builtin_bit_cast(bf16x8_t, a), acc[qi], 0, 0, 0);
       }
 #pragma unroll
       for (int qi = 0; qi < QPW; ++qi) {
         const int qd = qd0 + qi;
         const bool qvalid = qd < nq;
         const bool uvalid = qvalid && qd * 4 + ul < H;
-        // acc[r] = gate (lc & 3) of unit (lc >> 2), row rt*16 + lr*4 + r: 4x4 transpose inside the lane quad
-        float pre[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float v0 = quad_bcast(acc[qi][0], g), v1 = quad_bcast(acc[qi][1], g), v2 = quad_bcast(acc[qi][2], g),
-                      v3 = quad_bcast(acc[qi][3], g);
-          pre[g] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
-        }
+        // acc[g] = gate g of unit ul of the quad, sequence rt*16 + rl
+        const float pre[4] = {acc[qi][0], acc[qi][1], acc[qi][2], acc[qi][3]};
         const uint2 gxv = gxc[qi][rt];
         const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
         const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
@@ -222,7 +243,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
         const float cv = fv * cst[qi][rt] + iv * gv;
         cst[qi][rt] = cv;
         const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
-        if (qvalid) hstage[(rt * 16 + lr * 4 + q) * UW + (w * QPW + qi) * 4 + ul] = f32_to_bf16(hv);
+        if (qvalid) hstage[(rt * 16 + rl) * UW + (w * QPW + qi) * 4 + ul] = f32_to_bf16(hv);
         gsave[qi][rt].x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
         gsave[qi][rt].y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
         csave[qi][rt] = cv;
@@ -230,19 +251,14 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
     }
     __syncthreads();
     // 3. h_t of this workgroup's units -> exchange buffer (write-through, tagged) and hout
-    constexpr int SC = UW * 2 / 16;
     const unsigned tagv = tag_cur ? TAGM : 0u;
-    for (int idx = tid; idx < C2ROWS * SC; idx += NTHR) {
-      const int row = idx / SC, cc = idx - row * SC;
-      const int ucol = j * UW + cc * 8;
-      if (row >= nrows || ucol >= H) continue;
-      const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+      if (st_lds[i] < 0) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + st_lds[i]);
       if (step + 1 < p.seq_len)
-        store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)(row * HPB + ucol * 2),
-                  make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv));
-      const int seq = seq0 + row;
-      const long grow = (seq / p.inner) * p.outer + (seq % p.inner) + toff;
-      *reinterpret_cast<uint4*>(hout + grow * p.ldh + (long)dir * H + ucol) = v;    // H % 8 == 0: whole chunks
+        store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)st_x[i], make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv));
+      *reinterpret_cast<uint4*>(hout + ((long)(st_grow[i] + toff) * ldh_i + (hcol_i + st_u[i]))) = v;    // H % 8 == 0: whole chunks
     }
     if (p.save) {
 #pragma unroll
@@ -251,10 +267,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
         if (qd0 + qi < nq && u < H) {
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt)
-            if (rvalid[rt]) {
-              const long row = rowb[rt] + toff;
-              *reinterpret_cast<uint2*>(gx + row * p.ldg + gcol0 + u * 4) = gsave[qi][rt];
-              p.c[row * 2 * H + (long)dir * H + u] = csave[qi][rt];
+            if (rt < nrt && rvalid[rt]) {
+              const int row = rowb[rt] + toff;
+              *reinterpret_cast<uint2*>(gx + ((long)row * ldg_i + (gcol_i + u * 4))) = gsave[qi][rt];
+              p.c[(long)row * ldc_i + (hcol_i + u)] = csave[qi][rt];
             }
         }
       }
@@ -318,6 +334,8 @@ extern "C" int urse_lstm_cluster2_fwd(void* gx, int64_t ldg, const void* whhq, v
   URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldh >= 2L * H && (ldh * 2) % 16 == 0 && ((uintptr_t)hout % 16) == 0 &&
                      ((uintptr_t)hx % 16) == 0 && seq_len > 0 && inner > 0,
                  "urse_lstm_cluster2_fwd: bad leading dimension / alignment");
+  URSE_CHECK_ARG(ldg < (1L << 31) && ldh < (1L << 31) && stride * seq_len + (n_seq / inner + 1) * outer < (1L << 31),
+                 "urse_lstm_cluster2_fwd: row indices must fit 32 bits");
   Cluster2Args p;
   p.gx = gx; p.ldg = ldg; p.whhq = whhq; p.hout = hout; p.ldh = ldh; p.c = c; p.hx = (bf16_t*)hx; p.err = (unsigned*)err_flag;
   p.H = H; p.Hp = Hp; p.save = save; p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
