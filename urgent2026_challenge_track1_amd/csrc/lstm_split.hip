@@ -90,13 +90,14 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
       const int rb = (int)((seq / p.inner) * p.outer + (seq % p.inner));
       rowbase[rt][r] = ok ? rb : -rb - 1;
     }
-  auto rowb = [&](int rt, int r) -> long { return rowbase[rt][r] >= 0 ? rowbase[rt][r] : -(rowbase[rt][r] + 1); };
+  auto rowb = [&](int rt, int r) -> int { return rowbase[rt][r] >= 0 ? rowbase[rt][r] : -(rowbase[rt][r] + 1); };
 
   const char* whhT = reinterpret_cast<const char*>(p.whhT) + ((long)dir * nut * nslab) * 1024 + lane * 16;
   const bf16_t* dh = reinterpret_cast<const bf16_t*>(p.dh);
   bf16_t* gates = reinterpret_cast<bf16_t*>(p.gates);
-  const long gcol0 = (long)dir * G4;
-  const long prev_off = dir ? p.stride : -p.stride;
+  // 32-bit row indices / leading dimensions (checked on the host): an address costs one v_mad_i64_i32
+  const int ldg_i = (int)p.ldg, ldd_i = (int)p.ldd, ldc_i = 2 * H, stride_i = (int)p.stride;
+  const int gcol_i = dir * G4, hcol_i = dir * H, prev_i = dir ? stride_i : -stride_i;
   const unsigned src_bytes = (unsigned)(SROWS * UP * 4);                      // one source workgroup's block
   const unsigned cl_bytes = (unsigned)(((long)dir * p.ncl + cl) * ns) * src_bytes;
   const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * ns) * src_bytes;
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
 
   float dcs[SMAXO][SRT][4], dhr[SMAXO][SRT][4], ccur[SMAXO][SRT][4];
   {
-    const long toff0 = (long)(dir ? 0 : p.seq_len - 1) * p.stride;
+    const int toff0 = (dir ? 0 : p.seq_len - 1) * stride_i;
 #pragma unroll
     for (int o = 0; o < SMAXO; ++o) {
       const int u = own_tile(o) * 16 + lc;
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
         for (int r = 0; r < 4; ++r) {
           dcs[o][rt][r] = 0.f;
           dhr[o][rt][r] = 0.f;
-          ccur[o][rt][r] = p.c[(rowb(rt, r) + toff0) * 2 * H + (long)dir * H + uc];
+          ccur[o][rt][r] = p.c[(long)(rowb(rt, r) + toff0) * ldc_i + (hcol_i + uc)];
         }
     }
   }
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
   float cnx[SMAXO][SRT][4];
   bf16_t dnx[SMAXO][SRT][4];
   auto load_inputs = [&](int tt) {
-    const long toff_ = (long)tt * p.stride;
+    const int toff_ = tt * stride_i;
     const bool first_ = dir ? (tt == p.seq_len - 1) : (tt == 0);
 #pragma unroll
     for (int o = 0; o < SMAXO; ++o) {
@@ -134,10 +135,10 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
         for (int rt = 0; rt < SRT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const long row = rowb(rt, r) + toff_;
-            gnx[o][rt][r] = *reinterpret_cast<const uint2*>(gates + row * p.ldg + gcol0 + u * 4);
-            cnx[o][rt][r] = first_ ? 0.f : p.c[row * 2 * H + (long)dir * H + u + prev_off * 2 * H];
-            dnx[o][rt][r] = dh[row * p.ldd + (long)dir * H + u];
+            const int row = rowb(rt, r) + toff_;
+            gnx[o][rt][r] = *reinterpret_cast<const uint2*>(gates + ((long)row * ldg_i + (gcol_i + u * 4)));
+            cnx[o][rt][r] = first_ ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + u)];
+            dnx[o][rt][r] = dh[(long)row * ldd_i + (hcol_i + u)];
           }
       }
     }
@@ -147,35 +148,41 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
 
   const int in_cpr = tcnt * 4;                            // 16-byte chunks per received row (tcnt*16 f32)
   const int in_chunks = (ns - 1) * SROWS * in_cpr;
+  // the (at most four) received chunks of this thread: offset in the exchange planes and in `inbuf`, once (the run-time divisions
+  // by the split geometry cost more per step than the cell update)
+  constexpr int NCH = 4;                                  // chunks per thread (in_chunks <= 4 * 1024 for H <= 512 / 768 with 16 rows)
+  unsigned in_off[NCH];
+  int in_dst[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int idx = tid + i * STHR;
+    in_off[i] = 0u;
+    in_dst[i] = -1;
+    if (idx < in_chunks) {
+      const int s_ = idx / (SROWS * in_cpr), rem = idx - s_ * (SROWS * in_cpr);
+      const int row = rem / in_cpr, cc = rem - row * in_cpr;
+      const int js = s_ < j ? s_ : s_ + 1;
+      in_off[i] = cl_bytes + (unsigned)js * src_bytes + (unsigned)((row * UP + t0 * 16 + cc * 4) * 4);
+      in_dst[i] = (s_ * SROWS + row) * IP + cc * 4;
+    }
+  }
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? step : (p.seq_len - 1 - step);
-    const long toff = (long)t * p.stride;
+    const int toff = t * stride_i;
     const unsigned pprev = (unsigned)((step + 1) & 1), pcur = (unsigned)(step & 1);
     const unsigned tag_cur = (((unsigned)step >> 1) & 1u) ^ 1u;
     const unsigned tag_prev = (((unsigned)(step - 1) >> 1) & 1u) ^ 1u;
 
     // (A) partial recurrent gradients of my units published by the other workgroups during the previous step
     if (step > 0) {
-      constexpr int NCH = 4;                               // chunks per thread (in_chunks <= 4 * 1024 for H <= 512)
       uint4 v[NCH];
-      unsigned offs[NCH];
-      int dsts[NCH];
       unsigned pend = 0u;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int idx = tid + i * STHR;
         v[i] = make_uint4(0, 0, 0, 0);
-        offs[i] = 0u;
-        dsts[i] = -1;
-        if (idx < in_chunks) {
-          const int s = idx / (SROWS * in_cpr), rem = idx - s * (SROWS * in_cpr);
-          const int row = rem / in_cpr, cc = rem - row * in_cpr;
-          const int js = s < j ? s : s + 1;
-          offs[i] = pprev * plane_bytes + cl_bytes + (unsigned)js * src_bytes + (unsigned)((row * UP + t0 * 16 + cc * 4) * 4);
-          dsts[i] = (s * SROWS + row) * IP + cc * 4;
-          pend |= 1u << i;
-        }
+        if (in_dst[i] >= 0) pend |= 1u << i;
       }
+      const unsigned pbase = pprev * plane_bytes;
       if (pend && *reinterpret_cast<volatile unsigned*>(deadflag)) pend = 0u;
 #ifdef SABL_NO_WAIT
       pend = 0u;
@@ -184,7 +191,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
       while (pend) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
-          if (pend & (1u << i)) v[i] = split_load_sc1(rs, offs[i]);
+          if (pend & (1u << i)) v[i] = split_load_sc1(rs, pbase + in_off[i]);
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
           if ((pend & (1u << i)) && ((v[i].x & 1u) == tag_prev) && ((v[i].y & 1u) == tag_prev) && ((v[i].z & 1u) == tag_prev) &&
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < NCH; ++i)
-        if (dsts[i] >= 0) *reinterpret_cast<uint4*>(inbuf + dsts[i]) = v[i];
+        if (in_dst[i] >= 0) *reinterpret_cast<uint4*>(inbuf + in_dst[i]) = v[i];
     }
     __syncthreads();
 
@@ -235,7 +242,7 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
             pk.y = (unsigned)f32_to_bf16(d2) | ((unsigned)f32_to_bf16(d3) << 16);
             *reinterpret_cast<uint2*>(tile + lrow * tpitch + tcol) = pk;
 #ifndef SABL_NO_ST
-            if (rowbase[rt][r] >= 0) *reinterpret_cast<uint2*>(gates + (rowb(rt, r) + toff) * p.ldg + gcol0 + u * 4) = pk;
+            if (rowbase[rt][r] >= 0) *reinterpret_cast<uint2*>(gates + ((long)(rowbase[rt][r] + toff) * ldg_i + (gcol_i + u * 4))) = pk;
 #endif
           }
       } else {
@@ -308,16 +315,18 @@ __global__ void __launch_bounds__(STHR) lstm_bwd_split_kernel(SplitBwdArgs p) {
     // (D) publish the partials of the units the other workgroups own: tagged, write-through, 16 bytes per lane
     {
       const unsigned tagv = tag_cur;
-      const int cpr = UP / 4;
-      for (int idx = tid; idx < SROWS * cpr; idx += STHR) {
-        const int row = idx / cpr, cc = idx - row * cpr;
-        const int ut = cc >> 2;
-        if (ut >= t0 && ut < t1) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(stage + row * SP + cc * 4);
-        v.x = (v.x & ~1u) | tagv; v.y = (v.y & ~1u) | tagv; v.z = (v.z & ~1u) | tagv; v.w = (v.w & ~1u) | tagv;
+      const int cpr = UP / 4;                              // 16-byte chunks per row; wave w publishes rows w, w + 16, ...
+      const unsigned pub = pcur * plane_bytes + cl_bytes + (unsigned)j * src_bytes;
+      for (int row = w; row < SROWS; row += SW) {
+        for (int cc = lane; cc < cpr; cc += 64) {
+          const int ut = cc >> 2;
+          if (ut >= t0 && ut < t1) continue;
+          uint4 v = *reinterpret_cast<const uint4*>(stage + row * SP + cc * 4);
+          v.x = (v.x & ~1u) | tagv; v.y = (v.y & ~1u) | tagv; v.z = (v.z & ~1u) | tagv; v.w = (v.w & ~1u) | tagv;
 #ifndef SABL_NO_PUB
-        split_store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)j * src_bytes + (unsigned)((row * UP + cc * 4) * 4), v);
+          split_store_sc1(rs, pub + (unsigned)((row * UP + cc * 4) * 4), v);
 #endif
+        }
       }
     }
     // the next step's (A) writes inbuf (last read in (B) above, two barriers ago) and (B) rewrites the tile (last read
@@ -378,6 +387,8 @@ extern "C" int urse_lstm_split_bwd(const void* dh, int64_t ldd, void* gates, int
   URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldd >= 2L * H && ((uintptr_t)xbuf % 16) == 0 && seq_len > 0 && inner > 0,
                  "urse_lstm_split_bwd: bad leading dimension / alignment");
   URSE_CHECK_ARG(plan[2] * 4 < (1L << 31), "urse_lstm_split_bwd: exchange buffer exceeds the 2 GiB buffer-descriptor range");
+  URSE_CHECK_ARG(ldg < (1L << 31) && ldd < (1L << 31) && stride * seq_len + (n_seq / inner + 1) * outer < (1L << 31),
+                 "urse_lstm_split_bwd: row indices must fit 32 bits");
   SplitBwdArgs p;
   p.dh = dh; p.ldd = ldd; p.gates = gates; p.ldg = ldg; p.c = c; p.whhT = whhT; p.xbuf = (float*)xbuf;
   p.err = (unsigned*)err_flag; p.H = H; p.nsplit = (int)plan[0]; p.ncl = (int)plan[1];
