@@ -292,6 +292,12 @@ int urse_mix_noise(const float* speech, const float* noise_raw, const int32_t* n
                    double* scratch, void* stream);
 int urse_fir_full(const float* x, const int32_t* lens, int B, int64_t ld, const float* taps, const int32_t* ntaps, int64_t ldt,
                   int taps_per_utt, float* y, void* stream);
+/* urse_fft_convolve: the same result as urse_fir_full by power-of-two FFTs of M >= max_len + max_ntaps - 1 <= 2^20 points (float32
+ *   transforms: agrees with the direct form to ~1e-6 of the output's peak); max_len / max_ntaps bound lens / ntaps (host values),
+ *   workspace from urse_fft_convolve_workspace_bytes. */
+int urse_fft_convolve_workspace_bytes(int B, int max_len, int max_ntaps, int64_t* bytes);
+int urse_fft_convolve(const float* x, const int32_t* lens, int B, int64_t ld, const float* taps, const int32_t* ntaps, int64_t ldt,
+                      int taps_per_utt, float* y, int max_len, int max_ntaps, void* workspace, int64_t workspace_bytes, void* stream);
 int urse_filtfilt_fir(const float* x, const int32_t* lens, int B, int64_t ld, const float* taps, const int32_t* ntaps_dev,
                       int ntaps, float* y, float* scratch, int64_t lds, void* stream);
 int urse_quantile_clip(float* x, const int32_t* lens, int B, int64_t ld, const float* qmin, const float* qmax, float* bounds,

@@ -88,6 +88,34 @@ def test_fir_tap_counts_and_ragged_tiles(lib):
         assert np.all(out[b, lens[b]:] == 0), b
 
 
+@pytest.mark.parametrize("L,counts", [(50000, [5000, 4096, 100, 1]), (192000, [48000, 70001])])
+def test_fft_reverberation_matches_exact_convolution(lib, monkeypatch, L, counts):
+    """RIRs of 4,096 taps and more take the FFT form (urse_fft_convolve, float32 transforms of 2^16 .. 2^19 points): within 1e-5 of
+    the output's peak of the float64 convolution (the reference's scipy.signal.convolve runs its own float32 FFTs at these sizes),
+    zeros behind each utterance's length, and the same result as the direct form to that tolerance."""
+    from scipy.signal import fftconvolve
+    from urgent2026_challenge_track1_amd import mixing
+    rng = np.random.default_rng(21)
+    B = len(counts)
+    sp = rng.standard_normal((B, L)).astype(np.float32)
+    lens = [L - 37 * b for b in range(B)]
+    rir = np.zeros((B, max(counts)), np.float32)
+    for b, n in enumerate(counts):
+        rir[b, :n] = (rng.standard_normal(n) * np.exp(-np.arange(n) / max(1.0, n / 6))).astype(np.float32)
+        sp[b, lens[b]:] = 0
+    x, h = torch.tensor(sp).cuda(), torch.tensor(rir).cuda()
+    assert max(counts) >= mixing.FFT_CONV_MIN_TAPS
+    out = mixing.add_reverberation(x, lens, h, counts).cpu().numpy()
+    monkeypatch.setattr(mixing, "FFT_CONV_MIN_TAPS", 1 << 30)
+    direct = mixing.add_reverberation(x, lens, h, counts).cpu().numpy()
+    for b, n in enumerate(counts):
+        ref = fftconvolve(sp[b, :lens[b]].astype(np.float64), rir[b, :n].astype(np.float64))[:lens[b]]
+        peak = np.abs(ref).max()
+        assert np.abs(out[b, :lens[b]] - ref).max() <= 1e-5 * peak, (b, n, np.abs(out[b, :lens[b]] - ref).max() / peak)
+        assert np.abs(out[b, :lens[b]] - direct[b, :lens[b]]).max() <= 1e-5 * peak, (b, n)
+        assert np.all(out[b, lens[b]:] == 0), b
+
+
 def test_clipping_packet_loss_peak_norm(lib):
     from urgent2026_challenge_track1_amd import mixing
     from oracle import mix_ref

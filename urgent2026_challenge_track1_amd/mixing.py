@@ -7,6 +7,7 @@ noise offset, packet indices, quantiles: ``dataset.py:232-278``) stay on the hos
 FIR taps of the high-pass are designed on the host with the same ``scipy.signal.firwin2`` call as the reference.
 """
 import functools
+import os
 
 import torch
 
@@ -63,9 +64,34 @@ def mix_noise(speech, noise_raw, noise_lens, lens, snr_db, offsets=None):
     return noisy, noise
 
 
+FFT_CONV_MIN_TAPS = int(os.environ.get("URSE_FFT_CONV_MIN_TAPS", "4096"))    # longest RIR of the batch from which the FFT form is used
+_conv_ws = {}
+
+
 def add_reverberation(speech, lens, rir, rir_lens):
-    """one RIR per utterance, ``scipy.signal.convolve(..., "full")[:, :L]``."""
+    """one RIR per utterance, ``scipy.signal.convolve(..., "full")[:, :L]``.  Direct form (``urse_fir_full``: L x taps multiply-adds,
+    1.3 ms per call at 4 s x 1 s @ 48 kHz) for short filters; from ``FFT_CONV_MIN_TAPS`` taps on, the library's power-of-two FFTs
+    (``urse_fft_convolve``, float32 like scipy's own FFT path on float32 input: within 1e-5 of the output's peak of the exact result)."""
     ops.require_cuda(speech, rir)
+    B, L = speech.shape
+    dev = speech.device
+    host_taps = None if torch.is_tensor(rir_lens) else [int(n) for n in rir_lens]
+    if host_taps is not None and max(host_taps) >= FFT_CONV_MIN_TAPS and L + max(host_taps) - 1 <= (1 << 20) and speech.stride(1) == 1 \
+            and rir.stride(1) == 1:
+        import ctypes
+        lib = _lib.load()
+        mt = max(host_taps)
+        nb = ctypes.c_int64()
+        if lib.urse_fft_convolve_workspace_bytes(B, L, mt, ctypes.addressof(nb)) != 0:
+            raise _lib.UrseError(lib.urse_last_error().decode())
+        ws = _conv_ws.get(dev)
+        if ws is None or ws.numel() < nb.value:
+            ws = _conv_ws[dev] = torch.empty(nb.value, device=dev, dtype=torch.uint8)
+        out = torch.empty_like(speech)
+        call("fft_convolve", speech, _i32(lens, dev), B, speech.stride(0), rir, _i32(host_taps, dev), rir.stride(0), 1, out, L, mt,
+             ws, ws.numel(), stream_ptr())
+        ws.record_stream(torch.cuda.current_stream(dev))
+        return out
     out = torch.empty_like(speech)
     call("fir_full", speech, _i32(lens, speech.device), speech.shape[0], speech.stride(0), rir, _i32(rir_lens, rir.device),
          rir.stride(0), 1, out, stream_ptr())
