@@ -575,9 +575,46 @@ def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
 BWD_ROWS16 = {k: int(os.environ[e]) for k, e in (("t", "URSE_BWD_ROWS_T"), ("f", "URSE_BWD_ROWS_F")) if e in os.environ}
 
 
+# Band path (many short sequences, 32 per workgroup): 2 * ceil(n_seq / 32) workgroups rarely fill whole rounds of the 256 CUs (C2: 802 =
+# 3.13 rounds, the last one 13 % full).  With this switch the sequences of the incomplete round run as 16-sequence workgroups in a
+# second launch on another stream AT THE SAME TIME (their rows are independent; sequence s of a band-path layout is rows [s * K, (s + 1) * K),
+# so a sub-range is a pointer offset): alone 3.95 -> 3.67 ms per launch, bit-identical (scripts/exp_band_tail.py).  In the train step it
+# gains nothing (same-box 160.5 / 161.9 without, 161.4 - 163.6 with, profiles/r03_ab_band_tail_v1.log): the weight-gradient GEMMs of
+# the second queue already run in that last round.  Off.
+BAND_TAIL_SPLIT = os.environ.get("URSE_BAND_TAIL_SPLIT", "0") == "1"
+BAND_TAIL_EXTRA = int(os.environ.get("URSE_BAND_TAIL_EXTRA", "16"))      # 32-sequence workgroups per direction moved to the tail launch besides
+_tail_streams = {}
+
+
 def lstm_bwd(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride, rows16=0):
     """gates (saved activations) is overwritten with d(pre-activations)."""
-    timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_bidir_bwd", dh, dh.stride(0), gates,
+    tname = "lstm_bwd_time" if stride > 1 else "lstm_bwd_band"
+    if BAND_TAIL_SPLIT and gates.is_cuda and rows16 == 0 and inner == 1 and stride == 1 and outer == seq_len and n_seq >= 32 * 128 \
+            and gates.dtype == torch.bfloat16:
+        per_dir = -(-n_seq // 32)
+        full = (2 * per_dir // 256) * 128 - BAND_TAIL_EXTRA                  # workgroups per direction in whole rounds
+        tail = per_dir - full
+        if full > 0 and 0 < tail * 2 <= 192:
+            dev = gates.device
+            side = _tail_streams.get(dev)
+            if side is None:
+                side = _tail_streams[dev] = torch.cuda.Stream(device=dev)
+            n_main = full * 32
+            r0 = n_main * seq_len
+            main = torch.cuda.current_stream(dev)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side.wait_event(fork)
+            timed_call(tname, "lstm_bidir_bwd", dh, dh.stride(0), gates, gates.stride(0), c, whhT, H, n_main, seq_len, inner, outer, stride,
+                       _dt(gates), 0, stream_ptr())
+            with torch.cuda.stream(side):
+                call("lstm_bidir_bwd", dh[r0:], dh.stride(0), gates[r0:], gates.stride(0), c[r0:], whhT, H, n_seq - n_main, seq_len, inner,
+                     outer, stride, _dt(gates), 1, stream_ptr())
+                join = torch.cuda.Event()
+                join.record(side)
+            main.wait_event(join)
+            return gates
+    timed_call(tname, "lstm_bidir_bwd", dh, dh.stride(0), gates,
                gates.stride(0), c, whhT, H, n_seq, seq_len, inner, outer, stride, _dt(gates), rows16, stream_ptr())
     return gates
 
