@@ -180,3 +180,17 @@ def test_bench_gpus_n_launches_n_ranks_without_torchrun():
     # one rank per GPU over RCCL: asking for more ranks than visible GPUs is refused before anything is started
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 64
+
+
+def test_bench_weight_stream_bound_arithmetic():
+    """the supplementary bound of the bench line (recurrent weights streamed from L2 once per step and workgroup): bytes per launch,
+    workgroup counts of the two BPTT geometries, the per-CU figure against 34.5 TB/s / 256; forward kernels have none."""
+    import bench
+    B, T, K, H = 32, 401, 34, 392
+    t = bench.l2_port_roofline("lstm_bwd_time", 7.0, B, T, K, H)
+    assert t["workgroups"] == 2 * (B * K // 16) == 136 and t["cus"] == 136
+    assert t["bytes_per_launch"] == 136 * (T - 1) * 4 * H * H * 2
+    assert abs(t["GBs_per_cu"] - t["bytes_per_launch"] / 136 / 7.0e-3 / 1e9) < 1e-9 and 0.4 < t["frac"] < 0.6
+    b = bench.l2_port_roofline("lstm_bwd_band", 4.3, B, T, K, H)
+    assert b["workgroups"] == 2 * -(-B * T // 32) == 802 and b["cus"] == 256 and b["frac"] < t["frac"]
+    assert bench.l2_port_roofline("lstm_fwd_time", 3.5, B, T, K, H) is None

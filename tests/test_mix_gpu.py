@@ -116,6 +116,38 @@ def test_fft_reverberation_matches_exact_convolution(lib, monkeypatch, L, counts
         assert np.all(out[b, lens[b]:] == 0), b
 
 
+def test_fft_convolve_shared_filter_and_argument_checks(lib):
+    """urse_fft_convolve through the C ABI with ONE filter for the whole batch (taps_per_utt = 0), and its refusals: a workspace that
+    is too small, x == y, a length bound above the row pitch."""
+    import ctypes
+    from urgent2026_challenge_track1_amd import _lib
+    from urgent2026_challenge_track1_amd._lib import call, stream_ptr
+    rng = np.random.default_rng(5)
+    B, L, nt = 3, 20000, 4500
+    sp = rng.standard_normal((B, L)).astype(np.float32)
+    h = (rng.standard_normal(nt) * np.exp(-np.arange(nt) / 700.0)).astype(np.float32)
+    lens = [L, L - 1, 12345]
+    x = torch.tensor(sp).cuda()
+    taps = torch.tensor(h[None]).cuda()
+    y = torch.full_like(x, 7.0)
+    li = torch.tensor(lens, dtype=torch.int32).cuda()
+    ni = torch.tensor([nt], dtype=torch.int32).cuda()
+    nb = ctypes.c_int64()
+    assert _lib.load().urse_fft_convolve_workspace_bytes(B, L, nt, ctypes.addressof(nb)) == 0
+    ws = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
+    call("fft_convolve", x, li, B, x.stride(0), taps, ni, nt, 0, y, L, nt, ws, ws.numel(), stream_ptr())
+    out = y.cpu().numpy()
+    for b in range(B):
+        ref = np.convolve(sp[b, :lens[b]].astype(np.float64), h.astype(np.float64))[:lens[b]]
+        assert np.abs(out[b, :lens[b]] - ref).max() <= 1e-5 * np.abs(ref).max(), b
+        assert np.all(out[b, lens[b]:] == 0), b
+    for bad in (lambda: call("fft_convolve", x, li, B, x.stride(0), taps, ni, nt, 0, y, L, nt, ws, 1024, stream_ptr()),
+                lambda: call("fft_convolve", x, li, B, x.stride(0), taps, ni, nt, 0, x, L, nt, ws, ws.numel(), stream_ptr()),
+                lambda: call("fft_convolve", x, li, B, x.stride(0), taps, ni, nt, 0, y, L + 1, nt, ws, ws.numel(), stream_ptr())):
+        with pytest.raises(_lib.UrseError):
+            bad()
+
+
 def test_clipping_packet_loss_peak_norm(lib):
     from urgent2026_challenge_track1_amd import mixing
     from oracle import mix_ref
