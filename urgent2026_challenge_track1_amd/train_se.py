@@ -87,8 +87,11 @@ class DevicePrefetcher:
     its simulator kernels run beside the train step of batch i (whose recurrences leave most issue slots idle) instead of in front
     of step i+1.  The consumer's stream waits on the batch's event; the tensors are handed over with ``record_stream``."""
 
-    def __init__(self, loader, dev, skipped=None):
-        self.loader, self.dev, self.skipped = loader, dev, skipped
+    def __init__(self, loader, dev, skipped=None, depth=None):
+        """``depth`` batches are staged ahead (2: the simulation of batch i + 2 may start as soon as step i - 1 is done, so a simulation
+        that the low stream priority stretches past one step does not stall the next one)."""
+        depth = int(os.environ.get("URSE_PREFETCH_DEPTH", "2")) if depth is None else int(depth)
+        self.loader, self.dev, self.skipped, self.depth = loader, dev, skipped, max(1, depth)
         # lowest HIP priority: the simulator's thousands of small workgroups only take CUs the train step leaves idle, so they cannot
         # keep a workgroup of a cooperative recurrence kernel (which spins on its peers) off its CU (ADVICE r2)
         self.stream = ops.low_priority_stream(dev, force=True) if torch.device(dev).type == "cuda" else None
@@ -106,17 +109,21 @@ class DevicePrefetcher:
         return out, ev
 
     def __iter__(self):
+        import collections
         it = iter(self.loader)
-        try:
-            nxt = self._stage(next(it))
-        except StopIteration:
-            return
-        while nxt is not None:
-            (out, ev), nxt = nxt, None
-            try:
-                nxt = self._stage(next(it))
-            except StopIteration:
-                pass
+        staged, done = collections.deque(), False
+
+        def fill():
+            nonlocal done
+            while not done and len(staged) < self.depth:
+                try:
+                    staged.append(self._stage(next(it)))
+                except StopIteration:
+                    done = True
+        fill()
+        while staged:
+            out, ev = staged.popleft()
+            fill()
             if ev is not None:
                 cur = torch.cuda.current_stream(self.dev)
                 cur.wait_event(ev)
