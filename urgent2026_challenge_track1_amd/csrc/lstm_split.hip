@@ -351,11 +351,14 @@ extern "C" int urse_lstm_split_plan(int H, int n_seq, int reserved_cus, int64_t*
     set_error("urse_lstm_split_plan: unsupported H=%d", H);
     return URSE_ERR_UNSUPPORTED;
   }
-  // prefer 32-row clusters; fall back to 16 rows where the LDS tiles of a large H do not fit; as many splits (<= 6) as keep
+  // prefer 32-row clusters; fall back to 16 rows where the LDS tiles of a large H do not fit; as many splits (<= 3 / 12) as keep
   // every workgroup co-resident, give each at least two unit tiles and at most one owned tile per wave
   for (int rows = 32; rows >= 16; rows -= 16) {
     const int ncl = (n_seq + rows - 1) / rows;
-    for (int ns = rows == 32 ? 3 : 6; ns >= 2; --ns) {
+    // 16-row clusters: up to 12 splits (flow model, H = 768, B = 2: train step 103.3 ms with 6, 97.3 with 8, 89.4 with 12, 89.2 with 16 -
+    // the exchange per workgroup stays ~45 KB per step whatever the split, the weight pass shrinks with it)
+    static const int max16 = getenv("URSE_SPLIT_MAX_NS") ? atoi(getenv("URSE_SPLIT_MAX_NS")) : 12;
+    for (int ns = rows == 32 ? 3 : max16; ns >= 2; --ns) {
       const int tmax = (nut + ns - 1) / ns;
       if (2L * ncl * ns > device_cu_count() - reserved_cus - 6 || nut < 2 * ns || tmax > SMAXO * SW) continue;   // all workgroups resident
       if (split_lds(nut, ns, rows) > 160 * 1024) continue;
