@@ -799,7 +799,7 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
       return URSE_OK;
     }
   }
-  if (upw <= 2) URSE_LB(2) else if (upw <= 4) URSE_LB(4) else URSE_LB(6)
+  if (upw <= 2) URSE_LB(2) else if (upw <= 3) URSE_LB(3) else if (upw <= 4) URSE_LB(4) else URSE_LB(6)
 #undef URSE_LB
   URSE_CHECK_LAUNCH("urse_lstm_bwd");
   return URSE_OK;
