@@ -77,6 +77,8 @@ const char* urse_last_error(void);
 #define URSE_KV_STFT_GENERIC 20
 #define URSE_KV_ISTFT_GENERIC 21
 #define URSE_KV_ISTFT960 22
+#define URSE_KV_LSTM_FWD_RW 23     /* lstm_fwd_rw_kernel: 16 sequences per wave, weights shared through an LDS-DMA ring */
+#define URSE_KV_LSTM_BWD_RW 24     /* lstm_bwd_rw_kernel */
 #define URSE_KV_COUNT 32
 int urse_launch_count(int variant);
 int urse_launch_counts_reset(void);
@@ -232,6 +234,16 @@ int urse_lstm_wide_supported(int H, int Hp);
 int urse_lstm_pack_blocks(const float* whh, void* out, int H, int Hp, void* stream);
 int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_t ldh, float* c, int H, int Hp,
                        int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save, void* stream);
+/* "Row-wave" variant of urse_lstm_bidir_fwd for many short sequences (bf16; the band path of BSRNN, reference twin
+ * baseline_code/models/bsrnn_flowse.py:303-306): a wave owns 16 sequences (h_{t-1} register resident), the seven compute waves
+ * of a workgroup share one pass over W_hh per step, streamed L2 -> LDS by a loader wave (csrc/lstm_rw.hip).  No hand-off
+ * between workgroups and no co-residency requirement.  whhb from urse_lstm_pack_blocks; `c` is REQUIRED as in
+ * urse_lstm_wide_fwd; outputs equal urse_lstm_wide_fwd's bit for bit.  target_workgroups: workgroups the launch is dealt
+ * over (0 = one per CU); urse_lstm_rw_supported(H, Hp) != 0 tells whether the shape has a kernel (H = 392). */
+int urse_lstm_rw_supported(int H, int Hp);
+int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_t ldh, float* c, int H, int Hp,
+                     int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
+                     int target_workgroups, void* stream);
 /* Split BPTT (bf16) for few, long sequences (time path): 2-3 workgroups share 32 sequences and split the reduction of
  * the recurrent product; f32 partial sums are exchanged through `xbuf` (zeroed by the call) with the tag-in-data
  * hand-off (step parity in the mantissa LSB).  Arguments as urse_lstm_bidir_bwd (whhT from urse_lstm_pack).

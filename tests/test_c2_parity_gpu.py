@@ -1,5 +1,5 @@
 """GPU parity of the BENCHMARKED configuration (BASELINE.json configs[1]: N = 196, bf16 MFMA, default dispatch): the
-kernels bench.py times - cluster LSTM forward (time path), wide LSTM forward + 32-sequence BPTT (band path), 16-sequence
+kernels bench.py times - cluster LSTM forward (time path), row-wave LSTM forward + 32-sequence BPTT (band path), 16-sequence
 BPTT (time path), weight-stationary gate projection, ring NT / TN GEMMs, dual-operand TN weight gradients on the second
 stream, the 960-point register FFT - run together through BSRNN_SE / SEModel and are compared with the CPU oracle
 (oracle/bsrnn_ref.py) both in its bf16-emulating form (same rounding points) and in plain f32 (the reference
@@ -8,7 +8,7 @@ kernels, not their small-shape fallbacks, are what was compared.
 
 Shapes: B = 6 x 1 s @ 48 kHz -> T = 101, K = 34, M = B*T*K = 20,604 rows (>= the 8,192 / 16,384-row thresholds of the
 bres / ring kernels), time path 204 sequences x 101 steps, band path 606 sequences x 34 steps; the two band-path
-thresholds that depend on the NUMBER of sequences (>= 8,192 for the wide forward, >= 4,096 for the 32-row BPTT) are lowered
+thresholds that depend on the NUMBER of sequences (>= 6,144 for the row-wave forward, >= 4,096 for the 32-row BPTT) are lowered
 for the test, the band path skips the cluster forward as it does at C2 (12,832 sequences exceed its capacity) and the
 grouped ring GEMM accepts 606-row groups (1,024 by default); everything else is the default dispatch.
 """
@@ -20,7 +20,7 @@ from oracle import bsrnn_ref, losses_ref
 pytestmark = pytest.mark.gpu
 
 N, B, FS, SECONDS = 196, 6, 48000, 1.0
-C2_KERNELS = ("stft960", "nt_bres", "nt_ring", "lstm_fwd_cluster", "lstm_fwd_wide", "lstm_bwd_stream16", "lstm_bwd_stream32",
+C2_KERNELS = ("stft960", "nt_bres", "nt_ring", "lstm_fwd_cluster", "lstm_fwd_rw", "lstm_bwd_stream16", "lstm_bwd_stream32",
               "tn_dual", "tn_ring_t", "nt_grouped_ring", "tn_grouped")
 
 
@@ -28,6 +28,7 @@ C2_KERNELS = ("stft960", "nt_bres", "nt_ring", "lstm_fwd_cluster", "lstm_fwd_wid
 def c2_dispatch(monkeypatch):
     from urgent2026_challenge_track1_amd import ops
     monkeypatch.setattr(ops, "WIDE_MIN_SEQ", 1)
+    monkeypatch.setattr(ops, "RW_MIN_SEQ", 1)
     monkeypatch.setattr(ops, "BAND_PATH_NO_CLUSTER", True)
     monkeypatch.setenv("URSE_NT_GROUPED_MIN_M", "512")
     monkeypatch.setattr(ops, "BWD_ROWS16", {"f": 2 | 16})

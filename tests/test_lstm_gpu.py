@@ -331,3 +331,33 @@ def test_cooperative_kernel_timeout_is_reported(lib):
         pass
     torch.cuda.synchronize()
     ops.poll_kernel_errors(dev)                                  # clean again
+
+
+@pytest.mark.parametrize("sm", [dict(n_seq=100, seq_len=5, inner=1, outer=5, stride=1),          # ragged last tile, 7 workgroups of one tile
+                                dict(n_seq=1, seq_len=3, inner=1, outer=3, stride=1),
+                                dict(n_seq=2 * 34, seq_len=9, inner=34, outer=9 * 34, stride=34),   # time-path row map
+                                dict(n_seq=1900, seq_len=34, inner=1, outer=34, stride=1)])       # 119 tiles: workgroups of 1 and 0 ... 7 tiles
+@pytest.mark.parametrize("save", [True, False])
+def test_row_wave_forward_equals_wide_forward(lib, sm, save):
+    """csrc/lstm_rw.hip (16 sequences per wave, W_hh shared through an LDS-DMA ring) == csrc/lstm_wide.hip bit for bit: h, c and the
+    saved gate activations (same bf16 MFMA products in the same order, same f32 cell math)."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(3)
+    N, dev = 196, "cuda"
+    H, Hp = 2 * N, 416
+    assert ops.lstm_rw_supported(H, Hp)
+    whh = torch.randn(2 * 4 * H, H, device=dev) * 0.05
+    whhb = torch.empty(2 * 25 * 13 * 4 * 512, device=dev, dtype=torch.bfloat16)
+    ops.call("lstm_pack_blocks", whh, whhb, H, Hp, ops.stream_ptr())
+    M = sm["n_seq"] * sm["seq_len"]
+    gx = torch.randn(M, 8 * H, device=dev).to(torch.bfloat16)
+    g1, g2 = gx.clone(), gx.clone()
+    h1, c1 = ops.lstm_fwd_wide(g1, whhb, H, Hp, save=save, **sm)
+    for tw in (0, 16):
+        g2.copy_(gx)
+        h2, c2 = ops.lstm_fwd_rw(g2, whhb, H, Hp, save=save, target_wgs=tw, **sm)
+        assert torch.equal(h1.view(torch.int16), h2.view(torch.int16))
+        assert torch.equal(g1.view(torch.int16), g2.view(torch.int16))
+        if save:
+            assert torch.equal(c1, c2)
+    assert ops.launch_counts()["lstm_fwd_rw"] >= 2

@@ -486,6 +486,8 @@ class BSRNNCore(nn.Module):
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
             hout, c, err = ops.lstm_fwd_cluster(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
             self._cluster_err = err
+        elif ops.USE_RW_LSTM and pk.get(p + "whhb") is not None and sm["n_seq"] >= ops.RW_MIN_SEQ and ops.lstm_rw_supported(H, d["Hp"]):
+            hout, c = ops.lstm_fwd_rw(gx, pk[p + "whhb"], H, d["Hp"], save=save, **sm)
         elif ops.USE_WIDE_LSTM and pk.get(p + "whhb") is not None and sm["n_seq"] >= ops.WIDE_MIN_SEQ:
             hout, c = ops.lstm_fwd_wide(gx, pk[p + "whhb"], H, d["Hp"], save=save, **sm)
         else:

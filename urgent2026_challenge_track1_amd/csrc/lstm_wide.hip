@@ -209,7 +209,9 @@ __global__ void __launch_bounds__(WW * 64, 2) lstm_fwd_wide_kernel(WideArgs p) {
             const float hv = ov * cv;
 #else
             const float iv = sigmoidf_(gi), fv = sigmoidf_(gf), gv = tanhf_(gg), ov = sigmoidf_(go);
-            const float cv = fv * cprev[rt][r] + iv * gv;
+            // one contraction, spelled out: left to the compiler, 15 of the 16 unrolled instances became mul + fma and one a packed
+            // multiply + add (1 ulp apart), which made bit comparisons with lstm_rw.hip impossible
+            const float cv = __builtin_fmaf(fv, cprev[rt][r], __fmul_rn(iv, gv));
             const float hv = ov * tanhf_(cv);
 #endif
             if (nmy == 1) cnx[rt][r] = cv;       // a wave with one block keeps its cell state in registers

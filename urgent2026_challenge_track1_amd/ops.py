@@ -43,7 +43,7 @@ def timed_call(tname, name, *args):
 KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_ring", "nt_grouped_128", "tn_ring", "tn_ring_t",
                    "tn_dual", "tn_128", "tn_grouped", "lstm_fwd_stream", "lstm_fwd_wide", "lstm_fwd_cluster",
                    "lstm_fwd_cluster2", "lstm_bwd_stream16", "lstm_bwd_stream32", "lstm_bwd_cluster", "lstm_bwd_split",
-                   "stft960", "stft_generic", "istft_generic", "istft960")
+                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "lstm_bwd_rw")
 
 
 _PAGEABLE_UPLOADS = os.environ.get("URSE_PAGEABLE_UPLOADS", "0") == "1"
@@ -493,6 +493,27 @@ def lstm_fwd_wide(gx, whhb, H, Hp, n_seq, seq_len, inner, outer, stride, save=Tr
     c = torch.empty(M, 2 * H, device=gx.device, dtype=torch.float32)
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_wide_fwd", gx, gx.stride(0), whhb, hout, ldh,
                c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), stream_ptr())
+    return hout, (c if save else None)
+
+
+# the row-wave kernel (csrc/lstm_rw.hip) takes the band path once there are enough 16-sequence tiles to give every CU a
+# workgroup of 6-7 of them (C2: 802 tiles per direction); below that the wide / streaming kernels keep it
+USE_RW_LSTM = os.environ.get("URSE_LSTM_RW", "1") != "0"
+RW_MIN_SEQ = int(os.environ.get("URSE_LSTM_RW_MIN_SEQ", str(16 * 6 * 64)))
+
+
+def lstm_rw_supported(H, Hp):
+    return bool(_lib.load().urse_lstm_rw_supported(H, Hp))
+
+
+def lstm_fwd_rw(gx, whhb, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, target_wgs=0):
+    """row-wave LSTM forward (bf16, 16 sequences per wave, shared LDS weight ring): see csrc/lstm_rw.hip."""
+    M = gx.shape[0]
+    ldh = kpad(2 * H, gx.dtype)
+    hout = _hout_buffer(M, ldh, H, gx)
+    c = torch.empty(M, 2 * H, device=gx.device, dtype=torch.float32)
+    timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_rw_fwd", gx, gx.stride(0), whhb, hout, ldh,
+               c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), int(target_wgs), stream_ptr())
     return hout, (c if save else None)
 
 
