@@ -210,9 +210,13 @@ int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, void* strea
  *  (URSE_ERR_UNSUPPORTED, urse_last_error says why) when the sequences do not fit that many co-resident workgroups - the
  *  caller then takes the streaming kernel (urse_lstm_bidir_fwd / _bwd), which has no such requirement. */
 int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int reserved_cus, int64_t* plan);
+/* xcd_aware != 0: the clusters are formed at kernel start from workgroups that READ the same XCC id from the hardware (each
+ *  registers in `counters`, the grid waits for all registrations, every workgroup derives the same assignment): such a cluster
+ *  publishes h with stores that stay in its XCD's L2; the workgroups left over form mixed clusters (write-through stores, fewer
+ *  sequences).  Placement decides speed only; a pattern of counts the scheme cannot serve uses the static clusters. */
 int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                           void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
-                          int64_t outer, int64_t stride, int save, int reserved_cus, void* stream);
+                          int64_t outer, int64_t stride, int save, int reserved_cus, int xcd_aware, void* stream);
 /* Generalised cluster forward (csrc/lstm_cluster2.hip): same protocol and arguments, geometry chosen per hidden size
  * (H = 768, the flow model: 24 workgroups per cluster; H = 392: 7).  plan = {C, clusters per direction, rows per cluster,
  * hx bf16 elements}; hx is zeroed by the call; whhq from urse_lstm_pack_quads. */
@@ -239,11 +243,15 @@ int urse_lstm_wide_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int6
  * of a workgroup share one pass over W_hh per step, streamed L2 -> LDS by a loader wave (csrc/lstm_rw.hip).  No hand-off
  * between workgroups and no co-residency requirement.  whhb from urse_lstm_pack_blocks; `c` is REQUIRED as in
  * urse_lstm_wide_fwd; outputs equal urse_lstm_wide_fwd's bit for bit.  target_workgroups: workgroups the launch is dealt
- * over (0 = one per CU); urse_lstm_rw_supported(H, Hp) != 0 tells whether the shape has a kernel (H = 392). */
+ * over (0 = one per CU); urse_lstm_rw_supported(H, Hp) != 0 tells whether the shape has a kernel (H = 392).
+ * paired != 0: the kernel form that owns two ADJACENT units per lane and block pair (16 / 8 / 4-byte accesses of 256 / 128 / 64
+ * contiguous bytes per row); whhb must then come from urse_lstm_pack_blocks_rw, which permutes the weight columns accordingly
+ * (same size and fragment layout as urse_lstm_pack_blocks). */
 int urse_lstm_rw_supported(int H, int Hp);
+int urse_lstm_pack_blocks_rw(const float* whh, void* out, int H, int Hp, void* stream);
 int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_t ldh, float* c, int H, int Hp,
                      int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
-                     int target_workgroups, void* stream);
+                     int target_workgroups, int paired, void* stream);
 /* Split BPTT (bf16) for few, long sequences (time path): 2-3 workgroups share 32 sequences and split the reduction of
  * the recurrent product; f32 partial sums are exchanged through `xbuf` (zeroed by the call) with the tag-in-data
  * hand-off (step parity in the mantissa LSB).  Arguments as urse_lstm_bidir_bwd (whhT from urse_lstm_pack).

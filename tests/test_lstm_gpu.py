@@ -340,7 +340,8 @@ def test_cooperative_kernel_timeout_is_reported(lib):
 @pytest.mark.parametrize("save", [True, False])
 def test_row_wave_forward_equals_wide_forward(lib, sm, save):
     """csrc/lstm_rw.hip (16 sequences per wave, W_hh shared through an LDS-DMA ring) == csrc/lstm_wide.hip bit for bit: h, c and the
-    saved gate activations (same bf16 MFMA products in the same order, same f32 cell math)."""
+    saved gate activations (same bf16 MFMA products in the same order, same f32 cell math), in both kernel forms (one unit / two adjacent
+    units per lane)."""
     from urgent2026_challenge_track1_amd import ops
     torch.manual_seed(3)
     N, dev = 196, "cuda"
@@ -349,15 +350,45 @@ def test_row_wave_forward_equals_wide_forward(lib, sm, save):
     whh = torch.randn(2 * 4 * H, H, device=dev) * 0.05
     whhb = torch.empty(2 * 25 * 13 * 4 * 512, device=dev, dtype=torch.bfloat16)
     ops.call("lstm_pack_blocks", whh, whhb, H, Hp, ops.stream_ptr())
+    whhb_rw = torch.empty_like(whhb)
+    ops.call("lstm_pack_blocks_rw", whh, whhb_rw, H, Hp, ops.stream_ptr())
     M = sm["n_seq"] * sm["seq_len"]
     gx = torch.randn(M, 8 * H, device=dev).to(torch.bfloat16)
     g1, g2 = gx.clone(), gx.clone()
     h1, c1 = ops.lstm_fwd_wide(g1, whhb, H, Hp, save=save, **sm)
-    for tw in (0, 16):
+    for tw, paired in ((0, False), (16, False), (0, True), (16, True)):
         g2.copy_(gx)
-        h2, c2 = ops.lstm_fwd_rw(g2, whhb, H, Hp, save=save, target_wgs=tw, **sm)
+        h2, c2 = ops.lstm_fwd_rw(g2, whhb_rw if paired else whhb, H, Hp, save=save, target_wgs=tw, paired=paired, **sm)
         assert torch.equal(h1.view(torch.int16), h2.view(torch.int16))
         assert torch.equal(g1.view(torch.int16), g2.view(torch.int16))
         if save:
             assert torch.equal(c1, c2)
-    assert ops.launch_counts()["lstm_fwd_rw"] >= 2
+    assert ops.launch_counts()["lstm_fwd_rw"] >= 4
+
+
+@pytest.mark.parametrize("B,T,K", [(2, 9, 20), (32, 12, 34), (5, 40, 34)])
+def test_xcd_aware_clusters_equal_static_clusters(lib, B, T, K):
+    """cluster forward with clusters formed from workgroups that read the same XCC id (plain stores for the h hand-off inside an XCD,
+    mixed clusters with fewer sequences for the left-over workgroups) == the static clusters, bit for bit: which workgroups form a
+    cluster changes where the bytes travel, not one product or sum."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(5)
+    N, dev = 196, "cuda"
+    H, Hp = 2 * N, 416
+    whh = torch.randn(2 * 4 * H, H, device=dev) * 0.05
+    whhq = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=torch.bfloat16)
+    ops.call("lstm_pack_quads", whh, whhq, H, Hp, ops.stream_ptr())
+    M = B * T * K
+    sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+    assert ops.lstm_cluster_plan(H, Hp, sm["n_seq"]) is not None
+    gx = torch.randn(M, 8 * H, device=dev).to(torch.bfloat16)
+    outs = []
+    for xa in (False, True, True):
+        g = gx.clone()
+        h, c, err = ops.lstm_fwd_cluster(g, whhq, H, Hp, xcd_aware=xa, **sm)
+        assert int(err.item()) == 0
+        outs.append((g, h, c))
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0].view(torch.int16), o[0].view(torch.int16))
+        assert torch.equal(outs[0][1].view(torch.int16), o[1].view(torch.int16))
+        assert torch.equal(outs[0][2], o[2])

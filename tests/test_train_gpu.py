@@ -137,3 +137,29 @@ def test_single_rank_rccl_carries_the_gradient_buckets():
     assert gb["buckets"] >= 1 and gb["collectives_issued"] == gb["buckets"] * 4          # 1 warm-up + 3 timed steps
     # (the weight-gradient GEMMs sum their K slices with f32 atomics, so two runs agree to rounding, not bit for bit)
     assert abs(rccl["final_loss"] - plain["final_loss"]) <= 1e-3 * abs(plain["final_loss"]), (rccl["final_loss"], plain["final_loss"])
+
+
+def test_cooperative_bptt_beside_rccl_buckets_leaves_the_collective_its_cus():
+    """the flow model's backward runs the COOPERATIVE split BPTT (every workgroup must be resident) while the
+    reducer's all-reduce kernels occupy CUs.  From the first bucket to finish() `ops.reserved_cus()` includes RCCL's channel cap
+    (NCCL_MAX_NCHANNELS is capped before the communicator exists), so the split kernel is planned on the remaining CUs or refused
+    (counted) - never launched on a grid that cannot be co-resident.  Run: BSRNN-Flow C4 train steps through a single-rank RCCL group."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NCCL_MAX_NCHANNELS")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--model", "flow", "--gpus", "1", "--steps", "2", "--pretouch-gib", "0",
+           "--single-rank-collectives", "--dist-backend", "nccl"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    fb = line["flow_c4"]
+    assert "error" not in fb, fb
+    co = fb["cooperative_kernels_beside_rccl"]
+    assert co["kernel_error_flag"] == 0, co
+    assert co["reserved_cus_during_backward"] == 32 and co["reserved_cus_after_step"] == 0, co
+    assert co["collectives_issued"] == co["buckets"] * 3 and co["buckets"] >= 2, co          # 1 warm-up + 2 timed steps
+    # the cooperative kernel ran (on a smaller plan) or was refused and replaced by the streaming BPTT - either way every BPTT launched
+    lc = co["launch_counts"]
+    assert lc.get("lstm_bwd_split", 0) + lc.get("lstm_bwd_stream16", 0) + lc.get("lstm_bwd_stream32", 0) > 0, co
+    assert fb["final_loss"] == fb["final_loss"]

@@ -369,6 +369,7 @@ class BSRNNCore(nn.Module):
                 pk[p + "whh"], pk[p + "whhT"] = lp["whh"], lp["whhT"]
                 pk[p + "whhq"], pk[p + "whhTq"] = lp.get("whhq"), lp.get("whhTq")
                 pk[p + "whhb"] = lp.get("whhb")
+                pk[p + "whhb_rw"] = lp.get("whhb_rw")
         self._packed = pk
         self._packed_version = self.param_version
 
@@ -487,7 +488,10 @@ class BSRNNCore(nn.Module):
             hout, c, err = ops.lstm_fwd_cluster(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
             self._cluster_err = err
         elif ops.USE_RW_LSTM and pk.get(p + "whhb") is not None and sm["n_seq"] >= ops.RW_MIN_SEQ and ops.lstm_rw_supported(H, d["Hp"]):
-            hout, c = ops.lstm_fwd_rw(gx, pk[p + "whhb"], H, d["Hp"], save=save, **sm)
+            if ops.RW_PAIRED and pk.get(p + "whhb_rw") is not None:
+                hout, c = ops.lstm_fwd_rw(gx, pk[p + "whhb_rw"], H, d["Hp"], save=save, paired=True, **sm)
+            else:
+                hout, c = ops.lstm_fwd_rw(gx, pk[p + "whhb"], H, d["Hp"], save=save, **sm)
         elif ops.USE_WIDE_LSTM and pk.get(p + "whhb") is not None and sm["n_seq"] >= ops.WIDE_MIN_SEQ:
             hout, c = ops.lstm_fwd_wide(gx, pk[p + "whhb"], H, d["Hp"], save=save, **sm)
         else:
@@ -724,6 +728,7 @@ class BSRNNCore(nn.Module):
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)
         self._deferred, self._inflight, self._grad_pack = [], None, None     # nothing survives an aborted backward
+        ops.CO_RESIDENT_WGS = 0       # (an aborted backward may have left the second queue's reservation set: ADVICE r3)
         spec_ri = spec_ri.contiguous().float()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not train:

@@ -36,6 +36,7 @@ struct ClusterArgs {
   long inner, outer, stride;
   int n_seq, seq_len;
   int C, ncl, rows_per_cluster, rows_pad;
+  unsigned* xws;                  // XCD-aware formation (null = static clusters): [0..7] arrivals per XCD, [8] arrivals, zeroed per launch
 };
 
 __device__ __forceinline__ float quad_bcast(float v, int k) {
@@ -58,6 +59,10 @@ __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t rs, unsigned of
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs, (int)off, 0, 16);
 }
+__device__ __forceinline__ void store_plain(__amdgpu_buffer_rsrc_t rs, unsigned off, uint4 v) {      // keeps the line in this XCD's L2
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs, (int)off, 0, 0);
+}
 __device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
@@ -68,12 +73,71 @@ template <int NSLAB, int MAXCH>
 __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
-  const int dir = blockIdx.y;
-  const int cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
   const int H = p.H;
   constexpr int Hp = NSLAB * 32, pitch = lds_frag_pitch(Hp * 2);      // compile-time: the index arithmetic below folds to shifts / multiplies
   char* htile = smem;                                    // [CROWS][pitch]
   bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + CROWS * pitch);   // [CROWS][UW]
+  // ---- which cluster, which member, which sequences -------------------------------------------------------------------
+  // Static form: consecutive blockIdx.x form a cluster - under the round-robin dealing of workgroups to XCDs its seven members
+  // sit on seven DIFFERENT XCDs and every byte of the h all-gather crosses the fabric (14.3 GB per launch against 7.5 algorithmic,
+  // profiles/r02_pmc_hbm_traffic_v1.json).  XCD-aware form (p.xws): every workgroup registers under the XCC id it READS from the
+  // hardware (never inferred from blockIdx), waits until the whole grid has registered, and the final per-XCD counts then assign -
+  // identically in every workgroup - the first 7 * floor(n_x / 7) registrants of XCD x to clusters of their own XCD ("local":
+  // h is published with plain stores that stay in that XCD's L2, MI355X_MICROARCH.md: 104-122 GB/s same-XCD against 62-70) and
+  // the rest to mixed clusters (sc1 stores as before), which get fewer sequences.  A count pattern this cannot serve (odd cluster
+  // counts per kind) falls back to the static form.  Correctness never depends on where a workgroup runs: a local cluster is local
+  // because its members read the same XCC id.
+  int dir = blockIdx.y, cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
+  int seq0 = cl * p.rows_per_cluster, nrows_x = p.rows_per_cluster, clx = dir * p.ncl + cl;     // clx: index of the cluster's exchange block
+  bool local = false;
+  if (p.xws != nullptr) {
+    int* xs = reinterpret_cast<int*>(smem + CROWS * pitch + CROWS * UW * 2 + 16);      // [12] broadcast of the assignment
+    if (tid == 0) {
+      const int grid = gridDim.x * gridDim.y;
+      const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 7u;      // HW_REG_XCC_ID
+      const unsigned rank = __hip_atomic_fetch_add(p.xws + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(p.xws + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      bool ok = true;
+      while (__hip_atomic_load(p.xws + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)grid) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) { ok = false; atomicExch(p.err, 1u); break; }
+      }
+      int n[8], S = 0, before_full = 0, before_left = 0;
+      for (int x = 0; x < 8; ++x) {
+        n[x] = (int)__hip_atomic_load(p.xws + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int f = n[x] / p.C;
+        if (x < (int)xcc) { before_full += f; before_left += n[x] - f * p.C; }
+        S += f;
+      }
+      const int NC = grid / p.C, Mx = NC - S;                        // clusters in all, mixed ones
+      const int f_me = n[xcc] / p.C;
+      int mode = 0;                                                  // 0 = static fallback, 1 = XCD-aware
+      if (ok && S > 0 && (S & 1) == 0 && (Mx & 1) == 0) {
+        const int ns = S / 2, nm = Mx / 2;                           // per direction
+        int rows_m = 0;
+        if (nm > 0 && CROWS * ns < p.n_seq) rows_m = (p.n_seq - CROWS * ns + nm - 1) / nm;
+        const int rows_s = (p.n_seq - rows_m * nm + ns - 1) / ns;
+        if (rows_m <= CROWS && rows_s <= CROWS && rows_s > 0) {
+          mode = 1;
+          int ci, jj, lc_;
+          if ((int)rank < f_me * p.C) { ci = before_full + (int)rank / p.C; jj = (int)rank % p.C; lc_ = 1; }
+          else { const int li = before_left + ((int)rank - f_me * p.C); ci = S + li / p.C; jj = li % p.C; lc_ = 0; }
+          const int d = ci & 1, k = lc_ ? (ci >> 1) : ((ci - S) >> 1);            // direction, index among its kind in that direction
+          const int s0 = lc_ ? k * rows_s : ns * rows_s + k * rows_m;
+          int nr = lc_ ? rows_s : rows_m;
+          if (s0 + nr > p.n_seq) nr = p.n_seq - s0 > 0 ? p.n_seq - s0 : 0;
+          xs[0] = 1; xs[1] = d; xs[2] = ci; xs[3] = jj; xs[4] = s0 < p.n_seq ? s0 : 0; xs[5] = nr; xs[6] = lc_;
+        }
+      }
+      if (!mode) xs[0] = 0;
+      if (!ok) xs[0] = -1;
+    }
+    __syncthreads();
+    if (xs[0] < 0) return;                                           // the grid never assembled: flagged, nothing written
+    if (xs[0] == 1) { dir = xs[1]; clx = xs[2]; j = xs[3]; seq0 = xs[4]; nrows_x = xs[5]; local = xs[6] != 0; cl = clx; }
+    __syncthreads();
+  }
   const int nq = (H + 3) >> 2;
   const int qd = j * CW + w;                             // this wave's unit quad
   const bool qvalid = qd < nq;
@@ -100,14 +164,13 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) cst[a][b] = 0.f;
 
-  const int seq0 = cl * p.rows_per_cluster;
-  int seq1 = seq0 + p.rows_per_cluster;
+  int seq1 = seq0 + nrows_x;
   if (seq1 > p.n_seq) seq1 = p.n_seq;
-  const int nrows = seq1 - seq0;
+  const int nrows = seq1 > seq0 ? seq1 - seq0 : 0;
   bf16_t* gx = reinterpret_cast<bf16_t*>(p.gx);
   bf16_t* hout = reinterpret_cast<bf16_t*>(p.hout);
   const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * p.rows_pad * Hp * 2);
-  const unsigned cl_bytes = (unsigned)(((long)dir * p.ncl + cl) * p.rows_pad * Hp * 2);
+  const unsigned cl_bytes = (unsigned)((long)clx * p.rows_pad * Hp * 2);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2u * plane_bytes), 0x00020000);
   constexpr int cpr = Hp * 2 / 16;                       // 16-B chunks per h row
   constexpr int HL = (CROWS * 52 + CTHR - 1) / CTHR;     // h-tile chunks per thread (Hp <= 416)
@@ -251,7 +314,11 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
         uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
         const uint4 vt = make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv);
 #ifndef CABL_NO_XSTORE
-        if (step + 1 < p.seq_len) store_sc1(rs, pcur * plane_bytes + cl_bytes + (unsigned)((r0 + row) * Hp * 2 + ucol * 2), vt);
+        if (step + 1 < p.seq_len) {
+          const unsigned xo = pcur * plane_bytes + cl_bytes + (unsigned)((r0 + row) * Hp * 2 + ucol * 2);
+          if (local) store_plain(rs, xo, vt);       // the cluster's consumers read this XCD's L2 (sc1 loads bypass their L1 only)
+          else store_sc1(rs, xo, vt);
+        }
 #endif
         *reinterpret_cast<uint4*>(hout + ((long)(st_grow + toff) * ldh_i + (hcol_i + ucol))) = v;    // H % 8 == 0: whole chunks
       }
@@ -509,7 +576,7 @@ static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  const size_t lds = (size_t)CROWS * lds_frag_pitch(p.Hp * 2) + (size_t)CROWS * UW * 2 + 16;
+  const size_t lds = (size_t)CROWS * lds_frag_pitch(p.Hp * 2) + (size_t)CROWS * UW * 2 + 16 + 64;
   dim3 grid(p.C * p.ncl, 2);
   hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH>), grid, dim3(CTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_cluster_fwd");
@@ -609,7 +676,8 @@ extern "C" int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int reserved_cus
 
 extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                                      void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len,
-                                     int64_t inner, int64_t outer, int64_t stride, int save, int reserved_cus, void* stream) {
+                                     int64_t inner, int64_t outer, int64_t stride, int save, int reserved_cus, int xcd_aware,
+                                     void* stream) {
   URSE_CHECK_ARG(gx && whhq && hout && hx && counters && err_flag && (c || !save), "urse_lstm_cluster_fwd: null pointer");
   int64_t plan[6];
   int rc = urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus, plan);
@@ -627,6 +695,11 @@ extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, vo
   hipStream_t st = (hipStream_t)stream;
   // the exchange planes start with every tag bit clear (see the hand-off protocol in the kernel)
   (void)hipMemsetAsync(hx, 0, sizeof(bf16_t) * plan[4], st);
+  p.xws = nullptr;
+  if (xcd_aware && plan[5] >= 9) {       // clusters formed from workgroups that read the same XCC id (registration counters in `counters`)
+    (void)hipMemsetAsync(counters, 0, sizeof(unsigned) * plan[5], st);
+    p.xws = (unsigned*)counters;
+  }
   const int nslab = Hp / 32;
   note_launch(URSE_KV_LSTM_FWD_CLUSTER);
   if (nslab == 13) return launch_cluster<13, 1>(p, st);

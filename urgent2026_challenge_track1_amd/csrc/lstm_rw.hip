@@ -356,6 +356,303 @@ __global__ void __launch_bounds__(RW_WAVES * 64, 2) lstm_fwd_rw_kernel(RwArgs p)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Second form of the same kernel: the unit blocks are PAIRED.  Measured on the first form (profiles/r04_abl_rw_fwd_v3.log): with
+// all arithmetic switched off the launch takes as long as with it - the kernel is bound by its own memory pattern, and a
+// microbenchmark of that pattern (scripts/diag/stride_bw.hip) says why: 64-byte pieces per row (the f32 cell state of 16 units) load
+// at 3.5 TB/s where 256-byte pieces load at 6.2.  Here block 2p holds the EVEN units 32p, 32p + 2, .. and block 2p + 1 the odd ones
+// (urse_lstm_pack_blocks_rw permutes the weight columns), so that lane lc owns units 32p + 2 lc and 32p + 2 lc + 1 of a pair:
+// its pre-activations are one 16-byte load (256 contiguous bytes per row and wave-instruction), its two cell states one 8-byte
+// load (128 bytes per row), and the saved gates / c_t / h_t of a pair leave in one 16- / 8- / 4-byte store each - half the vector
+// memory instructions of the first form.  Units 384 .. 391 are a last single block.  Ring slots are addressed with a scalar
+// offset (5 slots, 8 stages per pair); everything else - loader, barriers, read-ahead, hout in the step's first block - is as above.
+constexpr int RW2_NPAIR = 12;     // pairs of 16-unit blocks (units 0 .. 383); block 24 = units 384 .. 391
+
+template <int H, int HP, bool SAVE>
+__global__ void __launch_bounds__(RW_WAVES * 64, 2) lstm_fwd_rw2_kernel(RwArgs p) {
+  constexpr int NBLK = (H + 15) / 16, NSLAB = HP / 32, NF = 4 * NSLAB;
+  constexpr int SF = NSLAB, SPS = NBLK * 4, SLOTB = SF * 1024, HPITCH = lds_frag_pitch(HP * 2);
+  static_assert(NBLK == 2 * RW2_NPAIR + 1 && SF == 13 && H % 8 == 0 && (4 * NF) % RW_D == 0 && NF % RW_D == 0, "geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;
+  char* hsb = smem + RW_NSLOT * SLOTB;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.x & 1, wi = blockIdx.x >> 1;
+  const int ntl = p.tiles_base + (wi < p.tiles_rem ? 1 : 0);
+  const int tile0 = wi * p.tiles_base + min(wi, p.tiles_rem);
+  const long total_stages = (long)p.seq_len * SPS;
+
+  if (w == RW_WAVES - 1) {       // loader: identical to the first form's
+    const char* wsrc = reinterpret_cast<const char*>(p.whhb) + (long)dir * NBLK * NF * 1024 + lane * 16;
+    const unsigned ring0 = (unsigned)(size_t)ring;
+    int sm = 0, slot = 0;
+    auto issue = [&]() {
+      const char* src = wsrc + (long)sm * SLOTB;
+      const unsigned dst = ring0 + slot * SLOTB;
+#pragma unroll
+      for (int f = 0; f < SF; ++f) rw_glds16(src + f * 1024, dst + f * 1024);
+      sm = (sm + 1 == SPS) ? 0 : sm + 1;
+      slot = (slot + 1 == RW_NSLOT) ? 0 : slot + 1;
+    };
+    issue(); issue(); issue(); issue();
+    asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+    issue();
+    __builtin_amdgcn_s_barrier();
+    for (long k = 0; k < total_stages; ++k) {
+      if (k >= 1) issue();
+      asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  if (w >= ntl) return;
+
+  char* hs = hsb + w * 16 * HPITCH;
+  const int seq0 = (tile0 + w) * 16;
+  for (int i = lane; i < 16 * HPITCH / 16; i += 64) reinterpret_cast<uint4*>(hs)[i] = make_uint4(0, 0, 0, 0);
+  constexpr unsigned OOB = 0xFFFFF000u;
+  const int ldg_i = (int)p.ldg, ldc_i = 2 * H, ldh_i = (int)p.ldh, gcol_i = dir * 4 * H, hcol_i = dir * H, stride_i = (int)p.stride;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(p.gx, 0, (int)p.gx_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(p.hout, 0, (int)p.h_bytes, 0x00020000);
+  // per-lane byte offsets of row 4 lr + r at t = 0: pair form (units 2 lc, 2 lc + 1 of pair 0) and tail form (unit 384 + lc)
+  // (a row past n_seq gets offsets outside the buffers: its loads return zeros, its stores are dropped)
+  unsigned goff[4], coff[4], hsoff[4];
+  const bool tvalid = 2 * RW2_NPAIR * 16 + lc < H;
+  const unsigned gtd = (unsigned)((2 * RW2_NPAIR * 16 * 4 - lc * 4) * 2), ctd = (unsigned)((2 * RW2_NPAIR * 16 - lc) * 4);   // tail - pair offset
+  int* rowtab = reinterpret_cast<int*>(hsb + RW_MAXT * 16 * HPITCH) + w * 16;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int seq = seq0 + lr * 4 + r;
+    const bool rvalid = seq < p.n_seq;
+    if (seq >= p.n_seq) seq = p.n_seq - 1;
+    const unsigned row = (unsigned)((seq / p.inner) * p.outer + (seq % p.inner));
+    goff[r] = rvalid ? (row * (unsigned)ldg_i + (unsigned)(gcol_i + lc * 8)) * 2u : OOB;
+    coff[r] = rvalid ? (row * (unsigned)ldc_i + (unsigned)(hcol_i + lc * 2)) * 4u : OOB;
+    hsoff[r] = (unsigned)((lr * 4 + r) * HPITCH + lc * 4);
+  }
+  constexpr int CPR = H * 2 / 16, HK = (16 * CPR + 63) / 64;
+  if (lane < 16) {                                                      // row of (sequence, t = 0), -1 past n_seq: the hout chunks look it up
+    const int seq = seq0 + lane;
+    rowtab[lane] = seq < p.n_seq ? (int)((seq / p.inner) * p.outer + (seq % p.inner)) : -1;
+  }
+  // chunk k of this lane: (row idx / 49, 16-byte piece idx % 49) of the wave's h tile, idx = lane + 64 k
+  auto hout_chunk = [&](int k, int soff, unsigned mask) {
+    const int idx = lane + 64 * k, row = idx / CPR, cc = idx - row * CPR;
+    const int rowc = idx < 16 * CPR ? row : 0;
+    const int grow = rowtab[rowc];
+    const uint4 v = *reinterpret_cast<const uint4*>(hs + rowc * HPITCH + cc * 16);
+    const unsigned off = (idx < 16 * CPR && grow >= 0) ? ((unsigned)grow * (unsigned)ldh_i + (unsigned)(hcol_i + cc * 8)) * 2u : OOB;
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4_{v.x, v.y, v.z, v.w}, rs_h, (int)(off | mask), soff, 0);
+  };
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  auto pack2 = [](float a, float b) -> unsigned {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+  };
+
+  uint4 hfrag[NSLAB];
+#pragma unroll
+  for (int ks = 0; ks < NSLAB; ++ks) hfrag[ks] = make_uint4(0, 0, 0, 0);
+  u32x4 gq[2][4];            // pre-activations of a pair (two slots): .xy = even unit, .zw = odd unit
+  u32x2 cq[2][4];            // c_{t-1} of a pair
+  u32x2 gt[4];               // ... of the tail block
+  unsigned ct[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    gq[0][r] = gq[1][r] = u32x4{0u, 0u, 0u, 0u};
+    cq[0][r] = cq[1][r] = u32x2{0u, 0u};
+    gt[r] = u32x2{0u, 0u};
+    ct[r] = 0u;
+  }
+  auto prefetch_pair = [&](int slot, int pr, int toff_, int toffc_, bool has_c) {
+    const int sg = (toff_ * ldg_i + pr * 128) * 2, sc = (toffc_ * ldc_i + pr * 32) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      gq[slot][r] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff[r], sg, 0);
+      cq[slot][r] = __builtin_amdgcn_raw_buffer_load_b64(rs_c, (int)(has_c ? coff[r] : OOB), sc, 0);
+    }
+  };
+  auto prefetch_tail = [&](int toff_, int toffc_, bool has_c) {
+    const int sg = toff_ * ldg_i * 2, sc = toffc_ * ldc_i * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      gt[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_g, (int)(goff[r] + gtd), sg, 0);       // (OOB + gtd stays outside the buffer)
+      ct[r] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)(has_c ? coff[r] + ctd : OOB), sc, 0);
+    }
+  };
+  {
+    const int t0 = (dir ? p.seq_len - 1 : 0) * stride_i;
+    prefetch_pair(0, 0, t0, t0, false);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                         // A_0
+  const unsigned loff = lane * 16;
+  int so_cur = 0, so_next = SLOTB;                                      // byte offsets of the ring slots of the current / next stage
+  uint4 bq[RW_D];
+#pragma unroll
+  for (int i = 0; i < RW_D; ++i) bq[i] = *reinterpret_cast<const uint4*>(ring + i * 1024 + loff);
+
+  f32x4_t accp[4];                                                      // gates of the previous block, waiting for their cell update
+  float cprevp[4];
+  float c_e[4], h_e[4];                                                 // results of a pair's even block, held until the odd one is done
+  u32x2 g_e[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) accp[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { cprevp[r] = 0.f; c_e[r] = 0.f; h_e[r] = 0.f; g_e[r] = u32x2{0u, 0u}; }
+
+  for (int step = 0; step < p.seq_len; ++step) {
+    const int t = dir ? (p.seq_len - 1 - step) : step;
+    const int toff = t * stride_i;
+    const bool more = step + 1 < p.seq_len;
+    const int toff_next = more ? (dir ? t - 1 : t + 1) * stride_i : toff;
+    const int toff_prev = step > 0 ? (dir ? t + 1 : t - 1) * stride_i : toff;
+    const int sg_t = toff * ldg_i * 2, sc_t = toff * ldc_i * 4;
+    const int sh_prev = toff_prev * ldh_i * 2;
+    const unsigned hmask = step > 0 ? 0u : OOB;
+
+    // the cell of row 4 lr + r from accp / cprevp: (c_t, h_t, packed gates)
+    auto cell_math = [&](int r, float& cv, float& hv, u32x2& gs) {
+      const float iv = sigmoidf_(accp[0][r]), fv = sigmoidf_(accp[1][r]), gv = tanhf_(accp[2][r]), ov = sigmoidf_(accp[3][r]);
+      cv = __builtin_fmaf(fv, cprevp[r], __fmul_rn(iv, gv));
+      hv = ov * tanhf_(cv);
+      gs = u32x2{pack2(iv, fv), pack2(gv, ov)};
+    };
+    auto cell_even = [&](int r) { cell_math(r, c_e[r], h_e[r], g_e[r]); };
+    auto cell_odd_store = [&](int pr, int r) {                          // second unit of pair `pr`, then the pair's stores
+      float cv, hv;
+      u32x2 gs;
+      cell_math(r, cv, hv, gs);
+      *reinterpret_cast<unsigned*>(hs + hsoff[r] + pr * 64) = pack2(h_e[r], hv);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(c_e[r]), __float_as_uint(cv)}, rs_c, (int)coff[r], sc_t + pr * 128, 0);
+      if constexpr (SAVE)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{g_e[r][0], g_e[r][1], gs[0], gs[1]}, rs_g, (int)goff[r], sg_t + pr * 256, 0);
+    };
+    auto cell_tail = [&](int r) {
+      float cv, hv;
+      u32x2 gs;
+      cell_math(r, cv, hv, gs);
+      *reinterpret_cast<bf16_t*>(hs + (lr * 4 + r) * HPITCH + (2 * RW2_NPAIR * 16 + lc) * 2) = f32_to_bf16(hv);   // (units past H: k padding)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cv), rs_c, (int)(tvalid ? coff[r] + ctd : OOB), sc_t, 0);
+      if constexpr (SAVE) __builtin_amdgcn_raw_buffer_store_b64(gs, rs_g, (int)(tvalid ? goff[r] + gtd : OOB), sg_t, 0);
+    };
+    auto hout_chunks = [&](int k0, int k1) {
+#pragma unroll
+      for (int k = k0; k < k1; ++k)
+        if (k < HK) hout_chunk(k, sh_prev, hmask);
+    };
+    // the 52 MFMAs of one block against the ring, four stages with a barrier each; `between(q)` is issued among the MFMAs of quarter q
+    auto block_mfma = [&](f32x4_t (&acc)[4], auto between) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int f = 0; f < SF; ++f) {
+          const int fb = q * SF + f, ks = fb >> 2, gate = fb & 3;
+          acc[gate] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, hfrag[ks]),
+                                                              __builtin_bit_cast(bf16x8_t, bq[fb % RW_D]), acc[gate], 0, 0, 0);
+          const int f2 = f + RW_D;                       // read-ahead: this stage's slot, or the head of the next one
+          bq[fb % RW_D] = (f2 < SF) ? *reinterpret_cast<const uint4*>(ring + so_cur + f2 * 1024 + loff)
+                                    : *reinterpret_cast<const uint4*>(ring + so_next + (f2 - SF) * 1024 + loff);
+        }
+        between(q);
+        __builtin_amdgcn_s_barrier();
+        so_cur = so_next;
+        so_next = (so_next + SLOTB == RW_NSLOT * SLOTB) ? 0 : so_next + SLOTB;
+      }
+    };
+    auto init_acc = [&](f32x4_t (&acc)[4], unsigned lo, unsigned hi, int r) {
+      acc[0][r] = __uint_as_float(lo << 16);
+      acc[1][r] = __uint_as_float(lo & 0xffff0000u);
+      acc[2][r] = __uint_as_float(hi << 16);
+      acc[3][r] = __uint_as_float(hi & 0xffff0000u);
+    };
+    auto retire = [&](const f32x4_t (&acc)[4], const float (&cprev)[4]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accp[g] = acc[g];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cprevp[r] = cprev[r];
+    };
+
+    // two pairs per body: the prefetch slots become constants
+    auto body = [&](int p0, auto first) {
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const int pr = p0 + pi;
+        f32x4_t acc[4];
+        float cprev[4];
+        // even block
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { init_acc(acc, gq[pi][r][0], gq[pi][r][1], r); cprev[r] = __uint_as_float(cq[pi][r][0]); }
+        block_mfma(acc, [&](int q) {
+          if (decltype(first)::value && pi == 0) hout_chunks(q * 4, q * 4 + 4);     // the step's first block: h of the previous step goes out
+          else cell_odd_store(pr - 1, q);
+        });
+        retire(acc, cprev);
+        {   // fetch what comes after the odd block (one block = ~3 us ahead): the next pair, or the tail block after the last pair
+          if (pr + 1 < RW2_NPAIR) prefetch_pair(pi ^ 1, pr + 1, toff, toff_prev, step > 0);
+          else prefetch_tail(toff, toff_prev, step > 0);
+        }
+        // odd block
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { init_acc(acc, gq[pi][r][2], gq[pi][r][3], r); cprev[r] = __uint_as_float(cq[pi][r][1]); }
+        block_mfma(acc, [&](int q) { cell_even(q); });
+        retire(acc, cprev);
+      }
+    };
+    body(0, std::true_type{});
+#pragma unroll 1
+    for (int p0 = 2; p0 < RW2_NPAIR; p0 += 2) body(p0, std::false_type{});
+    // tail block (units 384 ..): the last pair's second unit is updated and the pair stored meanwhile
+    {
+      prefetch_pair(0, 0, toff_next, toff, true);                        // next step's first pair (c_{t-1} = what this step stored)
+      f32x4_t acc[4];
+      float cprev[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { init_acc(acc, gt[r][0], gt[r][1], r); cprev[r] = __uint_as_float(ct[r]); }
+      block_mfma(acc, [&](int q) { cell_odd_store(RW2_NPAIR - 1, q); });
+      retire(acc, cprev);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cell_tail(r);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NSLAB; ++ks) hfrag[ks] = *reinterpret_cast<const uint4*>(hs + lc * HPITCH + ks * 64 + 16 * lr);
+  }
+  {
+    const int t = dir ? 0 : p.seq_len - 1;
+    const int sh = t * stride_i * ldh_i * 2;
+#pragma unroll
+    for (int k = 0; k < HK; ++k) hout_chunk(k, sh, 0u);
+  }
+}
+
+// block-ordered recurrent weights with the row-wave kernel's unit order: block b < 24, column lc = unit 32 (b / 2) + 2 lc + (b & 1);
+// block 24, column lc = unit 384 + lc.  Otherwise the layout of urse_lstm_pack_blocks: (dir, blk, ks, gate) = 64 lanes x 16 B,
+// lane (lr, lc): k = ks * 32 + 8 lr + j.
+__global__ void __launch_bounds__(256) lstm_pack_blocks_rw_kernel(const float* __restrict__ whh, bf16_t* __restrict__ out, int H, int Hp) {
+  const int nblk = (H + 15) >> 4, nslab = Hp / 32, G4 = 4 * H, npair = nblk / 2;
+  const long total = (long)2 * nblk * nslab * 4 * 64 * 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int jj = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int g = (int)(r % 4); r /= 4;
+    const int ks = (int)(r % nslab); r /= nslab;
+    const int blk = (int)(r % nblk);
+    const int d = (int)(r / nblk);
+    const int lc = lane & 15, lr = lane >> 4;
+    const int u = blk < 2 * npair ? 32 * (blk >> 1) + 2 * lc + (blk & 1) : blk * 16 + lc;
+    const int k = ks * 32 + 8 * lr + jj;
+    out[idx] = f32_to_bf16((u < H && k < H) ? whh[((long)d * G4 + g * H + u) * H + k] : 0.f);
+  }
+}
+
 static bool rw_shape(int H, int Hp) { return H == 392 && Hp == 416; }
 
 }  // namespace urse
@@ -364,15 +661,23 @@ using namespace urse;
 
 extern "C" int urse_lstm_rw_supported(int H, int Hp) { return rw_shape(H, Hp) ? 1 : 0; }
 
+extern "C" int urse_lstm_pack_blocks_rw(const float* whh, void* out, int H, int Hp, void* stream) {
+  URSE_CHECK_ARG(whh && out && rw_shape(H, Hp), "urse_lstm_pack_blocks_rw: bad argument (H=%d Hp=%d)", H, Hp);
+  hipLaunchKernelGGL(lstm_pack_blocks_rw_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, whh, (bf16_t*)out, H, Hp);
+  URSE_CHECK_LAUNCH("urse_lstm_pack_blocks_rw");
+  return URSE_OK;
+}
+
 extern "C" int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_t ldh, float* c, int H, int Hp,
                                 int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
-                                int target_workgroups, void* stream) {
+                                int target_workgroups, int paired, void* stream) {
   URSE_CHECK_ARG(gx && whhb && hout && c, "urse_lstm_rw_fwd: null pointer (c is required: it carries c_{t-1})");
   URSE_CHECK_ARG(rw_shape(H, Hp), "urse_lstm_rw_fwd: unsupported H=%d Hp=%d", H, Hp);
   URSE_CHECK_ARG(n_seq > 0 && seq_len > 0 && inner > 0 && target_workgroups >= 0, "urse_lstm_rw_fwd: bad sequence geometry");
   URSE_CHECK_ARG(ldg < (1L << 31) && ldh < (1L << 31) && stride * seq_len + (n_seq / inner + 1) * outer < (1L << 31),
                  "urse_lstm_rw_fwd: row indices must fit 32 bits");
-  URSE_CHECK_ARG(ldg >= 8L * H && ldg % 4 == 0 && ldh >= 2L * H && ldh % 8 == 0 && ((uintptr_t)gx % 8) == 0 && ((uintptr_t)hout % 16) == 0,
+  URSE_CHECK_ARG(ldg >= 8L * H && ldg % 8 == 0 && ldh >= 2L * H && ldh % 8 == 0 && ((uintptr_t)gx % 16) == 0 && ((uintptr_t)hout % 16) == 0 &&
+                     ((uintptr_t)c % 8) == 0,
                  "urse_lstm_rw_fwd: bad leading dimension / alignment (hout rows must be 16-byte aligned)");
   RwArgs p;
   p.gx = gx; p.ldg = ldg; p.whhb = whhb; p.hout = hout; p.ldh = ldh; p.c = c; p.save = save;
@@ -394,7 +699,19 @@ extern "C" int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* h
   p.tiles_base = ntile / G;
   p.tiles_rem = ntile % G;
   constexpr int HPITCH = lds_frag_pitch(416 * 2);
-  const size_t lds = (size_t)RW_NSLOT * 13 * 1024 + (size_t)RW_MAXT * 16 * HPITCH;
+  const size_t lds = (size_t)RW_NSLOT * 13 * 1024 + (size_t)RW_MAXT * 16 * HPITCH + (paired ? RW_MAXT * 16 * sizeof(int) : 0);
+  if (paired) {
+    static bool once2 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rw2_kernel<392, 416, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rw2_kernel<392, 416, false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once2;
+    note_launch(URSE_KV_LSTM_FWD_RW);
+    if (save) hipLaunchKernelGGL((lstm_fwd_rw2_kernel<392, 416, true>), dim3(2 * G), dim3(RW_WAVES * 64), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((lstm_fwd_rw2_kernel<392, 416, false>), dim3(2 * G), dim3(RW_WAVES * 64), lds, (hipStream_t)stream, p);
+    URSE_CHECK_LAUNCH("urse_lstm_rw_fwd");
+    return URSE_OK;
+  }
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rw_kernel<392, 416, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rw_kernel<392, 416, false>),

@@ -10,6 +10,8 @@ that got no gradient on a rank (bands above fs/2) are zeros in the f
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 class GradBucketReducer:
     def __init__(self, core, bucket_bytes=25 * 1024 * 1024, group=None, force=False):
@@ -44,6 +46,9 @@ class GradBucketReducer:
             return
         self.launched += 1
         if self.on_gpu:
+            # from the first bucket until finish() an all-reduce kernel may sit on up to RCCL_MAX_CHANNELS CUs: cooperative recurrences
+            # launched meanwhile (flow model: split BPTT) are planned on the rest, or refused (ops.reserved_cus)
+            ops.COMM_RESERVED_CUS = ops.RCCL_MAX_CHANNELS
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
@@ -61,11 +66,14 @@ class GradBucketReducer:
 
     def finish(self):
         """Block the compute stream until every bucket is reduced; returns the 1/world scale for the optimizer."""
-        for w in self._works:
-            w.wait()
-        if self.on_gpu and self.active:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
-        self._works = []
+        try:
+            for w in self._works:
+                w.wait()
+            if self.on_gpu and self.active:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+        finally:
+            self._works = []
+            ops.COMM_RESERVED_CUS = 0            # (the compute stream waits above: no all-reduce kernel is resident beside what follows)
         # every bucket must have been reduced by now: a bucket with tags still pending means this rank would step on
         # local, un-averaged gradients while its peers wait in an all-reduce - fail loudly instead
         for i, (tags, lo, hi) in enumerate(self.buckets):

@@ -146,7 +146,7 @@ def _poly_resample(x, fs_in, fs_out, design="scipy"):
         h, half = _design(design, up, down, int(fs_in))
         n_pre_pad = down - half % down
         hp = np.concatenate([np.zeros(n_pre_pad), h])
-        _cache[key] = (ops.upload(torch.from_numpy(hp), x.device), len(hp), (half + n_pre_pad) // down)
+        _cache[key] = (ops.upload(torch.from_numpy(hp), x.device, cached=True), len(hp), (half + n_pre_pad) // down)
     hp, hlen, npr = _cache[key]
     n_out = L * up // down + (1 if (L * up) % down else 0)
     y = torch.empty(P, n_out, device=x.device, dtype=torch.float32)

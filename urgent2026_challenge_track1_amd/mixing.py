@@ -84,9 +84,10 @@ def add_reverberation(speech, lens, rir, rir_lens):
         nb = ctypes.c_int64()
         if lib.urse_fft_convolve_workspace_bytes(B, L, mt, ctypes.addressof(nb)) != 0:
             raise _lib.UrseError(lib.urse_last_error().decode())
-        ws = _conv_ws.get(dev)
+        wkey = (dev, torch.cuda.current_stream(dev).cuda_stream)      # one workspace per stream: a main-stream call must not share it with staged batches
+        ws = _conv_ws.get(wkey)
         if ws is None or ws.numel() < nb.value:
-            ws = _conv_ws[dev] = torch.empty(nb.value, device=dev, dtype=torch.uint8)
+            ws = _conv_ws[wkey] = torch.empty(nb.value, device=dev, dtype=torch.uint8)
         out = torch.empty_like(speech)
         call("fft_convolve", speech, _i32(lens, dev), B, speech.stride(0), rir, _i32(host_taps, dev), rir.stride(0), 1, out, L, mt,
              ws, ws.numel(), stream_ptr())
@@ -215,6 +216,15 @@ def bandwidth_limitation_polyphase(speech, fs, fs_new):
     return fix(up, L)
 
 
+def _fft_resample_span(L, fs, fs_new):
+    """longest transform of the down / up round trip of `scipy.signal.resample`: the up leg's input has ceil(L * r) samples and its
+    output ceil(ceil(L * r) / r), which can exceed L by one."""
+    import math
+    r = float(fs_new) / float(fs)
+    n1 = int(math.ceil(L * r))
+    return max(L, n1, int(math.ceil(n1 / r)))
+
+
 _fft_plans = {}        # (device, length) -> plan tensor (chirp + transformed conjugate chirp); a handful of MB each, LRU of 16
 _fft_ws = {}
 
@@ -233,6 +243,9 @@ def _fft_plan(n, dev):
     tmp = torch.empty(nt.value, 2, device=dev, dtype=torch.float32)
     call("fft_resample_plan", plan, tmp, int(n), stream_ptr())
     tmp.record_stream(torch.cuda.current_stream(dev))
+    ev = torch.cuda.Event()               # the plan enters a cache other streams read without an event: built once, waited for once
+    ev.record(torch.cuda.current_stream(dev))
+    ev.synchronize()
     _fft_plans[key] = plan
     while len(_fft_plans) > 16:
         _fft_plans.pop(next(iter(_fft_plans)))
@@ -258,9 +271,10 @@ def _fft_resample(x, num):
     nb = ctypes.c_int64()
     if lib.urse_fft_resample_workspace_bytes(P, nx, num, ctypes.addressof(nb)) != 0:
         raise _lib.UrseError(lib.urse_last_error().decode())
-    ws = _fft_ws.get(dev)
+    wkey = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _fft_ws.get(wkey)
     if ws is None or ws.numel() < nb.value:
-        ws = _fft_ws[dev] = torch.empty(nb.value, device=dev, dtype=torch.uint8)
+        ws = _fft_ws[wkey] = torch.empty(nb.value, device=dev, dtype=torch.uint8)
     y = torch.empty(P, num, device=dev, dtype=torch.float32)
     call("fft_resample", x, x.stride(0) if P > 1 else nx, y, num, pa, pb, ws, ws.numel(), P, nx, num, stream_ptr())   # (a size-1 dim may carry stride 0)
     ws.record_stream(torch.cuda.current_stream(dev))
@@ -297,7 +311,7 @@ def _resampy_table(name, sample_ratio, dev):
         if sample_ratio < 1:
             win = sample_ratio * win
         delta = np.diff(win, append=win[-1])
-        _resampy_tables[key] = (ops.upload(torch.from_numpy(win), dev), ops.upload(torch.from_numpy(delta), dev), len(win), num_bits)
+        _resampy_tables[key] = (ops.upload(torch.from_numpy(win), dev, cached=True), ops.upload(torch.from_numpy(delta), dev, cached=True), len(win), num_bits)
     return _resampy_tables[key]
 
 
@@ -379,7 +393,7 @@ def simulate_recipes(speech, lens, noise_raw, noise_lens, rir, rir_lens, rir_ear
             if a in ("clipping", "packet_loss"):
                 mine.append(a)
             elif a == "bandwidth_limitation" and r["params"][a]["res_type"] in ("polyphase", "scipy", "kaiser_best", "kaiser_fast", "none") and not (
-                    r["params"][a]["res_type"] == "scipy" and int(r["length"]) > FFT_RESAMPLE_MAX):      # (> 10.9 s at 48 kHz)
+                    r["params"][a]["res_type"] == "scipy" and _fft_resample_span(int(r["length"]), fs, r["params"][a]["fs_new"]) > FFT_RESAMPLE_MAX):      # (> 10.9 s at 48 kHz)
                 mine.append(a)
             else:
                 count(a)

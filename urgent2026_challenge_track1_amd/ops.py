@@ -49,14 +49,22 @@ KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_r
 _PAGEABLE_UPLOADS = os.environ.get("URSE_PAGEABLE_UPLOADS", "0") == "1"
 
 
-def upload(host_tensor, device):
+def upload(host_tensor, device, cached=False):
     """small host table -> device through page-locked memory, non-blocking: a pageable `.to(device)` makes the host wait for
-    everything queued on the stream (the per-band descriptor tables go up eight times per step)."""
+    everything queued on the stream (the per-band descriptor tables go up eight times per step).
+    cached=True: the table goes into a process-wide cache that OTHER streams will read without an event (filter tables, resampler
+    tables): the copy is waited for once, here, so that no consumer can see a half-written table whatever stream touched the cache
+    first (the first toucher is often the lowest-priority prefetch stream with two batches of work queued)."""
     if torch.device(device).type != "cuda":
         return host_tensor
     if _PAGEABLE_UPLOADS:          # A/B switch: the blocking copies this replaced
         return host_tensor.to(device)
-    return host_tensor.contiguous().pin_memory().to(device, non_blocking=True)
+    out = host_tensor.contiguous().pin_memory().to(device, non_blocking=True)
+    if cached:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ev.synchronize()
+    return out
 
 
 def launch_counts(reset=False):
@@ -270,6 +278,10 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
             if "whhb" not in out:
                 out["whhb"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32) * 4 * 512, device=dev, dtype=dtype)
             call("lstm_pack_blocks", whh, out["whhb"], H, Hp, stream_ptr())
+        if _lib.load().urse_lstm_rw_supported(H, Hp):
+            if "whhb_rw" not in out:
+                out["whhb_rw"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32) * 4 * 512, device=dev, dtype=dtype)
+            call("lstm_pack_blocks_rw", whh, out["whhb_rw"], H, Hp, stream_ptr())
         if H % 8 == 0:
             C = ((H + 3) // 4 + 13) // 14
             if "whhTq" not in out:
@@ -335,8 +347,56 @@ CO_RESIDENT_WGS = 0
 PREFETCH_RESERVED_CUS = 0
 
 
+# ... and CUs left to RCCL's all-reduce kernels while a gradient bucket is in flight (ddp.GradBucketReducer sets it at its first bucket of
+# a backward pass and clears it in finish()): an all-reduce occupies up to NCCL_MAX_NCHANNELS workgroups (one per channel), which train_se /
+# bench.py cap at RCCL_MAX_CHANNELS before the communicator exists.  A cooperative recurrence launched between the first bucket and finish()
+# (the flow model's split BPTT; any cluster kernel) is then planned on the CUs that are left - or REFUSED and replaced by its streaming twin -
+# instead of spinning on a workgroup that RCCL keeps off the chip.
+COMM_RESERVED_CUS = 0
+RCCL_MAX_CHANNELS = int(os.environ.get("URSE_RCCL_MAX_CHANNELS", "32"))
+COOP_REFUSALS = 0                # cooperative plans refused because of reserved CUs (diagnostic: counted, never silent)
+
+
+def cap_rccl_channels():
+    """call BEFORE the first collective creates the RCCL communicator: bounds the workgroups an all-reduce can occupy to what
+    reserved_cus() sets aside for it."""
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_MAX_CHANNELS))
+
+
 def reserved_cus():
-    return int(CO_RESIDENT_WGS) + int(PREFETCH_RESERVED_CUS)
+    return int(CO_RESIDENT_WGS) + int(PREFETCH_RESERVED_CUS) + int(COMM_RESERVED_CUS)
+
+
+class reserve_cus:
+    """scoped reservation (the module globals used to stay set when an exception left the region that set them):
+    with ops.reserve_cus(prefetch=8): ...   /   with ops.reserve_cus(co_resident=98): ..."""
+
+    def __init__(self, co_resident=None, prefetch=None, comm=None):
+        self.new = (co_resident, prefetch, comm)
+
+    def __enter__(self):
+        global CO_RESIDENT_WGS, PREFETCH_RESERVED_CUS, COMM_RESERVED_CUS
+        self.old = (CO_RESIDENT_WGS, PREFETCH_RESERVED_CUS, COMM_RESERVED_CUS)
+        co, pf, cm = self.new
+        if co is not None:
+            CO_RESIDENT_WGS = co
+        if pf is not None:
+            PREFETCH_RESERVED_CUS = pf
+        if cm is not None:
+            COMM_RESERVED_CUS = cm
+        return self
+
+    def __exit__(self, *exc):
+        global CO_RESIDENT_WGS, PREFETCH_RESERVED_CUS, COMM_RESERVED_CUS
+        CO_RESIDENT_WGS, PREFETCH_RESERVED_CUS, COMM_RESERVED_CUS = self.old
+        return False
+
+
+def _note_refusal(fits_without_reservation):
+    """a cooperative plan failed: count it as a refusal if the reservation (not the shape) is why."""
+    global COOP_REFUSALS
+    if reserved_cus() > 0 and fits_without_reservation():
+        COOP_REFUSALS += 1
 
 
 def lstm_cluster_plan(H, Hp, n_seq):
@@ -345,12 +405,18 @@ def lstm_cluster_plan(H, Hp, n_seq):
     plan = (ctypes.c_int64 * 6)()
     lib = _lib.load()
     if lib.urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus(), plan) != 0:
+        _note_refusal(lambda: lib.urse_lstm_cluster_plan(H, Hp, n_seq, 0, plan) == 0)
         return None
     return list(plan)
 
 
-def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save=True):
+# clusters of the time path's forward formed from workgroups on ONE XCD (the h all-gather then stays in that XCD's L2)
+CLUSTER_XCD_AWARE = os.environ.get("URSE_LSTM_CLUSTER_XCD", "1") != "0"
+
+
+def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, xcd_aware=None):
     """persistent cluster LSTM forward (bf16): see csrc/lstm_cluster.hip."""
+    xcd_aware = CLUSTER_XCD_AWARE if xcd_aware is None else xcd_aware
     plan = lstm_cluster_plan(H, Hp, n_seq)
     M, dev = gx.shape[0], gx.device
     key = (dev, H, Hp, n_seq, plan[4], plan[5])
@@ -363,7 +429,7 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
     hout = _hout_buffer(M, ldh, H, gx)
     c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster_fwd", gx, gx.stride(0), whhq, hout, ldh,
-               c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), reserved_cus(), stream_ptr())
+               c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), reserved_cus(), int(bool(xcd_aware)), stream_ptr())
     return hout, c, err
 
 
@@ -375,6 +441,7 @@ def lstm_cluster2_plan(H, Hp, n_seq):
     import ctypes
     plan = (ctypes.c_int64 * 4)()
     if _lib.load().urse_lstm_cluster2_plan(H, Hp, n_seq, reserved_cus(), plan) != 0:
+        _note_refusal(lambda: _lib.load().urse_lstm_cluster2_plan(H, Hp, n_seq, 0, plan) == 0)
         return None
     return list(plan)
 
@@ -506,14 +573,19 @@ def lstm_rw_supported(H, Hp):
     return bool(_lib.load().urse_lstm_rw_supported(H, Hp))
 
 
-def lstm_fwd_rw(gx, whhb, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, target_wgs=0):
-    """row-wave LSTM forward (bf16, 16 sequences per wave, shared LDS weight ring): see csrc/lstm_rw.hip."""
+# the kernel form with two adjacent units per lane and block pair (wider, contiguous accesses); its weights come from lstm_pack_blocks_rw
+RW_PAIRED = os.environ.get("URSE_LSTM_RW_PAIRED", "1") != "0"
+
+
+def lstm_fwd_rw(gx, whhb, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, target_wgs=0, paired=False):
+    """row-wave LSTM forward (bf16, 16 sequences per wave, shared LDS weight ring): see csrc/lstm_rw.hip.
+    paired: whhb is the column-permuted packing of lstm_pack_blocks_rw."""
     M = gx.shape[0]
     ldh = kpad(2 * H, gx.dtype)
     hout = _hout_buffer(M, ldh, H, gx)
     c = torch.empty(M, 2 * H, device=gx.device, dtype=torch.float32)
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_rw_fwd", gx, gx.stride(0), whhb, hout, ldh,
-               c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), int(target_wgs), stream_ptr())
+               c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), int(target_wgs), int(paired), stream_ptr())
     return hout, (c if save else None)
 
 
@@ -546,6 +618,7 @@ def lstm_split_plan(H, n_seq):
     import ctypes
     plan = (ctypes.c_int64 * 4)()
     if _lib.load().urse_lstm_split_plan(H, n_seq, reserved_cus(), plan) != 0:
+        _note_refusal(lambda: _lib.load().urse_lstm_split_plan(H, n_seq, 0, plan) == 0)
         return None
     return list(plan)
 

@@ -60,8 +60,12 @@ def save_checkpoint(path, model, opt, sched, epoch, step, val_loss):
 
 def load_model_state(model, state_dict, with_ema=True):
     """weights of a checkpoint into the model.  with_ema=False is `init_from` (reference train_se.py:55-59: a plain
-    ``model.load_state_dict`` - Lightning's on_load_checkpoint hook does not run there, the EMA starts from the loaded weights);
-    with_ema=True is the resume path (Lightning restores checkpoint['ema'] through the hook, flow_model.py:98-113)."""
+    ``model.load_state_dict`` - Lightning's on_load_checkpoint hook does not run there); with_ema=True is the resume path
+    (Lightning restores checkpoint['ema'] through the hook, flow_model.py:98-113).
+    Deviation, stated (DESIGN.md quirk list): the reference builds ExponentialMovingAverage(self.parameters()) in
+    FlowSEModel.__init__, BEFORE train_se.py loads init_from, so its shadow starts from the random initialisation; here the EMA is
+    created lazily after the load and starts from the init_from weights.  The decay warm-up (1 + n) / (10 + n) forgets the
+    difference within a few hundred updates; EMA validation figures of the first steps differ from the reference's."""
     ck = state_dict
     if "state_dict" in state_dict:
         state_dict = state_dict["state_dict"]
@@ -120,17 +124,22 @@ class DevicePrefetcher:
                     staged.append(self._stage(next(it)))
                 except StopIteration:
                     done = True
-        fill()
-        while staged:
-            out, ev = staged.popleft()
+        try:
             fill()
-            if ev is not None:
-                cur = torch.cuda.current_stream(self.dev)
-                cur.wait_event(ev)
-                for t in out:
-                    if torch.is_tensor(t) and t.is_cuda:
-                        t.record_stream(cur)
-            yield out
+            while staged:
+                out, ev = staged.popleft()
+                fill()
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.dev)
+                    cur.wait_event(ev)
+                    for t in out:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)
+                yield out
+        finally:
+            # the reservation belongs to this iteration: validation / inference / metrics later in the process plan their cooperative
+            # kernels on the whole chip again
+            ops.PREFETCH_RESERVED_CUS = 0
 
 
 def validate(model, loader, dev):
@@ -176,6 +185,7 @@ def fit(cfg, max_steps=None, log_every=50):
     if world > 1 and not dist.is_initialized():
         backend = os.environ.get("URSE_DIST_BACKEND", "nccl")     # nccl = RCCL; gloo lets ranks share one GPU (tests)
         if backend == "nccl":
+            ops.cap_rccl_channels()         # bounds what an all-reduce kernel occupies: ops.reserved_cus() leaves it that many CUs
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -222,11 +232,18 @@ def fit(cfg, max_steps=None, log_every=50):
             loss.backward()
             model.optimizer_step(opt, reducer)
             step += 1
-            if skipped and not warned and policy != "count":
+            hit = bool(skipped)
+            if policy == "raise" and world > 1:
+                # every rank must leave the loop in the same step: a rank that raised alone would leave its peers in the next
+                # step's bucket all-reduce until the collective times out - agree on the flag first
+                flag = torch.tensor([1.0 if hit else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                hit = bool(flag.item() > 0)
+            if hit and not warned and policy != "count":
                 warned = True
                 msg = ("dynamic mixing drew an augmentation the device simulator does not apply (%s): it is skipped for that "
                        "utterance (wind noise is mixed additively); counters follow in every log line "
-                       "(cfg.unsupported_augmentation = warn | raise | count)" % sorted(skipped))
+                       "(cfg.unsupported_augmentation = warn | raise | count)" % (sorted(skipped) or "on another rank"))
                 if policy == "raise":
                     raise NotImplementedError(msg)
                 print("WARNING: " + msg, flush=True)
