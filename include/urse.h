@@ -79,6 +79,7 @@ const char* urse_last_error(void);
 #define URSE_KV_ISTFT960 22
 #define URSE_KV_LSTM_FWD_RW 23     /* lstm_fwd_rw_kernel: 16 sequences per wave, weights shared through an LDS-DMA ring */
 #define URSE_KV_LSTM_BWD_RW 24     /* lstm_bwd_rw_kernel */
+#define URSE_KV_LSTM_FWD_RWX 25    /* lstm_fwd_rwx_kernel: row-wave forward with the input projection fused */
 #define URSE_KV_COUNT 32
 int urse_launch_count(int variant);
 int urse_launch_counts_reset(void);
@@ -252,6 +253,18 @@ int urse_lstm_pack_blocks_rw(const float* whh, void* out, int H, int Hp, void* s
 int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_t ldh, float* c, int H, int Hp,
                      int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
                      int target_workgroups, int paired, void* stream);
+/* Row-wave forward with the INPUT PROJECTION FUSED (csrc/lstm_rwx.hip): replaces the pair {urse_gemm_nt (x W_ih^T + b -> gx),
+ * urse_lstm_rw_fwd} for the band path - nn.LSTM's x W_ih^T + b_ih + h W_hh^T + b_hh in one f32 accumulator per gate, no gx matrix
+ * written or read.  xn [M, ldx >= Np] bf16 = the (normalised) LSTM input with zero K padding; wx from urse_lstm_pack_blocks_x
+ * (2 * ceil(H/16) * (Hp/32 + Np/32) * 4 * 512 bf16 elements: W_hh and W_ih as one fragment stream); bias [2 * 4H] f32 in the (dir, unit,
+ * gate) order of urse_lstm_pack; gates [M, ldg >= 8H] (save != 0) receives the gate ACTIVATIONS the BPTT reads; hout, c, the sequence map,
+ * target_workgroups as urse_lstm_rw_fwd.  The pre-activation is not rounded to bf16 between the two products, so results differ
+ * from the two-kernel form by bf16 rounding of gx (closer to the f32 reference).  urse_lstm_rwx_supported: N = 196, H = 392. */
+int urse_lstm_rwx_supported(int N, int Np, int H, int Hp);
+int urse_lstm_pack_blocks_x(const float* wih, const float* whh, void* out, int N, int Np, int H, int Hp, void* stream);
+int urse_lstm_rwx_fwd(const void* xn, int64_t ldx, const void* wx, const float* bias, void* gates, int64_t ldg, void* hout,
+                      int64_t ldh, float* c, int N, int Np, int H, int Hp, int n_seq, int seq_len, int64_t inner,
+                      int64_t outer, int64_t stride, int save, int target_workgroups, void* stream);
 /* Split BPTT (bf16) for few, long sequences (time path): 2-3 workgroups share 32 sequences and split the reduction of
  * the recurrent product; f32 partial sums are exchanged through `xbuf` (zeroed by the call) with the tag-in-data
  * hand-off (step parity in the mantissa LSB).  Arguments as urse_lstm_bidir_bwd (whhT from urse_lstm_pack).

@@ -1,7 +1,7 @@
 """The benchmarked dispatch at its REAL size (BASELINE.json configs[1]: B 32 x 4 s @ 48 kHz, N = 196, L = 6, bf16, default
 dispatch, no threshold lowered) - the shapes bench.py times and the small-batch parity tests cannot reach: time path 1,088 sequences x
 401 steps (cluster forward on 252 co-resident workgroups, 16-sequence streaming BPTT on 136), band path 12,832 sequences x 34 steps
-(row-wave forward, 32-sequence BPTT), dual weight-gradient GEMMs on the second stream (reference step: baseline_code/d_model.py:61-89).
+(row-wave forward with the input projection fused, 32-sequence BPTT), dual weight-gradient GEMMs on the second stream (reference step: baseline_code/d_model.py:61-89).
   (a) forward in bf16 against the f32 oracle's forward on the host cores (loss <= 1e-3, waveform rel. L2 <= 1e-2), launch counters;
   (b) GPU against GPU at the same shapes: cluster forward == streaming forward, row-wave forward == wide forward (bit for bit),
       32-row BPTT == 16-row BPTT;
@@ -62,7 +62,7 @@ def test_fullsize_forward_matches_f32_oracle_and_runs_the_c2_kernels(lib):
     torch.cuda.synchronize()
     ops.poll_kernel_errors(torch.device("cuda", torch.cuda.current_device()), sync=True)
     counts = ops.launch_counts()
-    for k in ("lstm_fwd_cluster", "lstm_fwd_rw", "lstm_bwd_stream16", "lstm_bwd_stream32", "tn_dual", "nt_bres", "stft960"):
+    for k in ("lstm_fwd_cluster", "lstm_fwd_rwx", "lstm_bwd_stream16", "lstm_bwd_stream32", "tn_dual", "nt_bres", "stft960"):
         assert counts[k] > 0, (k, counts)
     assert counts["lstm_fwd_stream"] == 0 and counts["lstm_fwd_wide"] == 0, counts
     wav_c = wav.detach().cpu()

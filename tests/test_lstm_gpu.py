@@ -392,3 +392,45 @@ def test_xcd_aware_clusters_equal_static_clusters(lib, B, T, K):
         assert torch.equal(outs[0][0].view(torch.int16), o[0].view(torch.int16))
         assert torch.equal(outs[0][1].view(torch.int16), o[1].view(torch.int16))
         assert torch.equal(outs[0][2], o[2])
+
+
+@pytest.mark.parametrize("ns,sl,strided", [(300, 34, False), (37, 5, False), (2 * 34, 9, True), (1, 3, False)])
+def test_fused_row_wave_forward_matches_two_kernel_form_and_lstm(lib, ns, sl, strided):
+    """csrc/lstm_rwx.hip (x W_ih^T + b + h W_hh^T in one accumulator, no gx matrix) against {gate GEMM, lstm_rw} and against
+    torch.nn.LSTM in f32: the fused form skips the bf16 rounding of the pre-activation, so it differs from the two-kernel form by
+    that rounding and must not be farther from the f32 LSTM than the two-kernel form is."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(6)
+    N, dev, dt = 196, "cuda", torch.bfloat16
+    H = 2 * N
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dt)
+    assert "wx" in pk and ops.lstm_rwx_supported(N, pk["Np"], H, pk["Hp"])
+    x = torch.randn(ns, sl, N)
+    with torch.no_grad():
+        y, _ = lstm(x)
+    if strided:       # the time-path row map: sequence s = (b, k), rows (b * sl + t) * K + k
+        K, Bb = 34, ns // 34
+        rows = x.reshape(Bb, K, sl, N).permute(0, 2, 1, 3).reshape(-1, N)
+        yr = y.reshape(Bb, K, sl, 2 * H).permute(0, 2, 1, 3).reshape(-1, 2 * H)
+        sm = dict(n_seq=ns, seq_len=sl, inner=K, outer=sl * K, stride=K)
+    else:
+        rows, yr = x.reshape(-1, N), y.reshape(-1, 2 * H)
+        sm = dict(n_seq=ns, seq_len=sl, inner=1, outer=sl, stride=1)
+    M = rows.shape[0]
+    xr = ops.pack2d(rows.to(dev), M, pk["Np"], dt)
+    gx = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    h1, c1 = ops.lstm_fwd_rw(gx, pk["whhb"], H, pk["Hp"], **sm)
+    g2, h2, c2 = ops.lstm_fwd_rwx(xr, pk["wx"], pk["bias"], N, H, pk["Hp"], **sm)
+    _, h3, _ = ops.lstm_fwd_rwx(xr, pk["wx"], pk["bias"], N, H, pk["Hp"], save=False, target_wgs=8, **sm)
+    assert torch.equal(h2.view(torch.int16), h3.view(torch.int16))
+    assert torch.all(h2[:, 2 * H:] == 0)
+    e1 = (h1[:, :2 * H].float().cpu() - yr).abs()
+    e2 = (h2[:, :2 * H].float().cpu() - yr).abs()
+    assert e2.max().item() <= 2e-2 and e2.mean().item() <= 1.1 * e1.mean().item() + 1e-6, (e1.max().item(), e1.mean().item(), e2.max().item(), e2.mean().item())
+    assert (h1.float() - h2.float()).abs().max().item() <= 1.6e-2 and (h1.float() - h2.float()).abs().mean().item() <= 5e-4
+    assert (gx.float() - g2.float()).abs().max().item() <= 1.6e-2          # saved gate activations
+    assert (c1 - c2).abs().max().item() <= 2e-2
+    assert ops.launch_counts()["lstm_fwd_rwx"] >= 2

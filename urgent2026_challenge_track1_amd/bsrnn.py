@@ -370,6 +370,7 @@ class BSRNNCore(nn.Module):
                 pk[p + "whhq"], pk[p + "whhTq"] = lp.get("whhq"), lp.get("whhTq")
                 pk[p + "whhb"] = lp.get("whhb")
                 pk[p + "whhb_rw"] = lp.get("whhb_rw")
+                pk[p + "wx"] = lp.get("wx")
         self._packed = pk
         self._packed_version = self.param_version
 
@@ -477,9 +478,15 @@ class BSRNNCore(nn.Module):
         self._gn_stats = None
         xn, stats = ops.groupnorm_fwd(skip, self._p(p + "gamma", N), self._p(p + "beta", N), B, T, 1, K * N, N,
                                       d["Np"], 0, dt, GN_EPS, add=temb, stats=pre)
-        gx = ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
         sm = self._seqmap(path, B, T, K)
-        if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H in ops.CLUSTER2_H and \
+        fused = (ops.USE_RWX_LSTM and ops.USE_RW_LSTM and dt == torch.bfloat16 and pk.get(p + "wx") is not None and
+                 sm["n_seq"] >= ops.RW_MIN_SEQ and not (ops.USE_CLUSTER_LSTM and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
+                                                      ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None))
+        # (fused: the input projection runs inside the recurrence kernel - no gate GEMM, no [M, 8H] pre-activation matrix)
+        gx = None if fused else ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
+        if fused:
+            gx, hout, c = ops.lstm_fwd_rwx(xn, pk[p + "wx"], pk[p + "bias"], N, H, d["Hp"], save=save, **sm)
+        elif ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H in ops.CLUSTER2_H and \
                 ops.lstm_cluster2_chunks(H, d["Hp"], **sm) is not None:
             hout, c, err = ops.lstm_fwd_cluster2(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
             self._cluster_err = err

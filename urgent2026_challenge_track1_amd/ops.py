@@ -43,7 +43,7 @@ def timed_call(tname, name, *args):
 KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_ring", "nt_grouped_128", "tn_ring", "tn_ring_t",
                    "tn_dual", "tn_128", "tn_grouped", "lstm_fwd_stream", "lstm_fwd_wide", "lstm_fwd_cluster",
                    "lstm_fwd_cluster2", "lstm_bwd_stream16", "lstm_bwd_stream32", "lstm_bwd_cluster", "lstm_bwd_split",
-                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "lstm_bwd_rw")
+                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "lstm_bwd_rw", "lstm_fwd_rwx")
 
 
 _PAGEABLE_UPLOADS = os.environ.get("URSE_PAGEABLE_UPLOADS", "0") == "1"
@@ -282,6 +282,10 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
             if "whhb_rw" not in out:
                 out["whhb_rw"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32) * 4 * 512, device=dev, dtype=dtype)
             call("lstm_pack_blocks_rw", whh, out["whhb_rw"], H, Hp, stream_ptr())
+        if _lib.load().urse_lstm_rwx_supported(N, Np, H, Hp):
+            if "wx" not in out:
+                out["wx"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32 + Np // 32) * 4 * 512, device=dev, dtype=dtype)
+            call("lstm_pack_blocks_x", wih, whh, out["wx"], N, Np, H, Hp, stream_ptr())
         if H % 8 == 0:
             C = ((H + 3) // 4 + 13) // 14
             if "whhTq" not in out:
@@ -587,6 +591,26 @@ def lstm_fwd_rw(gx, whhb, H, Hp, n_seq, seq_len, inner, outer, stride, save=True
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_rw_fwd", gx, gx.stride(0), whhb, hout, ldh,
                c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), int(target_wgs), int(paired), stream_ptr())
     return hout, (c if save else None)
+
+
+# the fused form (input projection inside the recurrence, csrc/lstm_rwx.hip): no gate-projection GEMM, no gx matrix
+USE_RWX_LSTM = os.environ.get("URSE_LSTM_RWX", "1") != "0"
+
+
+def lstm_rwx_supported(N, Np, H, Hp):
+    return bool(_lib.load().urse_lstm_rwx_supported(N, Np, H, Hp))
+
+
+def lstm_fwd_rwx(xn, wx, bias, N, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, target_wgs=0):
+    """row-wave LSTM forward with the input projection fused: xn [M, Np] bf16 -> (gates [M, 8H] activations or None, hout, c)."""
+    M, Np = xn.shape[0], xn.shape[1]
+    ldh = kpad(2 * H, xn.dtype)
+    hout = _hout_buffer(M, ldh, H, xn)
+    c = torch.empty(M, 2 * H, device=xn.device, dtype=torch.float32)
+    gates = torch.empty(M, 8 * H, device=xn.device, dtype=xn.dtype) if save else None
+    timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_rwx_fwd", xn, xn.stride(0), wx, bias, gates, 8 * H, hout, ldh, c,
+               N, Np, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), int(target_wgs), stream_ptr())
+    return gates, hout, (c if save else None)
 
 
 def lstm_bwd_cluster(dh, gates, c, whhTq, H, Hp, n_seq, seq_len, inner, outer, stride):
