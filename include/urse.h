@@ -80,6 +80,7 @@ const char* urse_last_error(void);
 #define URSE_KV_LSTM_FWD_RW 23     /* lstm_fwd_rw_kernel: 16 sequences per wave, weights shared through an LDS-DMA ring */
 #define URSE_KV_LSTM_BWD_RW 24     /* lstm_bwd_rw_kernel */
 #define URSE_KV_LSTM_FWD_RWX 25    /* lstm_fwd_rwx_kernel: row-wave forward with the input projection fused */
+#define URSE_KV_LSTM_BWD_NSPLIT 26 /* lstm_bwd_nsplit_kernel: pairs of workgroups split the output columns of the recurrent product */
 #define URSE_KV_COUNT 32
 int urse_launch_count(int variant);
 int urse_launch_counts_reset(void);
@@ -274,6 +275,17 @@ int urse_lstm_split_plan(int H, int n_seq, int reserved_cus, int64_t* plan);
 int urse_lstm_split_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT, void* xbuf,
                         void* err_flag, int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride,
                         int reserved_cus, void* stream);
+/* N-split BPTT (bf16) for few, long sequences (csrc/lstm_nsplit.hip): two workgroups share 32 sequences, each owns half of the hidden
+ * units - cell gradients, state and ITS columns of W_hh^T (half the weight stream of urse_lstm_bidir_bwd per step) - and copies the
+ * partner's half of the step's gate gradients from the `gates` output (write-through stores + a flag per member and step; the
+ * hand-off travels while the member multiplies its own half).  Arguments as urse_lstm_bidir_bwd (whhT from urse_lstm_pack); flags =
+ * plan[2] uint32 words (zeroed by the call); err_flag: uint32 set to 1 if a hand-off timed out.  urse_lstm_nsplit_plan ->
+ * {pairs per direction, workgroups, flag words}, < 0 if unsupported (H != 392, or the workgroups - which wait for each other - would
+ * not be co-resident beside reserved_cus). */
+int urse_lstm_nsplit_plan(int H, int n_seq, int reserved_cus, int64_t* plan);
+int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT, void* flags,
+                         void* err_flag, int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride,
+                         int reserved_cus, void* stream);
 /* Backward through time.  dh [M, ldd>=2H] = gradient w.r.t. hout; gates: in = saved activations,
  * out = gradient w.r.t. the gate pre-activations (same interleaved layout); whhT = fragment-ordered
  * transposed recurrent weights from urse_lstm_pack. */

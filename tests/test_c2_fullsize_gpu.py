@@ -1,6 +1,6 @@
 """The benchmarked dispatch at its REAL size (BASELINE.json configs[1]: B 32 x 4 s @ 48 kHz, N = 196, L = 6, bf16, default
 dispatch, no threshold lowered) - the shapes bench.py times and the small-batch parity tests cannot reach: time path 1,088 sequences x
-401 steps (cluster forward on 252 co-resident workgroups, 16-sequence streaming BPTT on 136), band path 12,832 sequences x 34 steps
+401 steps (cluster forward on 252 co-resident workgroups, N-split BPTT on 68 pairs of workgroups), band path 12,832 sequences x 34 steps
 (row-wave forward with the input projection fused, 32-sequence BPTT), dual weight-gradient GEMMs on the second stream (reference step: baseline_code/d_model.py:61-89).
   (a) forward in bf16 against the f32 oracle's forward on the host cores (loss <= 1e-3, waveform rel. L2 <= 1e-2), launch counters;
   (b) GPU against GPU at the same shapes: cluster forward == streaming forward, row-wave forward == wide forward (bit for bit),
@@ -62,7 +62,7 @@ def test_fullsize_forward_matches_f32_oracle_and_runs_the_c2_kernels(lib):
     torch.cuda.synchronize()
     ops.poll_kernel_errors(torch.device("cuda", torch.cuda.current_device()), sync=True)
     counts = ops.launch_counts()
-    for k in ("lstm_fwd_cluster", "lstm_fwd_rwx", "lstm_bwd_stream16", "lstm_bwd_stream32", "tn_dual", "nt_bres", "stft960"):
+    for k in ("lstm_fwd_cluster", "lstm_fwd_rwx", "lstm_bwd_nsplit", "lstm_bwd_stream32", "tn_dual", "nt_bres", "stft960"):
         assert counts[k] > 0, (k, counts)
     assert counts["lstm_fwd_stream"] == 0 and counts["lstm_fwd_wide"] == 0, counts
     wav_c = wav.detach().cpu()
@@ -118,7 +118,13 @@ def test_fullsize_recurrence_variants_agree(lib):
     scale = ga.float().abs().max().item()
     out["time_bptt_16_vs_32"] = dict(max_over_scale=d.max().item() / scale, mean_over_scale=d.mean().item() / scale)
     assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, out
-    del ga, gb, d, g2, h2, c2
+    gc = g2.clone()
+    _, err = ops.lstm_bwd_nsplit(dh, gc, c2, pk["whhT"], H, **sm)
+    assert int(err.item()) == 0
+    d2 = (ga.float() - gc.float()).abs()
+    out["time_bptt_nsplit_vs_16"] = dict(max_over_scale=d2.max().item() / scale, mean_over_scale=d2.mean().item() / scale)
+    assert d2.max().item() <= 2e-2 * scale and d2.mean().item() <= 2e-4 * scale, out
+    del ga, gb, gc, d, d2, g2, h2, c2
     # ---- band path: row-wave forward == wide forward (bit for bit), then 32-row BPTT vs 16-row BPTT
     sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
     g1, g2 = gx0.clone(), gx0
@@ -135,7 +141,7 @@ def test_fullsize_recurrence_variants_agree(lib):
     out["band_bptt_16_vs_32"] = dict(max_over_scale=d.max().item() / scale, mean_over_scale=d.mean().item() / scale)
     assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, out
     counts = ops.launch_counts()
-    assert counts["lstm_bwd_stream32"] > 0 and counts["lstm_bwd_stream16"] > 0 and counts["lstm_fwd_cluster"] > 0
+    assert counts["lstm_bwd_stream32"] > 0 and counts["lstm_bwd_stream16"] > 0 and counts["lstm_fwd_cluster"] > 0 and counts["lstm_bwd_nsplit"] > 0
     parity_log.record("fullsize_recurrence_variants", **out)
 
 

@@ -1,5 +1,5 @@
 """GPU parity of the BENCHMARKED configuration (BASELINE.json configs[1]: N = 196, bf16 MFMA, default dispatch): the
-kernels bench.py times - cluster LSTM forward (time path), row-wave LSTM forward with the input projection fused + 32-sequence BPTT (band path), 16-sequence
+kernels bench.py times - cluster LSTM forward (time path), row-wave LSTM forward with the input projection fused + 32-sequence BPTT (band path), N-split
 BPTT (time path), weight-stationary gate projection, ring NT / TN GEMMs, dual-operand TN weight gradients on the second
 stream, the 960-point register FFT - run together through BSRNN_SE / SEModel and are compared with the CPU oracle
 (oracle/bsrnn_ref.py) both in its bf16-emulating form (same rounding points) and in plain f32 (the reference
@@ -21,7 +21,7 @@ from tests import parity_log
 pytestmark = pytest.mark.gpu
 
 N, B, FS, SECONDS = 196, 6, 48000, 1.0
-C2_KERNELS = ("stft960", "nt_bres", "nt_ring", "lstm_fwd_cluster", "lstm_fwd_rwx", "lstm_bwd_stream16", "lstm_bwd_stream32",
+C2_KERNELS = ("stft960", "nt_bres", "nt_ring", "lstm_fwd_cluster", "lstm_fwd_rwx", "lstm_bwd_nsplit", "lstm_bwd_stream32",
               "tn_dual", "tn_ring_t", "nt_grouped_ring", "tn_grouped")
 
 

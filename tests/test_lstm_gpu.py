@@ -434,3 +434,38 @@ def test_fused_row_wave_forward_matches_two_kernel_form_and_lstm(lib, ns, sl, st
     assert (gx.float() - g2.float()).abs().max().item() <= 1.6e-2          # saved gate activations
     assert (c1 - c2).abs().max().item() <= 2e-2
     assert ops.launch_counts()["lstm_fwd_rwx"] >= 2
+
+
+@pytest.mark.parametrize("B,T,K", [(1, 7, 34), (2, 21, 20), (3, 9, 34), (5, 40, 34)])
+def test_nsplit_bptt_matches_streaming_kernel(lib, B, T, K):
+    """time-path BPTT split over pairs of workgroups by OUTPUT columns (each member streams its half of W_hh^T, the halves of the gate
+    gradients are exchanged through the gates output with write-through stores and a flag) vs the one-workgroup streaming kernel: same
+    bf16 products; the second member adds its k-slabs in another order."""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(8)
+    N, dev, dt = 196, "cuda", torch.bfloat16
+    H = 2 * N
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dt)
+    M = B * T * K
+    sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+    assert ops.lstm_nsplit_plan(H, sm["n_seq"]) is not None
+    xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dt)
+    gx = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    hout, c = ops.lstm_fwd(gx, pk["whh"], H, pk["Hp"], **sm)
+    dh = ops.pack2d(torch.randn(M, 2 * H, device=dev), M, hout.shape[1], dt)
+    g1, g2 = gx.clone(), gx.clone()
+    ops.lstm_bwd(dh, g1, c, pk["whhT"], H, rows16=1, **sm)
+    _, err = ops.lstm_bwd_nsplit(dh, g2, c, pk["whhT"], H, **sm)
+    assert int(err.item()) == 0
+    d = (g1.float() - g2.float()).abs()
+    scale = g1.float().abs().max().item()
+    assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, (d.max().item(), d.mean().item(), scale)
+    # the units of member 0 (tiles 0 .. 12) see the k-slabs in the streaming kernel's order: bit-identical gate gradients
+    for dr in range(2):
+        a = g1[:, dr * 4 * H:dr * 4 * H + 13 * 64].view(torch.int16)
+        b = g2[:, dr * 4 * H:dr * 4 * H + 13 * 64].view(torch.int16)
+        frac = (a != b).float().mean().item()
+        assert frac <= 2e-2, frac          # (their dh_rec is exact; differences enter through the other half's gradients one step later)

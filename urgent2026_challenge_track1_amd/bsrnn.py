@@ -540,6 +540,9 @@ class BSRNNCore(nn.Module):
         elif (ops.USE_SPLIT_LSTM_BWD or H >= ops.SPLIT_BWD_MIN_H) and dt == torch.bfloat16 and \
                 ops.lstm_split_chunks(H, **sm) is not None:
             dg, self._cluster_err = ops.lstm_bwd_split(dh, gates, c, pk[p + "whhT"], H, **sm)
+        elif ops.USE_NSPLIT_LSTM_BWD and dt == torch.bfloat16 and path not in ops.BWD_ROWS16 and sm["n_seq"] <= ops.NSPLIT_MAX_SEQ and \
+                sm["n_seq"] * sm["seq_len"] >= 4096 and ops.lstm_nsplit_plan(H, sm["n_seq"]) is not None:
+            dg, self._cluster_err = ops.lstm_bwd_nsplit(dh, gates, c, pk[p + "whhT"], H, **sm)
         else:
             dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, rows16=ops.BWD_ROWS16.get(path, 0), **sm)   # dgates, gate-interleaved columns
         if overlap and path == "t":

@@ -1,0 +1,279 @@
+// "N-split" LSTM backward-through-time (bf16) for few, long sequences: the time path of BSRNN at C2 (1,088 sequences x 401 steps per
+// direction; espnet2 BSRNN's rnn_time, reference twin baseline_code/models/bsrnn_flowse.py:296-299).
+//
+// lstm_bwd_kernel gives 16 sequences to a workgroup, which re-streams all of W_hh^T (1.23 MB) from L2 every step: 10.3 of the step's
+// 17.6 us at 90 % of one CU's L2 port - the loop is at its floor, only a different division of labour helps.
+// Here TWO workgroups (a pair, one CU each, 136 workgroups in all as before) share 32 sequences and split the OUTPUT columns of the
+// recurrent product dh_rec[32, H] = dgates[32, 4H] x W_hh:
+//   * member m owns the hidden units of its half (m = 0: unit tiles 0 .. 12, m = 1: tiles 13 .. 24; one tile per wave, both
+//     16-row tiles of the pair's sequences) - it keeps dc / dh_rec / c for those units only, forms the gate gradients of those
+//     units and streams only ITS columns of W_hh^T: 0.64 MB per step instead of 1.23;
+//   * the product needs the gate gradients of ALL units (the reduction runs over 4H).  Each member writes its half to the `gates`
+//     output (which the weight-gradient GEMMs read after the launch anyway) with write-through (sc1) stores and raises a flag;
+//     the partner copies that half from there into its LDS tile.  The hand-off is issued BEFORE the member multiplies its own
+//     half (K range of its own units, already in LDS), so its latency hides behind ~2.5 us of weight stream; only then does the
+//     member wait for the partner's flag, copy 50 KB (L1-bypassing loads) and multiply the other half;
+//   * protocol (MI355X_MICROARCH.md, "Valid forms", row 1): every payload store sc1; every storing wave waits for its own stores
+//     (a counted vmcnt that leaves the weight fragments issued meanwhile in flight) and then adds to a counter in LDS; the wave
+//     whose add completes the count stores the flag (sc1); the consumer's wave 0 polls the flag with sc1 loads, a workgroup
+//     barrier follows, every load of the payload is an sc1 load.  Placement-independent; the two members of a pair are blockIdx.x
+//     eight apart, which under the round-robin dealing of workgroups puts them on ONE XCD (speed only).  Bounded spins, error flag.
+// Same math, layouts and outputs as lstm_bwd_kernel; member 0 adds the k-slabs in ascending order (bit-identical), member 1 adds
+// its own (upper) range first, i.e. the f32 sums of its units see the slabs in another order.
+#include "urse_common.h"
+
+namespace urse {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int NSW = 13;            // waves per workgroup: one unit tile each
+constexpr int NSTHR = NSW * 64;
+constexpr int NS_KB = 9;           // weight fragments in flight per wave (13 waves: 128-VGPR cap)
+
+struct NsplitArgs {
+  const void* dh; long ldd;
+  void* gates; long ldg;
+  const float* c;
+  const void* whhT;                // fragment-ordered [2][nut][nslab][64][16 B] (urse_lstm_pack)
+  unsigned* flags;                 // [2 dirs][npairs][2 members], zeroed per launch
+  unsigned* err;
+  long inner, outer, stride;
+  int n_seq, seq_len, npairs;
+  unsigned g_bytes;
+};
+
+template <int H>
+__global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
+  constexpr int NUT = (H + 15) / 16, G4 = 4 * H, NSLAB = G4 * 2 / 64, UT0 = (NUT + 1) / 2;     // 25 tiles, 49 slabs, member 0 owns 13 tiles
+  constexpr int PITCH = lds_frag_pitch(G4 * 2);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                                   // [32][PITCH] gate gradients of the step, all units (MFMA A operand)
+  unsigned* lsync = reinterpret_cast<unsigned*>(smem + 32 * PITCH);    // [0] waves whose stores are complete (monotonic), [1] dead flag
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // blockIdx.x = (P / 8) * 16 + m * 8 + P % 8: the members of pair-and-direction P are eight apart (same XCD under round-robin dealing)
+  const int lin = blockIdx.x, m = (lin >> 3) & 1, P = (lin >> 4) * 8 + (lin & 7);
+  const int dir = P & 1, pair = P >> 1;
+  if (pair >= p.npairs) return;
+  const int ut_lo = m ? UT0 : 0, ut_hi = m ? NUT : UT0;                 // owned unit tiles
+  const int ut = ut_lo + w;
+  const bool active = ut < ut_hi;
+  const int nact = ut_hi - ut_lo;                                       // storing waves of this member
+  const int ks_own0 = 2 * ut_lo, ks_own1 = (2 * ut_hi < NSLAB) ? 2 * ut_hi : NSLAB;        // k-slabs of the owned units' gate columns
+  const int u = ut * 16 + lc;
+  const bool uvalid = active && u < H;
+  const int uc = uvalid ? u : H - 1;
+  if (tid < 2) lsync[tid] = 0u;
+
+  int rowbase[2][4];                                                     // row of (sequence, t = 0); negative: beyond n_seq (clamped, never stored)
+  const int s0 = pair * 32;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int seq = s0 + rt * 16 + lr * 4 + r;
+      const bool ok = seq < p.n_seq;
+      if (!ok) seq = p.n_seq - 1;
+      const int rb = (int)((seq / p.inner) * p.outer + (seq % p.inner));
+      rowbase[rt][r] = ok ? rb : -rb - 1;
+    }
+  auto rowb = [&](int rt, int r) -> int { return rowbase[rt][r] >= 0 ? rowbase[rt][r] : -(rowbase[rt][r] + 1); };
+  const char* whhT = reinterpret_cast<const char*>(p.whhT) + ((long)dir * NUT * NSLAB + (long)(active ? ut : ut_lo) * NSLAB) * 1024 + lane * 16;
+  const bf16_t* dh = reinterpret_cast<const bf16_t*>(p.dh);
+  bf16_t* gates = reinterpret_cast<bf16_t*>(p.gates);
+  const int ldg_i = (int)p.ldg, ldd_i = (int)p.ldd, ldc_i = 2 * H, stride_i = (int)p.stride;
+  const int gcol_i = dir * G4, hcol_i = dir * H, prev_i = dir ? stride_i : -stride_i;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)p.g_bytes, 0x00020000);
+  unsigned* my_flag = p.flags + ((dir * p.npairs + pair) * 2 + m);
+  unsigned* partner_flag = p.flags + ((dir * p.npairs + pair) * 2 + (m ^ 1));
+  // the partner's half of a row of the tile: bytes [pb0, pb1) of the direction's 4H-column segment, in 16-byte chunks
+  const int pb0 = m ? 0 : UT0 * 128, pb1 = m ? UT0 * 128 : G4 * 2, pcpr = (pb1 - pb0) / 16;
+  // the rows of the pair's sequences (for the copy of the partner's half): row of sequence i at t = 0, -1 beyond n_seq
+  int* rowtab = reinterpret_cast<int*>(lsync + 4);
+  if (tid < 32) {
+    const int seq = s0 + tid;
+    rowtab[tid] = seq < p.n_seq ? (int)((seq / p.inner) * p.outer + (seq % p.inner)) : -1;
+  }
+  for (int i = tid; i < 32 * PITCH / 16; i += NSTHR) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
+
+  float dcs[2][4], dhr[2][4], ccur[2][4];
+  {
+    const int toff0 = (dir ? 0 : p.seq_len - 1) * stride_i;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dcs[rt][r] = 0.f;
+        dhr[rt][r] = 0.f;
+        ccur[rt][r] = p.c[(long)(rowb(rt, r) + toff0) * ldc_i + (hcol_i + uc)];
+      }
+  }
+  __syncthreads();
+  bool dead = false;
+
+  for (int step = 0; step < p.seq_len; ++step) {
+    const int t = dir ? step : (p.seq_len - 1 - step);
+    const int toff = t * stride_i;
+    const bool first_ = dir ? (t == p.seq_len - 1) : (t == 0);          // first step of the forward recurrence: c_{-1} = 0
+    const bool last = step + 1 == p.seq_len;
+    // ---- 1. gate gradients of the owned units: LDS tile (own columns) + the gates output (write-through: the partner reads them)
+    if (active) {
+      uint2 gpre[2][4];
+      float cpre[2][4];
+      bf16_t dhpre[2][4];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rowb(rt, r) + toff;
+          gpre[rt][r] = *reinterpret_cast<const uint2*>(gates + ((long)row * ldg_i + (gcol_i + uc * 4)));
+          cpre[rt][r] = first_ ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + uc)];
+          dhpre[rt][r] = dh[(long)row * ldd_i + (hcol_i + uc)];
+        }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float iv = __uint_as_float(gpre[rt][r].x << 16), fv = __uint_as_float(gpre[rt][r].x & 0xffff0000u);
+          const float gv = __uint_as_float(gpre[rt][r].y << 16), ov = __uint_as_float(gpre[rt][r].y & 0xffff0000u);
+          const float dht = bf16_to_f32(dhpre[rt][r]) + dhr[rt][r];
+          const float tc = tanhf_(ccur[rt][r]);
+          const float dct = dcs[rt][r] + dht * ov * (1.f - tc * tc);
+          const float d0 = dct * gv * iv * (1.f - iv), d1 = dct * cpre[rt][r] * fv * (1.f - fv);
+          const float d2 = dct * iv * (1.f - gv * gv), d3 = dht * tc * ov * (1.f - ov);
+          dcs[rt][r] = dct * fv;
+          ccur[rt][r] = cpre[rt][r];                                     // c_{t-1} is the next processed step's c_t
+          uint2 pk = make_uint2(0u, 0u);
+          if (uvalid) {
+            pk.x = (unsigned)f32_to_bf16(d0) | ((unsigned)f32_to_bf16(d1) << 16);
+            pk.y = (unsigned)f32_to_bf16(d2) | ((unsigned)f32_to_bf16(d3) << 16);
+          }
+          if (uvalid) *reinterpret_cast<uint2*>(tile + (rt * 16 + lr * 4 + r) * PITCH + u * 8) = pk;     // (columns past 4H stay zero)
+          if (uvalid && rowbase[rt][r] >= 0) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const unsigned off = (unsigned)(((long)(rowbase[rt][r] + toff) * ldg_i + (gcol_i + u * 4)) * 2);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rs_g, (int)off, 0, 16);          // sc1: write-through
+          }
+        }
+    }
+    if (last) break;
+    __syncthreads();                                                     // the own half of the tile is complete
+    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    const char* ar = tile + lc * PITCH + 16 * lr;
+    // k-slabs [k0, k1) of this wave's unit tile against the tile in LDS, NS_KB fragments in flight; `publish`: after the first batch
+    // of fragment loads is issued, wait for this wave's gate-gradient stores (older in the in-order vmcnt queue) and count the wave in
+    auto product = [&](int k0, int k1, bool publish) {
+#pragma unroll 1
+      for (int kb = k0; kb < k1; kb += NS_KB) {
+        uint4 b[NS_KB];
+#pragma unroll
+        for (int i = 0; i < NS_KB; ++i) {
+          const int ks = (kb + i < k1) ? kb + i : k1 - 1;
+          b[i] = *reinterpret_cast<const uint4*>(whhT + (long)ks * 1024);
+        }
+        if (publish && kb == k0) {
+          asm volatile("s_waitcnt vmcnt(9)" ::: "memory");              // NS_KB younger loads may stay in flight: the stores above are done
+          if (lane == 0) {
+            const unsigned n = __hip_atomic_fetch_add(&lsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+            if (n == (unsigned)nact * (unsigned)(step + 1))              // every storing wave of this member has waited for its stores
+              __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (sc1 store)
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NS_KB; ++i) {
+          if (kb + i < k1) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+              const uint4 a = *reinterpret_cast<const uint4*>(ar + rt * 16 * PITCH + (kb + i) * 64);
+              acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b[i]), acc[rt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    static_assert(NS_KB == 9, "the counted vmcnt above is written for 9 fragments in flight");
+    // ---- 2. the own K range (in LDS already); the hand-off to the partner travels meanwhile
+    if (active) product(ks_own0, ks_own1, true);
+    // ---- 3. the partner's half: wait for its flag, copy its columns of the 32 rows from the gates output into the tile
+    if (w == 0) {
+      unsigned spins = 0;
+      if (lane == 0) {
+        while (!dead && __hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 22)) { dead = true; atomicExch(p.err, 1u); lsync[1] = 1u; }
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * pcpr; idx += NSTHR) {
+      const int row = idx / pcpr, cc = idx - row * pcpr;
+      const int grow = rowtab[row];
+      if (grow < 0) continue;
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const unsigned off = (unsigned)(((long)(grow + toff) * ldg_i + gcol_i) * 2 + pb0 + cc * 16);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)off, 0, 16);                 // sc1: L1-bypassing
+      *reinterpret_cast<uint4*>(tile + row * PITCH + pb0 + cc * 16) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    // ---- 4. the other K range
+    if (active) {
+      if (m) product(0, ks_own0, false);
+      else product(ks_own1, NSLAB, false);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dhr[rt][r] = acc[rt][r];
+    }
+    __syncthreads();                                                     // the tile is rewritten by the next step
+  }
+}
+
+}  // namespace urse
+
+using namespace urse;
+
+// -> plan {pairs per direction, workgroups, flag words}; < 0 (URSE_ERR_UNSUPPORTED) if the shape has no kernel or the pairs would not
+// be co-resident beside the reserved CUs
+extern "C" int urse_lstm_nsplit_plan(int H, int n_seq, int reserved_cus, int64_t* plan) {
+  URSE_CHECK_ARG(plan && n_seq > 0 && reserved_cus >= 0, "urse_lstm_nsplit_plan: bad argument");
+  if (H != 392) {
+    set_error("urse_lstm_nsplit_plan: unsupported H=%d", H);
+    return URSE_ERR_UNSUPPORTED;
+  }
+  const int npairs = (n_seq + 31) / 32;
+  const int wgs = ((2 * npairs + 7) / 8) * 16;
+  if (wgs > device_cu_count() - reserved_cus) {
+    set_error("urse_lstm_nsplit_plan: %d workgroups do not fit beside %d reserved CUs", wgs, reserved_cus);
+    return URSE_ERR_UNSUPPORTED;
+  }
+  plan[0] = npairs; plan[1] = wgs; plan[2] = 2L * npairs * 2;
+  return URSE_OK;
+}
+
+extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT, void* flags,
+                                    void* err_flag, int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride,
+                                    int reserved_cus, void* stream) {
+  URSE_CHECK_ARG(dh && gates && c && whhT && flags && err_flag, "urse_lstm_nsplit_bwd: null pointer");
+  int64_t plan[3];
+  int rc = urse_lstm_nsplit_plan(H, n_seq, reserved_cus, plan);
+  if (rc) return rc;
+  URSE_CHECK_ARG(seq_len > 0 && inner > 0 && ldg >= 8L * H && ldd >= 2L * H && ldg % 8 == 0 && ((uintptr_t)gates % 16) == 0,
+                 "urse_lstm_nsplit_bwd: bad leading dimension / alignment");
+  const long rows = stride * (seq_len - 1) + ((n_seq - 1) / inner) * outer + ((n_seq - 1) % inner) + 1;
+  URSE_CHECK_ARG(rows * ldg * 2 < 0xFFFFF000L && ldd < (1L << 31), "urse_lstm_nsplit_bwd: the gates matrix exceeds 32-bit byte offsets");
+  NsplitArgs p;
+  p.dh = dh; p.ldd = ldd; p.gates = gates; p.ldg = ldg; p.c = c; p.whhT = whhT; p.flags = (unsigned*)flags; p.err = (unsigned*)err_flag;
+  p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len; p.npairs = (int)plan[0];
+  p.g_bytes = (unsigned)(rows * ldg * 2);
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(flags, 0, sizeof(unsigned) * plan[2], st);
+  const size_t lds = (size_t)32 * lds_frag_pitch(4 * 392 * 2) + 16 + 32 * sizeof(int);
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  note_launch(URSE_KV_LSTM_BWD_NSPLIT);
+  hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392>), dim3((unsigned)plan[1]), dim3(NSTHR), lds, st, p);
+  URSE_CHECK_LAUNCH("urse_lstm_nsplit_bwd");
+  return URSE_OK;
+}

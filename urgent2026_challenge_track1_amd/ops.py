@@ -43,7 +43,7 @@ def timed_call(tname, name, *args):
 KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_ring", "nt_grouped_128", "tn_ring", "tn_ring_t",
                    "tn_dual", "tn_128", "tn_grouped", "lstm_fwd_stream", "lstm_fwd_wide", "lstm_fwd_cluster",
                    "lstm_fwd_cluster2", "lstm_bwd_stream16", "lstm_bwd_stream32", "lstm_bwd_cluster", "lstm_bwd_split",
-                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "lstm_bwd_rw", "lstm_fwd_rwx")
+                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "lstm_bwd_rw", "lstm_fwd_rwx", "lstm_bwd_nsplit")
 
 
 _PAGEABLE_UPLOADS = os.environ.get("URSE_PAGEABLE_UPLOADS", "0") == "1"
@@ -684,6 +684,34 @@ def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
             d_, g_, c_ = dh[r0:r1], gates[r0:r1], c[r0:r1]
         timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_split_bwd", d_, dh.stride(0), g_, gates.stride(0), c_,
                    whhT, xbuf, err, H, n, seq_len, inner, outer, stride, reserved_cus(), stream_ptr())
+    return gates, err
+
+
+# N-split BPTT (csrc/lstm_nsplit.hip): pairs of workgroups split the output columns of the recurrent product - half the weight stream per
+# step and CU; the time path at C2 (1,088 sequences -> 136 workgroups, as many as the streaming kernel uses)
+USE_NSPLIT_LSTM_BWD = os.environ.get("URSE_LSTM_NSPLIT_BWD", "1") != "0"
+NSPLIT_MAX_SEQ = int(os.environ.get("URSE_LSTM_NSPLIT_MAX_SEQ", "2304"))       # beyond that the 32-sequence streaming geometry has the rows it needs
+
+
+def lstm_nsplit_plan(H, n_seq):
+    import ctypes
+    plan = (ctypes.c_int64 * 3)()
+    if _lib.load().urse_lstm_nsplit_plan(H, n_seq, reserved_cus(), plan) != 0:
+        _note_refusal(lambda: _lib.load().urse_lstm_nsplit_plan(H, n_seq, 0, plan) == 0)
+        return None
+    return list(plan)
+
+
+def lstm_bwd_nsplit(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
+    """N-split BPTT (bf16): gates (saved activations) is overwritten with d(pre-activations)."""
+    plan = lstm_nsplit_plan(H, n_seq)
+    dev = gates.device
+    key = ("nsplit", dev, plan[2])
+    if key not in _cluster_ws:
+        _cluster_ws[key] = (torch.zeros(plan[2], device=dev, dtype=torch.int32), kernel_error_flag(dev))
+    flags, err = _cluster_ws[key]
+    timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_nsplit_bwd", dh, dh.stride(0), gates, gates.stride(0), c, whhT,
+               flags, err, H, n_seq, seq_len, inner, outer, stride, reserved_cus(), stream_ptr())
     return gates, err
 
 
