@@ -29,6 +29,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int NSW = 13;            // waves per workgroup: one unit tile each
 constexpr int NSTHR = NSW * 64;
+#ifndef NS_PUB
+#define NS_PUB 1                  // the batch of the own-range product in front of which the wave publishes (0 .. 2)
+#endif
 constexpr int NS_KB = 9;           // weight fragments in flight per wave (13 waves: 128-VGPR cap)
 
 struct NsplitArgs {
@@ -36,7 +39,7 @@ struct NsplitArgs {
   void* gates; long ldg;
   const float* c;
   const void* whhT;                // fragment-ordered [2][nut][nslab][64][16 B] (urse_lstm_pack)
-  unsigned* flags;                 // [2 dirs][npairs][2 members], zeroed per launch
+  unsigned* flags;                 // [2 dirs][npairs][2 members] step flags, then as many XCC-id words; zeroed per launch
   unsigned* err;
   long inner, outer, stride;
   int n_seq, seq_len, npairs;
@@ -59,12 +62,11 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
   const int ut_lo = m ? UT0 : 0, ut_hi = m ? NUT : UT0;                 // owned unit tiles
   const int ut = ut_lo + w;
   const bool active = ut < ut_hi;
-  const int nact = ut_hi - ut_lo;                                       // storing waves of this member
   const int ks_own0 = 2 * ut_lo, ks_own1 = (2 * ut_hi < NSLAB) ? 2 * ut_hi : NSLAB;        // k-slabs of the owned units' gate columns
   const int u = ut * 16 + lc;
   const bool uvalid = active && u < H;
   const int uc = uvalid ? u : H - 1;
-  if (tid < 2) lsync[tid] = 0u;
+  if (tid < 3) lsync[tid] = 0u;
 
   int rowbase[2][4];                                                     // row of (sequence, t = 0); negative: beyond n_seq (clamped, never stored)
   const int s0 = pair * 32;
@@ -109,7 +111,23 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
         ccur[rt][r] = p.c[(long)(rowb(rt, r) + toff0) * ldc_i + (hcol_i + uc)];
       }
   }
+  // Same XCD?  Each member publishes the XCC id it READS from the hardware and reads its partner's: a pair on one XCD shares that XCD's
+  // L2, so its gate gradients can be handed over with plain stores (acknowledged by the L2, kept there for the partner's L1-bypassing
+  // loads) instead of write-through ones (acknowledged by memory: ~2 us that every later wait of the storing wave inherits through the
+  // in-order vmcnt).  A pair on two XCDs keeps the write-through stores.  Never inferred from blockIdx.
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 7u;      // HW_REG_XCC_ID
+    unsigned* xw = p.flags + 2 * 2 * p.npairs + ((dir * p.npairs + pair) * 2);
+    __hip_atomic_store(xw + m, xcc | 0x100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned v = 0u, spins = 0;
+    while ((v = __hip_atomic_load(xw + (m ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) { atomicExch(p.err, 1u); break; }
+    }
+    lsync[2] = (v == (xcc | 0x100u)) ? 1u : 0u;
+  }
   __syncthreads();
+  const bool local = lsync[2] != 0u;
   bool dead = false;
 
   for (int step = 0; step < p.seq_len; ++step) {
@@ -127,9 +145,13 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = rowb(rt, r) + toff;
+#ifdef NSABL_NO_LOAD      // timing diagnostics (wrong results): NSABL_NO_LOAD, NSABL_NO_STORE, NSABL_NO_MM, NSABL_NO_POLL, NSABL_NO_COPY (scripts/abl_nsplit.py)
+          gpre[rt][r] = make_uint2((unsigned)row, 0x3f003f00u); cpre[rt][r] = (float)(row & 3); dhpre[rt][r] = (bf16_t)(0x3c00 + (row & 7));
+#else
           gpre[rt][r] = *reinterpret_cast<const uint2*>(gates + ((long)row * ldg_i + (gcol_i + uc * 4)));
           cpre[rt][r] = first_ ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + uc)];
           dhpre[rt][r] = dh[(long)row * ldd_i + (hcol_i + uc)];
+#endif
         }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
@@ -150,15 +172,32 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
             pk.y = (unsigned)f32_to_bf16(d2) | ((unsigned)f32_to_bf16(d3) << 16);
           }
           if (uvalid) *reinterpret_cast<uint2*>(tile + (rt * 16 + lr * 4 + r) * PITCH + u * 8) = pk;     // (columns past 4H stay zero)
-          if (uvalid && rowbase[rt][r] >= 0) {
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            const unsigned off = (unsigned)(((long)(rowbase[rt][r] + toff) * ldg_i + (gcol_i + u * 4)) * 2);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rs_g, (int)off, 0, 16);          // sc1: write-through
-          }
         }
     }
-    if (last) break;
-    __syncthreads();                                                     // the own half of the tile is complete
+    // (raw barriers: __syncthreads() would also drain the write-through stores above - their latency belongs behind the weight stream)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                        // the own half of the tile is complete
+    // the own half of the tile -> the gates output, 16 bytes per lane along the rows (write-through).  (Stored from the cell phase,
+    // 8 bytes per lane and unit, the same bytes cost 3 us per step: an sc1 store of 8 bytes per lane moves at a third of the 16-byte
+    // form's rate per byte, MI355X_MICROARCH.md "stores of each flavour"; profiles/r04_abl_nsplit_v1.log.)
+    {
+      const int ob0 = m ? UT0 * 128 : 0, ocpr = ((m ? G4 * 2 : UT0 * 128) - ob0) / 16;       // own bytes [ob0, ob0 + 16 ocpr) of a row
+#ifdef NSABL_NO_STORE
+      for (int idx = tid; idx < 0 * ocpr; idx += NSTHR) {
+#else
+      for (int idx = tid; idx < 32 * ocpr; idx += NSTHR) {
+#endif
+        const int row = idx / ocpr, cc = idx - row * ocpr;
+        const int grow = rowtab[row];
+        if (grow < 0) continue;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + row * PITCH + ob0 + cc * 16);
+        const unsigned off = (unsigned)(((long)(grow + toff) * ldg_i + gcol_i) * 2 + ob0 + cc * 16);
+        if (local) __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_g, (int)off, 0, 0);       // stays in the pair's L2
+        else __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_g, (int)off, 0, 16);           // sc1: write-through
+      }
+    }
+    if (last) break;                                                     // (the last step's gradients are stored; nothing waits for them)
     f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
     const char* ar = tile + lc * PITCH + 16 * lr;
     // k-slabs [k0, k1) of this wave's unit tile against the tile in LDS, NS_KB fragments in flight; `publish`: after the first batch
@@ -172,15 +211,24 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
           const int ks = (kb + i < k1) ? kb + i : k1 - 1;
           b[i] = *reinterpret_cast<const uint4*>(whhT + (long)ks * 1024);
         }
-        if (publish && kb == k0) {
-          asm volatile("s_waitcnt vmcnt(9)" ::: "memory");              // NS_KB younger loads may stay in flight: the stores above are done
+        if (publish && kb == k0 + NS_PUB * NS_KB) {
+          // this batch's NS_KB fragment loads may stay in flight; everything older - the earlier batches and, before them, this wave's
+          // gate-gradient stores - is then complete.  (In front of the FIRST batch this wait put the write-through stores' ~2 us of
+          // acknowledge latency on the critical path: profiles/r04_abl_nsplit_v1.log, 14.5 -> 11.6 us per step without the stores.)
+          asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
           if (lane == 0) {
             const unsigned n = __hip_atomic_fetch_add(&lsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
-            if (n == (unsigned)nact * (unsigned)(step + 1))              // every storing wave of this member has waited for its stores
+            if (n == (unsigned)NSW * (unsigned)(step + 1))               // every wave of this member has waited for its stores
               __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (sc1 store)
           }
         }
+#ifndef NSABL_NO_MM
 #pragma unroll
+#else
+#pragma unroll
+        for (int i = 0; i < 1; ++i) acc[0][0] += __uint_as_float(b[0].x);
+        if (false)
+#endif
         for (int i = 0; i < NS_KB; ++i) {
           if (kb + i < k1) {
 #pragma unroll
@@ -194,19 +242,35 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
     };
     static_assert(NS_KB == 9, "the counted vmcnt above is written for 9 fragments in flight");
     // ---- 2. the own K range (in LDS already); the hand-off to the partner travels meanwhile
-    if (active) product(ks_own0, ks_own1, true);
+    if (active) {
+      product(ks_own0, ks_own1, true);
+    } else {                                                             // a wave without a unit tile stored its share of the rows too
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const unsigned n = __hip_atomic_fetch_add(&lsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+        if (n == (unsigned)NSW * (unsigned)(step + 1)) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     // ---- 3. the partner's half: wait for its flag, copy its columns of the 32 rows from the gates output into the tile
     if (w == 0) {
       unsigned spins = 0;
       if (lane == 0) {
+#ifdef NSABL_NO_POLL
+        while (false && __hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+#else
         while (!dead && __hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+#endif
           __builtin_amdgcn_s_sleep(1);
           if (++spins > (1u << 22)) { dead = true; atomicExch(p.err, 1u); lsync[1] = 1u; }
         }
       }
     }
     __syncthreads();
+#ifdef NSABL_NO_COPY
+    for (int idx = tid; idx < 0 * pcpr; idx += NSTHR) {
+#else
     for (int idx = tid; idx < 32 * pcpr; idx += NSTHR) {
+#endif
       const int row = idx / pcpr, cc = idx - row * pcpr;
       const int grow = rowtab[row];
       if (grow < 0) continue;
@@ -215,7 +279,8 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)off, 0, 16);                 // sc1: L1-bypassing
       *reinterpret_cast<uint4*>(tile + row * PITCH + pb0 + cc * 16) = make_uint4(v[0], v[1], v[2], v[3]);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     // ---- 4. the other K range
     if (active) {
       if (m) product(0, ks_own0, false);
@@ -225,7 +290,8 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) dhr[rt][r] = acc[rt][r];
     }
-    __syncthreads();                                                     // the tile is rewritten by the next step
+    // no barrier here: the next step's cell phase rewrites the OWN columns, whose last readers (this step's own-range product) sit
+    // behind two barriers; the next copy rewrites the PARTNER's columns behind the next step's two barriers
   }
 }
 
@@ -247,7 +313,7 @@ extern "C" int urse_lstm_nsplit_plan(int H, int n_seq, int reserved_cus, int64_t
     set_error("urse_lstm_nsplit_plan: %d workgroups do not fit beside %d reserved CUs", wgs, reserved_cus);
     return URSE_ERR_UNSUPPORTED;
   }
-  plan[0] = npairs; plan[1] = wgs; plan[2] = 2L * npairs * 2;
+  plan[0] = npairs; plan[1] = wgs; plan[2] = 2L * (2L * npairs * 2);      // step flags + XCC ids
   return URSE_OK;
 }
 
