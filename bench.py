@@ -60,12 +60,17 @@ def synth_batch(B, L, fs, seed, device):
 def l2_port_roofline(kernel, ms, B, T, K, H):
     """L2 -> CU bytes of the recurrent weights per launch of a streaming BPTT kernel against the CUs' L2 ports (None for the
     forward kernels, which keep W_hh in registers / stream it with other geometry)."""
+    from urgent2026_challenge_track1_amd import ops
+    nsplit = kernel == "lstm_bwd_time" and ops.launch_counts().get("lstm_bwd_nsplit", 0) > 0
+    # time path: N-split pairs (32 sequences per pair of workgroups, each streams HALF of W_hh^T) or 16 sequences per workgroup (all of it)
     geo = {"lstm_bwd_time": (B * K, T, 16), "lstm_bwd_band": (B * T, K, 32)}.get(kernel)
     if geo is None:
         return None
     n_seq, steps, rows = geo
     wgs = 2 * -(-n_seq // rows)                                  # both directions
     per_step = 4 * H * H * 2                                      # one direction's W_hh^T, bf16
+    if nsplit:
+        per_step //= 2                                            # (and the same number of workgroups: two per 32 sequences)
     total = wgs * (steps - 1) * per_step
     cus = min(wgs, 256)
     per_cu = total / cus / (ms * 1e-3) / 1e9                     # average over the CUs that hold workgroups
@@ -472,7 +477,7 @@ def parity_block(model, batch, args, dev):
         for k in ("bf16_fullsize_forward_vs_f32_oracle", "bf16_c2_kernel_set_L6", "f32_full_width_L6", "fullsize_two_identical_seed_runs"):
             if k in log:
                 out[k] = {a: b for a, b in log[k].items() if a not in ("launch_counts", "recorded_unix")}
-    if args.dtype == "bf16":
+    if args.dtype == "bf16" and not args.no_f32_mode:
         try:
             from urgent2026_challenge_track1_amd import ops
             from urgent2026_challenge_track1_amd.config import Config
@@ -554,7 +559,7 @@ def main():
                     help="pairs the metric leg scores (BASELINE.json configs[4] / SURVEY C5: 10 k pairs, as five launches of 2,048)")
     ap.add_argument("--launcher-selftest", default=None, choices=["ok", "fail"], help=argparse.SUPPRESS)
     ap.add_argument("--no-flow", action="store_true", help="skip the extra BSRNN-Flow (config C4) leg")
-    ap.add_argument("--no-f32-mode", action="store_true", help="skip the three extra steps in the exact-f32 MFMA mode")
+    ap.add_argument("--no-f32-mode", action="store_true", help="skip the three extra steps in the exact-f32 MFMA mode and the f32-mode forward of `parity.measured_this_run`")
     ap.add_argument("--model", default="bsrnn", choices=["bsrnn", "flow"],
                     help="flow: print the BSRNN-Flow (config C4) line instead of the headline one")
     ap.add_argument("--single-rank-collectives", action="store_true",
@@ -720,8 +725,9 @@ def main():
     # comes from the committed rocprofv3 passes of this same command (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
     # FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes); null if no summary matches this configuration
     traffic, traffic_src = None, None
-    pmc_names = {"lstm_bwd_time": "lstm_bwd_kernel<unsigned short, 1, 2, 16", "lstm_bwd_band": "lstm_bwd_kernel<unsigned short, 2, 4, 8",
-                 "lstm_fwd_time": "lstm_fwd_cluster_kernel", "lstm_fwd_band": "lstm_fwd_rw_kernel"}
+    pmc_names = {"lstm_bwd_time": "lstm_bwd_nsplit_kernel" if ops.launch_counts().get("lstm_bwd_nsplit", 0) else "lstm_bwd_kernel<unsigned short, 1, 2, 16",
+                 "lstm_bwd_band": "lstm_bwd_kernel<unsigned short, 2, 4, 8",
+                 "lstm_fwd_time": "lstm_fwd_cluster_kernel", "lstm_fwd_band": "lstm_fwd_rwx_kernel"}
     if (B, args.seconds, args.channels, args.layers, args.dtype) == (32, 4.0, 196, 6, "bf16"):
         import glob
         import re

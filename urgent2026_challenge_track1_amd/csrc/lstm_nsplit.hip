@@ -302,14 +302,16 @@ using namespace urse;
 // -> plan {pairs per direction, workgroups, flag words}; < 0 (URSE_ERR_UNSUPPORTED) if the shape has no kernel or the pairs would not
 // be co-resident beside the reserved CUs
 extern "C" int urse_lstm_nsplit_plan(int H, int n_seq, int reserved_cus, int64_t* plan) {
-  URSE_CHECK_ARG(plan && n_seq > 0 && reserved_cus >= 0, "urse_lstm_nsplit_plan: bad argument");
+  URSE_CHECK_ARG(plan && n_seq > 0, "urse_lstm_nsplit_plan: bad argument");
   if (H != 392) {
     set_error("urse_lstm_nsplit_plan: unsupported H=%d", H);
     return URSE_ERR_UNSUPPORTED;
   }
   const int npairs = (n_seq + 31) / 32;
   const int wgs = ((2 * npairs + 7) / 8) * 16;
-  if (wgs > device_cu_count() - reserved_cus) {
+  // (reserved_cus < 0: the caller accepts a grid of more workgroups than CUs - pairs are eight blocks apart, so under in-order dispatch a
+  //  member's partner starts at most eight workgroups later; spins are bounded either way)
+  if (reserved_cus >= 0 && wgs > device_cu_count() - reserved_cus) {
     set_error("urse_lstm_nsplit_plan: %d workgroups do not fit beside %d reserved CUs", wgs, reserved_cus);
     return URSE_ERR_UNSUPPORTED;
   }
