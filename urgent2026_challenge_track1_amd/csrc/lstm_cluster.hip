@@ -158,6 +158,8 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
     for (int ks = 0; ks < NSLAB; ++ks) breg[ks] = *reinterpret_cast<const uint4*>(src + ks * 1024);
   }
   for (int i = tid; i < CROWS * UW / 2; i += CTHR) reinterpret_cast<unsigned*>(hstage)[i] = 0u;   // pad units stay 0
+  for (int i = tid; i < CROWS * UW / 2; i += CTHR)
+    reinterpret_cast<unsigned*>(smem + CROWS * pitch + CROWS * UW * 2 + 16 + 64 + CROWS * sizeof(int))[i] = 0u;   // (the second h staging tile)
   float cst[MAXCH][4];
 #pragma unroll
   for (int a = 0; a < MAXCH; ++a)
@@ -216,6 +218,59 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   // poll round trips on the critical path, and correct at any placement / at 2-byte store granularity.  A plane is
   // overwritten only by a producer that has already consumed every workgroup's h of the step in between, which those
   // workgroups published only after consuming the data being overwritten.
+  // The step's plain stores (saved gates, c_t, h_t -> hout) are DEFERRED into the next step, behind the first round of its h gather:
+  // issued at the end of their own step they sit in front of the gather's loads in the wave's in-order vmcnt queue, and the wait for
+  // the first h chunk then also waits for their write acknowledges (~1.5 us per step); issued behind the gather's loads they complete
+  // while the MFMAs run.  With them gone from the step's tail the third barrier goes too: the h tile is rewritten by the gather behind
+  // barrier 2 of the step that read it, the staging tile by the cell phase behind the next step's barrier 1, which its last readers
+  // (the publication and the deferred hout store) precede.
+  // (they wait in LDS staging tiles - registers are at the 128 cap of 14 waves - and leave as 16-byte pieces along the rows: the 56 units
+  //  of this workgroup are 448 contiguous bytes of a gates row and 224 of a c row)
+  // LDS: [h tile][h staging 0][flags][rows][h staging 1][gates staging 0, 1][c staging 0, 1]: the staging tiles are double-buffered by step
+  // parity - a step's deferred stores read its tiles while the next step's cell phase fills the other set
+  int* rowtab = reinterpret_cast<int*>(smem + CROWS * pitch + CROWS * UW * 2 + 16 + 64);      // [CROWS] row of (sequence, t = 0)
+  char* hstage1 = reinterpret_cast<char*>(rowtab + CROWS);
+  char* gstage0 = hstage1 + CROWS * UW * 2;                            // [2][CROWS][UW][4 gates] bf16
+  char* cstage0 = gstage0 + 2 * CROWS * UW * 8;                        // [2][CROWS][UW] f32
+  if (tid < CROWS) {
+    int seq = seq0 + tid;
+    if (seq >= p.n_seq) seq = p.n_seq - 1;
+    rowtab[tid] = (int)((seq / p.inner) * p.outer + (seq % p.inner));
+  }
+  int toff_d = 0;
+  bool have_d = false;
+  constexpr int SC = UW * 2 / 16;   // 7 chunks of 16 B per staged row
+  static_assert(CROWS * SC <= CTHR, "one staged piece per thread");
+  const int nvu = (H - j * UW) < UW ? (H - j * UW > 0 ? H - j * UW : 0) : UW;     // valid units of this workgroup (a multiple of 8)
+  auto deferred_stores = [&](int par) {
+    const char* hst = par ? hstage1 : reinterpret_cast<const char*>(hstage);
+    const char* gstage = gstage0 + par * (CROWS * UW * 8);
+    const char* cstage = cstage0 + par * (CROWS * UW * 4);
+    if (tid < CROWS * SC) {
+      const int ucol = j * UW + st_cc * 8;
+      if (st_row < nrows && ucol < H) {
+        const uint4 v = *reinterpret_cast<const uint4*>(hst + st_row * (UW * 2) + st_cc * 16);
+        *reinterpret_cast<uint4*>(hout + ((long)(st_grow + toff_d) * ldh_i + (hcol_i + ucol))) = v;    // H % 8 == 0: whole chunks
+      }
+    }
+    if (p.save) {
+      constexpr int GC = UW * 8 / 16, CC = UW * 4 / 16;              // 28 / 14 chunks per row
+      for (int idx = tid; idx < CROWS * GC; idx += CTHR) {
+        const int row = idx / GC, cc = idx - row * GC;
+        if (row < nrows && cc * 2 < nvu) {                           // (a chunk = 2 units x 4 gates)
+          const uint4 v = *reinterpret_cast<const uint4*>(gstage + row * (UW * 8) + cc * 16);
+          *reinterpret_cast<uint4*>(gx + ((long)(rowtab[row] + toff_d) * ldg_i + (gcol_i + (j * UW + cc * 2) * 4))) = v;
+        }
+      }
+      for (int idx = tid; idx < CROWS * CC; idx += CTHR) {
+        const int row = idx / CC, cc = idx - row * CC;
+        if (row < nrows && cc * 4 < nvu) {
+          const uint4 v = *reinterpret_cast<const uint4*>(cstage + row * (UW * 4) + cc * 16);
+          *reinterpret_cast<uint4*>(p.c + ((long)(rowtab[row] + toff_d) * ldc_i + (hcol_i + j * UW + cc * 4))) = v;
+        }
+      }
+    }
+  };
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? (p.seq_len - 1 - step) : step;
     const int toff = t * stride_i;
@@ -272,12 +327,12 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
     uint2 gxc[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) gxc[rt] = gxn[rt];
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (raw barriers: the deferred stores stay in flight across them)
+    __builtin_amdgcn_s_barrier();
+    if (have_d) deferred_stores((step + 1) & 1);                       // the previous step's rows: behind this step's gather, under its MFMAs
     // prefetch the gate pre-activations of the next step (independent of the recurrence)
     if (step + 1 < p.seq_len) load_gx(0, (dir ? t - 1 : t + 1) * stride_i, gxn);
     // 2. gates for (64 rows) x (this wave's quad)
-    uint2 gsave[4];
-    float csave[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -297,21 +352,24 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
       const float cv = fv * cst[ch][rt] + iv * gv;
       cst[ch][rt] = cv;
       const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
-      if (qvalid) hstage[(rt * 16 + rl) * UW + w * 4 + ul] = f32_to_bf16(hv);
-      gsave[rt].x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
-      gsave[rt].y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
-      csave[rt] = cv;
+      if (qvalid) reinterpret_cast<bf16_t*>((step & 1) ? hstage1 : reinterpret_cast<char*>(hstage))[(rt * 16 + rl) * UW + w * 4 + ul] = f32_to_bf16(hv);
+      if (p.save && qvalid) {
+        uint2 gs;
+        gs.x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
+        gs.y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
+        *reinterpret_cast<uint2*>(gstage0 + (step & 1) * (CROWS * UW * 8) + (rt * 16 + rl) * (UW * 8) + (w * 4 + ul) * 8) = gs;
+        *reinterpret_cast<float*>(cstage0 + (step & 1) * (CROWS * UW * 4) + (rt * 16 + rl) * (UW * 4) + (w * 4 + ul) * 4) = cv;
+      }
     }
-    __syncthreads();
-    // 3. h_t of this workgroup's units -> exchange buffer FIRST (write-through, tagged), then the plain stores
-    constexpr int SC = UW * 2 / 16;   // 7 chunks per row
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // 3. h_t of this workgroup's units -> exchange buffer (tagged); the plain stores follow in the next step (see above)
     const unsigned tagv = tag_cur ? TAGM : 0u;
-    static_assert(CROWS * SC <= CTHR, "one staged piece per thread");
     if (tid < CROWS * SC) {
       const int row = st_row, cc = st_cc;
       const int ucol = j * UW + cc * 8;
       if (r0 + row < nrows && ucol < H) {
-        uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hstage) + row * (UW * 2) + cc * 16);
+        uint4 v = *reinterpret_cast<const uint4*>(((step & 1) ? hstage1 : reinterpret_cast<const char*>(hstage)) + row * (UW * 2) + cc * 16);
         const uint4 vt = make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv);
 #ifndef CABL_NO_XSTORE
         if (step + 1 < p.seq_len) {
@@ -320,20 +378,14 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
           else store_sc1(rs, xo, vt);
         }
 #endif
-        *reinterpret_cast<uint4*>(hout + ((long)(st_grow + toff) * ldh_i + (hcol_i + ucol))) = v;    // H % 8 == 0: whole chunks
       }
     }
-    if (p.save && uvalid) {
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        if (rowv[rt]) {
-          const int row = rowb[rt] + toff;
-          *reinterpret_cast<uint2*>(gx + ((long)row * ldg_i + (gcol_i + u * 4))) = gsave[rt];
-          p.c[(long)row * ldc_i + (hcol_i + u)] = csave[rt];
-        }
-      }
-    }
-    __syncthreads();   // hstage / htile are rewritten by the next step
+    toff_d = toff;
+    have_d = true;
+  }
+  if (have_d) {
+    __syncthreads();
+    deferred_stores((p.seq_len + 1) & 1);
   }
 }
 
@@ -576,7 +628,7 @@ static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  const size_t lds = (size_t)CROWS * lds_frag_pitch(p.Hp * 2) + (size_t)CROWS * UW * 2 + 16 + 64;
+  const size_t lds = (size_t)CROWS * lds_frag_pitch(p.Hp * 2) + (size_t)CROWS * UW * 2 + 16 + 64 + CROWS * sizeof(int) + (size_t)CROWS * UW * 14 + (size_t)CROWS * UW * 12;
   dim3 grid(p.C * p.ncl, 2);
   hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH>), grid, dim3(CTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_cluster_fwd");
