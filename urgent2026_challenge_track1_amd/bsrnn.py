@@ -363,7 +363,7 @@ class BSRNNCore(nn.Module):
                 p = "l%d%s." % (l, path)
                 lp = ops.lstm_pack(self._p(p + "wih", 8 * H * N), self._p(p + "whh", 8 * H * H),
                                    self._p(p + "bih", 8 * H), self._p(p + "bhh", 8 * H), N, H, dtype,
-                                   out=self._lstm_bufs.get(p))
+                                   out=self._lstm_bufs.get(p), layouts=self._lstm_layouts(path))
                 self._lstm_bufs[p] = lp
                 pk[p + "wih"], pk[p + "wihT"], pk[p + "bias"] = lp["wih"], lp["wihT"], lp["bias"]
                 pk[p + "whh"], pk[p + "whhT"] = lp["whh"], lp["whhT"]
@@ -373,6 +373,14 @@ class BSRNNCore(nn.Module):
                 pk[p + "wx"] = lp.get("wx")
         self._packed = pk
         self._packed_version = self.param_version
+
+    def _lstm_layouts(self, path):
+        """optional weight layouts this half layer's dispatch can reach (ops.model_lstm_layouts, narrowed by the path where the kernels are
+        path-specific at this hidden size: the fused row-wave forward and its unfused fallbacks serve many short sequences, i.e. the band path)."""
+        lay = ops.model_lstm_layouts()
+        if self.H == 392 and path == "t":
+            lay -= {"wx", "whhb_rw"}
+        return lay
 
     def _band_tables(self, F, dtype, device):
         key = (F, dtype, device)

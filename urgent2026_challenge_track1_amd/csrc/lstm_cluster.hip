@@ -36,6 +36,7 @@ struct ClusterArgs {
   long inner, outer, stride;
   int n_seq, seq_len;
   int C, ncl, rows_per_cluster, rows_pad;
+  unsigned g_bytes, c_bytes, h_bytes;   // sizes of the gx / c / hout matrices (range-checked deferred stores)
   unsigned* xws;                  // XCD-aware formation (null = static clusters): [0..7] arrivals per XCD, [8] arrivals, zeroed per launch
 };
 
@@ -199,13 +200,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
     if (seq >= p.n_seq) seq = p.n_seq - 1;
     st_grow = (int)((seq / p.inner) * p.outer + (seq % p.inner));
   }
-  auto load_gx = [&](int, int toff, uint2 (&dst)[4]) {
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-      dst[rt] = *reinterpret_cast<const uint2*>(gx + ((long)(rowb[rt] + toff) * ldg_i + (gcol_i + uc * 4)));
-  };
-  uint2 gxn[4];                                          // gate pre-activations, prefetched one step ahead
-  load_gx(0, (dir ? p.seq_len - 1 : 0) * stride_i, gxn);
+
   unsigned* deadflag = reinterpret_cast<unsigned*>(smem + CROWS * pitch + CROWS * UW * 2);
   if (tid == 0) *deadflag = 0u;
   const int hchunks = H / 8;                             // 16-byte chunks of a row that carry data (H % 8 == 0)
@@ -241,34 +236,57 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   bool have_d = false;
   constexpr int SC = UW * 2 / 16;   // 7 chunks of 16 B per staged row
   static_assert(CROWS * SC <= CTHR, "one staged piece per thread");
+  constexpr int GC = UW * 8 / 16, CC = UW * 4 / 16;                    // 28 / 14 chunks per gates / c row of this workgroup's units
+  static_assert(CROWS * GC == 2 * CTHR && CROWS * CC == CTHR, "two gates pieces and one c piece per thread, every step the same ones");
+  // The pieces a thread stores are the same every step, so their byte offsets are computed once (buffer addressing: the step is a scalar
+  // offset, a piece that must not be stored - row beyond the cluster's, unit beyond H - lies outside the buffer and is dropped):
+  // a deferred store is an LDS read and a buffer store, no arithmetic under the MFMAs.
+  constexpr unsigned COOB = 0xFFFFF000u;
+  const __amdgpu_buffer_rsrc_t rs_gs = __builtin_amdgcn_make_buffer_rsrc(p.gx, 0, (int)p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hs = __builtin_amdgcn_make_buffer_rsrc(p.hout, 0, (int)p.h_bytes, 0x00020000);
   const int nvu = (H - j * UW) < UW ? (H - j * UW > 0 ? H - j * UW : 0) : UW;     // valid units of this workgroup (a multiple of 8)
+  __syncthreads();                                                     // rowtab
+  unsigned dvo_g[2], dvo_c, dvo_h;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * CTHR, row = idx / GC, cc = idx - row * GC;
+    dvo_g[i] = (row < nrows && cc * 2 < nvu) ? ((unsigned)rowtab[row] * (unsigned)ldg_i + (unsigned)(gcol_i + (j * UW + cc * 2) * 4)) * 2u : COOB;
+  }
+  {
+    const int row = tid / CC, cc = tid - row * CC;
+    dvo_c = (row < nrows && cc * 4 < nvu) ? ((unsigned)rowtab[row] * (unsigned)ldc_i + (unsigned)(hcol_i + j * UW + cc * 4)) * 4u : COOB;
+    const int ucol = j * UW + st_cc * 8;
+    dvo_h = (tid < CROWS * SC && st_row < nrows && ucol < H) ? ((unsigned)st_grow * (unsigned)ldh_i + (unsigned)(hcol_i + ucol)) * 2u : COOB;
+  }
+  // The gate pre-activations of the NEXT step travel the same way in the other direction: each thread fetches the two 16-byte pieces it
+  // will later store (same offsets), one step ahead, and drops them into the gates staging tile of that step's parity, where a lane picks
+  // up its (sequence, unit) 8 bytes before it overwrites them with the activations.  (Fetched per lane - 8 bytes of 16 different rows per
+  // wave-instruction in this kernel's accumulator layout - the same 28 KB were 896 quarter-line requests per step: 1.8 us of 7.2.)
+  typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+  u32x4g gxl[2];
+  auto fetch_gx = [&](int toff_) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) gxl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, (int)dvo_g[i], toff_ * ldg_i * 2, 0);
+  };
+  fetch_gx((dir ? p.seq_len - 1 : 0) * stride_i);
   auto deferred_stores = [&](int par) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const char* hst = par ? hstage1 : reinterpret_cast<const char*>(hstage);
     const char* gstage = gstage0 + par * (CROWS * UW * 8);
     const char* cstage = cstage0 + par * (CROWS * UW * 4);
-    if (tid < CROWS * SC) {
-      const int ucol = j * UW + st_cc * 8;
-      if (st_row < nrows && ucol < H) {
-        const uint4 v = *reinterpret_cast<const uint4*>(hst + st_row * (UW * 2) + st_cc * 16);
-        *reinterpret_cast<uint4*>(hout + ((long)(st_grow + toff_d) * ldh_i + (hcol_i + ucol))) = v;    // H % 8 == 0: whole chunks
-      }
+    {
+      const uint4 v = *reinterpret_cast<const uint4*>(hst + (tid < CROWS * SC ? tid : 0) * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_hs, (int)dvo_h, toff_d * ldh_i * 2, 0);
     }
     if (p.save) {
-      constexpr int GC = UW * 8 / 16, CC = UW * 4 / 16;              // 28 / 14 chunks per row
-      for (int idx = tid; idx < CROWS * GC; idx += CTHR) {
-        const int row = idx / GC, cc = idx - row * GC;
-        if (row < nrows && cc * 2 < nvu) {                           // (a chunk = 2 units x 4 gates)
-          const uint4 v = *reinterpret_cast<const uint4*>(gstage + row * (UW * 8) + cc * 16);
-          *reinterpret_cast<uint4*>(gx + ((long)(rowtab[row] + toff_d) * ldg_i + (gcol_i + (j * UW + cc * 2) * 4))) = v;
-        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4*>(gstage + (tid + i * CTHR) * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_gs, (int)dvo_g[i], toff_d * ldg_i * 2, 0);
       }
-      for (int idx = tid; idx < CROWS * CC; idx += CTHR) {
-        const int row = idx / CC, cc = idx - row * CC;
-        if (row < nrows && cc * 4 < nvu) {
-          const uint4 v = *reinterpret_cast<const uint4*>(cstage + row * (UW * 4) + cc * 16);
-          *reinterpret_cast<uint4*>(p.c + ((long)(rowtab[row] + toff_d) * ldc_i + (hcol_i + j * UW + cc * 4))) = v;
-        }
-      }
+      const uint4 v = *reinterpret_cast<const uint4*>(cstage + tid * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_cs, (int)dvo_c, toff_d * ldc_i * 4, 0);
     }
   };
   for (int step = 0; step < p.seq_len; ++step) {
@@ -288,7 +306,9 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
         hn[i] = make_uint4(0, 0, 0, 0);
         const int idx = tid + i * CTHR;
         const int row = idx / cpr, cc = idx - row * cpr;
+#ifndef CABL_NO_GATHER      // timing diagnostics (wrong results): CABL_NO_GATHER, CABL_NO_MFMA, CABL_NO_CELL, CABL_NO_DEFERRED, CABL_NO_GX, CABL_NO_XSTORE
         if (step > 0 && idx < CROWS * cpr && row < nrows && cc < hchunks) pend |= 1u << i;
+#endif
       }
       if (pend && *reinterpret_cast<volatile unsigned*>(deadflag)) pend = 0u;
       const unsigned want = tag_prev ? TAGM : 0u;
@@ -324,14 +344,20 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
         if (idx < CROWS * cpr) *reinterpret_cast<uint4*>(htile + row * pitch + cc * 16) = v;
       }
     }
-    uint2 gxc[4];
+#ifndef CABL_NO_GX
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) gxc[rt] = gxn[rt];
+    for (int i = 0; i < 2; ++i)       // this step's pre-activations -> the staging tile of its parity (this thread read these pieces a step ago)
+      *reinterpret_cast<uint4*>(gstage0 + (step & 1) * (CROWS * UW * 8) + (tid + i * CTHR) * 16) = make_uint4(gxl[i][0], gxl[i][1], gxl[i][2], gxl[i][3]);
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (raw barriers: the deferred stores stay in flight across them)
     __builtin_amdgcn_s_barrier();
+#ifndef CABL_NO_DEFERRED
     if (have_d) deferred_stores((step + 1) & 1);                       // the previous step's rows: behind this step's gather, under its MFMAs
+#endif
     // prefetch the gate pre-activations of the next step (independent of the recurrence)
-    if (step + 1 < p.seq_len) load_gx(0, (dir ? t - 1 : t + 1) * stride_i, gxn);
+#ifndef CABL_NO_GX
+    if (step + 1 < p.seq_len) fetch_gx((dir ? t - 1 : t + 1) * stride_i);
+#endif
     // 2. gates for (64 rows) x (this wave's quad)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
@@ -339,19 +365,30 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
       const char* ar = htile + (rt * 16 + lc) * pitch + 16 * lr;
 #pragma unroll
       for (int ks = 0; ks < NSLAB; ++ks) {
+#ifndef CABL_NO_MFMA
         const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, breg[ks]),
                                                       __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
+#else
+        acc[ks & 3] += __uint_as_float(breg[ks].x);
+#endif
       }
       // acc[g] = gate g of unit ul, sequence rt*16 + rl
       const float pre[4] = {acc[0], acc[1], acc[2], acc[3]};
-      const uint2 gxv = gxc[rt];
+      const uint2 gxv = *reinterpret_cast<const uint2*>(gstage0 + (step & 1) * (CROWS * UW * 8) + (rt * 16 + rl) * (UW * 8) + (w * 4 + ul) * 8);
       const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
       const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
+#ifdef CABL_NO_CELL
+      const float iv = gi, fv = gf, gv = gg, ov = go;
+      const float cv = fv * cst[ch][rt] + iv * gv;
+      cst[ch][rt] = cv;
+      const float hv = uvalid ? ov * cv : 0.f;
+#else
       const float iv = sigmoidf_(gi), fv = sigmoidf_(gf), gv = tanhf_(gg), ov = sigmoidf_(go);
       const float cv = fv * cst[ch][rt] + iv * gv;
       cst[ch][rt] = cv;
       const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
+#endif
       if (qvalid) reinterpret_cast<bf16_t*>((step & 1) ? hstage1 : reinterpret_cast<char*>(hstage))[(rt * 16 + rl) * UW + w * 4 + ul] = f32_to_bf16(hv);
       if (p.save && qvalid) {
         uint2 gs;
@@ -740,6 +777,13 @@ extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, vo
   URSE_CHECK_ARG(ldg < (1L << 31) && ldh < (1L << 31) && stride * seq_len + (n_seq / inner + 1) * outer < (1L << 31),
                  "urse_lstm_cluster_fwd: row indices must fit 32 bits");
   ClusterArgs p;
+  {
+    const long rows = stride * (seq_len - 1) + ((n_seq - 1) / inner) * outer + ((n_seq - 1) % inner) + 1;
+    URSE_CHECK_ARG(rows * ldg * 2 < 0xFFFFF000L && rows * 2L * H * 4 < 0xFFFFF000L && rows * ldh * 2 < 0xFFFFF000L && ldg % 8 == 0 &&
+                       ((uintptr_t)gx % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0),
+                   "urse_lstm_cluster_fwd: matrices of %ld rows exceed 32-bit byte offsets, or gx / c are not 16-byte aligned", rows);
+    p.g_bytes = (unsigned)(rows * ldg * 2); p.c_bytes = c ? (unsigned)(rows * 2L * H * 4) : 0u; p.h_bytes = (unsigned)(rows * ldh * 2);
+  }
   p.gx = gx; p.ldg = ldg; p.whhq = whhq; p.hout = hout; p.ldh = ldh; p.c = c; p.hx = (bf16_t*)hx;
   p.cnt = (unsigned*)counters; p.err = (unsigned*)err_flag; p.H = H; p.Hp = Hp; p.save = save;
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;

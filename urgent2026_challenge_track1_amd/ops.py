@@ -257,8 +257,27 @@ def groupnorm_bwd(x, dy, stats, gamma, dres, dgamma, dbeta, B, T, Kg, W, N, gstr
     return (dx, dxp) if pack_ld else dx
 
 
-def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
-    """f32 nn.LSTM weights (fwd+reverse concatenated) -> dict of kernel-layout operands (see urse_lstm_pack)."""
+def model_lstm_layouts():
+    """the optional weight layouts the model's dispatch can reach with the current switches (the model re-packs 12 LSTMs after every
+    optimizer step: a layout nobody reads is a launch and a few MB of writes per LSTM and step)."""
+    lay = set()
+    if USE_CLUSTER_LSTM:
+        lay.add("whhq")
+    if USE_CLUSTER_LSTM_BWD:
+        lay.add("whhTq")
+    if USE_RW_LSTM and USE_RWX_LSTM:
+        lay.add("wx")
+    if USE_WIDE_LSTM or USE_RW_LSTM:
+        lay.add("whhb")          # (the unfused row-wave / wide forward; also what a shape without a fused kernel falls back to)
+    if USE_RW_LSTM and RW_PAIRED and not USE_RWX_LSTM:
+        lay.add("whhb_rw")
+    return lay
+
+
+def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None, layouts=None):
+    """f32 nn.LSTM weights (fwd+reverse concatenated) -> dict of kernel-layout operands (see urse_lstm_pack).
+    layouts: which of the optional layouts to produce ({"whhq", "whhTq", "whhb", "whhb_rw", "wx"}; None = all the shape supports)."""
+    want = lambda name: layouts is None or name in layouts
     dev = wih.device
     Np, Hp = kpad(N, dtype), kpad(pad_to(H, 16), dtype)
     nu = pad_to(H, 16)
@@ -271,22 +290,23 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None):
     call("lstm_pack", wih, whh, bih, bhh, out["wih"], out["wihT"], out["bias"], out["whh"], out["whhT"], N, Np, H, Hp,
          _dt(out["wih"]), stream_ptr())
     if dtype == torch.bfloat16 and Hp % 32 == 0:
-        if "whhq" not in out:
-            out["whhq"] = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=dtype)
-        call("lstm_pack_quads", whh, out["whhq"], H, Hp, stream_ptr())
-        if _lib.load().urse_lstm_wide_supported(H, Hp):
+        if want("whhq"):
+            if "whhq" not in out:
+                out["whhq"] = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=dtype)
+            call("lstm_pack_quads", whh, out["whhq"], H, Hp, stream_ptr())
+        if want("whhb") and _lib.load().urse_lstm_wide_supported(H, Hp):
             if "whhb" not in out:
                 out["whhb"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32) * 4 * 512, device=dev, dtype=dtype)
             call("lstm_pack_blocks", whh, out["whhb"], H, Hp, stream_ptr())
-        if _lib.load().urse_lstm_rw_supported(H, Hp):
+        if want("whhb_rw") and _lib.load().urse_lstm_rw_supported(H, Hp):
             if "whhb_rw" not in out:
                 out["whhb_rw"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32) * 4 * 512, device=dev, dtype=dtype)
             call("lstm_pack_blocks_rw", whh, out["whhb_rw"], H, Hp, stream_ptr())
-        if _lib.load().urse_lstm_rwx_supported(N, Np, H, Hp):
+        if want("wx") and _lib.load().urse_lstm_rwx_supported(N, Np, H, Hp):
             if "wx" not in out:
                 out["wx"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32 + Np // 32) * 4 * 512, device=dev, dtype=dtype)
             call("lstm_pack_blocks_x", wih, whh, out["wx"], N, Np, H, Hp, stream_ptr())
-        if H % 8 == 0:
+        if want("whhTq") and H % 8 == 0:
             C = ((H + 3) // 4 + 13) // 14
             if "whhTq" not in out:
                 out["whhTq"] = torch.empty(2 * C * 4 * (H // 8) * 512, device=dev, dtype=dtype)
