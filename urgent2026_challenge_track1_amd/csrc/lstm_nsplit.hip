@@ -18,6 +18,10 @@
 //     whose add completes the count stores the flag (sc1); the consumer's wave 0 polls the flag with sc1 loads, a workgroup
 //     barrier follows, every load of the payload is an sc1 load.  Placement-independent; the two members of a pair are blockIdx.x
 //     eight apart, which under the round-robin dealing of workgroups puts them on ONE XCD (speed only).  Bounded spins, error flag.
+// Tried and dropped (profiles/r04_ab_nsplit_band_v1.log): (i) roles taken by ARRIVAL (a ticket counter) instead of blockIdx, which would let the
+// grid exceed the chip: the tickets do not follow the round-robin dealing, partners land on different XCDs and the launch goes from 5.24 to
+// 5.6 ms (37.2 instead of 33.5 ms per step); (ii) this kernel on the band path (12,832 sequences = 1,604 workgroups): 3.50 against 3.85 ms
+// alone, but 28.3 against 25.6 ms per step beside the weight-gradient GEMMs of the second queue.
 // Same math, layouts and outputs as lstm_bwd_kernel; member 0 adds the k-slabs in ascending order (bit-identical), member 1 adds
 // its own (upper) range first, i.e. the f32 sums of its units see the slabs in another order.
 #include "urse_common.h"
@@ -302,16 +306,14 @@ using namespace urse;
 // -> plan {pairs per direction, workgroups, flag words}; < 0 (URSE_ERR_UNSUPPORTED) if the shape has no kernel or the pairs would not
 // be co-resident beside the reserved CUs
 extern "C" int urse_lstm_nsplit_plan(int H, int n_seq, int reserved_cus, int64_t* plan) {
-  URSE_CHECK_ARG(plan && n_seq > 0, "urse_lstm_nsplit_plan: bad argument");
+  URSE_CHECK_ARG(plan && n_seq > 0 && reserved_cus >= 0, "urse_lstm_nsplit_plan: bad argument");
   if (H != 392) {
     set_error("urse_lstm_nsplit_plan: unsupported H=%d", H);
     return URSE_ERR_UNSUPPORTED;
   }
   const int npairs = (n_seq + 31) / 32;
   const int wgs = ((2 * npairs + 7) / 8) * 16;
-  // (reserved_cus < 0: the caller accepts a grid of more workgroups than CUs - pairs are eight blocks apart, so under in-order dispatch a
-  //  member's partner starts at most eight workgroups later; spins are bounded either way)
-  if (reserved_cus >= 0 && wgs > device_cu_count() - reserved_cus) {
+  if (wgs > device_cu_count() - reserved_cus) {
     set_error("urse_lstm_nsplit_plan: %d workgroups do not fit beside %d reserved CUs", wgs, reserved_cus);
     return URSE_ERR_UNSUPPORTED;
   }
