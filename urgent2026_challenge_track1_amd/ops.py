@@ -713,11 +713,19 @@ USE_NSPLIT_LSTM_BWD = os.environ.get("URSE_LSTM_NSPLIT_BWD", "1") != "0"
 NSPLIT_MAX_SEQ = int(os.environ.get("URSE_LSTM_NSPLIT_MAX_SEQ", "2304"))       # beyond that the 32-sequence streaming geometry has the rows it needs
 
 
+def _nsplit_reserved():
+    """CUs the N-split plan must leave alone.  Its workgroups wait for ONE partner each, not for the whole grid: a member whose partner has
+    not started yet spins until any other workgroup on the chip retires.  Work that is finite and independent of this launch - the second
+    queue's weight-gradient GEMMs, RCCL's all-reduce kernels, the prefetcher's simulator kernels - therefore only delays a pair, it cannot
+    starve it (unlike the cluster / split kernels, whose every workgroup waits for all the others of its cluster): nothing is reserved, the
+    plan only checks that the grid itself fits the chip."""
+    return 0
+
+
 def lstm_nsplit_plan(H, n_seq):
     import ctypes
     plan = (ctypes.c_int64 * 3)()
-    if _lib.load().urse_lstm_nsplit_plan(H, n_seq, reserved_cus(), plan) != 0:
-        _note_refusal(lambda: _lib.load().urse_lstm_nsplit_plan(H, n_seq, 0, plan) == 0)
+    if _lib.load().urse_lstm_nsplit_plan(H, n_seq, _nsplit_reserved(), plan) != 0:
         return None
     return list(plan)
 
@@ -731,7 +739,7 @@ def lstm_bwd_nsplit(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride)
         _cluster_ws[key] = (torch.zeros(plan[2], device=dev, dtype=torch.int32), kernel_error_flag(dev))
     flags, err = _cluster_ws[key]
     timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_nsplit_bwd", dh, dh.stride(0), gates, gates.stride(0), c, whhT,
-               flags, err, H, n_seq, seq_len, inner, outer, stride, reserved_cus(), stream_ptr())
+               flags, err, H, n_seq, seq_len, inner, outer, stride, _nsplit_reserved(), stream_ptr())
     return gates, err
 
 
