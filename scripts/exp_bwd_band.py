@@ -1,0 +1,47 @@
+"""Band-path BPTT (12,832 x 34): gate gradients stored per lane from the cell phase against 16-byte row pieces from the LDS tile."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CODE = r'''
+import os, sys, time, torch
+sys.path.insert(0, %r)
+from urgent2026_challenge_track1_amd import ops
+dev, dt = "cuda", torch.bfloat16
+N, H = 196, 392
+torch.manual_seed(0)
+lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                   cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dt)
+B, T, K = 32, 401, 34
+M = B * T * K
+sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dt)
+gx, hout, c = ops.lstm_fwd_rwx(xr, pk["wx"], pk["bias"], N, H, pk["Hp"], **sm)
+dh = ops.pack2d(torch.randn(M, 2 * H, device=dev) * 0.1, M, hout.shape[1], dt)
+g = gx.clone()
+ops.lstm_bwd(dh, g, c, pk["whhT"], H, **sm); torch.cuda.synchronize()
+print("checksum %%.6f" %% g.float().abs().double().sum().item(), "hash", int(g.view(torch.int16).to(torch.int64).sum().item()))
+torch.save(g.cpu(), "/tmp/g_" + os.environ["URSE_BWD_STAGED_STORES"] + ".pt")
+ts = []
+for _ in range(5):
+    g.copy_(gx); torch.cuda.synchronize(); t0 = time.perf_counter()
+    ops.lstm_bwd(dh, g, c, pk["whhT"], H, **sm); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+print("%%.3f ms (min of 5: %%s)" %% (min(ts), " ".join("%%.3f" %% v for v in ts)))
+''' % ROOT
+for v in ("0", "1"):
+    env = dict(os.environ, URSE_BWD_STAGED_STORES=v)
+    r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
+    print("staged=%s" % v, r.stdout.strip().replace("\n", " | "), r.stderr[-300:] if r.returncode else "", flush=True)
+
+import torch
+a, b = torch.load("/tmp/g_0.pt"), torch.load("/tmp/g_1.pt")
+d = (a.view(torch.int16) != b.view(torch.int16))
+print("differing elements", int(d.sum()), "of", d.numel())
+if d.any():
+    idx = d.nonzero()
+    print("rows (first 10):", idx[:10, 0].tolist(), "cols:", idx[:10, 1].tolist())
+    rows = idx[:, 0]
+    print("t = row %% 34 histogram:", torch.bincount(rows % 34, minlength=34).tolist())
+    print("col // 64 (unit tile incl. dir) histogram:", torch.bincount(idx[:, 1] // 64, minlength=98).tolist())
+    da = (a.float() - b.float()).abs()
+    print("max abs diff", da.max().item(), "max |a|", a.float().abs().max().item())

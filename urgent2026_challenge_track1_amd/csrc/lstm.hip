@@ -229,7 +229,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
 // loads of step t + 1 for ALL the wave's unit tiles right after the cell update of step t, in front of the step's weight pass:
 // they are older than every weight fragment in the wave's in-order vmcnt queue, so they have landed when the first fragment
 // has, and the next step starts on registers.  Same arithmetic in the same order: bit-identical results.
-template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0, int PF = 0>
+// STG: the step's gate gradients leave through the LDS tile (which holds them anyway) as 16-byte pieces along the rows, after the barrier,
+// instead of 8 bytes per lane and unit from the cell phase (32 store instructions per lane and step in the 32-row geometry): what took
+// 1.2 us per step off the N-split kernel (lstm_nsplit.hip).  bf16, single direction segment of 4H columns a multiple of 8.
+template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0, int PF = 0, int STG = 0>
 __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #if URSE_BWD_PRIO
   __builtin_amdgcn_s_setprio(URSE_BWD_PRIO);   // the BPTT is on the step's critical path; the wgrad GEMMs it shares CUs with are not
@@ -257,6 +260,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
       rowbase[rt][r] = ok ? rb : -rb - 1;
     }
   auto rowb = [&](int rt, int r) -> long { return rowbase[rt][r] >= 0 ? rowbase[rt][r] : -(rowbase[rt][r] + 1); };
+  if constexpr (STG) {                       // row of each of the workgroup's sequences at t = 0 (-1 beyond n_seq), behind the tile(s)
+    int* rowtab = reinterpret_cast<int*>(smem + nbuf * R * pitch);
+    if (tid < R) {
+      const int seq = s0 + tid;
+      rowtab[tid] = seq < p.m.n_seq ? (int)((seq / p.m.inner) * p.m.outer + (seq % p.m.inner)) : -1;
+    }
+  }
   const int nslab = G4 * ES / 64;
   const char* whhT = reinterpret_cast<const char*>(p.whhT) + ((long)dir * nut * nslab) * 1024 + lane * 16;
   const T* dh = reinterpret_cast<const T*>(p.dh);
@@ -374,7 +384,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
               if (rowbase[rt][r] >= 0)
                 *reinterpret_cast<V4*>(gates + ((long)(rowbase[rt][r] + (p.m.seq_len / 2) * stride_i) * ldg_i + (gcol_i + u * 4))) = pk;
 #else
-              if (rowbase[rt][r] >= 0)
+              if (!STG && rowbase[rt][r] >= 0)
                 *reinterpret_cast<V4*>(gates + ((long)(rowbase[rt][r] + t * stride_i) * ldg_i + (gcol_i + u * 4))) = pk;
 #endif
 #endif
@@ -382,9 +392,25 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
         }
       }
     }
-    if (step + 1 == p.m.seq_len) break;
+    if constexpr (!STG) {
+      if (step + 1 == p.m.seq_len) break;
+    }
     if constexpr (PF == 1) load_all(dir ? t + 1 : t - 1);     // next step's inputs: in flight under the weight pass
     __syncthreads();
+    if constexpr (STG) {
+#ifndef BABL_NO_STORE
+      constexpr int CPR = 4 * HPC * ES / 16;                    // 16-byte pieces of a row's direction segment
+      const int* rowtab = reinterpret_cast<const int*>(smem + nbuf * R * pitch);
+      for (int idx = tid; idx < R * CPR; idx += NW * 64) {
+        const int row = idx / CPR, cc = idx - row * CPR;
+        const int grow = rowtab[row];
+        if (grow >= 0)
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gates) + ((long)(grow + t * stride_i) * ldg_i + gcol_i) * ES + cc * 16) =
+              *reinterpret_cast<const uint4*>(tile + row * pitch + cc * 16);
+      }
+#endif
+      if (step + 1 == p.m.seq_len) break;
+    }
 #ifdef BABL_NO_MM
     if (p.m.seq_len > 0) continue;
 #endif
@@ -739,9 +765,17 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
   }
   if constexpr (sizeof(T) == 2 && NW == 8 && RT == 2) {
     if (p.H == 392 && upw <= 4) {
-      static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392>), true);
-      (void)once;
-      hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392>), grid, dim3(NW * 64), lds, st, pa);
+      static const bool stg_on = !(getenv("URSE_BWD_STAGED_STORES") && atoi(getenv("URSE_BWD_STAGED_STORES")) == 0);     // (A/B switch)
+      const bool stg = stg_on && (p.ldg * 2) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.gates) % 16) == 0;
+      if (stg) {
+        static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 0, 1>), true);
+        (void)once;
+        hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 0, 1>), grid, dim3(NW * 64), lds + R * sizeof(int), st, pa);
+      } else {
+        static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392>), true);
+        (void)once;
+        hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392>), grid, dim3(NW * 64), lds, st, pa);
+      }
       URSE_CHECK_LAUNCH("urse_lstm_bwd");
       return URSE_OK;
     }
