@@ -21,27 +21,15 @@ dh = ops.pack2d(torch.randn(M, 2 * H, device=dev) * 0.1, M, hout.shape[1], dt)
 g = gx.clone()
 ops.lstm_bwd(dh, g, c, pk["whhT"], H, **sm); torch.cuda.synchronize()
 print("checksum %%.6f" %% g.float().abs().double().sum().item(), "hash", int(g.view(torch.int16).to(torch.int64).sum().item()))
-torch.save(g.cpu(), "/tmp/g_" + os.environ["URSE_BWD_STAGED_STORES"] + ".pt")
+
 ts = []
 for _ in range(5):
     g.copy_(gx); torch.cuda.synchronize(); t0 = time.perf_counter()
     ops.lstm_bwd(dh, g, c, pk["whhT"], H, **sm); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
 print("%%.3f ms (min of 5: %%s)" %% (min(ts), " ".join("%%.3f" %% v for v in ts)))
 ''' % ROOT
-for v in ("0", "1"):
-    env = dict(os.environ, URSE_BWD_STAGED_STORES=v)
+for v in ("1", "7", "1", "7"):
+    env = dict(os.environ, URSE_BWD_STAGED_STORES="1", URSE_BWD_VARIANT=("7" if v == "7" else "0"))
     r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
-    print("staged=%s" % v, r.stdout.strip().replace("\n", " | "), r.stderr[-300:] if r.returncode else "", flush=True)
+    print("variant=%s" % v, r.stdout.strip().replace("\n", " | "), r.stderr[-300:] if r.returncode else "", flush=True)
 
-import torch
-a, b = torch.load("/tmp/g_0.pt"), torch.load("/tmp/g_1.pt")
-d = (a.view(torch.int16) != b.view(torch.int16))
-print("differing elements", int(d.sum()), "of", d.numel())
-if d.any():
-    idx = d.nonzero()
-    print("rows (first 10):", idx[:10, 0].tolist(), "cols:", idx[:10, 1].tolist())
-    rows = idx[:, 0]
-    print("t = row %% 34 histogram:", torch.bincount(rows % 34, minlength=34).tolist())
-    print("col // 64 (unit tile incl. dir) histogram:", torch.bincount(idx[:, 1] // 64, minlength=98).tolist())
-    da = (a.float() - b.float()).abs()
-    print("max abs diff", da.max().item(), "max |a|", a.float().abs().max().item())

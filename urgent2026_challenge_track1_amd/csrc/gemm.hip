@@ -269,9 +269,12 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& p, const int bx, cons
       const int row = c / CPR, mc = c - row * CPR;
       const long r = r_begin + (long)kt * BKR + row;
       const long ca = m0 + mc * (16 / ES), cb = n0 + mc * (16 / ES);
-      ra[i] = (r < r_end && ca < p.lda) ? *reinterpret_cast<const uint4*>(p.A + (r * p.lda + ca) * ES)
+      // guards on Mo / No, not on the pitch: A and B may be COLUMN SLICES of wider matrices (per-band operands), where "column < lda"
+      // runs past the parent's row end - and, on the last row, past the allocation (a chunk that starts below Mo / No stays inside the
+      // parent row: operands and pitches are 16-byte aligned)
+      ra[i] = (r < r_end && ca < p.Mo) ? *reinterpret_cast<const uint4*>(p.A + (r * p.lda + ca) * ES)
                                         : make_uint4(0, 0, 0, 0);
-      bool ok = (r < r_end && cb < p.ldb);
+      bool ok = (r < r_end && cb < p.No);
       const long rs = r + p.shift;
       if (p.period) ok = ok && (((r / p.inner) % p.period) != p.invalid_step);
       ok = ok && rs >= 0 && rs < p.R;
@@ -505,8 +508,8 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
     const int cel = seg * 16 + (chunk & 1) * 8;          // element column inside the tile
     acol[j] = m0 + cel;
     bcol[j] = n0 + cel;
-    aok[j] = acol[j] < p.lda;
-    bok[j] = cel < BNX && bcol[j] < ldb_;
+    aok[j] = acol[j] < p.Mo;                             // (Mo / No, not the pitch: see gemm_tn_body)
+    bok[j] = cel < BNX && bcol[j] < No_;
   }
   // issue() is called for consecutive stages, so each lane's rows, source pointers and the (r / inner) % period phase
   // of the masked operand advance by constants: no multiply / divide in the loop.  (The kernel is issue-bound, not
@@ -982,7 +985,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
     init_row(rw1, rowl1);
     const int cel0 = (((chunk >> 1) ^ tn_swz(rowl0)) << 4) + (chunk & 1) * 8;
     const int cel1 = (((chunk >> 1) ^ tn_swz(rowl1)) << 4) + (chunk & 1) * 8;
-    const bool aok0 = cel0 < BMX && m0 + cel0 < p.lda, aok1 = cel1 < BMX && m0 + cel1 < p.lda;
+    const bool aok0 = cel0 < BMX && m0 + cel0 < p.Mo, aok1 = cel1 < BMX && m0 + cel1 < p.Mo;
     sa0.ptr = aok0 ? p.A + ((long)((int)r_begin + rowl0) * p.lda + m0 + cel0) * 2 : zsrc;
     sa1.ptr = aok1 ? p.A + ((long)((int)r_begin + rowl1) * p.lda + m0 + cel1) * 2 : zsrc;
     sa0.step = aok0 ? (unsigned)(64 * p.lda) : 0u;

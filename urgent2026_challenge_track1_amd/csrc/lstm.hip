@@ -295,7 +295,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
         }
     }
   }
-  constexpr int PU = PF ? MAXUT : 1;
+  // PF = 3: two register slots - the loads of unit tile ui + 1 are issued before tile ui is computed, so a step costs ONE exposed round trip
+  // to HBM plus what the compute of a tile does not cover, instead of MAXUT dependent ones (band path, 4 tiles per wave: the input loads are
+  // 1.2 of the launch's 3.8 ms, scripts/abl_lstm.py); the registers come out of the weight fragments in flight (URSE_BWD_KB2_PF3)
+  constexpr int PU = PF == 3 ? 2 : (PF ? MAXUT : 1);
   V4 gpf[PU][RT][4];
   float cpf[PU][RT][4];
   T dhpf[PU][RT][4];
@@ -350,6 +353,9 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
     const int t = dir ? step : (p.m.seq_len - 1 - step);
     char* tile = smem + (step % nbuf) * R * pitch;
     if constexpr (PF == 2) load_all(t);                 // all unit tiles' inputs in ONE round trip, still inside the step
+    if constexpr (PF == 3) {
+      if (w * 16 + lc < H) load_step(0, 0, t);
+    }
 #pragma unroll
     for (int ui = 0; ui < MAXUT; ++ui) {
       const int ut = w + NW * ui;
@@ -357,9 +363,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
         const int u = ut * 16 + lc;
         if (u < H) {
           if constexpr (!PF) load_step(ui, 0, t);
-          V4 (&gpre)[RT][4] = gpf[PF ? ui : 0];
-          float (&cpre)[RT][4] = cpf[PF ? ui : 0];
-          T (&dhpre)[RT][4] = dhpf[PF ? ui : 0];
+          if constexpr (PF == 3) {
+            if (ui + 1 < MAXUT && (w + NW * (ui + 1)) * 16 + lc < H) load_step(ui + 1, (ui + 1) & 1, t);
+          }
+          const int SL = PF == 3 ? (ui & 1) : (PF ? ui : 0);         // (a constant after unrolling)
+          V4 (&gpre)[RT][4] = gpf[SL];
+          float (&cpre)[RT][4] = cpf[SL];
+          T (&dhpre)[RT][4] = dhpf[SL];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -440,7 +450,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #ifndef URSE_BWD_KBPF12
 #define URSE_BWD_KBPF12 14
 #endif
-        constexpr int KB = (sizeof(T) == 2) ? (RT >= 2 ? URSE_BWD_KB2 : (NW == 8 ? URSE_BWD_KB8 : (PF == 1 ? (NW == 12 ? URSE_BWD_KBPF12 : URSE_BWD_KBPF16) : URSE_BWD_KB))) : 8;
+#ifndef URSE_BWD_KB2_PF3
+#define URSE_BWD_KB2_PF3 9
+#endif
+        constexpr int KB = (sizeof(T) == 2) ? (RT >= 2 ? (PF == 3 ? URSE_BWD_KB2_PF3 : URSE_BWD_KB2) : (NW == 8 ? URSE_BWD_KB8 : (PF == 1 ? (NW == 12 ? URSE_BWD_KBPF12 : URSE_BWD_KBPF16) : URSE_BWD_KB))) : 8;
         #pragma unroll 1
         for (int k0 = 0; k0 < nslab; k0 += KB) {
           uint4 b[KB];
@@ -767,7 +780,11 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
     if (p.H == 392 && upw <= 4) {
       static const bool stg_on = !(getenv("URSE_BWD_STAGED_STORES") && atoi(getenv("URSE_BWD_STAGED_STORES")) == 0);     // (A/B switch)
       const bool stg = stg_on && (p.ldg * 2) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.gates) % 16) == 0;
-      if (stg) {
+      if (stg && bwd_variant() == 7) {        // experiment: two-slot pipelined input loads (PF = 3)
+        static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 3, 1>), true);
+        (void)once;
+        hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 3, 1>), grid, dim3(NW * 64), lds + R * sizeof(int), st, pa);
+      } else if (stg) {
         static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 0, 1>), true);
         (void)once;
         hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 0, 1>), grid, dim3(NW * 64), lds + R * sizeof(int), st, pa);

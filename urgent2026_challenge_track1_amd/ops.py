@@ -187,6 +187,12 @@ def tn_desc(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=
     No = Bm.shape[1] if No is None else No
     assert Bm.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and A.dtype == Bm.dtype
     assert out.dtype == torch.float32 and out.stride(-1) == 1 and out.stride(0) >= No
+    # the kernel reads whole 16-byte chunks that START below Mo / No (A and Bm may be column slices of wider matrices): the last
+    # row must hold round_up(Mo | No, 16 / itemsize) elements inside its storage
+    epc = 16 // A.element_size()
+    for t, n in ((A, Mo), (Bm, No)):
+        last = t.storage_offset() + (R - 1) * t.stride(0) + (n + epc - 1) // epc * epc
+        assert last * t.element_size() <= t.untyped_storage().nbytes(), "tn_desc: operand rows are not padded to 16 bytes"
     return [A.data_ptr(), Bm.data_ptr(), out.data_ptr(), 0 if colsum is None else colsum.data_ptr(), A.stride(0),
             Bm.stride(0), out.stride(0), R, Mo, No, shift, max(1, inner), period, invalid_step, 0, perm_h] + [0] * 8
 
