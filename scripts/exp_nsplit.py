@@ -21,13 +21,18 @@ def case(B, T, K, time_runs=0):
     g1, g2 = gx.clone(), gx.clone()
     ops.lstm_bwd(dh, g1, c, pk["whhT"], H, rows16=1, **sm)
     assert ops.lstm_nsplit_plan(H, sm["n_seq"]) is not None
+    os.environ["URSE_NSPLIT_HELPERS"] = "0"
+    g3 = gx.clone()
+    ops.lstm_bwd_nsplit(dh, g3, c, pk["whhT"], H, **sm)
+    os.environ["URSE_NSPLIT_HELPERS"] = "3"
     _, err = ops.lstm_bwd_nsplit(dh, g2, c, pk["whhT"], H, **sm)
     torch.cuda.synchronize()
+    print("  helper waves == no helpers: %s" % torch.equal(g2, g3), flush=True)
     d = (g1.float() - g2.float()).abs()
     scale = g1.float().abs().max().item()
     print("B%d T%d K%d: err flag %d, max |d| / scale %.2e, mean %.2e, finite %s" % (B, T, K, int(err.item()), d.max().item() / scale, d.mean().item() / scale,
                                                                                 bool(torch.isfinite(g2.float()).all())), flush=True)
-    for name in (("stream16", "nsplit") * 2 if time_runs else ()):
+    for name in (("stream16", "nsplit0", "nsplit3") * 2 if time_runs else ()):
         ts = []
         for _ in range(time_runs):
             g2.copy_(gx); torch.cuda.synchronize()
@@ -35,6 +40,7 @@ def case(B, T, K, time_runs=0):
             if name == "stream16":
                 ops.lstm_bwd(dh, g2, c, pk["whhT"], H, rows16=1, **sm)
             else:
+                os.environ["URSE_NSPLIT_HELPERS"] = name[-1]
                 ops.lstm_bwd_nsplit(dh, g2, c, pk["whhT"], H, **sm)
             torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
         print("  %-8s %.3f ms (min of %d: %s)" % (name, min(ts), time_runs, " ".join("%.3f" % v for v in ts)), flush=True)

@@ -50,8 +50,14 @@ struct NsplitArgs {
   unsigned g_bytes;
 };
 
-template <int H>
-__global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
+// HELP > 0: that many HELPER waves beside the 13 compute waves.  The helpers own the hand-off: after the barrier that completes the own
+// half of the tile they store it (16-byte row pieces), wait for those stores, raise the flag, wait for the partner's flag and copy the
+// partner's half into the tile - all of it WHILE the compute waves multiply the own K range, which then starts on a vmcnt queue with no
+// store in it.  The ablation of the helper-less form (profiles/r04_abl_nsplit_v4.log) priced the own-half stores at 1.2 us and the copy at
+// 1.2 us of a 12.7 us step, both in series with the products; 16 waves = 4 per SIMD, the 128-VGPR cap the 13-wave form already had.
+template <int H, int HELP>
+__global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(NsplitArgs p) {
+  constexpr int NTHR_ALL = (NSW + HELP) * 64;
   constexpr int NUT = (H + 15) / 16, G4 = 4 * H, NSLAB = G4 * 2 / 64, UT0 = (NUT + 1) / 2;     // 25 tiles, 49 slabs, member 0 owns 13 tiles
   constexpr int PITCH = lds_frag_pitch(G4 * 2);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -66,6 +72,8 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
   const int ut_lo = m ? UT0 : 0, ut_hi = m ? NUT : UT0;                 // owned unit tiles
   const int ut = ut_lo + w;
   const bool active = ut < ut_hi;
+  const bool helper = HELP > 0 && w >= NSW;
+  const int hidx = (w - NSW) * 64 + lane;                               // helper lane index 0 .. 64 HELP - 1
   const int ks_own0 = 2 * ut_lo, ks_own1 = (2 * ut_hi < NSLAB) ? 2 * ut_hi : NSLAB;        // k-slabs of the owned units' gate columns
   const int u = ut * 16 + lc;
   const bool uvalid = active && u < H;
@@ -101,7 +109,7 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
     const int seq = s0 + tid;
     rowtab[tid] = seq < p.n_seq ? (int)((seq / p.inner) * p.outer + (seq % p.inner)) : -1;
   }
-  for (int i = tid; i < 32 * PITCH / 16; i += NSTHR) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 32 * PITCH / 16; i += NTHR_ALL) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
 
   float dcs[2][4], dhr[2][4], ccur[2][4];
   {
@@ -133,6 +141,83 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
   __syncthreads();
   const bool local = lsync[2] != 0u;
   bool dead = false;
+  if constexpr (HELP > 0) {
+    if (helper) {
+      // ---- the helper waves' own time loop (same barriers as the compute waves': one after the cell phase, one after the hand-off) ----
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const int ob0 = m ? UT0 * 128 : 0;
+      // helper lanes: the 16-byte pieces this lane moves each step, as (tile offset, gates offset at t = 0) without the half's column base;
+      // one mapping for both halves (104 pieces per row, the wider half): bit i of h_own / h_par says whether piece i exists in that half
+      constexpr int HCPR = UT0 * 8, HCH = HELP ? (32 * HCPR + 64 * HELP - 1) / (64 * HELP) : 1;
+      int h_lds[HCH];
+      unsigned h_glb[HCH];
+      unsigned h_own = 0u, h_par = 0u;
+      {
+        const int ocpr_ = m ? (G4 * 2 - UT0 * 128) / 16 : HCPR, pcpr_ = m ? HCPR : (G4 * 2 - UT0 * 128) / 16;
+    #pragma unroll
+        for (int i = 0; i < HCH; ++i) {
+          const int idx = hidx + i * 64 * HELP;
+          const int row = idx / HCPR, cc = idx - row * HCPR;
+          int seq = s0 + row;
+          const bool rok = helper && row < 32 && seq < p.n_seq;
+          if (!rok) seq = 0;
+          const long grow = (seq / p.inner) * p.outer + (seq % p.inner);
+          h_lds[i] = (row & 31) * PITCH + cc * 16;
+          h_glb[i] = (unsigned)((grow * ldg_i + gcol_i) * 2 + cc * 16);
+          if (rok && cc < ocpr_) h_own |= 1u << i;
+          if (rok && cc < pcpr_) h_par |= 1u << i;
+        }
+      }
+
+      for (int step = 0; step < p.seq_len; ++step) {
+        const int t = dir ? step : (p.seq_len - 1 - step);
+        const unsigned step_off = (unsigned)((long)t * stride_i * ldg_i * 2);
+        __builtin_amdgcn_s_barrier();                                    // the own half of the tile is complete
+#ifndef NSABL_NO_STORE
+#pragma unroll
+        for (int i = 0; i < HCH; ++i) {
+          if ((h_own >> i) & 1u) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + h_lds[i] + ob0);
+            const unsigned off = h_glb[i] + step_off + (unsigned)ob0;
+            if (local) __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_g, (int)off, 0, 0);       // stays in the pair's L2
+            else __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_g, (int)off, 0, 16);           // sc1: write-through
+          }
+        }
+#endif
+        if (step + 1 == p.seq_len) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+          const unsigned n = __hip_atomic_fetch_add(&lsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+          if (n == (unsigned)HELP * (unsigned)(step + 1))                // every helper wave has waited for its stores
+            __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned spins = 0;
+#ifdef NSABL_NO_POLL
+          while (false && __hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+#else
+          while (!dead && __hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+#endif
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) { dead = true; atomicExch(p.err, 1u); lsync[1] = 1u; }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#ifndef NSABL_NO_COPY
+        u32x4 v[HCH];
+#pragma unroll
+        for (int i = 0; i < HCH; ++i) {
+          const unsigned off = ((h_par >> i) & 1u) ? h_glb[i] + step_off + (unsigned)pb0 : 0xFFFFF000u;     // (outside the buffer: returns 0, never written)
+          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)off, 0, 16);                               // sc1: L1-bypassing
+        }
+#pragma unroll
+        for (int i = 0; i < HCH; ++i)
+          if ((h_par >> i) & 1u) *reinterpret_cast<uint4*>(tile + h_lds[i] + pb0) = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // the partner's half is in the tile
+      }
+      return;
+    }
+  }
 
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? step : (p.seq_len - 1 - step);
@@ -184,8 +269,10 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
     // the own half of the tile -> the gates output, 16 bytes per lane along the rows (write-through).  (Stored from the cell phase,
     // 8 bytes per lane and unit, the same bytes cost 3 us per step: an sc1 store of 8 bytes per lane moves at a third of the 16-byte
     // form's rate per byte, MI355X_MICROARCH.md "stores of each flavour"; profiles/r04_abl_nsplit_v1.log.)
-    {
-      const int ob0 = m ? UT0 * 128 : 0, ocpr = ((m ? G4 * 2 : UT0 * 128) - ob0) / 16;       // own bytes [ob0, ob0 + 16 ocpr) of a row
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int ob0 = m ? UT0 * 128 : 0, ocpr = ((m ? G4 * 2 : UT0 * 128) - ob0) / 16;       // own bytes [ob0, ob0 + 16 ocpr) of a row
+    const unsigned step_off = (unsigned)((long)toff * ldg_i * 2);
+    if constexpr (HELP == 0) {
 #ifdef NSABL_NO_STORE
       for (int idx = tid; idx < 0 * ocpr; idx += NSTHR) {
 #else
@@ -194,7 +281,6 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
         const int row = idx / ocpr, cc = idx - row * ocpr;
         const int grow = rowtab[row];
         if (grow < 0) continue;
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const uint4 v = *reinterpret_cast<const uint4*>(tile + row * PITCH + ob0 + cc * 16);
         const unsigned off = (unsigned)(((long)(grow + toff) * ldg_i + gcol_i) * 2 + ob0 + cc * 16);
         if (local) __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_g, (int)off, 0, 0);       // stays in the pair's L2
@@ -245,6 +331,15 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
       }
     };
     static_assert(NS_KB == 9, "the counted vmcnt above is written for 9 fragments in flight");
+    if constexpr (HELP > 0) {
+      // ---- 2 + 3 (helper form). compute waves: the own K range.  Helper waves: wait for the own half's stores, raise the flag, wait for the
+      // partner's, copy its half into the tile.  One barrier ends both.
+      if (active) {
+        product(ks_own0, ks_own1, false);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
     // ---- 2. the own K range (in LDS already); the hand-off to the partner travels meanwhile
     if (active) {
       product(ks_own0, ks_own1, true);
@@ -285,6 +380,7 @@ __global__ void __launch_bounds__(NSTHR) lstm_bwd_nsplit_kernel(NsplitArgs p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    }
     // ---- 4. the other K range
     if (active) {
       if (m) product(0, ks_own0, false);
@@ -339,11 +435,15 @@ extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, in
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(flags, 0, sizeof(unsigned) * plan[2], st);
   const size_t lds = (size_t)32 * lds_frag_pitch(4 * 392 * 2) + 16 + 32 * sizeof(int);
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392>),
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 0>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 3>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   note_launch(URSE_KV_LSTM_BWD_NSPLIT);
-  hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392>), dim3((unsigned)plan[1]), dim3(NSTHR), lds, st, p);
+  const int helpers = getenv("URSE_NSPLIT_HELPERS") ? atoi(getenv("URSE_NSPLIT_HELPERS")) : 3;
+  if (helpers > 0) hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 3>), dim3((unsigned)plan[1]), dim3((NSW + 3) * 64), lds, st, p);
+  else hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 0>), dim3((unsigned)plan[1]), dim3(NSTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_nsplit_bwd");
   return URSE_OK;
 }
