@@ -16,6 +16,7 @@
 #include <math.h>
 
 #include "fft_lds.h"
+#include "fft_reg.h"
 
 namespace urse {
 
@@ -54,9 +55,31 @@ __global__ void __launch_bounds__(256) pair_sums_kernel(const float* __restrict_
   const float* tb = t + (long)b * L;
   const float* eb = e + (long)b * L;
   double s[5] = {0, 0, 0, 0, 0};
-  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-    const double tv = tb[i], ev = eb[i];
-    s[0] += tv; s[1] += tv * tv; s[2] += ev; s[3] += ev * ev; s[4] += ev * tv;
+  if ((L & 3) == 0 && (i0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(e)) & 15) == 0) {
+    // 16-byte loads, two of each signal in flight per thread (the scalar loop ran at 1.6 TB/s: one 4-byte load per thread and trip)
+    const float4* t4 = reinterpret_cast<const float4*>(tb + i0);
+    const float4* e4 = reinterpret_cast<const float4*>(eb + i0);
+    const int n4 = (i1 - i0) >> 2;
+    auto add = [&](const float4& a, const float4& c) {
+      const double tv[4] = {a.x, a.y, a.z, a.w}, ev[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { s[0] += tv[q]; s[1] += tv[q] * tv[q]; s[2] += ev[q]; s[3] += ev[q] * ev[q]; s[4] += ev[q] * tv[q]; }
+    };
+    int v = threadIdx.x;
+    for (; v + (int)blockDim.x < n4; v += 2 * blockDim.x) {
+      const float4 a0 = t4[v], c0 = e4[v], a1 = t4[v + blockDim.x], c1 = e4[v + blockDim.x];
+      add(a0, c0); add(a1, c1);
+    }
+    if (v < n4) add(t4[v], e4[v]);
+    for (int i = i0 + (n4 << 2) + threadIdx.x; i < i1; i += blockDim.x) {
+      const double tv = tb[i], ev = eb[i];
+      s[0] += tv; s[1] += tv * tv; s[2] += ev; s[3] += ev * ev; s[4] += ev * tv;
+    }
+  } else {
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+      const double tv = tb[i], ev = eb[i];
+      s[0] += tv; s[1] += tv * tv; s[2] += ev; s[3] += ev * ev; s[4] += ev * tv;
+    }
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -97,6 +120,28 @@ __global__ void __launch_bounds__(256) mrl1_td_kernel(const float* __restrict__ 
   int i1 = i0 + chunk;
   if (i1 > L) i1 = L;
   double s = 0;
+  if ((L & 3) == 0 && (i0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(G)) & 15) == 0) {
+    const float4* t4 = reinterpret_cast<const float4*>(t + (long)b * L + i0);
+    const float4* e4 = reinterpret_cast<const float4*>(e + (long)b * L + i0);
+    float4* G4 = G ? reinterpret_cast<float4*>(G + (long)b * L + i0) : nullptr;
+    const int n4 = (i1 - i0) >> 2;
+    for (int v = threadIdx.x; v < n4; v += blockDim.x) {
+      const float4 a = t4[v], c = e4[v];
+      const float d[4] = {sc.a * c.x - sc.b * a.x, sc.a * c.y - sc.b * a.y, sc.a * c.z - sc.b * a.z, sc.a * c.w - sc.b * a.w};
+      float sg[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s += fabsf(d[q]);
+        sg[q] = w_td * (d[q] > 0.f ? 1.f : (d[q] < 0.f ? -1.f : 0.f));
+      }
+      if (G4) G4[v] = make_float4(sg[0], sg[1], sg[2], sg[3]);
+    }
+    for (int i = i0 + (n4 << 2) + threadIdx.x; i < i1; i += blockDim.x) {
+      const float d = sc.a * e[(long)b * L + i] - sc.b * t[(long)b * L + i];
+      s += fabsf(d);
+      if (G) G[(long)b * L + i] = w_td * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    }
+  } else
   for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
     const float d = sc.a * e[(long)b * L + i] - sc.b * t[(long)b * L + i];
     s += fabsf(d);
@@ -143,7 +188,11 @@ __global__ void __launch_bounds__(256) mrl1_spec_kernel(const float* __restrict_
     bufA[idx] = v;
   }
   __syncthreads();
+#ifdef MABL_NO_FFT
+  float2* Z = bufA;
+#else
   float2* Z = fft_lds_forward(bufA, bufB, NF, plan, tw);
+#endif
   float2* Y = (Z == bufA) ? bufB : bufA;
   double s = 0;
   for (int idx = threadIdx.x; idx < NF * (half + 1); idx += blockDim.x) {
@@ -181,15 +230,171 @@ __global__ void __launch_bounds__(256) mrl1_spec_kernel(const float* __restrict_
       Z[idx] = make_float2(ya.x - yb.y, -(ya.y + yb.x));
     }
     __syncthreads();
+#ifdef MABL_NO_FFT
+    const float2* R = Z;
+#else
     const float2* R = fft_lds_forward(Z, Y, NP, plan, tw);
+#endif
     for (int idx = threadIdx.x; idx < NP * n; idx += blockDim.x) {
       const int pidx = fastdiv(idx, plan.m_n), i = idx - pidx * n;
       const float2 r = R[idx];
       const int fa = t0 + 2 * pidx;
+#ifdef MABL_NO_ATOMIC     // timing diagnostics (wrong results): scripts/abl_mrl1.py
+      if (fa < T) G[(long)b * L + reflect_idx(fa * hop + i - half, L)] = r.x;
+      if (fa + 1 < T) G[(long)b * L + reflect_idx((fa + 1) * hop + i - half, L)] = -r.y;
+#elif defined(MABL_NO_SCATTER)
+      if (r.x == 123.456f) G[0] = r.y;
+#else
       if (fa < T) atomicAdd(G + (long)b * L + reflect_idx(fa * hop + i - half, L), r.x);
       if (fa + 1 < T) atomicAdd(G + (long)b * L + reflect_idx((fa + 1) * hop + i - half, L), -r.y);
+#endif
     }
   }
+}
+
+// The same resolution on the REGISTER FFT (windows 32 * M, M = 8 / 16 / 24 / 32: the loss's 256 / 512 / 768 / 1024).  The kernel above walks
+// log4(n) radix passes through LDS with run-time index arithmetic; its ablation (scripts/abl_mrl1.py, n = 1024: 162 us per launch) prices the
+// FFTs at 78 us and the passes around them (frame fill, magnitudes, pair packing: one LDS trip and a barrier each) at 68.  Here a HALF-WAVE owns
+// a frame from the samples to the gradient spectrum, as stft960_kernel does for the 960-point STFT:
+//   pass 1: lane j (M lanes) loads z[j + M m] = a e + i b t, m = 0 .. 31 (lanes read consecutive samples), 32-point DFT in registers,
+//           times W_n^(j k1), written transposed to the half-wave's LDS buffer;
+//   pass 2: lane k1 (32 lanes) reads its M values, M-point DFT in registers -> Z[k1 + 32 k2], written back in natural order;
+//   magnitudes / L1 / gradient spectrum in place (a lane owns the pair k, n - k);
+//   gradient: the first half-wave of each wave transforms the PAIR's packed spectrum conj(Ya + i Yb) the same way and scatters
+//           Re -> frame a, -Im -> frame b into G straight from its registers (lanes hold consecutive samples).
+// Two LDS round trips per transform, no workgroup barrier after the twiddle table is in, every index a compile-time constant.
+template <int R1, int R2, bool GRAD>
+__global__ void __launch_bounds__(256) mrl1_spec_reg_kernel(const float* __restrict__ t, const float* __restrict__ e,
+                                                            const double* __restrict__ sums, double* __restrict__ acc,
+                                                            float* __restrict__ G, int L, int T, const float2* __restrict__ tw_g,
+                                                            double eps, float w_spec) {
+  // n = R1 * R2: pass 1 = R2 lanes x R1-point DFTs, pass 2 = R1 lanes x R2-point DFTs, LPF = max lanes of a frame's group
+  constexpr int N = R1 * R2, HALF = N / 2, HOP = N / 2, LPF = R1 > R2 ? R1 : R2, NFR = 256 / LPF, ZP = R2 + 1, ZS = N + R1, LG1 = fr_log2(R1);
+  static_assert(LPF == 16 || LPF == 32, "a frame's lane group is a quarter or a half wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[4];
+  float2* tw = reinterpret_cast<float2*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, l = tid % LPF, hw = tid / LPF;
+  float2* zb = tw + N + hw * ZS;
+  const int b = blockIdx.y, fr = blockIdx.x * NFR + hw;
+  const bool fok = fr < T;
+  const Mrl1Scalars sc = mrl1_scalars(sums + (long)b * 5, L, eps);
+  const float* tb = t + (long)b * L;
+  const float* eb = e + (long)b * L;
+  for (int i = tid; i < N; i += 256) tw[i] = tw_g[i];
+  float2 v[R1];
+  if (l < R2) {
+    const int base = (fok ? fr : T - 1) * HOP - HALF + l;
+    const float ma = fok ? sc.a : 0.f, mb = fok ? sc.b : 0.f;
+#pragma unroll
+    for (int m = 0; m < R1; ++m) {
+      const int p = reflect_idx(base + R2 * m, L);
+      v[m] = make_float2(ma * eb[p], mb * tb[p]);
+    }
+  }
+  __syncthreads();                                            // the twiddle table is complete
+  if (l < R2) {
+#ifndef MABL_NO_FFT
+    dft_pow2_dif<R1>(v);
+#endif
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+      const float2 a = v[fr_brev(k1, LG1)];
+      const float2 w = tw[l * k1];
+      zb[k1 * ZP + l] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();        // a group's reads follow its writes in the wave's in-order LDS queue; this keeps the wave converged
+  if (l < R1) {
+    float2 u[R2];
+#pragma unroll
+    for (int j = 0; j < R2; ++j) u[j] = zb[l * ZP + j];
+#ifndef MABL_NO_FFT
+    dft_small<R2>(u);
+#endif
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) zb[l + R1 * k2] = u[k2];
+  }
+  __builtin_amdgcn_wave_barrier();
+  double s = 0;
+#pragma unroll 1
+  for (int k = l; k <= HALF; k += LPF) {
+    const float2 zk = zb[k];
+    const float2 zc = zb[k == 0 ? 0 : N - k];
+    const float2 U = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+    const float2 Tt = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+    const float mu = sqrtf(U.x * U.x + U.y * U.y), mt = sqrtf(Tt.x * Tt.x + Tt.y * Tt.y);
+    const float d = mu - mt;
+    if (fok) s += fabsf(d);
+    if (GRAD) {
+      const float sg = (d > 0.f ? w_spec : (d < 0.f ? -w_spec : 0.f));
+      float2 g = make_float2(0.f, 0.f);
+      if (mu > 0.f && fok) g = make_float2(sg * U.x / mu, sg * U.y / mu);
+      if (k == 0 || k == HALF) {
+        zb[k] = make_float2(g.x, 0.f);
+      } else {
+        zb[k] = make_float2(0.5f * g.x, 0.5f * g.y);
+        zb[N - k] = make_float2(0.5f * g.x, -0.5f * g.y);
+      }
+    }
+  }
+  s = wave_sum_d(s);
+  if (lane == 0) red[tid >> 6] = s;
+  if (GRAD) {
+    __builtin_amdgcn_wave_barrier();
+    // the pair (frames 2p, 2p + 1 = two adjacent lane groups of one wave): in = conj(Ya + i Yb), one transform, by the pair's first group
+    if ((hw & 1) == 0) {
+      const float2* za = zb;
+      const float2* zo = zb + ZS;
+      if (l < R2) {
+#pragma unroll
+        for (int m = 0; m < R1; ++m) {
+          const float2 ya = za[l + R2 * m], yb = zo[l + R2 * m];
+          v[m] = make_float2(ya.x - yb.y, -(ya.y + yb.x));
+        }
+#ifndef MABL_NO_FFT
+        dft_pow2_dif<R1>(v);
+#endif
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+          const float2 a = v[fr_brev(k1, LG1)];
+          const float2 w = tw[l * k1];
+          zb[k1 * ZP + l] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (l < R1) {
+        float2 u[R2];
+#pragma unroll
+        for (int j = 0; j < R2; ++j) u[j] = zb[l * ZP + j];
+#ifndef MABL_NO_FFT
+        dft_small<R2>(u);
+#endif
+        // y = FFT(in): Re -> frame a (samples pa0 + i), -Im -> frame b (one hop later).  A lane holds i = l + R1 k2, and one hop is R2 / 2
+        // values of k2: the two frames' overlap is summed in registers, so the pair issues three half-frames of atomics instead of four
+        float* Gb = G + (long)b * L;
+        const int pa0 = fr * HOP - HALF + l;
+        const bool oka = fr < T, okb = fr + 1 < T;
+#ifndef MABL_NO_SCATTER
+#pragma unroll
+        for (int k2 = 0; k2 < R2 / 2; ++k2)
+          if (oka) atomicAdd(Gb + reflect_idx(pa0 + R1 * k2, L), u[k2].x);
+#pragma unroll
+        for (int k2 = 0; k2 < R2 / 2; ++k2) {
+          const float ov = (oka ? u[k2 + R2 / 2].x : 0.f) - (okb ? u[k2].y : 0.f);
+          if (oka) atomicAdd(Gb + reflect_idx(pa0 + HOP + R1 * k2, L), ov);
+        }
+#pragma unroll
+        for (int k2 = R2 / 2; k2 < R2; ++k2)
+          if (okb) atomicAdd(Gb + reflect_idx(pa0 + HOP + R1 * k2, L), -u[k2].y);
+#else
+        if (u[0].x == 123.456f) Gb[0] = u[1].y;
+#endif
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) atomicAdd(acc + (long)b * 2 + 1, red[0] + red[1] + red[2] + red[3]);
 }
 
 __global__ void mrl1_final_kernel(const double* __restrict__ acc, float* __restrict__ loss, int B, float w_td,
@@ -367,7 +572,7 @@ extern "C" int urse_pair_sums(const float* target, const float* estimate, double
   URSE_CHECK_ARG(target && estimate && sums && B > 0 && L > 1, "urse_pair_sums: bad argument");
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(sums, 0, sizeof(double) * 5 * B, st);
-  const int chunk = 16384;
+  const int chunk = 4096;
   hipLaunchKernelGGL(pair_sums_kernel, dim3(ceil_div(L, chunk), B), dim3(256), 0, st, target, estimate, sums, L, chunk);
   URSE_CHECK_LAUNCH("urse_pair_sums");
   return URSE_OK;
@@ -389,7 +594,7 @@ extern "C" int urse_mrl1_loss_fwd(const float* target, const float* estimate, fl
   int rc = urse_pair_sums(target, estimate, sums, B, L, stream);
   if (rc) return rc;
   (void)hipMemsetAsync(acc, 0, sizeof(double) * 2 * B, st);
-  const int chunk = 16384;
+  const int chunk = 4096;
   hipLaunchKernelGGL(mrl1_td_kernel, dim3(ceil_div(L, chunk), B), dim3(256), 0, st, target, estimate, sums, acc, G, L,
                      chunk, (double)eps, td_weight);
   const float w_spec = (1.f - td_weight) / (float)n_windows;
@@ -400,6 +605,28 @@ extern "C" int urse_mrl1_loss_fwd(const float* target, const float* estimate, fl
     rc = loss_tables(n, &tb);
     if (rc) return rc;
     const int T = L / hop + 1;
+    const bool no_reg = getenv("URSE_MRL1_NO_REG_FFT") != nullptr;          // (A/B switch: the LDS-pass kernel)
+    if (!no_reg && (n == 256 || n == 512 || n == 768 || n == 1024)) {
+      // 256 = 16 x 16 (a quarter wave per frame, 16 frames per workgroup), 512 = 32 x 16, 768 = 32 x 24, 1024 = 32 x 32 (half waves, 8 frames)
+      const int r1 = n == 256 ? 16 : 32, nfr = 256 / r1;
+      const size_t lds = (size_t)(n + nfr * (n + r1)) * 8;
+      dim3 grid(ceil_div(T, nfr), B);
+#define URSE_MRL1_REG(R1_, R2_)                                                                                                           \
+  {                                                                                                                                       \
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mrl1_spec_reg_kernel<R1_, R2_, true>),                    \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),                                \
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mrl1_spec_reg_kernel<R1_, R2_, false>),                   \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);                         \
+    (void)once;                                                                                                                           \
+    if (G) hipLaunchKernelGGL((mrl1_spec_reg_kernel<R1_, R2_, true>), grid, dim3(256), lds, st, target, estimate, sums, acc, G, L, T,     \
+                              tb.tw, (double)eps, w_spec);                                                                                \
+    else hipLaunchKernelGGL((mrl1_spec_reg_kernel<R1_, R2_, false>), grid, dim3(256), lds, st, target, estimate, sums, acc, G, L, T,      \
+                            tb.tw, (double)eps, w_spec);                                                                                  \
+  }
+      if (n == 256) URSE_MRL1_REG(16, 16) else if (n == 512) URSE_MRL1_REG(32, 16) else if (n == 768) URSE_MRL1_REG(32, 24) else URSE_MRL1_REG(32, 32)
+#undef URSE_MRL1_REG
+      continue;
+    }
     int NF = 8;
     while (NF > 2 && (size_t)(2 * NF + 1) * n * 8 > 72 * 1024) NF -= 2;
     const size_t lds = (size_t)(2 * NF + 1) * n * 8;
@@ -423,7 +650,7 @@ extern "C" int urse_mrl1_loss_bwd(const float* target, const float* estimate, co
                  "urse_mrl1_loss_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(c1, 0, sizeof(double) * B, st);
-  const int chunk = 16384;
+  const int chunk = 4096;
   hipLaunchKernelGGL(dot_kernel, dim3(ceil_div(L, chunk), B), dim3(256), 0, st, G, estimate, c1, L, chunk);
   hipLaunchKernelGGL(mrl1_bwd_kernel, dim3(ceil_div(L, 1024), B), dim3(256), 0, st, target, estimate, G, sums, c1,
                      grad_loss, grad_estimate, L, (double)eps, (const float*)nullptr, B);
@@ -438,7 +665,7 @@ extern "C" int urse_mrl1_loss_bwd_guarded(const float* target, const float* esti
                  "urse_mrl1_loss_bwd_guarded: bad argument");
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(c1, 0, sizeof(double) * B, st);
-  const int chunk = 16384;
+  const int chunk = 4096;
   hipLaunchKernelGGL(dot_kernel, dim3(ceil_div(L, chunk), B), dim3(256), 0, st, G, estimate, c1, L, chunk);
   hipLaunchKernelGGL(mrl1_bwd_kernel, dim3(ceil_div(L, 1024), B), dim3(256), 0, st, target, estimate, G, sums, c1,
                      grad_loss, grad_estimate, L, (double)eps, loss, B);
