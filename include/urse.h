@@ -119,6 +119,15 @@ int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C
 int urse_gemm_nt_gnstats(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
                          const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K, int in_dtype, int act,
                          double* stats, int64_t rows_per_group, void* stream);
+/* the dgrad GEMM in front of a GroupNorm backward: C[M,N] (f32, dense) = A[M,K] * B[N,K]^T (bf16 operands) and, from the tile while it is on
+ * the chip, the sums the GroupNorm backward needs of C = dy against the normalised tensor x ([M,N] f32; groups of rows_per_group rows; stats as
+ * urse_groupnorm_fwd wrote them): sums[g] = (sum dy*gamma, sum dy*gamma*xhat) (f64, overwritten), dgamma[c] += sum dy*xhat, dbeta[c] += sum dy.
+ * Replaces the reduce pass of urse_groupnorm_bwd (autograd of torch.nn.GroupNorm(1, N) behind espnet2 BSRNN's norm_time / norm_freq, twin
+ * baseline_code/models/bsrnn_flowse.py:291,302); follow with urse_groupnorm_bwd_apply.  part: slots*2*N floats of workspace.
+ * URSE_ERR_UNSUPPORTED (nothing launched) unless bf16, M >= 2048, 160 <= N <= 224, N % 4 == 0, K % 32 == 0, rows_per_group >= 256 divides M. */
+int urse_gemm_nt_gnbwd(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, int in_dtype,
+                       const float* x, const double* stats, const float* gamma, double* sums, float* dgamma, float* dbeta, float* part,
+                       int slots, int64_t rows_per_group, float eps, void* stream);
 /* grouped form: `descs` = device array of `groups` records of 12 int64
  * {A, B, C, bias, resid, lda, ldb, ldc, M, N, K, ldr}; grid.x = max_blocks (largest tile count). */
 int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_dtype, int out_dtype, int act,
@@ -169,6 +178,10 @@ int urse_groupnorm_apply(const float* x, const float* gamma, const float* beta, 
 int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, const float* gamma, const float* dres,
                        float* dx, float* dgamma, float* dbeta, double* sums, int B, int T, int Kg, int W, int N,
                        int gstride, float eps, void* dx_packed, int ldp, void* stream);
+/* the apply pass of urse_groupnorm_bwd alone, with sums that came out of urse_gemm_nt_gnbwd (N % 4 == 0) */
+int urse_groupnorm_bwd_apply(const float* x, const float* dy, const double* stats, const double* sums, const float* gamma,
+                             const float* dres, float* dx, int B, int T, int Kg, int W, int N, int gstride, float eps, void* dx_packed,
+                             int ldp, void* stream);
 /* out[out_rows, out_cols] (pitch ldo) = zero-padded copy of in[rows, cols] (or its transpose), with cast. */
 int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int rows, int cols,
                 int out_rows, int out_cols, int transpose, void* stream);

@@ -42,3 +42,18 @@ t("torch tn whh", lambda: torch.mm(dg[:, :4 * H].t(), hh, out=o5), 2.0 * M * 4 *
 gw1, gw2 = torch.zeros(4 * H, N, device=dev), torch.zeros(4 * H, H, device=dev)
 t("tn dual (wih_d + whh_d)", lambda: ops.gemm_tn_dual(dg[:, :4 * H], xn, gw1, cs[:4 * H], hout[:, :H], gw2, 4 * H, N, H, -34, 34, 401, 0, perm_h=H),
   2.0 * M * 4 * H * (196 + H))
+# dgrad + GroupNorm backward: two-pass (GEMM, reduce + apply) against the reduce on the GEMM's epilogue (urse_gemm_nt_gnbwd)
+Bn, rows = 32, 401 * 34
+xs = torch.randn(Bn, 401, 34, N, device=dev)
+gam, bet = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
+_, stats = ops.groupnorm_fwd(xs, gam, bet, Bn, 401, 1, 34 * N, N, 224, 0, bf)
+dgm, dbt, dres = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.randn(Bn, 401, 34, N, device=dev)
+def two_pass():
+    dy = ops.gemm_nt(dg, wihT, out_dtype=torch.float32, N=N)
+    return ops.groupnorm_bwd(xs, dy, stats, gam, dres, dgm, dbt, Bn, 401, 1, 34 * N, N, 0, pack_ld=224)
+def fused():
+    dy, sm = ops.gemm_nt_gnbwd(dg, wihT, N, xs, stats, gam, dgm, dbt, rows)
+    return ops.groupnorm_bwd(xs, dy, stats, gam, dres, dgm, dbt, Bn, 401, 1, 34 * N, N, 0, pack_ld=224, sums=sm)
+t("dgrad + GN bwd, two-pass", two_pass, 2.0 * M * N * 8 * H)
+t("dgrad + GN bwd, fused reduce", fused, 2.0 * M * N * 8 * H)
+t("  fused GEMM alone", lambda: ops.gemm_nt_gnbwd(dg, wihT, N, xs, stats, gam, dgm, dbt, rows), 2.0 * M * N * 8 * H)

@@ -278,3 +278,40 @@ def test_gemm_nt_with_groupnorm_statistics(lib, M, N, K, rows, resid):
     y1, s1 = ops.groupnorm_fwd(ref, gamma, beta, M // rows, rows, 1, N, N, Np, 0, torch.bfloat16)
     y2, _ = ops.groupnorm_fwd(ref, gamma, beta, M // rows, rows, 1, N, N, Np, 0, torch.bfloat16, stats=st)
     assert (y1.float() - y2.float()).abs().max().item() <= 1e-2 and (s1 - st).abs().max().item() <= 1e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,rows", [(4096, 196, 3136, 1024), (6 * 640, 196, 416, 640), (5 * 512 + 0, 196, 800, 512)])
+def test_dgrad_gemm_with_groupnorm_backward_sums(lib, M, N, K, rows):
+    """urse_gemm_nt_gnbwd + urse_groupnorm_bwd_apply == urse_gemm_nt + urse_groupnorm_bwd: the dgrad output bit for bit, the group sums,
+    dgamma / dbeta and dx to f32 rounding (different summation order).  Tiles that span two groups (rows not a multiple of 256) included."""
+    from urgent2026_challenge_track1_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    Bn = M // rows
+    x = torch.randn(Bn, rows, 1, N, device="cuda", generator=g) * 2 + 0.3
+    gamma, beta = torch.rand(N, device="cuda", generator=g) + 0.5, torch.randn(N, device="cuda", generator=g)
+    dres = torch.randn(Bn, rows, 1, N, device="cuda", generator=g)
+    Np = (N + 31) // 32 * 32
+    _, stats = ops.groupnorm_fwd(x, gamma, beta, Bn, rows, 1, N, N, Np, 0, torch.bfloat16)
+    assert ops.gemm_nt_gnbwd_supported(M, N, K, rows, torch.bfloat16)
+    # two-pass reference
+    dy0 = ops.gemm_nt(A, W, out_dtype=torch.float32)
+    dg0, db0 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    dx0, p0 = ops.groupnorm_bwd(x, dy0, stats, gamma, dres, dg0, db0, Bn, rows, 1, N, N, 0, pack_ld=Np)
+    # fused
+    dg1, db1 = torch.ones(N, device="cuda"), torch.ones(N, device="cuda")          # (accumulated: += on top of what is there)
+    dy1, sums = ops.gemm_nt_gnbwd(A, W, N, x, stats, gamma, dg1, db1, rows)
+    dx1, p1 = ops.groupnorm_bwd(x, dy1, stats, gamma, dres, dg1, db1, Bn, rows, 1, N, N, 0, pack_ld=Np, sums=sums)
+    assert torch.equal(dy0, dy1)
+    xd = x.double().view(Bn, rows * N)
+    mu = xd.mean(1, keepdim=True)
+    xh = ((xd - mu) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-5)).view(M, N)
+    dyd = dy0.double()
+    want = torch.stack([(dyd * gamma.double()).view(Bn, -1).sum(1), (dyd * gamma.double() * xh).view(Bn, -1).sum(1)], 1).reshape(-1)
+    scale = (dyd.abs() * gamma.double()).view(Bn, -1).sum(1).max().item()
+    assert (sums - want).abs().max().item() <= 1e-5 * scale, (sums, want)
+    for a, b in ((dg1 - 1, dg0), (db1 - 1, db0)):
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), (a - b).abs().max()
+    assert (dx1 - dx0).abs().max().item() <= 1e-4 * max(1.0, dx0.abs().max().item())
+    assert (p1.float() - p0.float()).abs().max().item() <= 2e-2 * max(1.0, dx0.abs().max().item())

@@ -587,10 +587,16 @@ class BSRNNCore(nn.Module):
         else:
             for fn, _ in parts:
                 fn()
-        dxn = ops.gemm_nt(dg, pk[p + "wihT"], out_dtype=torch.float32, N=N)
+        gn_sums = None
+        if ops.FUSE_GN_BWD and ops.gemm_nt_gnbwd_supported(M, N, dg.shape[1], T * K, dt):
+            # the reduce pass of the GroupNorm backward (sums of dxn against the normalised skip) rides on the dgrad GEMM's epilogue
+            dxn, gn_sums = ops.gemm_nt_gnbwd(dg, pk[p + "wihT"], N, skip, stats, self._p(p + "gamma", N), self._g(p + "gamma", N),
+                                             self._g(p + "beta", N), T * K, GN_EPS)
+        else:
+            dxn = ops.gemm_nt(dg, pk[p + "wihT"], out_dtype=torch.float32, N=N)
         if dt == torch.bfloat16 and N % 4 == 0:
             dskip, packed = ops.groupnorm_bwd(skip, dxn, stats, self._p(p + "gamma", N), dout, self._g(p + "gamma", N),
-                                              self._g(p + "beta", N), B, T, 1, K * N, N, 0, GN_EPS, pack_ld=d["Np"])
+                                              self._g(p + "beta", N), B, T, 1, K * N, N, 0, GN_EPS, pack_ld=d["Np"], sums=gn_sums)
             self._grad_pack = (dskip.data_ptr(), packed)
         else:
             dskip = ops.groupnorm_bwd(skip, dxn, stats, self._p(p + "gamma", N), dout, self._g(p + "gamma", N),

@@ -1153,8 +1153,24 @@ static void launch_tn_dma(int ntw, int csm, dim3 grid, hipStream_t st, const TnA
 // 16 B); physical chunk = k-chunk ^ ((row >> 1) & 3), applied on the DMA source address and on the ds_read_b128
 // fragment reads, so the 16 rows of a fragment hit 16 different 16-byte bank groups.  Epilogue as gemm_nt_kernel
 // (bias / tanh / tanh-backward / residual, output staged through LDS for 16-byte coalesced stores).
-template <typename TO, int NTW, int ACT, int BMX, int WNC>
-__device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gstats = nullptr, long rpg = 0) {
+struct NtExtra {       // optional outputs of the ring NT kernel beside C (null / 0 = none)
+  double* gstats;      // GroupNorm statistics of C per group of `rpg` rows: [groups][2] (sum, sum of squares), pre-zeroed
+  long rpg;
+  // GroupNorm BACKWARD sums of C (= dy, the gradient w.r.t. the normalised tensor) against the normalised input x (GNB kernels only):
+  //   gnb_sums[g] += (sum dy * gamma, sum dy * gamma * xhat) over group g (rpg rows x N), xhat = (x - mean_g) * rstd_g from gnb_stats;
+  //   gnb_part[slot][0][c] += sum dy * xhat, gnb_part[slot][1][c] += sum dy per channel c (slot = workgroup % gnb_slots: the 1,704
+  //   workgroups of a C2 launch would serialise on 2 N addresses otherwise, norm.hip "red_elems"); a fold kernel adds the slots up
+  const float* gnb_x;
+  const double* gnb_stats;
+  const float* gnb_gamma;
+  double* gnb_sums;
+  float* gnb_part;
+  int gnb_slots;
+  float gnb_eps;
+};
+
+template <typename TO, int NTW, int ACT, int BMX, int WNC, int GNB = 0>
+__device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gstats = nullptr, long rpg = 0, const NtExtra* xt = nullptr) {
   // tile = BMX rows x (16 * NTW * WNC) columns; waves BMX/64 (m) x WNC (n), each 64 x 16*NTW
   // <256, 2>: 8 waves, 256 x 224/256, 4 stages of 32 KB (long K: least operand traffic per FLOP)
   // <128, 4>: 8 waves, 128 x 448, 4 stages of 36 KB (short K, write-bound outputs: 896-byte row segments reach 5.4 TB/s
@@ -1288,9 +1304,45 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
   float gsa = 0.f, gqa = 0.f, gsb = 0.f, gqb = 0.f;
   const bool gst = OS == 4 && gstats != nullptr;
   const long gidx = gst ? m0 / rpg : 0, gbound = gst ? (gidx + 1) * rpg : 0;
+  // GNB: group means / rstds of the (at most two) groups of this tile, the thread's four gammas, per-channel partial sums
+  float gnb_m[2] = {0.f, 0.f}, gnb_r[2] = {0.f, 0.f}, gnb_ga[4] = {0.f, 0.f, 0.f, 0.f}, gnb_dg[4] = {0.f, 0.f, 0.f, 0.f}, gnb_db[4] = {0.f, 0.f, 0.f, 0.f};
+  long gnb_g0 = 0, gnb_bound = 0;
+  float4 gnb_xpre[GNB ? (RPP + NTHR / CPR - 1) / (NTHR / CPR) : 1];
+  if constexpr (GNB) {
+    gnb_g0 = m0 / xt->rpg;
+    gnb_bound = (gnb_g0 + 1) * xt->rpg;
+    const double cnt = (double)xt->rpg * (double)d.N;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const long g = gnb_g0 + q;
+      if (g * xt->rpg < d.M) {
+        const double mu = xt->gnb_stats[g * 2] / cnt;
+        double var = xt->gnb_stats[g * 2 + 1] / cnt - mu * mu;
+        if (var < 0.0) var = 0.0;
+        gnb_m[q] = (float)mu;
+        gnb_r[q] = (float)(1.0 / sqrt(var + (double)xt->gnb_eps));
+      }
+    }
+    const int chf = tid % (BNX / (16 / OS));
+    const long col = n0 + chf * (16 / OS);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gnb_ga[q] = (col + q < d.N) ? xt->gnb_gamma[col + q] : 0.f;
+  }
 #pragma unroll 1
   for (int pass = 0; pass < BMX / RPP; ++pass) {
     if (pass > 0) __syncthreads();
+    if constexpr (GNB) {
+      constexpr int SLOTS = NTHR / CPR, XI = (RPP + SLOTS - 1) / SLOTS;
+      const int slot = tid / CPR, chf = tid - slot * CPR;
+      const long col = n0 + chf * EPC;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int lr_ = slot + i * SLOTS;
+        const long row = m0 + pass * RPP + lr_;
+        const bool ok = slot < SLOTS && col < d.N && lr_ < RPP && row < d.M;
+        gnb_xpre[i] = ok ? *reinterpret_cast<const float4*>(xt->gnb_x + row * d.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     if ((wm * 64) / RPP == pass) {
       const int rbase = (wm * 64) % RPP;
 #pragma unroll
@@ -1336,6 +1388,39 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
       }
     }
     __syncthreads();
+    if constexpr (GNB) {
+      // fixed column chunk per thread (NTHR / CPR row slots), so the per-channel sums stay in registers; a tile spans at most two groups.
+      // The thread's x values of this pass were requested before the staging (gnb_xpre): their HBM latency is behind it
+      constexpr int SLOTS = NTHR / CPR, XI = (RPP + SLOTS - 1) / SLOTS;
+      const int slot = tid / CPR, chf = tid - slot * CPR;
+      const long col = n0 + chf * EPC;
+      if (slot < SLOTS && col < d.N) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          const int lr_ = slot + i * SLOTS;
+          const long row = m0 + pass * RPP + lr_;
+          if (lr_ < RPP && row < d.M) {
+            const float4 f = *reinterpret_cast<const float4*>(lds + lr_ * CP + chf * 16);
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4_t*>(&f), reinterpret_cast<f32x4_t*>(C + row * d.ldc + col));
+            const float4 xv = gnb_xpre[i];
+            const bool first = row < gnb_bound;
+            const float mean = first ? gnb_m[0] : gnb_m[1], rstd = first ? gnb_r[0] : gnb_r[1];
+            const float dy[4] = {f.x, f.y, f.z, f.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float xh = (xs[q] - mean) * rstd;
+              gnb_dg[q] += dy[q] * xh;
+              gnb_db[q] += dy[q];
+              a1 += dy[q] * gnb_ga[q];
+              a2 += dy[q] * gnb_ga[q] * xh;
+            }
+            if (first) { gsa += a1; gqa += a2; } else { gsb += a1; gqb += a2; }
+          }
+        }
+      }
+      continue;
+    }
     // the threads sweep RPP rows x CPR 16-byte chunks; (lrow, ch) advance incrementally (no division in the loop)
     int lrow = tid / CPR, ch = tid - lrow * CPR;
     constexpr int DROW = NTHR / CPR, DCH = NTHR - DROW * CPR;
@@ -1377,6 +1462,45 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
       if (ch >= CPR) { ch -= CPR; ++lrow; }
     }
   }
+  if constexpr (GNB) {
+    __syncthreads();                                           // the staging area is free again
+    constexpr int SLOTS = NTHR / CPR;
+    double* red = reinterpret_cast<double*>(lds);
+    float4* pg = reinterpret_cast<float4*>(lds + 1024);       // [SLOTS][CPR] sum dy * xhat, then [SLOTS][CPR] sum dy
+    float4* pb = pg + SLOTS * CPR;
+    const double r0 = wave_sum_d((double)gsa), r1 = wave_sum_d((double)gqa), r2 = wave_sum_d((double)gsb), r3 = wave_sum_d((double)gqb);
+    if (lane == 0) { red[w * 4] = r0; red[w * 4 + 1] = r1; red[w * 4 + 2] = r2; red[w * 4 + 3] = r3; }
+    if (tid < SLOTS * CPR) {
+      pg[tid] = make_float4(gnb_dg[0], gnb_dg[1], gnb_dg[2], gnb_dg[3]);
+      pb[tid] = make_float4(gnb_db[0], gnb_db[1], gnb_db[2], gnb_db[3]);
+    }
+    __syncthreads();
+    if (tid < 4) {
+      double t = 0.0;
+      for (int i = 0; i < NWV; ++i) t += red[i * 4 + tid];
+      const long g = gnb_g0 + (tid >> 1);
+      if ((tid < 2 || gnb_bound < m0 + BMX) && g * xt->rpg < d.M) atomicAdd(xt->gnb_sums + g * 2 + (tid & 1), t);
+    }
+    if (tid >= 64 && tid < 64 + CPR) {
+      const int chf = tid - 64;
+      const long col = n0 + chf * EPC;
+      if (col < d.N) {
+        float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
+        for (int i = 0; i < SLOTS; ++i) {
+          const float4 a = pg[i * CPR + chf], bq = pb[i * CPR + chf];
+          sg.x += a.x; sg.y += a.y; sg.z += a.z; sg.w += a.w;
+          sb.x += bq.x; sb.y += bq.y; sb.z += bq.z; sb.w += bq.w;
+        }
+        float* part = xt->gnb_part + (long)(blockIdx.x % xt->gnb_slots) * 2 * d.N;
+        const float vg[4] = {sg.x, sg.y, sg.z, sg.w}, vb[4] = {sb.x, sb.y, sb.z, sb.w};
+        for (int q = 0; q < 4 && col + q < d.N; ++q) {
+          atomicAdd(part + col + q, vg[q]);
+          atomicAdd(part + d.N + col + q, vb[q]);
+        }
+      }
+    }
+    return;
+  }
   if (gst) {
     __syncthreads();                                           // the staging area is free again
     double* red = reinterpret_cast<double*>(lds);
@@ -1394,14 +1518,24 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
   }
 }
 
-struct NtExtra {       // optional outputs of the ring NT kernel beside C (null / 0 = none)
-  double* gstats;      // GroupNorm statistics of C per group of `rpg` rows: [groups][2] (sum, sum of squares), pre-zeroed
-  long rpg;
-};
-
 template <typename TO, int NTW, int ACT, int BMX, int WNC = 2>
 __global__ void __launch_bounds__(BMX / 64 * WNC * 64) gemm_nt_dma_kernel(GemmDesc d, NtExtra x) {
   gemm_nt_dma_body<TO, NTW, ACT, BMX, WNC>(d, x.gstats, x.rpg);
+}
+
+// f32 output + the GroupNorm-backward sums of that output (see NtExtra): the dgrad GEMM whose result feeds urse_groupnorm_bwd_apply
+__global__ void __launch_bounds__(512) gemm_nt_dma_gnb_kernel(GemmDesc d, NtExtra x) {
+  gemm_nt_dma_body<float, 7, 0, 256, 2, 1>(d, nullptr, 0, &x);
+}
+
+// dgamma[c] += sum over slots part[s][0][c], dbeta[c] += sum over slots part[s][1][c]
+__global__ void gnb_fold_kernel(const float* __restrict__ part, int slots, int N, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < slots; ++s) { a += part[(long)s * 2 * N + c]; b += part[(long)s * 2 * N + N + c]; }
+  dgamma[c] += a;
+  dbeta[c] += b;
 }
 
 // grouped form (one descriptor per band, blockIdx.y = group): the per-band 1x1 convolutions of the mask decoder /
@@ -1591,7 +1725,7 @@ static long g_nt_wide_maxk = 256;
 static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                         const float* bias, const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K,
                         int in_dtype, int out_dtype, int act, void* stream, double* gstats, long rpg, int* fused) {
-  NtExtra xtra{nullptr, 0};
+  NtExtra xtra{};
   GemmDesc d;
   d.A = (const char*)A; d.B = (const char*)B; d.C = (char*)C; d.bias = bias; d.resid = resid;
   d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.ldr = ldr;
@@ -1677,6 +1811,43 @@ extern "C" int urse_gemm_nt_gnstats(const void* A, int64_t lda, const void* B, i
                         &fused);
   if (rc || fused) return rc;
   return urse_groupnorm_stats(C, stats, groups, (int)rows_per_group, 1, (int)N, (int)N, stream);
+}
+
+// C[M, N] (f32, dense) = A[M, K] @ B[N, K]^T, and - from the tile while it is on the chip - the sums the GroupNorm backward needs of C = dy
+// against the tensor x that was normalised (same [M, N] layout; groups of rows_per_group rows; `stats` as urse_groupnorm_fwd wrote them):
+//   sums[g] = (sum dy * gamma, sum dy * gamma * xhat) (f64, overwritten), dgamma[c] += sum dy * xhat, dbeta[c] += sum dy.
+// Replaces the reduce pass of urse_groupnorm_bwd (one read of x and of dy: 684 MB per half layer at C2); urse_groupnorm_bwd_apply takes the sums.
+// part: workspace of slots * 2 * N floats.  URSE_ERR_UNSUPPORTED when the shape does not run on the ring kernel - the caller then
+// uses urse_gemm_nt + urse_groupnorm_bwd.   (espnet2 BSRNN: the LayerNorm/GroupNorm in front of every LSTM, baseline twin bsrnn_flowse.py:296-306)
+extern "C" int urse_gemm_nt_gnbwd(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t M, int64_t N, int64_t K,
+                                  int in_dtype, const float* x, const double* stats, const float* gamma, double* sums, float* dgamma,
+                                  float* dbeta, float* part, int slots, int64_t rows_per_group, float eps, void* stream) {
+  URSE_CHECK_ARG(A && B && C && x && stats && gamma && sums && dgamma && dbeta && part && slots > 0 && rows_per_group > 0,
+                 "urse_gemm_nt_gnbwd: bad argument");
+  static const bool no_dma = getenv("URSE_NT_NO_DMA") != nullptr;
+  if (no_dma || in_dtype != URSE_BF16 || M < 2048 || N < 160 || N > 224 || N % 4 || K % 32 || K < 96 || rows_per_group < 256 ||
+      M % rows_per_group || ((uintptr_t)C % 16) || ((uintptr_t)x % 16)) {
+    set_error("urse_gemm_nt_gnbwd: shape M%ld N%ld K%ld not served by the fused kernel", (long)M, (long)N, (long)K);
+    return URSE_ERR_UNSUPPORTED;
+  }
+  GemmDesc d;
+  d.A = (const char*)A; d.B = (const char*)B; d.C = (char*)C; d.bias = nullptr; d.resid = nullptr;
+  d.lda = lda; d.ldb = ldb; d.ldc = N; d.M = M; d.N = N; d.K = K; d.ldr = 0;
+  int rc = check_desc_host(d, 2, "urse_gemm_nt_gnbwd");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * (M / rows_per_group), st);
+  (void)hipMemsetAsync(part, 0, sizeof(float) * 2 * N * slots, st);
+  NtExtra xt{};
+  xt.rpg = rows_per_group; xt.gnb_x = x; xt.gnb_stats = stats; xt.gnb_gamma = gamma; xt.gnb_sums = sums; xt.gnb_part = part;
+  xt.gnb_slots = slots; xt.gnb_eps = eps;
+  const long tl = (M + 255) / 256;
+  URSE_CHECK_ARG(tl < (1L << 31), "urse_gemm_nt_gnbwd: too many tiles");
+  note_launch(URSE_KV_NT_RING);
+  hipLaunchKernelGGL(gemm_nt_dma_gnb_kernel, dim3((unsigned)tl), dim3(512), 0, st, d, xt);
+  hipLaunchKernelGGL(gnb_fold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, part, slots, (int)N, dgamma, dbeta);
+  URSE_CHECK_LAUNCH("urse_gemm_nt_gnbwd");
+  return URSE_OK;
 }
 
 extern "C" int urse_gemm_nt_grouped(const void* descs, int groups, int max_blocks, int in_dtype, int out_dtype,

@@ -432,6 +432,24 @@ extern "C" int urse_groupnorm_bwd(const float* x, const float* dy, const double*
   return URSE_OK;
 }
 
+// the apply pass of urse_groupnorm_bwd alone, for sums that came out of the GEMM that produced dy (urse_gemm_nt_gnbwd)
+extern "C" int urse_groupnorm_bwd_apply(const float* x, const float* dy, const double* stats, const double* sums, const float* gamma,
+                                        const float* dres, float* dx, int B, int T, int Kg, int W, int N, int gstride, float eps,
+                                        void* dx_packed, int ldp, void* stream) {
+  URSE_CHECK_ARG(!dx_packed || (ldp >= N && ldp % 4 == 0 && N % 4 == 0 && ((uintptr_t)dx_packed % 8) == 0),
+                 "urse_groupnorm_bwd_apply: packed copy needs N, ldp multiples of 4 and an 8-byte aligned buffer");
+  GnShape s;
+  int rc = make_shape(&s, B, T, Kg, W, N, N, gstride, "urse_groupnorm_bwd_apply");
+  if (rc) return rc;
+  URSE_CHECK_ARG(x && dy && stats && gamma && dx && sums && N % 4 == 0 && N / 4 <= 256 && W % N == 0, "urse_groupnorm_bwd_apply: bad argument");
+  const int vpb_b = 256 / (N / 4);
+  dim3 grid_a(ceil_div((long)T * (W / N), (long)vpb_b * GN_ITER), Kg, B);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid_a, dim3(256), 0, (hipStream_t)stream, x, dy, stats, sums, gamma, dres, dx, s, eps,
+                     (bf16_t*)dx_packed, ldp);
+  URSE_CHECK_LAUNCH("urse_groupnorm_bwd_apply");
+  return URSE_OK;
+}
+
 extern "C" int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out, int64_t ldo, int out_dtype, int rows,
                            int cols, int out_rows, int out_cols, int transpose, void* stream) {
   URSE_CHECK_ARG(in && out && rows >= 0 && cols >= 0 && out_rows > 0 && out_cols > 0 && ldo >= out_cols,

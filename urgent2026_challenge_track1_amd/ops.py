@@ -252,15 +252,42 @@ def groupnorm_fwd(x, gamma, beta, B, T, Kg, W, N, Np, gstride, dtype, eps=1e-5, 
     return y, stats
 
 
-def groupnorm_bwd(x, dy, stats, gamma, dres, dgamma, dbeta, B, T, Kg, W, N, gstride, eps=1e-5, pack_ld=0):
+def groupnorm_bwd(x, dy, stats, gamma, dres, dgamma, dbeta, B, T, Kg, W, N, gstride, eps=1e-5, pack_ld=0, sums=None):
     """returns dx f32 (same layout as x); dgamma/dbeta accumulated in place.  pack_ld > 0: also returns the bf16 copy of dx
-    as rows of pack_ld columns (zero padded) -> (dx, dx_packed)."""
+    as rows of pack_ld columns (zero padded) -> (dx, dx_packed).  sums: the reduce pass's results when the GEMM that produced dy
+    computed them (gemm_nt_gnbwd; dgamma / dbeta are accumulated there) - only the apply pass runs."""
     dx = torch.empty_like(x)
-    sums = torch.empty(B * Kg * 2, device=x.device, dtype=torch.float64)
     dxp = torch.empty(x.numel() // N, pack_ld, device=x.device, dtype=torch.bfloat16) if pack_ld else None
+    if sums is not None:
+        call("groupnorm_bwd_apply", x, dy, stats, sums, gamma, dres, dx, B, T, Kg, W, N, gstride, float(eps), dxp, pack_ld, stream_ptr())
+        return (dx, dxp) if pack_ld else dx
+    sums = torch.empty(B * Kg * 2, device=x.device, dtype=torch.float64)
     call("groupnorm_bwd", x, dy, stats, gamma, dres, dx, dgamma, dbeta, sums, B, T, Kg, W, N, gstride, float(eps), dxp,
          pack_ld, stream_ptr())
     return (dx, dxp) if pack_ld else dx
+
+
+FUSE_GN_BWD = os.environ.get("URSE_FUSE_GN_BWD", "1") != "0"      # GroupNorm-backward sums on the dgrad GEMM's epilogue
+GN_BWD_SLOTS = 16
+
+
+def gemm_nt_gnbwd_supported(M, N, K, rows_per_group, dtype):
+    return (dtype == torch.bfloat16 and M >= 2048 and 160 <= N <= 224 and N % 4 == 0 and K % 32 == 0 and K >= 96 and
+            rows_per_group >= 256 and M % rows_per_group == 0 and not os.environ.get("URSE_NT_NO_DMA"))
+
+
+def gemm_nt_gnbwd(A, W, N, x, stats, gamma, dgamma, dbeta, rows_per_group, eps=1e-5):
+    """dy[M, N] f32 = A[M, K] @ W[N.., K]^T plus the GroupNorm-backward reduce of dy against x (f32 [M, N], same row order) in the same
+    launch -> (dy, sums) with sums for groupnorm_bwd(sums=); dgamma / dbeta are accumulated here.  Check gemm_nt_gnbwd_supported first."""
+    require_cuda(A, W, x)
+    M, K = A.shape
+    assert W.shape[1] == K and A.stride(1) == 1 and W.stride(1) == 1 and A.dtype == W.dtype and x.is_contiguous() and x.numel() == M * N
+    dy = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    sums = torch.empty(M // rows_per_group * 2, device=A.device, dtype=torch.float64)
+    part = torch.empty(GN_BWD_SLOTS * 2 * N, device=A.device, dtype=torch.float32)
+    call("gemm_nt_gnbwd", A, A.stride(0), W, W.stride(0), dy, M, N, K, _dt(A), x, stats, gamma, sums, dgamma, dbeta, part, GN_BWD_SLOTS,
+         rows_per_group, float(eps), stream_ptr())
+    return dy, sums
 
 
 def model_lstm_layouts():
