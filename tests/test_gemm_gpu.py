@@ -61,7 +61,7 @@ def test_gemm_nt_wide_tile_matches_default(lib, monkeypatch, M, N, K):
         assert torch.equal(a, b)          # same k order per output element -> bit-identical
 
 
-@pytest.mark.parametrize("M,N,K,act", [(8300, 3136, 224, 0), (9001, 1800, 96, 1), (8200, 2000, 160, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(8300, 3136, 224, 0), (9001, 1800, 96, 1), (8200, 2000, 160, 0), (8500, 784, 224, 0), (8193, 500, 128, 1)])
 def test_gemm_nt_weight_stationary_matches_ring_kernel(lib, monkeypatch, M, N, K, act):
     """short K, wide N, bf16 out: the weight-stationary kernel (resident 224 x K weight slice, 256-row tiles streamed)
     against the ring kernel - same k order per output element, so bit-identical - and against float64; ragged M and N"""

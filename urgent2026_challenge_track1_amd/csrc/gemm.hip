@@ -1717,7 +1717,7 @@ static int dispatch_nt(const GemmDesc* descs, const GemmDesc& single, int groups
 
 // measured (scripts/abl_nt_wide.py): 128x448 tiles win only on the [M, 8H] gate projection (K=224, bf16 out: 1.32 -> 1.22 ms);
 // at N=800 / K>=512 / f32 out the 256x224 tile stays ahead
-static long g_nt_bres_min_n = getenv("URSE_NT_BRES_MIN_N") ? atol(getenv("URSE_NT_BRES_MIN_N")) : 1792;   // (448 also takes the fc dgrad: 0.37 -> 0.28 ms alone, but 170.6 vs 169.7 ms/step)
+static long g_nt_bres_min_n = getenv("URSE_NT_BRES_MIN_N") ? atol(getenv("URSE_NT_BRES_MIN_N")) : 448;   // (448 also takes the fc dgrad, N = 784: 0.37 -> 0.28 ms alone; in the step 135.43 against 135.83 ms, mean of six interleaved same-box runs each, profiles/r04_ab_nt_bres_fc_dgrad_v1.log; round 3 had measured it 0.9 ms slower beside that round's second queue)
 static int g_nt_bres_wgs = 256;      // persistent workgroups of the weight-stationary NT kernel (one per CU)
 static int g_nt_wide_default = 1;
 static long g_nt_wide_maxk = 256;
