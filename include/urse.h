@@ -274,6 +274,14 @@ int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_
  * gate) order of urse_lstm_pack; gates [M, ldg >= 8H] (save != 0) receives the gate ACTIVATIONS the BPTT reads; hout, c, the sequence map,
  * target_workgroups as urse_lstm_rw_fwd.  The pre-activation is not rounded to bf16 between the two products, so results differ
  * from the two-kernel form by bf16 rounding of gx (closer to the f32 reference).  urse_lstm_rwx_supported: N = 196, H = 392. */
+/* The pack entry points for ALL LSTMs of a model in one launch each (the model re-packs its 12 BLSTMs after every optimizer step:
+ * espnet2 BSRNN keeps nn.LSTM's own layout, here the kernels' fragment orders have to follow the f32 master weights).  table = device array of
+ * n_lstm rows of 12 pointers {wih, whh, bih, bhh, wih_p, wihT_p, bias, whh_frag, whhT_frag, whhq, whhb, wx}: the operands of urse_lstm_pack,
+ * then the destinations of urse_lstm_pack_quads / _blocks / _blocks_x (NULL = that LSTM does not use the layout).  Same shapes for all rows. */
+int urse_lstm_pack_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, int dtype, void* stream);
+int urse_lstm_pack_quads_multi(const void* table, int n_lstm, int H, int Hp, void* stream);
+int urse_lstm_pack_blocks_multi(const void* table, int n_lstm, int H, int Hp, void* stream);
+int urse_lstm_pack_blocks_x_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, void* stream);
 int urse_lstm_rwx_supported(int N, int Np, int H, int Hp);
 int urse_lstm_pack_blocks_x(const float* wih, const float* whh, void* out, int N, int Np, int H, int Hp, void* stream);
 int urse_lstm_rwx_fwd(const void* xn, int64_t ldx, const void* wx, const float* bias, void* gates, int64_t ldg, void* hout,

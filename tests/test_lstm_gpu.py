@@ -469,3 +469,27 @@ def test_nsplit_bptt_matches_streaming_kernel(lib, B, T, K):
         b = g2[:, dr * 4 * H:dr * 4 * H + 13 * 64].view(torch.int16)
         frac = (a != b).float().mean().item()
         assert frac <= 2e-2, frac          # (their dh_rec is exact; differences enter through the other half's gradients one step later)
+
+
+def test_multi_pack_equals_per_lstm_pack(lib):
+    """urse_lstm_pack*_multi (one launch per layout for all LSTMs of a model, what every step after the first runs) writes exactly what the
+    per-LSTM entry points write, at the C2 widths (N = 196, H = 392), for rows with different optional layouts (time / band path)."""
+    from urgent2026_challenge_track1_amd import ops
+    N, H, dt = 196, 392, torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    entries, want = [], []
+    for i, lay in enumerate(({"whhq", "whhb"}, {"whhq", "whhb", "wx"}, {"wx"})):
+        w = [torch.randn(8 * H, N, device="cuda", generator=g), torch.randn(8 * H, H, device="cuda", generator=g),
+             torch.randn(8 * H, device="cuda", generator=g), torch.randn(8 * H, device="cuda", generator=g)]
+        ref = ops.lstm_pack(*w, N, H, dt, layouts=lay)
+        out = {k: (torch.full_like(v, 7) if torch.is_tensor(v) else v) for k, v in ref.items()}
+        entries.append(tuple(w) + (out,))
+        want.append(ref)
+    table = ops.lstm_pack_multi(entries, N, H, dt)
+    table2 = ops.lstm_pack_multi(entries, N, H, dt, table=table)
+    assert table2[0].data_ptr() == table[0].data_ptr()               # same buffers: the pointer table is reused
+    for (_, _, _, _, out), ref in zip(entries, want):
+        assert set(out) == set(ref)
+        for k, v in ref.items():
+            if torch.is_tensor(v):
+                assert torch.equal(out[k], v), k

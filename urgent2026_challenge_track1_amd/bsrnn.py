@@ -358,12 +358,21 @@ class BSRNNCore(nn.Module):
         N = self.N
         if not hasattr(self, "_lstm_bufs") or self._lstm_bufs.get("key") != (dtype, self._flat.device):
             self._lstm_bufs = {"key": (dtype, self._flat.device)}
+        names = ["l%d%s." % (l, path) for l in range(self.num_layer) for path in "tf"]
+        srcs = {p: (self._p(p + "wih", 8 * H * N), self._p(p + "whh", 8 * H * H), self._p(p + "bih", 8 * H), self._p(p + "bhh", 8 * H))
+                for p in names}
+        multi = (ops.PACK_MULTI and self._flat.is_cuda and all(p in self._lstm_bufs for p in names) and
+                 all(set(k for k in ("whhq", "whhb", "wx", "whhb_rw", "whhTq") if self._lstm_bufs[p].get(k) is not None) ==
+                     self._lstm_layouts(p[-2]) <= {"whhq", "whhb", "wx"} for p in names))
+        if multi:
+            # the buffers exist (every step after the first): one launch per layout for all 12 LSTMs instead of three to five per LSTM
+            self._lstm_bufs["table"] = ops.lstm_pack_multi([srcs[p] + (self._lstm_bufs[p],) for p in names], N, H, dtype,
+                                                           table=self._lstm_bufs.get("table"))
         for l in range(self.num_layer):
             for path in "tf":
                 p = "l%d%s." % (l, path)
-                lp = ops.lstm_pack(self._p(p + "wih", 8 * H * N), self._p(p + "whh", 8 * H * H),
-                                   self._p(p + "bih", 8 * H), self._p(p + "bhh", 8 * H), N, H, dtype,
-                                   out=self._lstm_bufs.get(p), layouts=self._lstm_layouts(path))
+                lp = self._lstm_bufs[p] if multi else ops.lstm_pack(*srcs[p], N, H, dtype, out=self._lstm_bufs.get(p),
+                                                                    layouts=self._lstm_layouts(path))
                 self._lstm_bufs[p] = lp
                 pk[p + "wih"], pk[p + "wihT"], pk[p + "bias"] = lp["wih"], lp["wihT"], lp["bias"]
                 pk[p + "whh"], pk[p + "whhT"] = lp["whh"], lp["whhT"]

@@ -1836,8 +1836,13 @@ extern "C" int urse_gemm_nt_gnbwd(const void* A, int64_t lda, const void* B, int
   int rc = check_desc_host(d, 2, "urse_gemm_nt_gnbwd");
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * (M / rows_per_group), st);
-  (void)hipMemsetAsync(part, 0, sizeof(float) * 2 * N * slots, st);
+  const size_t sums_bytes = sizeof(double) * 2 * (size_t)(M / rows_per_group), part_bytes = sizeof(float) * 2 * (size_t)N * slots;
+  if (reinterpret_cast<char*>(part) == reinterpret_cast<char*>(sums) + sums_bytes) {      // one workspace, sums then part: one fill
+    (void)hipMemsetAsync(sums, 0, sums_bytes + part_bytes, st);
+  } else {
+    (void)hipMemsetAsync(sums, 0, sums_bytes, st);
+    (void)hipMemsetAsync(part, 0, part_bytes, st);
+  }
   NtExtra xt{};
   xt.rpg = rows_per_group; xt.gnb_x = x; xt.gnb_stats = stats; xt.gnb_gamma = gamma; xt.gnb_sums = sums; xt.gnb_part = part;
   xt.gnb_slots = slots; xt.gnb_eps = eps;

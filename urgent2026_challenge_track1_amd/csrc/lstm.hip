@@ -670,11 +670,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_tr_kernel(LstmBwdArgs p) {
 //  out 3: whh fragments     [2][nut][nslab][4][64 lanes][16 B]   (B operand of h * W_hh^T)
 //  out 4: whhT fragments    [2][nut][nslabT][64 lanes][16 B]     (B operand of dgates * W_hh, k = unit*4+gate)
 template <typename T>
-__global__ void __launch_bounds__(256) lstm_pack_kernel(const float* __restrict__ wih, const float* __restrict__ whh,
-                                                        const float* __restrict__ bih, const float* __restrict__ bhh,
-                                                        T* __restrict__ wih_p, T* __restrict__ wihT_p,
-                                                        float* __restrict__ bias, T* __restrict__ whh_f,
-                                                        T* __restrict__ whhT_f, int N, int Np, int H, int Hp) {
+__device__ __forceinline__ void lstm_pack_dev(const float* __restrict__ wih, const float* __restrict__ whh,
+                                              const float* __restrict__ bih, const float* __restrict__ bhh,
+                                              T* __restrict__ wih_p, T* __restrict__ wihT_p,
+                                              float* __restrict__ bias, T* __restrict__ whh_f,
+                                              T* __restrict__ whhT_f, int N, int Np, int H, int Hp) {
   constexpr int ES = sizeof(T), EPL = 16 / ES, SK = 64 / ES;
   const int nut = (H + 15) >> 4, G4 = 4 * H;
   const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -726,6 +726,21 @@ __global__ void __launch_bounds__(256) lstm_pack_kernel(const float* __restrict_
       whhT_f[idx] = from_f32<T>(n < H ? whh[((long)d * G4 + gp * H + up) * H + n] : 0.f);
     }
   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) lstm_pack_kernel(const float* __restrict__ wih, const float* __restrict__ whh,
+                                                        const float* __restrict__ bih, const float* __restrict__ bhh,
+                                                        T* __restrict__ wih_p, T* __restrict__ wihT_p,
+                                                        float* __restrict__ bias, T* __restrict__ whh_f,
+                                                        T* __restrict__ whhT_f, int N, int Np, int H, int Hp) {
+  lstm_pack_dev<T>(wih, whh, bih, bhh, wih_p, wihT_p, bias, whh_f, whhT_f, N, Np, H, Hp);
+}
+// all LSTMs of a model in one launch: blockIdx.z = row of the pointer table (the model re-packs its 12 LSTMs after every optimizer step)
+template <typename T>
+__global__ void __launch_bounds__(256) lstm_pack_multi_kernel(const PackRow* __restrict__ tab, int N, int Np, int H, int Hp) {
+  const PackRow r = tab[blockIdx.z];
+  lstm_pack_dev<T>(r.wih, r.whh, r.bih, r.bhh, (T*)r.wih_p, (T*)r.wihT_p, r.bias, (T*)r.whh_f, (T*)r.whhT_f, N, Np, H, Hp);
 }
 
 template <typename K>
@@ -883,6 +898,19 @@ extern "C" int urse_lstm_pack(const float* wih, const float* whh, const float* b
     hipLaunchKernelGGL(lstm_pack_kernel<float>, grid, blk, 0, (hipStream_t)stream, wih, whh, bih, bhh, (float*)wih_p,
                        (float*)wihT_p, bias, (float*)whh_frag, (float*)whhT_frag, N, Np, H, Hp);
   URSE_CHECK_LAUNCH("urse_lstm_pack");
+  return URSE_OK;
+}
+
+extern "C" int urse_lstm_pack_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, int dtype, void* stream) {
+  const int es = dtype == URSE_BF16 ? 2 : 4;
+  URSE_CHECK_ARG(table && n_lstm > 0 && n_lstm < 65536 && N > 0 && H > 0 && Np >= N && (Hp * es) % 64 == 0 && Hp >= ((H + 15) / 16) * 16 &&
+                     (4 * H * es) % 64 == 0, "urse_lstm_pack_multi: bad argument N%d Np%d H%d Hp%d", N, Np, H, Hp);
+  dim3 grid(256, 5, (unsigned)n_lstm), blk(256);
+  if (dtype == URSE_BF16)
+    hipLaunchKernelGGL(lstm_pack_multi_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const PackRow*)table, N, Np, H, Hp);
+  else
+    hipLaunchKernelGGL(lstm_pack_multi_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const PackRow*)table, N, Np, H, Hp);
+  URSE_CHECK_LAUNCH("urse_lstm_pack_multi");
   return URSE_OK;
 }
 

@@ -428,8 +428,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
 
 // quad-ordered recurrent weights: block (dir, quad, slab) = 64 lanes x 16 B; lane (lr, lc): unit quad*4 + (lc>>2),
 // gate lc & 3, k = slab*32 + 8*lr + j
-__global__ void __launch_bounds__(256) lstm_pack_quads_kernel(const float* __restrict__ whh, bf16_t* __restrict__ out,
-                                                              int H, int Hp) {
+__device__ __forceinline__ void lstm_pack_quads_dev(const float* __restrict__ whh, bf16_t* __restrict__ out, int H, int Hp) {
   const int nq = (H + 3) >> 2, nslab = Hp / 32, G4 = 4 * H;
   const long total = (long)2 * nq * nslab * 64 * 8;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -443,6 +442,13 @@ __global__ void __launch_bounds__(256) lstm_pack_quads_kernel(const float* __res
     const int u = qd * 4 + (lc >> 2), g = lc & 3, k = ks * 32 + 8 * lr + jj;
     out[idx] = f32_to_bf16((u < H && k < H) ? whh[((long)d * G4 + g * H + u) * H + k] : 0.f);
   }
+}
+__global__ void __launch_bounds__(256) lstm_pack_quads_kernel(const float* __restrict__ whh, bf16_t* __restrict__ out, int H, int Hp) {
+  lstm_pack_quads_dev(whh, out, H, Hp);
+}
+__global__ void __launch_bounds__(256) lstm_pack_quads_multi_kernel(const PackRow* __restrict__ tab, int H, int Hp) {
+  const PackRow r = tab[blockIdx.y];
+  if (r.whhq) lstm_pack_quads_dev(r.whh, (bf16_t*)r.whhq, H, Hp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -680,6 +686,13 @@ extern "C" int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, 
   URSE_CHECK_ARG(whh && out && H > 0 && Hp % 32 == 0 && Hp >= H, "urse_lstm_pack_quads: bad argument");
   hipLaunchKernelGGL(lstm_pack_quads_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, whh, (bf16_t*)out, H, Hp);
   URSE_CHECK_LAUNCH("urse_lstm_pack_quads");
+  return URSE_OK;
+}
+
+extern "C" int urse_lstm_pack_quads_multi(const void* table, int n_lstm, int H, int Hp, void* stream) {
+  URSE_CHECK_ARG(table && n_lstm > 0 && n_lstm < 65536 && H > 0 && Hp % 32 == 0 && Hp >= H, "urse_lstm_pack_quads_multi: bad argument");
+  hipLaunchKernelGGL(lstm_pack_quads_multi_kernel, dim3(256, (unsigned)n_lstm), dim3(256), 0, (hipStream_t)stream, (const PackRow*)table, H, Hp);
+  URSE_CHECK_LAUNCH("urse_lstm_pack_quads_multi");
   return URSE_OK;
 }
 

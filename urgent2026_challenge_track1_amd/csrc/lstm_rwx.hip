@@ -317,8 +317,8 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
 // Block-ordered weights of the fused kernel: (dir, blk, slab, gate) = 64 lanes x 16 B; lane (lr, lc): unit blk * 16 + lc;
 // slab ks < Hp / 32: W_hh[gate * H + unit][ks * 32 + 8 lr + j]; the following Np / 32 slabs: W_ih[gate * H + unit][(ks - Hp / 32) * 32 + 8 lr + j];
 // zeros past H / N.
-__global__ void __launch_bounds__(256) lstm_pack_blocks_x_kernel(const float* __restrict__ wih, const float* __restrict__ whh,
-                                                                 bf16_t* __restrict__ out, int N, int Np, int H, int Hp) {
+__device__ __forceinline__ void lstm_pack_blocks_x_dev(const float* __restrict__ wih, const float* __restrict__ whh,
+                                                       bf16_t* __restrict__ out, int N, int Np, int H, int Hp) {
   const int nblk = (H + 15) >> 4, nsh = Hp / 32, ns = nsh + Np / 32, G4 = 4 * H;
   const long total = (long)2 * nblk * ns * 4 * 64 * 8;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -344,6 +344,14 @@ __global__ void __launch_bounds__(256) lstm_pack_blocks_x_kernel(const float* __
     out[idx] = f32_to_bf16(v);
   }
 }
+__global__ void __launch_bounds__(256) lstm_pack_blocks_x_kernel(const float* __restrict__ wih, const float* __restrict__ whh,
+                                                                 bf16_t* __restrict__ out, int N, int Np, int H, int Hp) {
+  lstm_pack_blocks_x_dev(wih, whh, out, N, Np, H, Hp);
+}
+__global__ void __launch_bounds__(256) lstm_pack_blocks_x_multi_kernel(const PackRow* __restrict__ tab, int N, int Np, int H, int Hp) {
+  const PackRow r = tab[blockIdx.y];
+  if (r.wx) lstm_pack_blocks_x_dev(r.wih, r.whh, (bf16_t*)r.wx, N, Np, H, Hp);
+}
 
 static bool rx_shape(int N, int Np, int H, int Hp) { return N == 196 && Np == 224 && H == 392 && Hp == 416; }
 
@@ -357,6 +365,13 @@ extern "C" int urse_lstm_pack_blocks_x(const float* wih, const float* whh, void*
   URSE_CHECK_ARG(wih && whh && out && rx_shape(N, Np, H, Hp), "urse_lstm_pack_blocks_x: bad argument (N=%d Np=%d H=%d Hp=%d)", N, Np, H, Hp);
   hipLaunchKernelGGL(lstm_pack_blocks_x_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, wih, whh, (bf16_t*)out, N, Np, H, Hp);
   URSE_CHECK_LAUNCH("urse_lstm_pack_blocks_x");
+  return URSE_OK;
+}
+
+extern "C" int urse_lstm_pack_blocks_x_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, void* stream) {
+  URSE_CHECK_ARG(table && n_lstm > 0 && n_lstm < 65536 && rx_shape(N, Np, H, Hp), "urse_lstm_pack_blocks_x_multi: bad argument (N=%d Np=%d H=%d Hp=%d)", N, Np, H, Hp);
+  hipLaunchKernelGGL(lstm_pack_blocks_x_multi_kernel, dim3(512, (unsigned)n_lstm), dim3(256), 0, (hipStream_t)stream, (const PackRow*)table, N, Np, H, Hp);
+  URSE_CHECK_LAUNCH("urse_lstm_pack_blocks_x_multi");
   return URSE_OK;
 }
 

@@ -254,8 +254,7 @@ __global__ void __launch_bounds__(WW * 64, 2) lstm_fwd_wide_kernel(WideArgs p) {
 
 // block-ordered recurrent weights: (dir, blk, ks, gate) = 64 lanes x 16 B; lane (lr, lc): unit blk*16 + lc,
 // k = ks*32 + 8*lr + j
-__global__ void __launch_bounds__(256) lstm_pack_blocks_kernel(const float* __restrict__ whh, bf16_t* __restrict__ out,
-                                                               int H, int Hp) {
+__device__ __forceinline__ void lstm_pack_blocks_dev(const float* __restrict__ whh, bf16_t* __restrict__ out, int H, int Hp) {
   const int nblk = (H + 15) >> 4, nslab = Hp / 32, G4 = 4 * H;
   const long total = (long)2 * nblk * nslab * 4 * 64 * 8;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -270,6 +269,13 @@ __global__ void __launch_bounds__(256) lstm_pack_blocks_kernel(const float* __re
     const int u = blk * 16 + lc, k = ks * 32 + 8 * lr + jj;
     out[idx] = f32_to_bf16((u < H && k < H) ? whh[((long)d * G4 + g * H + u) * H + k] : 0.f);
   }
+}
+__global__ void __launch_bounds__(256) lstm_pack_blocks_kernel(const float* __restrict__ whh, bf16_t* __restrict__ out, int H, int Hp) {
+  lstm_pack_blocks_dev(whh, out, H, Hp);
+}
+__global__ void __launch_bounds__(256) lstm_pack_blocks_multi_kernel(const PackRow* __restrict__ tab, int H, int Hp) {
+  const PackRow r = tab[blockIdx.y];
+  if (r.whhb) lstm_pack_blocks_dev(r.whh, (bf16_t*)r.whhb, H, Hp);
 }
 
 template <int NSLAB, int MAXG, int RT, int WW>
@@ -306,6 +312,13 @@ extern "C" int urse_lstm_pack_blocks(const float* whh, void* out, int H, int Hp,
   URSE_CHECK_ARG(whh && out && H > 0 && Hp % 32 == 0 && Hp >= H, "urse_lstm_pack_blocks: bad argument");
   hipLaunchKernelGGL(lstm_pack_blocks_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, whh, (bf16_t*)out, H, Hp);
   URSE_CHECK_LAUNCH("urse_lstm_pack_blocks");
+  return URSE_OK;
+}
+
+extern "C" int urse_lstm_pack_blocks_multi(const void* table, int n_lstm, int H, int Hp, void* stream) {
+  URSE_CHECK_ARG(table && n_lstm > 0 && n_lstm < 65536 && H > 0 && Hp % 32 == 0 && Hp >= H, "urse_lstm_pack_blocks_multi: bad argument");
+  hipLaunchKernelGGL(lstm_pack_blocks_multi_kernel, dim3(256, (unsigned)n_lstm), dim3(256), 0, (hipStream_t)stream, (const PackRow*)table, H, Hp);
+  URSE_CHECK_LAUNCH("urse_lstm_pack_blocks_multi");
   return URSE_OK;
 }
 

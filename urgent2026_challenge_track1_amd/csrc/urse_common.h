@@ -117,4 +117,11 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // other (cluster / split LSTM) size their grids against it: every workgroup must be resident, one per CU.
 int device_cu_count();
 
+// one LSTM's row of the pointer table of the urse_lstm_pack*_multi entry points (12 device pointers; a null destination = layout not wanted)
+struct PackRow {
+  const float* wih; const float* whh; const float* bih; const float* bhh;
+  void* wih_p; void* wihT_p; float* bias; void* whh_f; void* whhT_f;
+  void* whhq; void* whhb; void* wx;
+};
+
 }  // namespace urse

@@ -283,8 +283,9 @@ def gemm_nt_gnbwd(A, W, N, x, stats, gamma, dgamma, dbeta, rows_per_group, eps=1
     M, K = A.shape
     assert W.shape[1] == K and A.stride(1) == 1 and W.stride(1) == 1 and A.dtype == W.dtype and x.is_contiguous() and x.numel() == M * N
     dy = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    sums = torch.empty(M // rows_per_group * 2, device=A.device, dtype=torch.float64)
-    part = torch.empty(GN_BWD_SLOTS * 2 * N, device=A.device, dtype=torch.float32)
+    ng = M // rows_per_group * 2
+    ws = torch.empty(ng + GN_BWD_SLOTS * N, device=A.device, dtype=torch.float64)      # sums, then the per-channel slots (f32): one fill
+    sums, part = ws[:ng], ws[ng:].view(torch.float32)
     call("gemm_nt_gnbwd", A, A.stride(0), W, W.stride(0), dy, M, N, K, _dt(A), x, stats, gamma, sums, dgamma, dbeta, part, GN_BWD_SLOTS,
          rows_per_group, float(eps), stream_ptr())
     return dy, sums
@@ -345,6 +346,31 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None, layouts=None):
                 out["whhTq"] = torch.empty(2 * C * 4 * (H // 8) * 512, device=dev, dtype=dtype)
             call("lstm_pack_bwd_quads", whh, out["whhTq"], H, C, stream_ptr())
     return out
+
+
+PACK_MULTI = os.environ.get("URSE_LSTM_PACK_MULTI", "1") != "0"     # re-pack all LSTMs of a model with one launch per layout
+
+
+def lstm_pack_multi(entries, N, H, dtype, table=None):
+    """re-pack LSTMs whose packed buffers exist already (entries: [(wih, whh, bih, bhh, out dict of lstm_pack)]) with ONE launch per
+    layout instead of up to five per LSTM.  Returns the device pointer table (pass it back in while the buffers stay the same)."""
+    first = entries[0][4]
+    Np, Hp = first["Np"], first["Hp"]
+    dev = entries[0][0].device
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    rows = [[ptr(wih), ptr(whh), ptr(bih), ptr(bhh), ptr(o["wih"]), ptr(o["wihT"]), ptr(o["bias"]), ptr(o["whh"]), ptr(o["whhT"]),
+             ptr(o.get("whhq")), ptr(o.get("whhb")), ptr(o.get("wx"))] for wih, whh, bih, bhh, o in entries]
+    if table is None or table[1] != rows:
+        table = (upload(torch.tensor(rows, dtype=torch.int64), dev, cached=True), rows)
+    n = len(rows)
+    call("lstm_pack_multi", table[0], n, N, Np, H, Hp, _dt(first["wih"]), stream_ptr())
+    if any(r[9] for r in rows):
+        call("lstm_pack_quads_multi", table[0], n, H, Hp, stream_ptr())
+    if any(r[10] for r in rows):
+        call("lstm_pack_blocks_multi", table[0], n, H, Hp, stream_ptr())
+    if any(r[11] for r in rows):
+        call("lstm_pack_blocks_x_multi", table[0], n, N, Np, H, Hp, stream_ptr())
+    return table
 
 
 _err_state = {}
