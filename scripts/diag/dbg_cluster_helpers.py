@@ -1,0 +1,41 @@
+import os, sys, torch
+sys.path.insert(0, "/root/repo")
+from urgent2026_challenge_track1_amd import ops
+dev = "cuda"
+N, B, T, K = 196, 32, 401, 34
+H, Hp = 2 * N, 416
+torch.manual_seed(0)
+whh = torch.randn(2 * 4 * H, H, device=dev) * 0.05
+whhq = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=torch.bfloat16)
+ops.call("lstm_pack_quads", whh, whhq, H, Hp, ops.stream_ptr())
+M = B * T * K
+sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+gx = torch.randn(M, 8 * H, device=dev).to(torch.bfloat16)
+outs = {}
+for hp in ("0", "2"):
+    os.environ["URSE_CLUSTER_HELPERS"] = hp
+    g = gx.clone()
+    h, c, err = ops.lstm_fwd_cluster(g, whhq, H, Hp, xcd_aware=True, **sm)
+    torch.cuda.synchronize()
+    outs[hp] = g
+d = (outs["0"].view(torch.int16) != outs["2"].view(torch.int16))
+print("differing elements", int(d.sum()), "of", d.numel())
+rows = d.any(1).nonzero().flatten()
+cols = d.any(0).nonzero().flatten()
+print("rows", rows.numel(), rows[:20].tolist(), "... last", rows[-5:].tolist())
+print("cols", cols.numel(), cols[:40].tolist())
+r = rows[0].item()
+b, t, k = r // (T * K), (r // K) % T, r % K
+print("first row", r, "= b", b, "t", t, "k", k)
+ts = ((rows // K) % T).unique()
+print("times", ts[:20].tolist(), ts.numel())
+# does the helper output equal the INPUT there (store never happened)?
+same_as_in = (outs["2"].view(torch.int16)[d] == gx.view(torch.int16)[d]).float().mean().item()
+print("fraction of differing elements equal to the pre-activation input:", same_as_in)
+idx = d.nonzero()[:12]
+for r_, c_ in idx.tolist():
+    print("row %d col %d (dir %d unit %d gate %d): helper %.4f ref %.4f input %.4f | neighbours helper %s ref %s" % (
+        r_, c_, c_ // (4 * H), (c_ % (4 * H)) // 4, c_ % 4, outs["2"][r_, c_].item(), outs["0"][r_, c_].item(), gx[r_, c_].item(),
+        [round(v, 3) for v in outs["2"][r_, c_ - c_ % 8: c_ - c_ % 8 + 8].float().tolist()], [round(v, 3) for v in outs["0"][r_, c_ - c_ % 8: c_ - c_ % 8 + 8].float().tolist()]))
+# per (row) how many differing elements
+print("differing elements per differing row: mean %.1f" % (d.sum().item() / rows.numel()))

@@ -37,3 +37,24 @@ for xa in (False, True, False, True):
         ops.lstm_fwd_cluster(g, whhq, H, Hp, xcd_aware=xa, **sm)
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
     print("xcd_aware %-5s %.3f ms (min of 4: %s)" % (xa, min(ts), " ".join("%.3f" % v for v in ts)), flush=True)
+# helper waves (URSE_CLUSTER_HELPERS: 0 = 14 working waves do everything, 2 = two helper waves own the plain stores and the pre-activations)
+outs = {}
+for hp in ("0", "2"):
+    os.environ["URSE_CLUSTER_HELPERS"] = hp
+    g = gx.clone()
+    h, c, err = ops.lstm_fwd_cluster(g, whhq, H, Hp, xcd_aware=True, **sm)
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0, "kernel error flag"
+    outs[hp] = (g, h.clone(), c.clone())
+print("helper waves == none: gates %s  h %s  c %s" % tuple(eq(outs["0"][i], outs["2"][i]) for i in range(3)), flush=True)
+del outs
+g = gx.clone()
+for hp in ("0", "2", "0", "2"):
+    os.environ["URSE_CLUSTER_HELPERS"] = hp
+    ts = []
+    for _ in range(4):
+        g.copy_(gx); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ops.lstm_fwd_cluster(g, whhq, H, Hp, xcd_aware=True, **sm)
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    print("helpers %s  %.3f ms (min of 4: %s)" % (hp, min(ts), " ".join("%.3f" % v for v in ts)), flush=True)

@@ -70,8 +70,16 @@ __device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned of
   return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
-template <int NSLAB, int MAXCH>
-__global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
+// HELP > 0: that many HELPER waves beside the 14 working waves.  They own everything that is not on the recurrence's critical path: the
+// previous step's plain stores (h_t -> hout, saved gates, c_t: 3,136 16-byte pieces) and the next step's gate pre-activations (1,792
+// pieces), between the same two barriers as the working waves, whose instruction streams and in-order vmcnt queues then hold the h gather,
+// the MFMAs, the cell update and the publication only.  (The ablation of the helper-less form priced the deferred stores at 1.7 us and the
+// staged pre-activations at 1.3 us of a 6.4 us step - at 21 GB/s per CU this kernel is bound by its step latency, not by bytes.)
+#ifndef CHELP_MODE
+#define CHELP_MODE 3     // (diagnostic builds: bit 0 = the helpers stage the pre-activations, bit 1 = the helpers issue the plain stores)
+#endif
+template <int NSLAB, int MAXCH, int HELP = 0>
+__global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(ClusterArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   const int H = p.H;
@@ -263,13 +271,78 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
   // will later store (same offsets), one step ahead, and drops them into the gates staging tile of that step's parity, where a lane picks
   // up its (sequence, unit) 8 bytes before it overwrites them with the activations.  (Fetched per lane - 8 bytes of 16 different rows per
   // wave-instruction in this kernel's accumulator layout - the same 28 KB were 896 quarter-line requests per step: 1.8 us of 7.2.)
+  if constexpr (HELP > 0) {
+    if (w >= CW) {
+      // ---- helper waves: their own time loop, the working waves' two barriers per step ----
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      constexpr int HT = 64 * HELP, NG = CROWS * GC / HT;
+      static_assert(NG * HT == CROWS * GC, "the helper lanes divide the staged pieces evenly");
+      const int ht = tid - CTHR;
+      unsigned og[NG];
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const int idx = ht + i * HT, row = idx / GC, cc = idx - row * GC;
+        og[i] = (row < nrows && cc * 2 < nvu) ? ((unsigned)rowtab[row] * (unsigned)ldg_i + (unsigned)(gcol_i + (j * UW + cc * 2) * 4)) * 2u : COOB;
+      }
+      u32x4 gxr[NG];
+      auto fetch = [&](int toff_) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) gxr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, (int)og[i], toff_ * ldg_i * 2, 0);
+      };
+      // The saved gates of a step: every staged piece into its OWN registers, then the stores, then a wait for the stores before the
+      // registers take the next step's pre-activations.  (With LDS reads and stores interleaved the compiler recycled a store's four data
+      // registers for an LDS read three instructions later and 0.2 % of the stored pieces came out with a wrong first dword - correct as soon
+      // as no register was reused, scripts/diag/dbg_cluster_helpers.py: a 16-byte buffer store's data registers are evidently not safe
+      // against an LDS return that soon on this part.  h_t -> hout and c_t stay with the working waves - one piece each per thread -: 25 pieces per
+      // helper lane do not fit 128 VGPRs.)
+      uint4 vg[NG];
+      auto stores = [&](int par, int toff_) {
+        if (!p.save) return;
+        const char* gst = gstage0 + par * (CROWS * UW * 8);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) vg[i] = *reinterpret_cast<const uint4*>(gst + (ht + i * HT) * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{vg[i].x, vg[i].y, vg[i].z, vg[i].w}, rs_gs, (int)og[i], toff_ * ldg_i * 2, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the stores have read their registers
+      };
+      if (CHELP_MODE & 1) fetch((dir ? p.seq_len - 1 : 0) * stride_i);
+      int toff_prev = 0;
+      for (int step = 0; step < p.seq_len; ++step) {
+        const int t = dir ? (p.seq_len - 1 - step) : step;
+#ifndef CABL_NO_GX
+        if (CHELP_MODE & 1) {
+#pragma unroll
+          for (int i = 0; i < NG; ++i)       // this step's pre-activations -> the staging tile of its parity
+            *reinterpret_cast<uint4*>(gstage0 + (step & 1) * (CROWS * UW * 8) + (ht + i * HT) * 16) = make_uint4(gxr[i][0], gxr[i][1], gxr[i][2], gxr[i][3]);
+        }
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#ifndef CABL_NO_DEFERRED
+        if ((CHELP_MODE & 2) && step > 0) stores((step + 1) & 1, toff_prev);
+#endif
+#ifndef CABL_NO_GX
+        if ((CHELP_MODE & 1) && step + 1 < p.seq_len) fetch((dir ? t - 1 : t + 1) * stride_i);
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the staged pieces are in registers before the next cell phase can rewrite them
+        __builtin_amdgcn_s_barrier();
+        toff_prev = t * stride_i;
+      }
+#ifndef CABL_NO_DEFERRED
+      if (CHELP_MODE & 2) stores((p.seq_len + 1) & 1, toff_prev);
+#endif
+      return;
+    }
+  }
   typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
   u32x4g gxl[2];
   auto fetch_gx = [&](int toff_) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) gxl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, (int)dvo_g[i], toff_ * ldg_i * 2, 0);
   };
-  fetch_gx((dir ? p.seq_len - 1 : 0) * stride_i);
+  if constexpr (HELP == 0 || !(CHELP_MODE & 1)) fetch_gx((dir ? p.seq_len - 1 : 0) * stride_i);
   auto deferred_stores = [&](int par) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const char* hst = par ? hstage1 : reinterpret_cast<const char*>(hstage);
@@ -280,10 +353,12 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_hs, (int)dvo_h, toff_d * ldh_i * 2, 0);
     }
     if (p.save) {
+      if constexpr (HELP == 0 || !(CHELP_MODE & 2)) {                    // (helper form: the helper waves store the gates)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const uint4 v = *reinterpret_cast<const uint4*>(gstage + (tid + i * CTHR) * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_gs, (int)dvo_g[i], toff_d * ldg_i * 2, 0);
+        for (int i = 0; i < 2; ++i) {
+          const uint4 v = *reinterpret_cast<const uint4*>(gstage + (tid + i * CTHR) * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_gs, (int)dvo_g[i], toff_d * ldg_i * 2, 0);
+        }
       }
       const uint4 v = *reinterpret_cast<const uint4*>(cstage + tid * 16);
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_cs, (int)dvo_c, toff_d * ldc_i * 4, 0);
@@ -345,18 +420,22 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
       }
     }
 #ifndef CABL_NO_GX
+    if constexpr (HELP == 0 || !(CHELP_MODE & 1)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)       // this step's pre-activations -> the staging tile of its parity (this thread read these pieces a step ago)
-      *reinterpret_cast<uint4*>(gstage0 + (step & 1) * (CROWS * UW * 8) + (tid + i * CTHR) * 16) = make_uint4(gxl[i][0], gxl[i][1], gxl[i][2], gxl[i][3]);
+      for (int i = 0; i < 2; ++i)       // this step's pre-activations -> the staging tile of its parity (this thread read these pieces a step ago)
+        *reinterpret_cast<uint4*>(gstage0 + (step & 1) * (CROWS * UW * 8) + (tid + i * CTHR) * 16) = make_uint4(gxl[i][0], gxl[i][1], gxl[i][2], gxl[i][3]);
+    }
 #endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (raw barriers: the deferred stores stay in flight across them)
     __builtin_amdgcn_s_barrier();
 #ifndef CABL_NO_DEFERRED
-    if (have_d) deferred_stores((step + 1) & 1);                       // the previous step's rows: behind this step's gather, under its MFMAs
+    if (have_d) deferred_stores((step + 1) & 1);                         // the previous step's rows: behind this step's gather, under its MFMAs
 #endif
     // prefetch the gate pre-activations of the next step (independent of the recurrence)
 #ifndef CABL_NO_GX
-    if (step + 1 < p.seq_len) fetch_gx((dir ? t - 1 : t + 1) * stride_i);
+    if constexpr (HELP == 0 || !(CHELP_MODE & 1)) {
+      if (step + 1 < p.seq_len) fetch_gx((dir ? t - 1 : t + 1) * stride_i);
+    }
 #endif
     // 2. gates for (64 rows) x (this wave's quad)
 #pragma unroll
@@ -421,7 +500,7 @@ __global__ void __launch_bounds__(CTHR) lstm_fwd_cluster_kernel(ClusterArgs p) {
     have_d = true;
   }
   if (have_d) {
-    __syncthreads();
+    if constexpr (HELP == 0) __syncthreads();                           // (helper form: the last step's second barrier already separates the tiles' writers and readers)
     deferred_stores((p.seq_len + 1) & 1);
   }
 }
@@ -669,11 +748,15 @@ __global__ void __launch_bounds__(256) lstm_pack_bwd_quads_kernel(const float* _
 template <int NSLAB, int MAXCH>
 static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH, 2>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
+  const int helpers = getenv("URSE_CLUSTER_HELPERS") ? atoi(getenv("URSE_CLUSTER_HELPERS")) : 2;     // (A/B switch; 0 = the 14-wave form)
   const size_t lds = (size_t)CROWS * lds_frag_pitch(p.Hp * 2) + (size_t)CROWS * UW * 2 + 16 + 64 + CROWS * sizeof(int) + (size_t)CROWS * UW * 14 + (size_t)CROWS * UW * 12;
   dim3 grid(p.C * p.ncl, 2);
-  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH>), grid, dim3(CTHR), lds, st, p);
+  if (helpers > 0) hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH, 2>), grid, dim3(CTHR + 128), lds, st, p);
+  else hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH>), grid, dim3(CTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_cluster_fwd");
   return URSE_OK;
 }
