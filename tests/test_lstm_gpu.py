@@ -394,6 +394,33 @@ def test_xcd_aware_clusters_equal_static_clusters(lib, B, T, K):
         assert torch.equal(outs[0][2], o[2])
 
 
+def test_cluster_helper_waves_equal_the_fourteen_wave_form_at_full_size(lib, monkeypatch):
+    """the time path at C2 (1,088 sequences x 401 steps per direction): the form with two helper waves (saved-gate stores and the next
+    step's pre-activations off the working waves) against the 14-wave form, every saved gate, h and c bit for bit.  (A first helper form
+    stored 0.03 % of the saved gates with a zeroed first dword - profiles/r04_exp_cluster_helpers_v1.log; only a full-size comparison saw it.)"""
+    from urgent2026_challenge_track1_amd import ops
+    torch.manual_seed(6)
+    N, dev, B, T, K = 196, "cuda", 32, 401, 34
+    H, Hp = 2 * N, 416
+    whh = torch.randn(2 * 4 * H, H, device=dev) * 0.05
+    whhq = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=torch.bfloat16)
+    ops.call("lstm_pack_quads", whh, whhq, H, Hp, ops.stream_ptr())
+    M = B * T * K
+    sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+    gx = torch.randn(M, 8 * H, device=dev).to(torch.bfloat16)
+    outs = []
+    for hp in ("0", "2", "2"):
+        monkeypatch.setenv("URSE_CLUSTER_HELPERS", hp)
+        g = gx.clone()
+        h, c, err = ops.lstm_fwd_cluster(g, whhq, H, Hp, **sm)
+        assert int(err.item()) == 0
+        outs.append((g, h.clone(), c.clone()))
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0].view(torch.int16), o[0].view(torch.int16))
+        assert torch.equal(outs[0][1].view(torch.int16), o[1].view(torch.int16))
+        assert torch.equal(outs[0][2], o[2])
+
+
 @pytest.mark.parametrize("ns,sl,strided", [(300, 34, False), (37, 5, False), (2 * 34, 9, True), (1, 3, False)])
 def test_fused_row_wave_forward_matches_two_kernel_form_and_lstm(lib, ns, sl, strided):
     """csrc/lstm_rwx.hip (x W_ih^T + b + h W_hh^T in one accumulator, no gx matrix) against {gate GEMM, lstm_rw} and against
@@ -436,7 +463,7 @@ def test_fused_row_wave_forward_matches_two_kernel_form_and_lstm(lib, ns, sl, st
     assert ops.launch_counts()["lstm_fwd_rwx"] >= 2
 
 
-@pytest.mark.parametrize("B,T,K", [(1, 7, 34), (2, 21, 20), (3, 9, 34), (5, 40, 34)])
+@pytest.mark.parametrize("B,T,K", [(1, 7, 34), (2, 21, 20), (3, 9, 34), (5, 40, 34), (32, 401, 34)])
 def test_nsplit_bptt_matches_streaming_kernel(lib, B, T, K):
     """time-path BPTT split over pairs of workgroups by OUTPUT columns (each member streams its half of W_hh^T, the halves of the gate
     gradients are exchanged through the gates output with write-through stores and a flag) vs the one-workgroup streaming kernel: same
@@ -469,6 +496,19 @@ def test_nsplit_bptt_matches_streaming_kernel(lib, B, T, K):
         b = g2[:, dr * 4 * H:dr * 4 * H + 13 * 64].view(torch.int16)
         frac = (a != b).float().mean().item()
         assert frac <= 2e-2, frac          # (their dh_rec is exact; differences enter through the other half's gradients one step later)
+    # the helper-wave form (default) against the 13-wave form: the same sums in the same order, bit for bit
+    import os
+    prev = os.environ.get("URSE_NSPLIT_HELPERS")
+    try:
+        os.environ["URSE_NSPLIT_HELPERS"] = "0"
+        g3 = gx.clone()
+        ops.lstm_bwd_nsplit(dh, g3, c, pk["whhT"], H, **sm)
+    finally:
+        if prev is None:
+            os.environ.pop("URSE_NSPLIT_HELPERS", None)
+        else:
+            os.environ["URSE_NSPLIT_HELPERS"] = prev
+    assert torch.equal(g2.view(torch.int16), g3.view(torch.int16))
 
 
 def test_multi_pack_equals_per_lstm_pack(lib):
