@@ -75,9 +75,6 @@ __device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned of
 // pieces), between the same two barriers as the working waves, whose instruction streams and in-order vmcnt queues then hold the h gather,
 // the MFMAs, the cell update and the publication only.  (The ablation of the helper-less form priced the deferred stores at 1.7 us and the
 // staged pre-activations at 1.3 us of a 6.4 us step - at 21 GB/s per CU this kernel is bound by its step latency, not by bytes.)
-#ifndef CHELP_MODE
-#define CHELP_MODE 3     // (diagnostic builds: bit 0 = the helpers stage the pre-activations, bit 1 = the helpers issue the plain stores)
-#endif
 template <int NSLAB, int MAXCH, int HELP = 0>
 __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(ClusterArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,63 +272,95 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
     if (w >= CW) {
       // ---- helper waves: their own time loop, the working waves' two barriers per step ----
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      constexpr int HT = 64 * HELP, NG = CROWS * GC / HT;
-      static_assert(NG * HT == CROWS * GC, "the helper lanes divide the staged pieces evenly");
+      constexpr int HT = 64 * HELP, NG = CROWS * GC / HT, NC = CROWS * CC / HT;
+      static_assert(NG * HT == CROWS * GC && NC * HT == CROWS * CC, "the helper lanes divide the staged pieces evenly");
       const int ht = tid - CTHR;
-      unsigned og[NG];
+      unsigned og[NG], oc[NC];
 #pragma unroll
       for (int i = 0; i < NG; ++i) {
         const int idx = ht + i * HT, row = idx / GC, cc = idx - row * GC;
         og[i] = (row < nrows && cc * 2 < nvu) ? ((unsigned)rowtab[row] * (unsigned)ldg_i + (unsigned)(gcol_i + (j * UW + cc * 2) * 4)) * 2u : COOB;
       }
-      u32x4 gxr[NG];
-      auto fetch = [&](int toff_) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) gxr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, (int)og[i], toff_ * ldg_i * 2, 0);
+      for (int i = 0; i < NC; ++i) {
+        const int idx = ht + i * HT, row = idx / CC, cc = idx - row * CC;
+        oc[i] = (row < nrows && cc * 4 < nvu) ? ((unsigned)rowtab[row] * (unsigned)ldc_i + (unsigned)(hcol_i + j * UW + cc * 4)) * 4u : COOB;
+      }
+      // The next step's pre-activations go global -> LDS without passing through registers (buffer_load ... lds: 64 lanes x 16 B land lane-linear
+      // at a wave-uniform LDS address - exactly the staging tile's piece order; a piece outside the buffer arrives as zeros).
+      const unsigned long gb = (unsigned long)p.gx;
+      typedef int rsrc4 __attribute__((ext_vector_type(4)));
+      const rsrc4 rg = rsrc4{(int)(unsigned)gb, (int)(unsigned)((gb >> 32) & 0xffffu), (int)p.g_bytes, 0x00020000};
+      const unsigned lds_g0 = (unsigned)(size_t)gstage0 + (unsigned)((w - CW) * 64 * 16);
+      auto fetch = [&](int par, int toff_) {
+        const unsigned soff = (unsigned)(toff_ * ldg_i * 2);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+          const unsigned dst = __builtin_amdgcn_readfirstlane(lds_g0 + (unsigned)(par * (CROWS * UW * 8) + i * HT * 16));
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(og[i]), "s"(rg), "s"(soff), "s"(dst) : "memory");
+        }
       };
-      // The saved gates of a step: every staged piece into its OWN registers, then the stores, then a wait for the stores before the
-      // registers take the next step's pre-activations.  (With LDS reads and stores interleaved the compiler recycled a store's four data
-      // registers for an LDS read three instructions later and 0.2 % of the stored pieces came out with a wrong first dword - correct as soon
-      // as no register was reused, scripts/diag/dbg_cluster_helpers.py: a 16-byte buffer store's data registers are evidently not safe
-      // against an LDS return that soon on this part.  h_t -> hout and c_t stay with the working waves - one piece each per thread -: 25 pieces per
-      // helper lane do not fit 128 VGPRs.)
-      uint4 vg[NG];
-      auto stores = [&](int par, int toff_) {
-        if (!p.save) return;
-        const char* gst = gstage0 + par * (CROWS * UW * 8);
-#pragma unroll
-        for (int i = 0; i < NG; ++i) vg[i] = *reinterpret_cast<const uint4*>(gst + (ht + i * HT) * 16);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < NG; ++i)
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{vg[i].x, vg[i].y, vg[i].z, vg[i].w}, rs_gs, (int)og[i], toff_ * ldg_i * 2, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the stores have read their registers
-      };
-      if (CHELP_MODE & 1) fetch((dir ? p.seq_len - 1 : 0) * stride_i);
+      // The saved gates and c_t of a step: every staged piece into its OWN registers, then the stores; the registers are not written again before
+      // the vmcnt(0) at the top of the next step.  (With LDS reads and stores interleaved the compiler recycled a store's four data registers
+      // for an LDS read three instructions later and 0.2 % of the stored pieces came out with a zeroed first dword - correct as soon as no
+      // register was reused, scripts/diag/dbg_cluster_helpers.py.  h_t -> hout stays with the working waves, which read that piece for the
+      // publication anyway.)
+      uint4 vg[NG], vc[NC];
+      fetch(0, (dir ? p.seq_len - 1 : 0) * stride_i);
       int toff_prev = 0;
       for (int step = 0; step < p.seq_len; ++step) {
         const int t = dir ? (p.seq_len - 1 - step) : step;
-#ifndef CABL_NO_GX
-        if (CHELP_MODE & 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this step's pre-activations have landed; the previous stores are done
+        __builtin_amdgcn_s_barrier();
+        const int pp = (step + 1) & 1;                                   // parity of the previous step = of the next one
+        const bool st = p.save && step > 0;
+#ifndef CABL_NO_DEFERRED
+        if (st) {
+          const char* gst = gstage0 + pp * (CROWS * UW * 8);
+          const char* cst_ = cstage0 + pp * (CROWS * UW * 4);
 #pragma unroll
-          for (int i = 0; i < NG; ++i)       // this step's pre-activations -> the staging tile of its parity
-            *reinterpret_cast<uint4*>(gstage0 + (step & 1) * (CROWS * UW * 8) + (ht + i * HT) * 16) = make_uint4(gxr[i][0], gxr[i][1], gxr[i][2], gxr[i][3]);
+          for (int i = 0; i < NG; ++i) vg[i] = *reinterpret_cast<const uint4*>(gst + (ht + i * HT) * 16);
+#pragma unroll
+          for (int i = 0; i < NC; ++i) vc[i] = *reinterpret_cast<const uint4*>(cst_ + (ht + i * HT) * 16);
         }
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#ifndef CABL_NO_DEFERRED
-        if ((CHELP_MODE & 2) && step > 0) stores((step + 1) & 1, toff_prev);
-#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the tile is in registers: the next step's pre-activations may overwrite it
 #ifndef CABL_NO_GX
-        if ((CHELP_MODE & 1) && step + 1 < p.seq_len) fetch((dir ? t - 1 : t + 1) * stride_i);
+        if (step + 1 < p.seq_len) fetch(pp, (dir ? t - 1 : t + 1) * stride_i);
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the staged pieces are in registers before the next cell phase can rewrite them
+#ifndef CABL_NO_DEFERRED
+        if (st) {
+#pragma unroll
+          for (int i = 0; i < NG; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{vg[i].x, vg[i].y, vg[i].z, vg[i].w}, rs_gs, (int)og[i], toff_prev * ldg_i * 2, 0);
+#pragma unroll
+          for (int i = 0; i < NC; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{vc[i].x, vc[i].y, vc[i].z, vc[i].w}, rs_cs, (int)oc[i], toff_prev * ldc_i * 4, 0);
+        }
+#endif
         __builtin_amdgcn_s_barrier();
         toff_prev = t * stride_i;
       }
 #ifndef CABL_NO_DEFERRED
-      if (CHELP_MODE & 2) stores((p.seq_len + 1) & 1, toff_prev);
+      if (p.save) {                                                      // the last step's tiles (complete behind its second barrier)
+        const int pp = (p.seq_len + 1) & 1;
+        const char* gst = gstage0 + pp * (CROWS * UW * 8);
+        const char* cst_ = cstage0 + pp * (CROWS * UW * 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NG; ++i) vg[i] = *reinterpret_cast<const uint4*>(gst + (ht + i * HT) * 16);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) vc[i] = *reinterpret_cast<const uint4*>(cst_ + (ht + i * HT) * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{vg[i].x, vg[i].y, vg[i].z, vg[i].w}, rs_gs, (int)og[i], toff_prev * ldg_i * 2, 0);
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{vc[i].x, vc[i].y, vc[i].z, vc[i].w}, rs_cs, (int)oc[i], toff_prev * ldc_i * 4, 0);
+      }
 #endif
       return;
     }
@@ -342,7 +371,7 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
 #pragma unroll
     for (int i = 0; i < 2; ++i) gxl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gs, (int)dvo_g[i], toff_ * ldg_i * 2, 0);
   };
-  if constexpr (HELP == 0 || !(CHELP_MODE & 1)) fetch_gx((dir ? p.seq_len - 1 : 0) * stride_i);
+  if constexpr (HELP == 0) fetch_gx((dir ? p.seq_len - 1 : 0) * stride_i);
   auto deferred_stores = [&](int par) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const char* hst = par ? hstage1 : reinterpret_cast<const char*>(hstage);
@@ -352,13 +381,11 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
       const uint4 v = *reinterpret_cast<const uint4*>(hst + (tid < CROWS * SC ? tid : 0) * 16);
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_hs, (int)dvo_h, toff_d * ldh_i * 2, 0);
     }
-    if (p.save) {
-      if constexpr (HELP == 0 || !(CHELP_MODE & 2)) {                    // (helper form: the helper waves store the gates)
+    if (p.save && HELP == 0) {                                           // (helper form: the helper waves store the gates and c)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint4 v = *reinterpret_cast<const uint4*>(gstage + (tid + i * CTHR) * 16);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_gs, (int)dvo_g[i], toff_d * ldg_i * 2, 0);
-        }
+      for (int i = 0; i < 2; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4*>(gstage + (tid + i * CTHR) * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_gs, (int)dvo_g[i], toff_d * ldg_i * 2, 0);
       }
       const uint4 v = *reinterpret_cast<const uint4*>(cstage + tid * 16);
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_cs, (int)dvo_c, toff_d * ldc_i * 4, 0);
@@ -420,7 +447,7 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
       }
     }
 #ifndef CABL_NO_GX
-    if constexpr (HELP == 0 || !(CHELP_MODE & 1)) {
+    if constexpr (HELP == 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)       // this step's pre-activations -> the staging tile of its parity (this thread read these pieces a step ago)
         *reinterpret_cast<uint4*>(gstage0 + (step & 1) * (CROWS * UW * 8) + (tid + i * CTHR) * 16) = make_uint4(gxl[i][0], gxl[i][1], gxl[i][2], gxl[i][3]);
@@ -433,7 +460,7 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
 #endif
     // prefetch the gate pre-activations of the next step (independent of the recurrence)
 #ifndef CABL_NO_GX
-    if constexpr (HELP == 0 || !(CHELP_MODE & 1)) {
+    if constexpr (HELP == 0) {
       if (step + 1 < p.seq_len) fetch_gx((dir ? t - 1 : t + 1) * stride_i);
     }
 #endif
