@@ -619,7 +619,7 @@ def low_priority_stream(device, force=False):
 # workgroups the TN launches of the second queue are sized to (bsrnn._run_deferred_wgrads): 120 = the CUs the time path's
 # BPTT (136 workgroups) leaves idle; beside the band path's BPTT, which fills the chip, four R-slices (84 workgroups) are
 # the best trade (same-box: 180.9 ms/step at 120, 175.3 at 84, 186 at 63; measured with the faster TN kernel)
-TN_SHADOW_WGS = int(os.environ.get("URSE_TN_SHADOW_WGS", "98"))
+TN_SHADOW_WGS = int(os.environ.get("URSE_TN_SHADOW_WGS", "112"))     # (round 4, beside the N-split BPTT: 134.3 / 134.3 / 133.3 / 137.7 ms per step at 84 / 98 / 112 / 126, profiles/r04_ab_tn_shadow_v1.log)
 TN_SHADOW_WGS_BAND = int(os.environ.get("URSE_TN_SHADOW_WGS_BAND", "84"))
 # batches the join behind the time path's BPTT leaves running (their operands stay alive that much longer)
 TN_JOIN_LAG = int(os.environ.get("URSE_TN_JOIN_LAG", "2"))   # same-box: 176.7 (0), 175.3 (1), 174.4 (2), 174.3 (4) ms/step
