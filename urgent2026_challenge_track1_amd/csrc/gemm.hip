@@ -1687,6 +1687,163 @@ __global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_pe
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the last (zero-page) prefetch must not outlive the workgroup
 }
 
+// Weights resident in REGISTERS, for K = 224 and wide N with bf16 output (the time path's gate projection: N = 3,136).
+// gemm_nt_bres_kernel keeps a 224-column weight slice in LDS, so a workgroup writes 448-byte pieces of an output row, and 448-byte
+// segments cap the HBM write rate at 3.7 TB/s where 896-byte segments reach 5.4 (scripts/diag/write_pattern.py) - the kernel is bound by its
+// 2.74 GB of output.  Here a workgroup owns 448 COLUMNS: seven compute waves hold 64 columns each as MFMA operand fragments (4 column
+// tiles x 7 k-slabs x 4 VGPRs = 112 registers, loaded once), an eighth wave streams 32-row activation stages (14 KB, the ring GEMMs'
+// swizzled 64-byte-row image) through a 5-slot LDS ring with four stages in flight, one raw barrier per stage (the row-wave LSTM's
+// protocol: at barrier k stage k has landed and the slot of stage k - 1 is free).  A stage's 32 x 448 outputs go to one of two LDS
+// staging tiles and leave during the NEXT stage as 16-byte pieces of 896-byte row segments.  Same k order per output element as the
+// ring / LDS-resident kernels: bit-identical results.
+constexpr int WR_ROWS = 32, WR_KS = 7, WR_NSLOT = 7, WR_STAGE = WR_KS * 2 * 1024, WR_BNX = 448, WR_CP = WR_BNX * 2 + 16, WR_AHEAD = WR_NSLOT - 1;
+template <int ACT>
+__global__ void __launch_bounds__(448) gemm_nt_wreg_kernel(GemmDesc d, int parts, long rows_per_part) {
+  __shared__ __attribute__((aligned(1024))) char lds[WR_NSLOT * WR_STAGE + 2 * WR_ROWS * WR_CP];
+  char* outs = lds + WR_NSLOT * WR_STAGE;
+  // the column slices of one row part take consecutive ids on ONE XCD (xcd_remap): its activation rows come from HBM once and from that XCD's L2
+  // for the other slices
+  const int tn_ = (int)gridDim.x / parts;
+  const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int part = lid / tn_, tile_n = lid - part * tn_;
+  const long n0 = (long)tile_n * WR_BNX;
+  const long r_begin = (long)part * rows_per_part;
+  long r_end = r_begin + rows_per_part;
+  if (r_end > d.M) r_end = d.M;
+  if (r_begin >= r_end) return;
+  const int nst = (int)((r_end - r_begin + WR_ROWS - 1) / WR_ROWS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lc = lane & 15, lr = lane >> 4;
+  // activation stages: stage s = rows r_begin + 32 s ..; image block (ks, half) = 16 rows x 64 B of k-slab ks, chunk swizzled as in the ring
+  // GEMMs; wave w brings k-slab w of every stage (two DMAs); a row at or beyond r_end lies outside the buffer resource and arrives as zeros
+  const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 3) & 3);
+  const rsrc_v4i_t ra = make_rsrc(d.A, (unsigned)(r_end * d.lda * 2));
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  auto issue = [&](int s) __attribute__((always_inline)) {
+    const int slot = s % WR_NSLOT;
+    const long row0 = r_begin + (long)s * WR_ROWS + srow;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const long row = row0 + hf * 16;
+#ifdef WRABL_NO_DMA
+      const unsigned voff = (s < 0 && row < r_end) ? (unsigned)((row * d.lda + w * 32) * 2 + schunk * 16) : 0xFFFFF000u;
+#else
+      const unsigned voff = (s < nst && row < r_end) ? (unsigned)((row * d.lda + w * 32) * 2 + schunk * 16) : 0xFFFFF000u;
+#endif
+      blds16(voff, ra, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(slot * WR_STAGE + (w * 2 + hf) * 1024)));
+    }
+  };
+  const long nw = n0 + w * 64;                                          // this wave's 64 columns
+  short8_t wreg[4][WR_KS];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long n = nw + j * 16 + lc;
+#pragma unroll
+    for (int ks = 0; ks < WR_KS; ++ks)
+      wreg[j][ks] = n < d.N ? *reinterpret_cast<const short8_t*>(d.B + (n * d.ldb + ks * 32 + 8 * lr) * 2) : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  f32x4_t bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long col = nw + j * 16 + lr * 4 + r;
+      bv[j][r] = (d.bias && col < d.N) ? d.bias[col] : 0.f;
+    }
+  bf16_t* C = reinterpret_cast<bf16_t*>(d.C);
+  const int foff = lc * 64 + ((lr ^ ((lc >> 1) & 3)) << 4);
+  constexpr int CPR = WR_BNX / 8, NTHC = 7 * 64, NPC = WR_ROWS * CPR / NTHC;     // 56 pieces of 16 B per output row, 4 per thread and stage
+  static_assert(WR_ROWS * CPR % NTHC == 0, "the threads divide a stage's output pieces evenly");
+  auto sweep = [&](int k) __attribute__((always_inline)) {              // the staged outputs of stage k -> global, 16-byte pieces along the rows
+    const char* ob = outs + (k & 1) * (WR_ROWS * WR_CP);
+    const long row0 = r_begin + (long)k * WR_ROWS;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(d.C, 0, (int)0xFFFFF000u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int idx = tid + i * NTHC, lrow = idx / CPR, ch = idx - lrow * CPR;
+      const long row = row0 + lrow, col = n0 + ch * 8;
+      const uint4 v = *reinterpret_cast<const uint4*>(ob + lrow * WR_CP + ch * 16);
+      // one buffer store per piece whatever its fate (the counted vmcnt below relies on NPC stores per stage): a piece that must not be
+      // stored gets an offset outside the buffer; the ragged last 16 bytes of a row (N % 8 != 0) are written element by element instead
+#ifdef WRABL_NO_STORE      // timing diagnostics (wrong results): WRABL_NO_STORE, WRABL_NO_DMA, WRABL_NO_MFMA
+      const bool whole = false && row < r_end && col + 8 <= d.N;
+#else
+      const bool whole = row < r_end && col + 8 <= d.N;
+#endif
+      const unsigned off = whole ? (unsigned)((row * d.ldc + col) * 2) : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rc, (int)off, 0, 2);      // (aux 2 = nt / slc: streaming output)
+      if (!whole && row < r_end && col < d.N) {
+        const bf16_t* sv = reinterpret_cast<const bf16_t*>(ob + lrow * WR_CP + ch * 16);
+        for (int e = 0; e < 8 && col + e < d.N; ++e) C[row * d.ldc + col + e] = sv[e];
+      }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < WR_AHEAD; ++s) issue(s);
+  // stage 0: everything but the five younger stages' DMAs of this wave (and, before them in the queue, the weight fragments) has landed
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int k = 0; k < nst; ++k) {
+    issue(k + WR_AHEAD);                                                // into the slot of stage k - 1, free behind the barrier just passed
+    if (k > 0) sweep(k - 1);                                            // complete behind that barrier; the stores overlap this stage's MFMAs
+    const char* st = lds + (k % WR_NSLOT) * WR_STAGE + foff;
+    f32x4_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < WR_KS; ++ks) {
+      short8_t x[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) x[i] = *reinterpret_cast<const short8_t*>(st + (ks * 2 + i) * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+#ifdef WRABL_NO_MFMA
+        for (int i = 0; i < 2; ++i) acc[i][j][ks & 3] += __builtin_bit_cast(float, (int)x[i][0] | ((int)wreg[j][ks][1] << 16));
+#else
+        for (int i = 0; i < 2; ++i) acc[i][j] = Frag<bf16_t>::mma(wreg[j][ks], x[i], acc[i][j]);     // D[n][m]: lane (lr, lc) = row lc, columns 4 lr ..
+#endif
+    }
+    char* ob = outs + (k & 1) * (WR_ROWS * WR_CP);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4_t v = acc[i][j] + bv[j];
+        if (ACT == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
+        }
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(ob + (i * 16 + lc) * WR_CP + (w * 64 + j * 16 + lr * 4) * 2) = pk;
+      }
+    // this wave's part of stage k + 1 has landed: behind its two DMAs the queue holds the DMAs of stages k + 2 .. k + 6 (10) and the NPC
+    // stores of each sweep since (iterations 1 .. k, at most the last six count)
+    {
+      const int kk = k < 6 ? k : 6;
+      switch (kk) {
+        case 0: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+      }
+    }
+    static_assert(WR_AHEAD == 6 && NPC == 4, "the counted waits above are written for six stages ahead and four stores per sweep");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // stage k + 1 has landed; every wave's outputs of stage k are staged
+  }
+  sweep(nst - 1);
+}
+
 static int check_desc_host(const GemmDesc& d, int es, const char* who) {
   URSE_CHECK_ARG(d.A && d.B && d.C, "%s: null operand", who);
   URSE_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "%s: empty problem", who);
@@ -1736,6 +1893,26 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   static const bool no_dma = getenv("URSE_NT_NO_DMA") != nullptr;
   const char* bres_env = getenv("URSE_NT_BRES");
   const int bres_mode = bres_env ? atoi(bres_env) : 1;
+  // OFF by default (0): 1.11 -> 0.80 ms per launch alone (scripts/bench_gemm.py), but 1.01 ms in the step's profile against 0.96 for the
+  // LDS-resident kernel, and no difference in the step (136.1 / 135.1 vs 136.3 / 135.1 ms, profiles/r04_exp_nt_wreg_v1.log): with one barrier
+  // per 32-row stage its MFMA phase (0.33 ms, seven waves on four SIMDs) is in series with the memory phases.  Read per call: tests switch it.
+  const long wreg_min_n = getenv("URSE_NT_WREG_MIN_N") ? atol(getenv("URSE_NT_WREG_MIN_N")) : 0;
+  if (wreg_min_n > 0 && in_dtype == URSE_BF16 && out_dtype == URSE_BF16 && !no_dma && M >= 8192 && N >= wreg_min_n && K == 32 * WR_KS &&
+      !resid && act != 2 && (ldc * 2) % 16 == 0 && ((uintptr_t)C % 16) == 0 && M * lda * 2 < 0xFFFFF000L && M * ldc * 2 < 0xFFFFF000L) {
+    // weights resident in registers, 448-column slices: see gemm_nt_wreg_kernel
+    const int tn = (int)((N + WR_BNX - 1) / WR_BNX);
+    int parts = 252 / tn;
+    if (parts < 1) parts = 1;
+    long rpp = (M + parts - 1) / parts;
+    rpp = (rpp + WR_ROWS - 1) / WR_ROWS * WR_ROWS;
+    dim3 grid((unsigned)(tn * parts));
+    hipStream_t st = (hipStream_t)stream;
+    note_launch(URSE_KV_NT_BRES);
+    if (act == 0) hipLaunchKernelGGL(gemm_nt_wreg_kernel<0>, grid, dim3(448), 0, st, d, parts, rpp);
+    else hipLaunchKernelGGL(gemm_nt_wreg_kernel<1>, grid, dim3(448), 0, st, d, parts, rpp);
+    URSE_CHECK_LAUNCH("urse_gemm_nt");
+    return URSE_OK;
+  }
   if (bres_mode && in_dtype == URSE_BF16 && out_dtype == URSE_BF16 && !no_dma && M >= 8192 && N >= g_nt_bres_min_n && K % 32 == 0 &&
       K >= 96 && K <= 224 && !resid && act != 2 && (ldc * 2) % 16 == 0 && ((uintptr_t)C % 16) == 0) {
     // weight-stationary tiles: see gemm_nt_bres_kernel
