@@ -545,11 +545,15 @@ class BSRNNCore(nn.Module):
         ops.gemm_nt(doT, pk[p + "wfcT"], out=dh, N=2 * H)
         sm = self._seqmap(path, B, T, K)
         overlap = ops.TN_OVERLAP and skip.is_cuda
+        use_nsplit = (not (ops.USE_CLUSTER_LSTM_BWD and pk.get(p + "whhTq") is not None and ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None) and
+                      not ((ops.USE_SPLIT_LSTM_BWD or H >= ops.SPLIT_BWD_MIN_H) and dt == torch.bfloat16 and ops.lstm_split_chunks(H, **sm) is not None) and
+                      ops.USE_NSPLIT_LSTM_BWD and dt == torch.bfloat16 and path not in ops.BWD_ROWS16 and sm["n_seq"] <= ops.NSPLIT_MAX_SEQ and
+                      sm["n_seq"] * sm["seq_len"] >= 4096 and ops.lstm_nsplit_plan(H, sm["n_seq"]) is not None)
         if overlap and (path == "t" or ops.TN_OVERLAP_BAND):
             # the time path's BPTT occupies 136 of the 256 CUs for ~7 ms (and the band path's last round of workgroups
             # leaves most CUs idle): the weight-gradient GEMMs deferred by the previous half layers run beside it on a
             # second stream (they only feed the optimizer / all-reduce)
-            self._run_deferred_wgrads(skip.device, ops.TN_SHADOW_WGS if path == "t" else ops.TN_SHADOW_WGS_BAND,
+            self._run_deferred_wgrads(skip.device, (ops.TN_SHADOW_WGS_NSPLIT if use_nsplit else ops.TN_SHADOW_WGS) if path == "t" else ops.TN_SHADOW_WGS_BAND,
                                       None if path == "t" else ops.TN_BAND_PARTS)
         if ops.USE_CLUSTER_LSTM_BWD and pk.get(p + "whhTq") is not None and \
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
@@ -557,8 +561,7 @@ class BSRNNCore(nn.Module):
         elif (ops.USE_SPLIT_LSTM_BWD or H >= ops.SPLIT_BWD_MIN_H) and dt == torch.bfloat16 and \
                 ops.lstm_split_chunks(H, **sm) is not None:
             dg, self._cluster_err = ops.lstm_bwd_split(dh, gates, c, pk[p + "whhT"], H, **sm)
-        elif ops.USE_NSPLIT_LSTM_BWD and dt == torch.bfloat16 and path not in ops.BWD_ROWS16 and sm["n_seq"] <= ops.NSPLIT_MAX_SEQ and \
-                sm["n_seq"] * sm["seq_len"] >= 4096 and ops.lstm_nsplit_plan(H, sm["n_seq"]) is not None:
+        elif use_nsplit:
             dg, self._cluster_err = ops.lstm_bwd_nsplit(dh, gates, c, pk[p + "whhT"], H, **sm)
         else:
             dg = ops.lstm_bwd(dh, gates, c, pk[p + "whhT"], H, rows16=ops.BWD_ROWS16.get(path, 0), **sm)   # dgates, gate-interleaved columns
@@ -734,7 +737,17 @@ class BSRNNCore(nn.Module):
                                            colsum=self._g(p + "b1", 4 * N, k * 4 * N), Mo=4 * N, No=N))
                 w2_off += 16 * sb * N
                 b2_off += 4 * sb
-        ops.gemm_tn_grouped(tn_rows, dt, dev)     # 4 x K weight / bias gradients in one launch
+        defer_md = ops.TN_OVERLAP and ops.DEFER_MASKDEC_WGRADS and skip.is_cuda
+        if defer_md:
+            # the decoder's weight gradients feed nothing but the optimizer: they join the second queue (and start beside the first BPTT, when that
+            # queue is still empty) instead of taking 0.86 ms of the compute stream; the closure keeps their operands alive
+            keep = (dpre, hids, dhp, xns)
+
+            def wg_md(target_wgs=0, _rows=tn_rows, _keep=keep):
+                ops.gemm_tn_grouped(_rows, dt, dev)
+            self._deferred.append((wg_md, "md"))
+        else:
+            ops.gemm_tn_grouped(tn_rows, dt, dev)     # 4 x K weight / bias gradients in one launch
         nt_grouped(rows_b, dev, ops._dt(dhp[0]), ops.F32)
         dskip = None
         for i, tag in enumerate("mr"):
@@ -746,7 +759,8 @@ class BSRNNCore(nn.Module):
             if last:                              # the last dual-path half layer consumes this gradient next
                 dskip, packed = dskip
                 self._grad_pack = (dskip.data_ptr(), packed)
-        self._ready("md")
+        if not defer_md:
+            self._ready("md")
         return dskip
 
     # ------------------------------------------------------------------------------------------

@@ -619,7 +619,11 @@ def low_priority_stream(device, force=False):
 # workgroups the TN launches of the second queue are sized to (bsrnn._run_deferred_wgrads): 120 = the CUs the time path's
 # BPTT (136 workgroups) leaves idle; beside the band path's BPTT, which fills the chip, four R-slices (84 workgroups) are
 # the best trade (same-box: 180.9 ms/step at 120, 175.3 at 84, 186 at 63; measured with the faster TN kernel)
-TN_SHADOW_WGS = int(os.environ.get("URSE_TN_SHADOW_WGS", "112"))     # (round 4, beside the N-split BPTT: 134.3 / 134.3 / 133.3 / 137.7 ms per step at 84 / 98 / 112 / 126, profiles/r04_ab_tn_shadow_v1.log)
+TN_SHADOW_WGS = int(os.environ.get("URSE_TN_SHADOW_WGS", "98"))
+# ... beside the N-split BPTT (136 workgroups of 16 waves): 134.3 / 134.3 / 133.3 / 137.7 ms per step at 84 / 98 / 112 / 126 (profiles/r04_ab_tn_shadow_v1.log).
+# Its own switch: the flow model's cooperative split BPTT plans its grid on the CUs this number leaves, and at 112 it no longer fit (its train step went
+# from 87.8 to 104.3 ms when the one number served both)
+TN_SHADOW_WGS_NSPLIT = int(os.environ.get("URSE_TN_SHADOW_WGS_NSPLIT", "112"))
 TN_SHADOW_WGS_BAND = int(os.environ.get("URSE_TN_SHADOW_WGS_BAND", "84"))
 # batches the join behind the time path's BPTT leaves running (their operands stay alive that much longer)
 TN_JOIN_LAG = int(os.environ.get("URSE_TN_JOIN_LAG", "2"))   # same-box: 176.7 (0), 175.3 (1), 174.4 (2), 174.3 (4) ms/step
@@ -627,6 +631,7 @@ TN_JOIN_LAG = int(os.environ.get("URSE_TN_JOIN_LAG", "2"))   # same-box: 176.7 (
 # for the time path's, which leaves 120 CUs idle (unset / negative = all; 2 or 1 measured 182-185 vs 174 ms/step)
 TN_BAND_PARTS = int(os.environ.get("URSE_TN_BAND_PARTS", "-1"))
 TN_BAND_PARTS = None if TN_BAND_PARTS < 0 else TN_BAND_PARTS
+DEFER_MASKDEC_WGRADS = os.environ.get("URSE_DEFER_MASKDEC_WGRADS", "1") != "0"   # the mask decoder's grouped weight gradients on the second queue
 TN_OVERLAP_BAND = os.environ.get("URSE_TN_OVERLAP_BAND", "1") != "0"   # also start deferred wgrads beside the band path's BPTT
 # the wide kernel wins once there are enough 64-sequence workgroups to fill the chip in both directions
 WIDE_MIN_SEQ = int(os.environ.get("URSE_LSTM_WIDE_MIN_SEQ", str(64 * 128)))
