@@ -451,7 +451,13 @@ class BSRNNCore(nn.Module):
         dt, dev, N = self.compute_dtype, spec.device, self.N
         K, pk, Np = tb["K"], self._packed, self._dims["Np"]
         M = B * T
-        self._flush_deferred_wgrads()            # the dual-path layers are behind us: nothing left to hide them under
+        tail_overlap = ops.TN_OVERLAP and ops.TN_OVERLAP_TAIL and spec.is_cuda and bool(self._deferred)
+        if tail_overlap:
+            # the last half layer's weight gradients (2.4 ms alone) have no recurrence left to hide under: they run on the second queue beside
+            # this function's small kernels and are joined at its end
+            self._run_deferred_wgrads(dev, 256)
+        else:
+            self._flush_deferred_wgrads()        # the dual-path layers are behind us: nothing left to hide them under
         if dzT is None:
             dzT, width = ops.pack2d(dz.reshape(M * K, N), M * K, Np, dt), Np
         dxnb = torch.empty(M, tb["ldx"], dtype=torch.float32, device=dev)
@@ -473,6 +479,8 @@ class BSRNNCore(nn.Module):
         n_gb = 2 * sum(self.subbands)
         call("bandsplit_norm_bwd", spec, dxnb, tb["bands"], stats, self._g(prefix + ".gamma", n_gb),
              self._g(prefix + ".beta", n_gb), B, T, F, K, tb["ldx"], GN_EPS, stream_ptr())
+        if tail_overlap:
+            self._flush_deferred_wgrads()        # joins the second queue (and signals the joined gradients' tags)
         if ready:
             self._ready("bs")
 

@@ -631,6 +631,7 @@ TN_JOIN_LAG = int(os.environ.get("URSE_TN_JOIN_LAG", "2"))   # same-box: 176.7 (
 # for the time path's, which leaves 120 CUs idle (unset / negative = all; 2 or 1 measured 182-185 vs 174 ms/step)
 TN_BAND_PARTS = int(os.environ.get("URSE_TN_BAND_PARTS", "-1"))
 TN_BAND_PARTS = None if TN_BAND_PARTS < 0 else TN_BAND_PARTS
+TN_OVERLAP_TAIL = os.environ.get("URSE_TN_OVERLAP_TAIL", "0") != "0"     # the last half layer's weight gradients beside the band split's backward (measured: 132.95 / 134.61 ms per step off, 135.01 / 134.19 on - no gain, off)
 DEFER_MASKDEC_WGRADS = os.environ.get("URSE_DEFER_MASKDEC_WGRADS", "1") != "0"   # the mask decoder's grouped weight gradients on the second queue
 TN_OVERLAP_BAND = os.environ.get("URSE_TN_OVERLAP_BAND", "1") != "0"   # also start deferred wgrads beside the band path's BPTT
 # the wide kernel wins once there are enough 64-sequence workgroups to fill the chip in both directions
