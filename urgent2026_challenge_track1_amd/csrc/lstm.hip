@@ -453,7 +453,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #ifndef URSE_BWD_KB2_PF3
 #define URSE_BWD_KB2_PF3 9
 #endif
-        constexpr int KB = (sizeof(T) == 2) ? (RT >= 2 ? (PF == 3 ? URSE_BWD_KB2_PF3 : URSE_BWD_KB2) : (NW == 8 ? URSE_BWD_KB8 : (PF == 1 ? (NW == 12 ? URSE_BWD_KBPF12 : URSE_BWD_KBPF16) : URSE_BWD_KB))) : 8;
+#ifndef URSE_BWD_KB2_STG
+#define URSE_BWD_KB2_STG 25   // the staged-store form of the 32-sequence geometry has the registers for 49 = 25 + 24 fragments in flight (246 VGPRs, no
+                              // spill): 3.69 -> 3.61 ms per launch, same bits (scripts/diag/kb2_sweep.sh; 19 and 21 leave ragged last batches and lose)
+#endif
+        constexpr int KB = (sizeof(T) == 2) ? (RT >= 2 ? (PF == 3 ? URSE_BWD_KB2_PF3 : (STG ? URSE_BWD_KB2_STG : URSE_BWD_KB2)) : (NW == 8 ? URSE_BWD_KB8 : (PF == 1 ? (NW == 12 ? URSE_BWD_KBPF12 : URSE_BWD_KBPF16) : URSE_BWD_KB))) : 8;
         #pragma unroll 1
         for (int k0 = 0; k0 < nslab; k0 += KB) {
           uint4 b[KB];
