@@ -748,7 +748,8 @@ class BSRNNCore(nn.Module):
         defer_md = ops.TN_OVERLAP and ops.DEFER_MASKDEC_WGRADS and skip.is_cuda
         if defer_md:
             # the decoder's weight gradients feed nothing but the optimizer: they join the second queue (and start beside the first BPTT, when that
-            # queue is still empty) instead of taking 0.86 ms of the compute stream; the closure keeps their operands alive
+            # queue is still empty) instead of taking 0.86 ms of the compute stream (step time: neutral within the run-to-run spread,
+            # profiles/r04_ab_order_bias_v1.log); the closure keeps their operands alive
             keep = (dpre, hids, dhp, xns)
 
             def wg_md(target_wgs=0, _rows=tn_rows, _keep=keep):

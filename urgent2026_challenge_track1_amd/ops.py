@@ -620,7 +620,8 @@ def low_priority_stream(device, force=False):
 # BPTT (136 workgroups) leaves idle; beside the band path's BPTT, which fills the chip, four R-slices (84 workgroups) are
 # the best trade (same-box: 180.9 ms/step at 120, 175.3 at 84, 186 at 63; measured with the faster TN kernel)
 TN_SHADOW_WGS = int(os.environ.get("URSE_TN_SHADOW_WGS", "98"))
-# ... beside the N-split BPTT (136 workgroups of 16 waves): 134.3 / 134.3 / 133.3 / 137.7 ms per step at 84 / 98 / 112 / 126 (profiles/r04_ab_tn_shadow_v1.log).
+# ... beside the N-split BPTT (136 workgroups of 16 waves): 134.3 / 134.3 / 133.3 / 137.7 ms per step at 84 / 98 / 112 / 126 (profiles/r04_ab_tn_shadow_v1.log;
+# 112 against 98 alone, order reversed: inside the spread, r04_ab_order_bias_v1.log).
 # Its own switch: the flow model's cooperative split BPTT plans its grid on the CUs this number leaves, and at 112 it no longer fit (its train step went
 # from 87.8 to 104.3 ms when the one number served both)
 TN_SHADOW_WGS_NSPLIT = int(os.environ.get("URSE_TN_SHADOW_WGS_NSPLIT", "112"))
