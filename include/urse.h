@@ -108,7 +108,10 @@ int urse_istft_bwd(const float* grad_wav, float* grad_spec, int B, int T, int n_
  * of 32 (bf16) / 16 (f32) -- callers keep zero-padded channel dims.
  */
 /* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]) (+ resid[M,N] f32).  act: 0 none, 1 tanh,
- * 2 tanh-backward: C = (A*B^T) * (1 - h^2) with h [M,N] (output dtype) passed in the resid slot. */
+ * 2 tanh-backward: C = (A*B^T) * (1 - h^2) with h [M,N] (output dtype) passed in the resid slot.
+ * Kernel choice is by shape (ring / LDS-resident weights / 128 x 128); all of them add the k-slabs of an output element in the same order, so the
+ * choice never changes a bit of the result.  Environment switches for A/Bs: URSE_NT_BRES_MIN_N (LDS-resident weights from this N on, default 448),
+ * URSE_NT_WREG_MIN_N (register-resident weights for K = 224, bf16 out; default 0 = off), URSE_NT_NO_DMA (ring kernels off). */
 int urse_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                  const float* resid, int64_t ldr, int64_t M, int64_t N, int64_t K, int in_dtype, int out_dtype,
                  int act, void* stream);

@@ -1,4 +1,5 @@
 for kb in base 19 21 25 base 19 21 25; do
+# (needs variants/liburse_kb<N>.so built with: bash scripts/build_variant.sh kb<N> lstm "-DURSE_BWD_KB2_STG=<N>")
   if [ $kb = base ]; then unset URSE_LIB_PATH; else export URSE_LIB_PATH=$PWD/variants/liburse_kb$kb.so; fi
   echo -n "KB2=$kb: "; python - <<'PY'
 import os, sys, time, torch
