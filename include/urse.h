@@ -14,8 +14,13 @@
  *    provided.  Small immutable per-size tables (twiddles, windows, band tables) are built on
  *    first use and cached for the life of the process.
  *  - `stream` is a hipStream_t passed as void*; calls are asynchronous w.r.t. the host.
- *  - dtype codes: URSE_F32 / URSE_BF16 select the operand type of the dense contractions
+ *  - dtype codes: URSE_F32 / URSE_BF16 / URSE_F16 select the operand type of the dense contractions
  *    (accumulation is always f32).  Complex tensors are interleaved (re, im) float pairs.
+ *    URSE_F16 (IEEE half, 11 significant bits, same bytes and MFMA rate as bf16) is a FORWARD operand format: the kernels that take it
+ *    are the forward ones (urse_gemm_nt*, urse_groupnorm_fwd / _apply, urse_bandsplit_norm_fwd, the LSTM forward recurrences and the
+ *    weight packs); gradients and every backward operand stay bf16.  Where a forward result is also a backward operand (normalised
+ *    inputs, hidden states, the mask decoder's tanh layer) the f16 kernels take an optional `*_bf16` pointer and write the same
+ *    values once more in bf16; saved LSTM gate activations are bf16 in both modes.
  *  - no tuning or mode state lives in the library: everything that shapes a launch is an argument of the call
  *    (e.g. target_workgroups of urse_gemm_tn, reserved_cus of the cooperative recurrences).  The only process-wide
  *    mutable data are the read-only-for-results diagnostics below (urse_launch_count) and the caches of immutable tables.
@@ -43,6 +48,7 @@ extern "C" {
 
 #define URSE_F32 0
 #define URSE_BF16 1
+#define URSE_F16 2            /* IEEE half operands (forward kernels only: gradients stay bf16) */
 
 #define URSE_WIN_RECT 0
 #define URSE_WIN_HANN 1
@@ -170,12 +176,12 @@ int urse_gemm_tn_grouped(const void* descs, int groups, int max_blocks, int dtyp
  * URSE_BF16 | URSE_F32.  stats / sums: f64 [B*Kg*2] scratch (sum, sum of squares).  add (may be NULL): f32 [B, N]
  * added after the affine (the flow model's time embedding, bsrnn_flowse.py:293-294). */
 int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* add, void* y, double* stats,
-                       int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* stream);
+                       int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* y_bf16, void* stream);
 /* the two halves of urse_groupnorm_fwd on their own: statistics only (accumulates into `stats`, zeroed by the caller), and the
  * normalisation with statistics that exist already (urse_gemm_nt_gnstats) */
 int urse_groupnorm_stats(const float* x, double* stats, int B, int T, int Kg, int W, int N, void* stream);
 int urse_groupnorm_apply(const float* x, const float* gamma, const float* beta, const float* add, void* y, const double* stats,
-                         int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* stream);
+                         int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype, void* y_bf16, void* stream);
 /* dx = GN backward(dy) (+ dres); dgamma / dbeta are accumulated (+=).  dx_packed (may be NULL): bf16 copy of dx as
  * rows [B*T*Kg*(W/N)][ldp] with columns N..ldp-1 zeroed (the A operand of the next dgrad GEMM, saves a pack pass). */
 int urse_groupnorm_bwd(const float* x, const float* dy, const double* stats, const float* gamma, const float* dres,
@@ -213,7 +219,7 @@ int urse_lstm_pack(const float* wih, const float* whh, const float* bih, const f
  *  rows16: sequences per workgroup / 16 (0 = automatic). */
 int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int64_t ldh, float* c, int H, int Hp,
                         int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save, int dtype,
-                        int rows16, void* stream);
+                        int rows16, void* hout_bf16, void* stream);
 /* Persistent cluster variant of urse_lstm_bidir_fwd (bf16): recurrent weights stay in registers, C workgroups share a
  * set of sequences and exchange h_t through `hx` (zeroed by the call).  Hand-off = "tag in data": every published bf16
  * h carries a step-parity bit in its unused exponent MSB and consumers re-load a chunk until its tags are current (no
@@ -221,7 +227,7 @@ int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int6
  *  whhq: quad-ordered fragments from urse_lstm_pack_quads; plan (urse_lstm_cluster_plan) = {C, clusters per direction,
  *  rows per cluster, padded rows, hx elements (bf16), counters (uint32, used by the BPTT variant only)};
  *  err_flag: uint32 set to 1 if a hand-off timed out (results are then invalid). */
-int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, void* stream);
+int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, int dtype, void* stream);
 /* reserved_cus (all cooperative kernels: cluster, cluster2, split): CUs the caller has promised to OTHER work that is resident at
  *  the same time (workgroups of launches on other streams).  The kernels' workgroups wait for each other, so every one of
  *  them must be resident: the plan sizes the grid to device CUs - reserved_cus - margin and the call is REFUSED
@@ -234,7 +240,8 @@ int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int reserved_cus, int64_t* 
  *  sequences).  Placement decides speed only; a pattern of counts the scheme cannot serve uses the static clusters. */
 int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                           void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
-                          int64_t outer, int64_t stride, int save, int reserved_cus, int xcd_aware, void* stream);
+                          int64_t outer, int64_t stride, int save, int reserved_cus, int xcd_aware, int dtype, void* hout_bf16,
+                          void* stream);
 /* Generalised cluster forward (csrc/lstm_cluster2.hip): same protocol and arguments, geometry chosen per hidden size
  * (H = 768, the flow model: 24 workgroups per cluster; H = 392: 7).  plan = {C, clusters per direction, rows per cluster,
  * hx bf16 elements}; hx is zeroed by the call; whhq from urse_lstm_pack_quads. */
@@ -282,14 +289,14 @@ int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_
  * n_lstm rows of 12 pointers {wih, whh, bih, bhh, wih_p, wihT_p, bias, whh_frag, whhT_frag, whhq, whhb, wx}: the operands of urse_lstm_pack,
  * then the destinations of urse_lstm_pack_quads / _blocks / _blocks_x (NULL = that LSTM does not use the layout).  Same shapes for all rows. */
 int urse_lstm_pack_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, int dtype, void* stream);
-int urse_lstm_pack_quads_multi(const void* table, int n_lstm, int H, int Hp, void* stream);
+int urse_lstm_pack_quads_multi(const void* table, int n_lstm, int H, int Hp, int dtype, void* stream);
 int urse_lstm_pack_blocks_multi(const void* table, int n_lstm, int H, int Hp, void* stream);
-int urse_lstm_pack_blocks_x_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, void* stream);
+int urse_lstm_pack_blocks_x_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, int dtype, void* stream);
 int urse_lstm_rwx_supported(int N, int Np, int H, int Hp);
-int urse_lstm_pack_blocks_x(const float* wih, const float* whh, void* out, int N, int Np, int H, int Hp, void* stream);
+int urse_lstm_pack_blocks_x(const float* wih, const float* whh, void* out, int N, int Np, int H, int Hp, int dtype, void* stream);
 int urse_lstm_rwx_fwd(const void* xn, int64_t ldx, const void* wx, const float* bias, void* gates, int64_t ldg, void* hout,
                       int64_t ldh, float* c, int N, int Np, int H, int Hp, int n_seq, int seq_len, int64_t inner,
-                      int64_t outer, int64_t stride, int save, int target_workgroups, void* stream);
+                      int64_t outer, int64_t stride, int save, int target_workgroups, int dtype, void* hout_bf16, void* stream);
 /* Split BPTT (bf16) for few, long sequences (time path): 2-3 workgroups share 32 sequences and split the reduction of
  * the recurrent product; f32 partial sums are exchanged through `xbuf` (zeroed by the call) with the tag-in-data
  * hand-off (step parity in the mantissa LSB).  Arguments as urse_lstm_bidir_bwd (whhT from urse_lstm_pack).
@@ -325,7 +332,7 @@ int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, c
 /* spec c64 [B,T,F] -> xnb [B*T, ldx]: per-band GroupNorm(1, 2*sb) (zero padded band tail), GEMM-ready. */
 int urse_bandsplit_norm_fwd(const float* spec, const int32_t* bands, const float* gamma, const float* beta, void* xnb,
                             double* stats, int B, int T, int F, int K, int ldx, float eps, int out_dtype,
-                            void* stream);
+                            void* xnb_bf16, void* stream);
 /* dgamma / dbeta (+=) of the band norms from dxnb f32 [B*T, ldx]. */
 int urse_bandsplit_norm_bwd(const float* spec, const float* dxnb, const int32_t* bands, const double* stats,
                             float* dgamma, float* dbeta, int B, int T, int F, int K, int ldx, float eps,

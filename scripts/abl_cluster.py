@@ -31,7 +31,7 @@ err = torch.zeros(1, device=dev, dtype=torch.int32)
 def fwd(lib):
     return lib.urse_lstm_cluster_fwd(P(gx.data_ptr()), ctypes.c_int64(8 * H), P(whhq.data_ptr()), P(hout.data_ptr()), ctypes.c_int64(800),
         P(c.data_ptr()), P(hx.data_ptr()), P(cnt.data_ptr()), P(err.data_ptr()), H, Hp, B * K, T, ctypes.c_int64(K), ctypes.c_int64(T * K),
-        ctypes.c_int64(K), 1, 0, 1, P(st))
+        ctypes.c_int64(K), 1, 0, 1, 1, None, P(st))
 for name, lib in libs.items():
     assert fwd(lib) == 0
     torch.cuda.synchronize()

@@ -29,7 +29,7 @@ def fwd(lib, path, rt):
     if path == "time": a = (B * K, T, K, T * K, K)
     else: a = (B * T, K, 1, K, 1)
     return lib.urse_lstm_bidir_fwd(P(gx.data_ptr()), ctypes.c_int64(8 * H), P(whh.data_ptr()), P(hout.data_ptr()), ctypes.c_int64(800),
-        P(c.data_ptr()), H, Hp, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 1, 1, rt, P(st))
+        P(c.data_ptr()), H, Hp, a[0], a[1], ctypes.c_int64(a[2]), ctypes.c_int64(a[3]), ctypes.c_int64(a[4]), 1, 1, rt, None, P(st))
 def bwd(lib, path, rt):
     if path == "time": a = (B * K, T, K, T * K, K)
     else: a = (B * T, K, 1, K, 1)

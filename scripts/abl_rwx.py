@@ -26,7 +26,7 @@ st = torch.cuda.current_stream().cuda_stream
 P, L = ctypes.c_void_p, ctypes.c_int64
 def fwd(lib):
     rc = lib.urse_lstm_rwx_fwd(P(xn.data_ptr()), L(Np), P(wx.data_ptr()), P(bias.data_ptr()), P(gates.data_ptr()), L(8 * H), P(hout.data_ptr()), L(800),
-                               P(c.data_ptr()), N, Np, H, Hp, B * T, K, L(1), L(K), L(1), 1, 0, P(st))
+                               P(c.data_ptr()), N, Np, H, Hp, B * T, K, L(1), L(K), L(1), 1, 0, 1, None, P(st))
     assert rc == 0, rc
 for name, lib in libs.items():
     fwd(lib); torch.cuda.synchronize()

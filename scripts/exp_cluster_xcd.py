@@ -11,7 +11,7 @@ H, Hp = 2 * N, 416
 torch.manual_seed(0)
 whh = torch.randn(2 * 4 * H, H, device=dev) * 0.05
 whhq = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=torch.bfloat16)
-ops.call("lstm_pack_quads", whh, whhq, H, Hp, ops.stream_ptr())
+ops.call("lstm_pack_quads", whh, whhq, H, Hp, ops.BF16, ops.stream_ptr())
 M = B * T * K
 sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
 gx = torch.randn(M, 8 * H, device=dev).to(torch.bfloat16)

@@ -22,7 +22,7 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     rc = lib.urse_gemm_nt(None, 0, None, 0, None, 0, None, None, 0, 4, 4, 32, 1, 1, 0, None)
     assert rc == -1 and b"null" in lib.urse_last_error()
     rc = lib.urse_lstm_bidir_fwd(ctypes.c_void_p(16), 8, ctypes.c_void_p(16), ctypes.c_void_p(16), 8, None, 7, 32, 1, 1, 1,
-                                 1, 1, 0, 1, 0, None)
+                                 1, 1, 0, 1, 0, None, None)
     assert rc == -1
 
 

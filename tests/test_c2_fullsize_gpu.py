@@ -5,6 +5,8 @@ dispatch, no threshold lowered) - the shapes bench.py times and the small-batch 
   (a) forward in bf16 against the f32 oracle's forward on the host cores (loss <= 1e-3, waveform rel. L2 <= 1e-2), launch counters;
   (b) GPU against GPU at the same shapes: cluster forward == streaming forward, row-wave forward == wide forward (bit for bit),
       32-row BPTT == 16-row BPTT;
+  (d) FULL-LENGTH gradients: B 8 x 4 s (401 steps on the time path, default dispatch with only the sequence-COUNT thresholds of the band path
+      lowered) forward + backward against the f32 oracle's backward on the host cores;
   (c) two identical-seed runs of 5 optimisation steps: the f32 atomicAdd accumulation of the weight gradients / GroupNorm-backward
       sums makes a step non-reproducible bit for bit; the spread of the loss after 5 steps is stated and bounded."""
 import pytest
@@ -32,28 +34,44 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def test_fullsize_forward_matches_f32_oracle_and_runs_the_c2_kernels(lib):
+_ORACLE = {}
+
+
+def _fullsize_oracle():
+    """f32 oracle forward of the bench batch on the host cores (~1 min), shared by the bf16 and the f16 test"""
+    if not _ORACLE:
+        torch.manual_seed(21)
+        ref = bsrnn_ref.BSRNN_SE(N, L)
+        with torch.no_grad():
+            for n, p in ref.named_parameters():
+                if "norm" in n:
+                    p.add_(0.1 * torch.randn_like(p))
+        clean, noisy, lens = _batch()
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(min(32, max(1, nthr)))          # (more threads than that slow the oracle's LSTMs down on the GPU box's host)
+        try:
+            with torch.no_grad():
+                wav_r, _ = ref(noisy, lens, FS, False)
+                loss_r = float(losses_ref.mr_l1_loss(clean, wav_r).mean())
+        finally:
+            torch.set_num_threads(nthr)
+        _ORACLE.update(ref=ref, wav_r=wav_r, loss_r=loss_r, batch=(clean, noisy, lens))
+    return _ORACLE
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_fullsize_forward_matches_f32_oracle_and_runs_the_c2_kernels(lib, dtype):
+    """bf16: loss within 1e-3, waveform 4e-3 (8-bit operand mantissas; bounded at 1e-2); f16 (compute_dtype "f16": IEEE-half forward operands at the
+    same bytes and MFMA rate): loss AND waveform within north_star's 1e-3."""
     from urgent2026_challenge_track1_amd import ops
     from urgent2026_challenge_track1_amd.config import Config
     from urgent2026_challenge_track1_amd.d_model import SEModel
-    torch.manual_seed(21)
-    ref = bsrnn_ref.BSRNN_SE(N, L)
-    with torch.no_grad():
-        for n, p in ref.named_parameters():
-            if "norm" in n:
-                p.add_(0.1 * torch.randn_like(p))
-    model = SEModel(Config(model_configs={"num_channel": N, "num_layer": L}, compute_dtype="bf16"))
+    o = _fullsize_oracle()
+    ref, wav_r, loss_r = o["ref"], o["wav_r"], o["loss_r"]
+    clean, noisy, lens = o["batch"]
+    model = SEModel(Config(model_configs={"num_channel": N, "num_layer": L}, compute_dtype=dtype))
     model.se_model.load_state_dict(ref.state_dict())
     model = model.cuda()
-    clean, noisy, lens = _batch()
-    nthr = torch.get_num_threads()
-    torch.set_num_threads(min(32, max(1, nthr)))          # (more threads than that slow the oracle's LSTMs down on the GPU box's host)
-    try:
-        with torch.no_grad():
-            wav_r, _ = ref(noisy, lens, FS, False)
-            loss_r = float(losses_ref.mr_l1_loss(clean, wav_r).mean())
-    finally:
-        torch.set_num_threads(nthr)
     ops.launch_counts(reset=True)
     wav = model.se_model(noisy.cuda(), lens, FS)[0]
     loss = ops.mr_l1_loss(clean.cuda(), wav).mean()
@@ -70,11 +88,14 @@ def test_fullsize_forward_matches_f32_oracle_and_runs_the_c2_kernels(lib):
     l2 = _rel(wav_c, wav_r)
     e_max = float((wav_c - wav_r).abs().max() / wav_r.abs().max())
     gsum = float(model.se_model.core.flat_grads.double().abs().sum())
-    print("C2 full size: loss %.2e, wav rel. L2 %.2e, max / peak %.2e" % (e_loss, l2, e_max))
-    parity_log.record("bf16_fullsize_forward_vs_f32_oracle", loss_rel=e_loss, wav_rel_l2=l2, wav_max_over_peak=e_max,
+    print("C2 full size, %s: loss %.2e, wav rel. L2 %.2e, max / peak %.2e" % (dtype, e_loss, l2, e_max))
+    parity_log.record("%s_fullsize_forward_vs_f32_oracle" % dtype, loss_rel=e_loss, wav_rel_l2=l2, wav_max_over_peak=e_max,
                       shape="B32 x 4 s @ 48 kHz, N=196, L=6, default dispatch",
                       launch_counts={k: v for k, v in counts.items() if v})
-    assert e_loss <= 1e-3 and l2 <= 1e-2, (e_loss, l2, e_max)
+    if dtype == "f16":
+        assert e_loss <= 1e-3 and l2 <= 1e-3 and e_max <= 1e-3, (e_loss, l2, e_max)      # north_star's tolerance
+    else:
+        assert e_loss <= 1e-3 and l2 <= 1e-2, (e_loss, l2, e_max)
     assert gsum > 0 and gsum == gsum
 
 
@@ -180,3 +201,64 @@ def test_fullsize_training_is_reproducible_within_a_stated_bound(lib):
                       abs_weight_sum_rel_spread=w_spread, losses_run0=[firsts[0], finals[0]], losses_run1=[firsts[1], finals[1]])
     assert first_spread <= 1e-6            # the forward has no atomics: the first loss is reproducible to f32 round-off of the reduction
     assert final_spread <= 2e-2 and w_spread <= 1e-5, (final_spread, w_spread)
+
+
+def test_full_length_gradients_match_f32_oracle(lib, monkeypatch):
+    """VERDICT r4, missing 3: gradients vs the oracle stopped at B6 x 1 s = 101 steps.  Here 401 steps (4 s @ 48 kHz), B = 8: the time path
+    (272 sequences x 401 steps) runs the cluster forward and the N-split BPTT exactly as at B = 32; the band path has 3,208 sequences instead of
+    12,832, so the two thresholds that depend on the NUMBER of sequences are lowered (row-wave forward >= 6,144, 32-row BPTT >= 4,096) - never the
+    length.  Reference step: baseline_code/d_model.py:61-89."""
+    from urgent2026_challenge_track1_amd import ops
+    from urgent2026_challenge_track1_amd.config import Config
+    from urgent2026_challenge_track1_amd.d_model import SEModel
+    Bg = 8
+    monkeypatch.setattr(ops, "RW_MIN_SEQ", 1)
+    monkeypatch.setattr(ops, "BWD_ROWS16", {"f": 2 | 16})
+    torch.manual_seed(23)
+    ref = bsrnn_ref.BSRNN_SE(N, L)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    model = SEModel(Config(model_configs={"num_channel": N, "num_layer": L}, compute_dtype="bf16"))
+    model.se_model.load_state_dict(ref.state_dict())
+    model = model.cuda()
+    g = torch.Generator().manual_seed(6)
+    Ls = int(SECONDS * FS)
+    clean = 0.3 * torch.randn(Bg, Ls, generator=g)
+    noisy = clean + 0.1 * torch.randn(Bg, Ls, generator=g)
+    lens = torch.full((Bg,), Ls, dtype=torch.int32)
+    lens[2] = Ls - 7000
+    wav_r, _ = ref(noisy, lens, FS, False)
+    loss_r = losses_ref.mr_l1_loss(clean, wav_r).mean()
+    loss_r.backward()
+    ops.launch_counts(reset=True)
+    wav = model.se_model(noisy.cuda(), lens, FS)[0]
+    loss = ops.mr_l1_loss(clean.cuda(), wav).mean()
+    loss.backward()
+    model.se_model.core._flush_deferred_wgrads()
+    torch.cuda.synchronize()
+    ops.poll_kernel_errors(torch.device("cuda", torch.cuda.current_device()), sync=True)
+    counts = ops.launch_counts()
+    for k in ("lstm_fwd_cluster", "lstm_fwd_rwx", "lstm_bwd_nsplit", "lstm_bwd_stream32", "tn_dual", "nt_bres", "stft960"):
+        assert counts[k] > 0, (k, counts)
+    mine = dict(model.se_model.named_parameters())
+    worst, wn, per_group = 0.0, None, {}
+    num = den = 0.0
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        gm = mine[n].grad.cpu()
+        r = _rel(gm, p.grad)
+        num += float((gm - p.grad).double().pow(2).sum()); den += float(p.grad.double().pow(2).sum())
+        key = n.split(".")[2] if n.startswith("bsrnn.bsrnn.") else n
+        per_group[key] = max(per_group.get(key, 0.0), r)
+        if r > worst:
+            worst, wn = r, n
+    e_loss = abs(float(loss) - float(loss_r)) / abs(float(loss_r))
+    l2 = _rel(wav.detach().cpu(), wav_r.detach())
+    print("C2 full length (B8 x 4 s): loss %.2e, wav rel. L2 %.2e, worst grad rel. L2 %.2e (%s), all grads %.2e" % (e_loss, l2, worst, wn, (num / den) ** 0.5), per_group)
+    parity_log.record("bf16_full_length_gradients_vs_f32_oracle", shape="B8 x 4 s @ 48 kHz (401 steps), N=196, L=6", loss_rel=e_loss, wav_rel_l2=l2,
+                      worst_grad_rel_l2=worst, worst_grad=wn, all_grads_rel_l2=(num / den) ** 0.5, worst_by_module=per_group)
+    # bf16 operands (8 significant bits) through 6 layers x 401 steps: bounds = 2x observed (profiles/r05_c2_parity*.json)
+    assert e_loss <= 1e-3 and l2 <= 1e-2 and worst <= 6e-2, (e_loss, l2, worst, wn)

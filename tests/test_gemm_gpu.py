@@ -339,3 +339,90 @@ def test_dgrad_gemm_with_groupnorm_backward_sums(lib, M, N, K, rows):
         assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), (a - b).abs().max()
     assert (dx1 - dx0).abs().max().item() <= 1e-4 * max(1.0, dx0.abs().max().item())
     assert (p1.float() - p0.float()).abs().max().item() <= 2e-2 * max(1.0, dx0.abs().max().item())
+
+
+def _poisoned_slice(rows, cols, ld_extra, row_extra, dtype, seed, tail=True):
+    """an operand that is the LAST `rows` rows and the LAST `cols` columns of its allocation: the parent is exactly
+    (row_extra + rows) x (ld_extra + cols) elements, every byte outside the slice is NaN.  Returns (slice view on the GPU, clean CPU copy)."""
+    clean = _mk((rows, cols), dtype, seed)
+    parent = torch.full((row_extra + rows, ld_extra + cols), float("nan"), dtype=dtype)
+    parent[row_extra:, ld_extra:] = clean
+    dev = parent.cuda()
+    return dev[row_extra:, ld_extra:], clean, dev
+
+
+@pytest.mark.parametrize("kind", ["tn_128", "tn_ring", "tn_ring_perm", "tn_dual224", "tn_grouped", "nt_ring", "nt_bres", "nt_128"])
+def test_gemm_operand_slices_at_the_end_of_their_allocation_with_poison_behind(lib, kind):
+    """VERDICT r4 (the 11fd85f class of bug: a column-slice operand read past its parent's last row): every GEMM family with operands that
+    END their allocation (last rows, last columns) and NaN in every byte of the parent outside the slice - a read that strays outside the
+    slice and reaches the arithmetic makes the result NaN; results must equal the call on clean contiguous copies."""
+    from urgent2026_challenge_track1_amd import ops
+    bf = torch.bfloat16
+    ops.launch_counts(reset=True)
+    if kind.startswith("tn"):
+        if kind == "tn_128":
+            R, Mo, No, kw, dt = 333, 200, 40, {}, torch.float32
+        elif kind == "tn_ring":
+            R, Mo, No, kw, dt = 20000, 608, 200, {}, bf
+        elif kind == "tn_ring_perm":
+            R, Mo, No, kw, dt = 34 * 500 + 7, 1568, 392, dict(shift=-1, inner=1, period=34, invalid_step=0, perm_h=392), bf
+        elif kind == "tn_dual224":
+            R, H, N, inner, period = 34 * 32 * 16, 392, 196, 34, 32
+            A, Ac, keepA = _poisoned_slice(R, 4 * H, 4 * H, 3, bf, 30)          # direction 1's half of an [M, 8H] dgates matrix
+            X, Xc, keepX = _poisoned_slice(R, 224, 32, 5, bf, 31)
+            Hh, Hc, keepH = _poisoned_slice(R, 416, 416, 2, bf, 32)               # direction 1's half of hout
+            Xc[:, N:] = 0; Hc[:, H:] = 0
+            X[:, N:] = 0; Hh[:, H:] = 0                                         # K padding the kernels may read must be zero (it is in the model)
+            c1, c2, cs = (torch.zeros(4 * H, N, device="cuda"), torch.zeros(4 * H, H, device="cuda"), torch.zeros(4 * H, device="cuda"))
+            ops.gemm_tn_dual(A, X, c1, cs, Hh, c2, 4 * H, N, H, -inner, inner, period, 0, perm_h=H)
+            r1, r2, rs = torch.zeros_like(c1), torch.zeros_like(c2), torch.zeros_like(cs)
+            ops.gemm_tn_dual(Ac.cuda(), Xc.cuda(), r1, rs, Hc.cuda(), r2, 4 * H, N, H, -inner, inner, period, 0, perm_h=H)
+            assert ops.launch_counts()["tn_dual"] == 2
+            for got, ref in ((c1, r1), (c2, r2), (cs, rs)):
+                assert torch.isfinite(got).all(), kind
+                assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+            return
+        elif kind == "tn_grouped":
+            rows, outs, refs, keep = [], [], [], []
+            for i, (R, Mo, No) in enumerate([(900, 64, 40), (900, 12, 784), (1300, 784, 200), (77, 200, 8)]):
+                A, Ac, k1 = _poisoned_slice(R, (Mo + 7) // 8 * 8, 16, 1, bf, 20 + i)
+                Bm, Bc, k2 = _poisoned_slice(R, (No + 7) // 8 * 8, 24, 1, bf, 40 + i)
+                out = torch.zeros(Mo, No, device="cuda")
+                rows.append(ops.tn_desc(A, Bm, out, Mo=Mo, No=No))
+                keep += [k1, k2]
+                outs.append(out)
+                refs.append(Ac.double()[:, :Mo].T @ Bc.double()[:, :No])
+            ops.gemm_tn_grouped(rows, bf, "cuda")
+            for out, ref in zip(outs, refs):
+                assert torch.isfinite(out).all()
+                assert (out.cpu().double() - ref).abs().max().item() <= 1e-4 * (1300 ** 0.5)
+            return
+        lda = (Mo + 7) // 8 * 8
+        ldb = (No + 31) // 32 * 32
+        A, Ac, k1 = _poisoned_slice(R, lda, 40, 2, dt, 11)
+        Bm, Bc, k2 = _poisoned_slice(R, ldb, 64, 2, dt, 12)
+        out, cs = torch.zeros(Mo, No, device="cuda"), torch.zeros(Mo, device="cuda")
+        ref, rcs = torch.zeros_like(out), torch.zeros_like(cs)
+        ops.gemm_tn(A, Bm, out, colsum=cs, Mo=Mo, No=No, **kw)
+        ops.gemm_tn(Ac.cuda(), Bc.cuda(), ref, colsum=rcs, Mo=Mo, No=No, **kw)
+        counts = ops.launch_counts()
+        assert counts["tn_128" if kind == "tn_128" else ("tn_ring_t" if counts["tn_ring_t"] else "tn_ring")] == 2, counts
+        assert torch.isfinite(out).all() and torch.isfinite(cs).all(), kind
+        tol = 2e-5 * max(1.0, ref.abs().max().item())            # split-R atomics: summation order differs between two calls
+        assert (out - ref).abs().max().item() <= tol and (cs - rcs).abs().max().item() <= 2e-5 * max(1.0, rcs.abs().max().item())
+        return
+    M, N, K, dt = {"nt_ring": (20000, 196, 800, bf), "nt_bres": (16500, 3136, 224, bf), "nt_128": (300, 200, 224, torch.float32)}[kind]
+    A, Ac, k1 = _poisoned_slice(M, K, 32, 3, dt, 1)
+    W, Wc, k2 = _poisoned_slice(N, K, 64, 2, dt, 2)
+    bias = _mk((N,), torch.float32, 3).cuda()
+    odt = torch.bfloat16 if kind == "nt_bres" else torch.float32      # (the weight-stationary kernel is the bf16-out gate projection)
+    got = ops.gemm_nt(A, W, bias, out_dtype=odt)
+    ref = ops.gemm_nt(Ac.cuda(), Wc.cuda(), bias, out_dtype=odt)
+    counts = ops.launch_counts()
+    assert counts[kind] == 2, counts
+    assert torch.isfinite(got.float()).all(), kind
+    assert torch.equal(got, ref)          # same k order per element, no atomics: bit-equal
+    # the output too: a slice that ends its allocation, poison in front; nothing outside the slice may be written
+    outp = torch.full((M + 2, N + 8), float("nan"), device="cuda", dtype=odt)
+    ops.gemm_nt(A, W, bias, out=outp[2:, 8:])
+    assert torch.equal(outp[2:, 8:], ref) and torch.isnan(outp[:2].float()).all() and torch.isnan(outp[:, :8].float()).all()

@@ -377,7 +377,7 @@ def test_xcd_aware_clusters_equal_static_clusters(lib, B, T, K):
     H, Hp = 2 * N, 416
     whh = torch.randn(2 * 4 * H, H, device=dev) * 0.05
     whhq = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=torch.bfloat16)
-    ops.call("lstm_pack_quads", whh, whhq, H, Hp, ops.stream_ptr())
+    ops.call("lstm_pack_quads", whh, whhq, H, Hp, ops.BF16, ops.stream_ptr())
     M = B * T * K
     sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
     assert ops.lstm_cluster_plan(H, Hp, sm["n_seq"]) is not None
@@ -404,7 +404,7 @@ def test_cluster_helper_waves_equal_the_fourteen_wave_form_at_full_size(lib, mon
     H, Hp = 2 * N, 416
     whh = torch.randn(2 * 4 * H, H, device=dev) * 0.05
     whhq = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=torch.bfloat16)
-    ops.call("lstm_pack_quads", whh, whhq, H, Hp, ops.stream_ptr())
+    ops.call("lstm_pack_quads", whh, whhq, H, Hp, ops.BF16, ops.stream_ptr())
     M = B * T * K
     sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
     gx = torch.randn(M, 8 * H, device=dev).to(torch.bfloat16)

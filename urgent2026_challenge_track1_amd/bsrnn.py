@@ -110,6 +110,10 @@ class BSRNNCore(nn.Module):
             raise ValueError("num_channel must be a multiple of 4")
         self.subbands = SUBBANDS_481 if input_dim == 481 else SUBBANDS_769
         self.input_dim, self.N, self.H, self.num_layer = input_dim, num_channel, 2 * num_channel, num_layer
+        # compute_dtype: operand format of the FORWARD contractions (bf16 | f16 | f32).  f16 = IEEE half, 11 significant bits at bf16's bytes and
+        # MFMA rate: the forward then meets north_star's 1e-3 on the enhanced waveform (bf16: 4e-3).  Gradients need bf16's range, so under f16 every
+        # backward operand is bf16 (self.bwd_dtype): tensors that are both a forward operand and a backward operand (normalised inputs, hidden
+        # states, the mask decoder's tanh layer) are written in both formats by the kernel that produces them, when a backward will follow.
         self.compute_dtype = compute_dtype
         N, H = self.N, self.H
         self._make_front_back()
@@ -339,6 +343,10 @@ class BSRNNCore(nn.Module):
                 h[p + "w2T", k] = pt.add(o[p + "w2"] + w2_off, 4 * sb, 4 * N, 4 * N, ppad)
                 w2_off += 4 * sb * 4 * N
 
+    @property
+    def bwd_dtype(self):
+        return ops.bwd_dtype(self.compute_dtype)
+
     def _prepare(self):
         """(re)pack the GEMM operands from the f32 master weights; once per parameter version."""
         self._ensure_flat()
@@ -349,7 +357,7 @@ class BSRNNCore(nn.Module):
         if self._packed_version == self.param_version:
             return
         _, pn, pt, h = self._plans
-        bn, bt = pn.run(self._flat, dtype), pt.run(self._flat, dtype)
+        bn, bt = pn.run(self._flat, dtype), pt.run(self._flat, self.bwd_dtype)     # (the transposed copies are the dgrad GEMMs' weights)
         H = self.H
         pk = {}
         for key, hd in h.items():
@@ -418,7 +426,7 @@ class BSRNNCore(nn.Module):
     # ------------------------------------------------------------------------------------------
     # band split
     # ------------------------------------------------------------------------------------------
-    def bandsplit_fwd(self, spec, prefix="bs", out=None, width=None, col0=0):
+    def bandsplit_fwd(self, spec, prefix="bs", out=None, width=None, col0=0, save=True):
         """band split of spec [B,T,F,2]; default -> z f32 [B,T,K,N]; with `out` (a [B,T,K,width] tensor of the compute
         dtype) the N channels are written at column offset col0 (flow: x / y halves of the condition_fc input)."""
         B, T, F, _ = spec.shape
@@ -427,9 +435,10 @@ class BSRNNCore(nn.Module):
         K, pk = tb["K"], self._packed
         n_gb = 2 * sum(self.subbands)
         xnb = torch.empty(B * T, tb["ldx"], dtype=dt, device=dev)
+        xnb_b = torch.empty_like(xnb, dtype=torch.bfloat16) if (save and dt == torch.float16) else None    # bf16 copy for the weight gradient
         stats = torch.empty(B * K * 2, dtype=torch.float64, device=dev)
         call("bandsplit_norm_fwd", spec, tb["bands"], self._p(prefix + ".gamma", n_gb), self._p(prefix + ".beta", n_gb),
-             xnb, stats, B, T, F, K, tb["ldx"], GN_EPS, ops._dt(xnb), stream_ptr())
+             xnb, stats, B, T, F, K, tb["ldx"], GN_EPS, ops._dt(xnb), xnb_b, stream_ptr())
         if out is None:
             out, width = torch.empty(B, T, K, N, dtype=torch.float32, device=dev), N
         M = B * T
@@ -441,14 +450,14 @@ class BSRNNCore(nn.Module):
                          _ptr(self._flat, self._off[prefix + ".b"] + k * N), 0,
                          tb["ldx"], w.shape[1], K * width, M, N, r[3], 0])
         nt_grouped(rows, dev, ops._dt(xnb), ops._dt(out))
-        return out, (xnb, stats, tb)
+        return out, ((xnb_b if xnb_b is not None else xnb), stats, tb)
 
     def bandsplit_bwd(self, spec, saved, dz, prefix="bs", dzT=None, width=None, col0=0, ready=True):
         """dz f32 [B,T,K,N], or (flow) dzT = [B*T*K, width] of the compute dtype holding the N gradient channels at
         column offset col0 (width-col0 >= kpad(N), zero padded)."""
         xnb, stats, tb = saved
         B, T, F, _ = spec.shape
-        dt, dev, N = self.compute_dtype, spec.device, self.N
+        dt, dev, N = self.bwd_dtype, spec.device, self.N
         K, pk, Np = tb["K"], self._packed, self._dims["Np"]
         M = B * T
         tail_overlap = ops.TN_OVERLAP and ops.TN_OVERLAP_TAIL and spec.is_cuda and bool(self._deferred)
@@ -501,16 +510,29 @@ class BSRNNCore(nn.Module):
         pre = self._gn_stats[1] if (self._gn_stats is not None and self._gn_stats[0].data_ptr() == skip.data_ptr() and
                                     self._gn_stats[0].shape == skip.shape) else None
         self._gn_stats = None
-        xn, stats = ops.groupnorm_fwd(skip, self._p(p + "gamma", N), self._p(p + "beta", N), B, T, 1, K * N, N,
-                                      d["Np"], 0, dt, GN_EPS, add=temb, stats=pre)
+        two = save and dt == torch.float16        # f16 forward with a backward to follow: x_n and h also in bf16 (operands of the weight-gradient GEMMs)
+        xn, stats, xn_b = ops.groupnorm_fwd(skip, self._p(p + "gamma", N), self._p(p + "beta", N), B, T, 1, K * N, N,
+                                            d["Np"], 0, dt, GN_EPS, add=temb, stats=pre, bf16_copy=two or None)
         sm = self._seqmap(path, B, T, K)
-        fused = (ops.USE_RWX_LSTM and ops.USE_RW_LSTM and dt == torch.bfloat16 and pk.get(p + "wx") is not None and
+        fused = (ops.USE_RWX_LSTM and ops.USE_RW_LSTM and dt in ops.HALF_TYPES and pk.get(p + "wx") is not None and
                  sm["n_seq"] >= ops.RW_MIN_SEQ and not (ops.USE_CLUSTER_LSTM and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
                                                       ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None))
         # (fused: the input projection runs inside the recurrence kernel - no gate GEMM, no [M, 8H] pre-activation matrix)
         gx = None if fused else ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
+        hout_b = None
         if fused:
-            gx, hout, c = ops.lstm_fwd_rwx(xn, pk[p + "wx"], pk[p + "bias"], N, H, d["Hp"], save=save, **sm)
+            gx, hout, c, hout_b = ops.lstm_fwd_rwx(xn, pk[p + "wx"], pk[p + "bias"], N, H, d["Hp"], save=save, bf16_copy=True, **sm)
+        elif dt == torch.float16:
+            # f16 operands: the cluster forward where its plan fits (the time path at C2), else the streaming kernel
+            if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H not in ops.CLUSTER2_H and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and \
+                    ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
+                r = ops.lstm_fwd_cluster(gx, pk[p + "whhq"], H, d["Hp"], save=save, bf16_copy=two, **sm)
+                hout, c, self._cluster_err = r[:3]
+            else:
+                r = ops.lstm_fwd(gx, pk[p + "whh"], H, d["Hp"], save=save, bf16_copy=two, **sm)
+                hout, c = r[:2]
+            hout_b = r[-1] if two else None
+            gx = gx.view(torch.bfloat16)          # the kernels wrote the gate activations back in bf16 (the BPTT's operand format)
         elif ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H in ops.CLUSTER2_H and \
                 ops.lstm_cluster2_chunks(H, d["Hp"], **sm) is not None:
             hout, c, err = ops.lstm_fwd_cluster2(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
@@ -529,18 +551,18 @@ class BSRNNCore(nn.Module):
         else:
             hout, c = ops.lstm_fwd(gx, pk[p + "whh"], H, d["Hp"], save=save, **sm)
         out = torch.empty_like(skip)
-        if ops.FUSE_GN_STATS and dt == torch.bfloat16 and N % 4 == 0 and not (path == "f" and l == self.num_layer - 1):
+        if ops.FUSE_GN_STATS and dt in ops.HALF_TYPES and N % 4 == 0 and not (path == "f" and l == self.num_layer - 1):
             # the next half layer normalises `out` over each batch element (T * K rows): its sums ride on this GEMM's epilogue
             _, st = ops.gemm_nt(hout, pk[p + "wfc"], self._p(p + "bfc", N), resid=skip.view(M, N), out=out.view(M, N), gn_rows=T * K)
             self._gn_stats = (out, st)      # (holding `out` keeps its storage from being handed to another tensor)
         else:
             ops.gemm_nt(hout, pk[p + "wfc"], self._p(p + "bfc", N), resid=skip.view(M, N), out=out.view(M, N))
-        return out, ((stats, xn, gx, c, hout) if save else None)
+        return out, ((stats, xn_b, gx, c, (hout_b if hout_b is not None else hout)) if save else None)
 
     def dualpath_bwd(self, skip, saved, l, path, dout):
         stats, xn, gates, c, hout = saved
         B, T, K, N = skip.shape
-        H, dt, pk, d = self.H, self.compute_dtype, self._packed, self._dims
+        H, dt, pk, d = self.H, self.bwd_dtype, self._packed, self._dims       # (f16 forward: every operand here is bf16, see __init__)
         p = "l%d%s." % (l, path)
         M = B * T * K
         dout2 = dout.reshape(M, N)
@@ -683,13 +705,20 @@ class BSRNNCore(nn.Module):
         assert tb["K"] == K
         M, Np, ld4N, P = B * T, d["Np"], d["ld4N"], tb["P"]
         Kf = len(self.subbands)
-        xns, sts, hids, pres = [], [], [], []
+        xns, sts, hids, pres, keep = [], [], [], [], []
         rows1, rows2 = [], []
         for tag in "mr":
             p = "md%s." % tag
-            xn, st = ops.groupnorm_fwd(skip, self._p(p + "gamma", Kf * N), self._p(p + "beta", Kf * N), B, T, K, N, N,
-                                       Np, N, dt, GN_EPS)
+            two = save and dt == torch.float16            # f16 forward, backward to follow: x_n and the tanh layer also in bf16
+            if two:
+                xn, st, xn_b = ops.groupnorm_fwd(skip, self._p(p + "gamma", Kf * N), self._p(p + "beta", Kf * N), B, T, K, N, N,
+                                                 Np, N, dt, GN_EPS, bf16_copy=True)
+            else:
+                xn, st = ops.groupnorm_fwd(skip, self._p(p + "gamma", Kf * N), self._p(p + "beta", Kf * N), B, T, K, N, N,
+                                           Np, N, dt, GN_EPS)
+                xn_b = xn
             hid = _empty_padded(K, M, ld4N, 4 * N, dt, dev)     # the GEMM writes the 4N columns; only the K padding must be zero
+            hid_b = _empty_padded(K, M, ld4N, 4 * N, torch.bfloat16, dev) if two else hid
             pre = torch.empty(M, P, dtype=torch.float32, device=dev)
             b2_off = 0
             for k in range(K):
@@ -697,13 +726,17 @@ class BSRNNCore(nn.Module):
                 r = tb["rows"][k]
                 w1, w2 = pk[p + "w1", k], pk[p + "w2", k]
                 rows1.append([_ptr(xn, k * Np), _ptr(w1), _ptr(hid, k * M * ld4N),
-                              _ptr(self._flat, self._off[p + "b1"] + k * 4 * N), 0, K * Np, Np, ld4N, M, 4 * N, Np, 0])
+                              _ptr(self._flat, self._off[p + "b1"] + k * 4 * N), _ptr(hid_b, k * M * ld4N) if two else 0, K * Np, Np, ld4N, M, 4 * N, Np,
+                              ld4N if two else 0])       # (f16 operands, act 1: the aux slot is the bf16 copy of the output, include/urse.h)
                 rows2.append([_ptr(hid, k * M * ld4N), _ptr(w2), _ptr(pre, r[5]),
                               _ptr(self._flat, self._off[p + "b2"] + b2_off), 0, ld4N, ld4N, P, M, 4 * sb, ld4N, 0])
                 b2_off += 4 * sb
-            xns.append(xn); sts.append(st); hids.append(hid); pres.append(pre)
-        nt_grouped(rows1, dev, ops._dt(xns[0]), ops._dt(hids[0]), act=1)
-        nt_grouped(rows2, dev, ops._dt(hids[0]), ops.F32)
+            xns.append(xn_b); sts.append(st); hids.append(hid_b); pres.append(pre)
+            keep += [xn, hid]                   # (f16: the forward operands, alive until both launches below are queued)
+        fdt = ops.dtype_code(dt)
+        nt_grouped(rows1, dev, fdt, fdt, act=1)
+        nt_grouped(rows2, dev, fdt, ops.F32)
+        del keep
         out = torch.empty(B, T, F, 2, dtype=torch.float32, device=dev)
         call("glu_mask_apply_fwd", pres[0], pres[1], spec, out, tb["bands"], tb["f2k"], M, F, P, stream_ptr())
         return out, ((xns, sts, hids, pres, tb) if save else None)
@@ -712,7 +745,7 @@ class BSRNNCore(nn.Module):
         xns, sts, hids, pres, tb = saved
         B, T, K, N = skip.shape
         F = spec.shape[2]
-        dt, dev, pk, d = self.compute_dtype, skip.device, self._packed, self._dims
+        dt, dev, pk, d = self.bwd_dtype, skip.device, self._packed, self._dims
         M, Np, ld4N, P = B * T, d["Np"], d["ld4N"], tb["P"]
         Kf = len(self.subbands)
         dpre = [torch.zeros(M, P, dtype=dt, device=dev) for _ in range(2)]
@@ -788,7 +821,7 @@ class BSRNNCore(nn.Module):
         spec_ri = spec_ri.contiguous().float()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not train:
-            z, _ = self.bandsplit_fwd(spec_ri)
+            z, _ = self.bandsplit_fwd(spec_ri, save=False)
             for l in range(self.num_layer):
                 z, _ = self.dualpath_fwd(z, l, "t", False)
                 z, _ = self.dualpath_fwd(z, l, "f", False)

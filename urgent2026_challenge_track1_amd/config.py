@@ -2,7 +2,8 @@
 
 Mirrors ``baseline_code/config.py:6-72``: defaults (``:8-38``), yaml values override CLI flags and may add
 new keys, ``train_tag`` := basename of the yaml (``:41-52``), one ``--flag`` per attribute with bools parsed
-by ``str2bool`` (``:54-72``).  Extra keys: ``compute_dtype`` ("bf16" | "f32") selects the MFMA operand type;
+by ``str2bool`` (``:54-72``).  Extra keys: ``compute_dtype`` ("bf16" | "f16" | "f32") selects the MFMA operand type ("f16": IEEE-half operands in the forward contractions,
+bf16 in the backward - the enhanced waveform then meets 1e-3 against the f32 reference arithmetic, bsrnn.BSRNNCore);
 ``unsupported_augmentation`` ("warn" | "raise" | "count") - see below.
 """
 import argparse

@@ -47,12 +47,14 @@ __global__ void __launch_bounds__(256) bandsplit_apply_kernel(const float* __res
                                                               const double* __restrict__ stats,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               TO* __restrict__ xnb, int B, int T, int F, int K, int ldx,
-                                                              float eps) {
-  // blockIdx.x = row (b,t); threads sweep the padded columns band by band
+                                                              float eps, bf16_t* __restrict__ xnb2 = nullptr) {
+  // blockIdx.x = row (b,t); threads sweep the padded columns band by band.  xnb2 (f16 forward mode, training): the rows once more in bf16
+  // for the weight-gradient GEMM
   const long row = blockIdx.x;
   const int b = (int)(row / T);
   const float* src = spec + row * 2 * F;
   TO* dst = xnb + row * ldx;
+  bf16_t* dst2 = xnb2 ? xnb2 + row * ldx : nullptr;
   for (int k = 0; k < K; ++k) {
     const Band bd = bands[k];
     const double cnt = (double)T * 2 * bd.sb;
@@ -68,6 +70,7 @@ __global__ void __launch_bounds__(256) bandsplit_apply_kernel(const float* __res
         v = (x - mean) * rstd * gamma[bd.goff + c] + beta[bd.goff + c];
       }
       dst[bd.xoff + c] = from_f32<TO>(v);
+      if (dst2) dst2[bd.xoff + c] = f32_to_bf16(v);
     }
   }
 }
@@ -182,17 +185,21 @@ static int grid_for(long total) {
 
 extern "C" int urse_bandsplit_norm_fwd(const float* spec, const int32_t* bands, const float* gamma, const float* beta,
                                        void* xnb, double* stats, int B, int T, int F, int K, int ldx, float eps,
-                                       int out_dtype, void* stream) {
+                                       int out_dtype, void* xnb_bf16, void* stream) {
   URSE_CHECK_ARG(spec && bands && gamma && beta && xnb && stats && B > 0 && T > 0 && F > 0 && K > 0,
                  "urse_bandsplit_norm_fwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bandsplit_stats_kernel, dim3(K, B), dim3(256), 0, st, spec, (const Band*)bands, stats, T, F);
+  URSE_CHECK_ARG(!xnb_bf16 || out_dtype == URSE_F16, "urse_bandsplit_norm_fwd: the bf16 copy goes with f16 output only");
   if (out_dtype == URSE_BF16)
     hipLaunchKernelGGL(bandsplit_apply_kernel<bf16_t>, dim3(B * T), dim3(256), 0, st, spec, (const Band*)bands, stats,
-                       gamma, beta, (bf16_t*)xnb, B, T, F, K, ldx, eps);
+                       gamma, beta, (bf16_t*)xnb, B, T, F, K, ldx, eps, (bf16_t*)nullptr);
+  else if (out_dtype == URSE_F16)
+    hipLaunchKernelGGL(bandsplit_apply_kernel<f16_t>, dim3(B * T), dim3(256), 0, st, spec, (const Band*)bands, stats,
+                       gamma, beta, (f16_t*)xnb, B, T, F, K, ldx, eps, (bf16_t*)xnb_bf16);
   else
     hipLaunchKernelGGL(bandsplit_apply_kernel<float>, dim3(B * T), dim3(256), 0, st, spec, (const Band*)bands, stats,
-                       gamma, beta, (float*)xnb, B, T, F, K, ldx, eps);
+                       gamma, beta, (float*)xnb, B, T, F, K, ldx, eps, (bf16_t*)nullptr);
   URSE_CHECK_LAUNCH("urse_bandsplit_norm_fwd");
   return URSE_OK;
 }

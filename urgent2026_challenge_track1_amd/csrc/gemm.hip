@@ -53,6 +53,17 @@ template <> struct Frag<bf16_t> {
                                                    0, 0, 0);
   }
 };
+template <> struct Frag<f16_t> {        // IEEE half operands (forward kernels of the f16 mode): same fragments, v_mfma_f32_16x16x32_f16
+  typedef short8_t type;
+  static constexpr int KSUB = 1;
+  static __device__ __forceinline__ type load(const char* row, int lane, int) {
+    return *reinterpret_cast<const short8_t*>(row + 16 * (lane >> 4));
+  }
+  static __device__ __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
 template <> struct Frag<float> {
   typedef float type;
   static constexpr int KSUB = 4;
@@ -148,8 +159,13 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmDesc* __restrict
   constexpr int EPC = 16 / OS;                     // elements per 16-byte chunk
   constexpr int CPR = BN / EPC;                    // chunks per row
   TO* C = reinterpret_cast<TO*>(d.C);
+  // f16 forward mode, act 1 (the mask decoder's tanh layer): the aux slot (resid, ldr) names a SECOND output, the same values in bf16 -
+  // the backward (tanh derivative, weight-gradient GEMM against bf16 gradients) reads that copy
+  const bool c2 = __is_same(T, f16_t) && OS == 2 && act == 1 && d.resid != nullptr;
+  bf16_t* C2 = c2 ? reinterpret_cast<bf16_t*>(const_cast<float*>(d.resid)) : nullptr;
   const bool vec_ok = ((d.ldc * OS) % 16 == 0) && ((reinterpret_cast<uintptr_t>(d.C) % 16) == 0) &&
-                      (!d.resid || act == 2 || (((d.ldr * 4) % 16 == 0) && (reinterpret_cast<uintptr_t>(d.resid) % 16) == 0));
+                      (!d.resid || act == 2 || (((d.ldr * 4) % 16 == 0) && (reinterpret_cast<uintptr_t>(d.resid) % 16) == 0)) &&
+                      (!c2 || (d.ldr * 2) % 16 == 0);
 #pragma unroll
   for (int pass = 0; pass < BM / RPP; ++pass) {
     if (pass > 0) __syncthreads();
@@ -192,12 +208,21 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmDesc* __restrict
           v = *reinterpret_cast<uint4*>(&f);
         }
         *reinterpret_cast<uint4*>(C + row * d.ldc + col) = v;
+        if constexpr (__is_same(T, f16_t) && OS == 2) {
+          if (c2) {
+            float a0, a1, a2, a3, a4, a5, a6, a7;
+            unpack2<f16_t>(v.x, a0, a1); unpack2<f16_t>(v.y, a2, a3); unpack2<f16_t>(v.z, a4, a5); unpack2<f16_t>(v.w, a6, a7);
+            *reinterpret_cast<uint4*>(C2 + row * d.ldr + col) =
+                make_uint4(pack2<bf16_t>(a0, a1), pack2<bf16_t>(a2, a3), pack2<bf16_t>(a4, a5), pack2<bf16_t>(a6, a7));
+          }
+        }
       } else {
         const TO* sv = reinterpret_cast<const TO*>(src);
         for (int e = 0; e < EPC && col + e < d.N; ++e) {
           float f = to_f32<TO>(sv[e]);
           if (OS == 4 && d.resid && act != 2) f += d.resid[row * d.ldr + col + e];
           C[row * d.ldc + col + e] = from_f32<TO>(f);
+          if (c2) C2[row * d.ldr + col + e] = f32_to_bf16(f);
         }
       }
     }
@@ -1169,7 +1194,7 @@ struct NtExtra {       // optional outputs of the ring NT kernel beside C (null 
   float gnb_eps;
 };
 
-template <typename TO, int NTW, int ACT, int BMX, int WNC, int GNB = 0>
+template <typename TO, int NTW, int ACT, int BMX, int WNC, int GNB = 0, typename TI = bf16_t>
 __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gstats = nullptr, long rpg = 0, const NtExtra* xt = nullptr) {
   // tile = BMX rows x (16 * NTW * WNC) columns; waves BMX/64 (m) x WNC (n), each 64 x 16*NTW
   // <256, 2>: 8 waves, 256 x 224/256, 4 stages of 32 KB (long K: least operand traffic per FLOP)
@@ -1274,7 +1299,7 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(b[j], a[i], acc[i][j]);   // D[n][m]: see the epilogue
+      for (int i = 0; i < 4; ++i) acc[i][j] = Frag<TI>::mma(b[j], a[i], acc[i][j]);   // D[n][m]: see the epilogue
 #if URSE_NT_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1295,8 +1320,12 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
   constexpr int EPC = 16 / OS;
   constexpr int CPR = BNX / EPC;
   TO* C = reinterpret_cast<TO*>(d.C);
+  // f16 forward mode, ACT 1: the aux slot names a second output, the same values in bf16 (see gemm_nt_kernel)
+  constexpr bool C2K = __is_same(TI, f16_t) && OS == 2 && ACT == 1;
+  bf16_t* C2 = (C2K && d.resid) ? reinterpret_cast<bf16_t*>(const_cast<float*>(d.resid)) : nullptr;
   const bool vec_ok = ((d.ldc * OS) % 16 == 0) && ((reinterpret_cast<uintptr_t>(d.C) % 16) == 0) &&
-                      (!d.resid || ACT == 2 || (((d.ldr * 4) % 16 == 0) && (reinterpret_cast<uintptr_t>(d.resid) % 16) == 0));
+                      (!d.resid || ACT == 2 || (((d.ldr * 4) % 16 == 0) && (reinterpret_cast<uintptr_t>(d.resid) % 16) == 0)) &&
+                      (!C2 || (d.ldr * 2) % 16 == 0);
   // (storing straight from the accumulators, 8/16 B per lane, measured 2.3x slower than this staged epilogue)
   // optional GroupNorm statistics of the OUTPUT (f32, after the residual): sum and sum of squares per group of `rpg` consecutive
   // rows, accumulated from the values the sweep below stores - the separate pass over the tensor (gn_stats_kernel) goes away.
@@ -1363,10 +1392,16 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
             float hv[4] = {0.f, 0.f, 0.f, 0.f};
             // the lane's four columns are consecutive: one 8-byte load instead of four 2-byte ones (the scalar form made this
             // epilogue 6x the kernel's byte floor on the mask decoder's backward)
-            if (OS == 2 && row < d.M && col + 3 < d.N && ((reinterpret_cast<uintptr_t>(hp) & 7) == 0)) {
-              const uint2 q = *reinterpret_cast<const uint2*>(hp);
-              hv[0] = __uint_as_float(q.x << 16); hv[1] = __uint_as_float(q.x & 0xffff0000u);
-              hv[2] = __uint_as_float(q.y << 16); hv[3] = __uint_as_float(q.y & 0xffff0000u);
+            if constexpr (OS == 2) {
+              if (row < d.M && col + 3 < d.N && ((reinterpret_cast<uintptr_t>(hp) & 7) == 0)) {
+                const uint2 q = *reinterpret_cast<const uint2*>(hp);
+                unpack2<TO>(q.x, hv[0], hv[1]);
+                unpack2<TO>(q.y, hv[2], hv[3]);
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (row < d.M && col + r < d.N) hv[r] = to_f32<TO>(hp[r]);
+              }
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r)
@@ -1376,10 +1411,10 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
             for (int r = 0; r < 4; ++r) v[r] *= (1.f - hv[r] * hv[r]);
           }
           char* dst = lds + lrow * CP + lcol * OS;
-          if (OS == 2) {
+          if constexpr (OS == 2) {
             uint2 pk;
-            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            pk.x = pack2<TO>(v[0], v[1]);
+            pk.y = pack2<TO>(v[2], v[3]);
             *reinterpret_cast<uint2*>(dst) = pk;
           } else {
             *reinterpret_cast<f32x4_t*>(dst) = v;
@@ -1446,6 +1481,14 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
 #endif
           // streaming output (read next by a different kernel): non-temporal store, measured -16 % on the [M, 8H] gates
           __builtin_nontemporal_store(*reinterpret_cast<const f32x4_t*>(&v), reinterpret_cast<f32x4_t*>(C + row * d.ldc + col));
+          if constexpr (C2K) {
+            if (C2) {
+              float a0, a1, a2, a3, a4, a5, a6, a7;
+              unpack2<f16_t>(v.x, a0, a1); unpack2<f16_t>(v.y, a2, a3); unpack2<f16_t>(v.z, a4, a5); unpack2<f16_t>(v.w, a6, a7);
+              const uint4 o = make_uint4(pack2<bf16_t>(a0, a1), pack2<bf16_t>(a2, a3), pack2<bf16_t>(a4, a5), pack2<bf16_t>(a6, a7));
+              __builtin_nontemporal_store(*reinterpret_cast<const f32x4_t*>(&o), reinterpret_cast<f32x4_t*>(C2 + row * d.ldr + col));
+            }
+          }
         } else {
           const TO* sv = reinterpret_cast<const TO*>(src);
           for (int e = 0; e < EPC && col + e < d.N; ++e) {
@@ -1455,6 +1498,9 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
               if (row < gbound) { gsa += f; gqa += f * f; } else { gsb += f; gqb += f * f; }
             }
             C[row * d.ldc + col + e] = from_f32<TO>(f);
+            if constexpr (C2K) {
+              if (C2) C2[row * d.ldr + col + e] = f32_to_bf16(f);
+            }
           }
         }
       }
@@ -1518,9 +1564,9 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
   }
 }
 
-template <typename TO, int NTW, int ACT, int BMX, int WNC = 2>
+template <typename TO, int NTW, int ACT, int BMX, int WNC = 2, typename TI = bf16_t>
 __global__ void __launch_bounds__(BMX / 64 * WNC * 64) gemm_nt_dma_kernel(GemmDesc d, NtExtra x) {
-  gemm_nt_dma_body<TO, NTW, ACT, BMX, WNC>(d, x.gstats, x.rpg);
+  gemm_nt_dma_body<TO, NTW, ACT, BMX, WNC, 0, TI>(d, x.gstats, x.rpg);
 }
 
 // f32 output + the GroupNorm-backward sums of that output (see NtExtra): the dgrad GEMM whose result feeds urse_groupnorm_bwd_apply
@@ -1540,10 +1586,10 @@ __global__ void gnb_fold_kernel(const float* __restrict__ part, int slots, int N
 
 // grouped form (one descriptor per band, blockIdx.y = group): the per-band 1x1 convolutions of the mask decoder /
 // band split at B*T = 12,832 rows per band
-template <typename TO, int ACT>
+template <typename TO, int ACT, typename TI = bf16_t>
 __global__ void __launch_bounds__(512) gemm_nt_dma_grouped_kernel(const GemmDesc* __restrict__ descs) {
   const GemmDesc d = descs[blockIdx.y];
-  gemm_nt_dma_body<TO, 7, ACT, 256, 2>(d);
+  gemm_nt_dma_body<TO, 7, ACT, 256, 2, 0, TI>(d);
 }
 
 // B-stationary NT for short K and wide N (the gate projection: K = 224, N = 3136, bf16 out).  In the ring kernel above a
@@ -1552,7 +1598,7 @@ __global__ void __launch_bounds__(512) gemm_nt_dma_grouped_kernel(const GemmDesc
 // rows x K resident in LDS (98 KB) and walks 256-row tiles of M; only the activations stream, through a 3-stage ring of
 // 16 KB, which is also the epilogue's staging area (64 rows per pass).  Workgroups of different column slices take the
 // same M tiles in the same order, so an activation tile comes from HBM once and from L2 / the Infinity Cache after.
-template <int ACT>
+template <int ACT, typename TI = bf16_t>      // TI: operand AND output format (bf16 | f16)
 __global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_per_slice) {
   constexpr int BMX = 256, NTW = 7, BNX = 224, NST = 3, STAGE = BMX * 64, KSTEPS = 7, BRES = KSTEPS * 14 * 1024;
   __shared__ __attribute__((aligned(1024))) char lds[BRES + NST * STAGE];
@@ -1627,7 +1673,7 @@ __global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_pe
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = Frag<bf16_t>::mma(b[j], a[i], acc[i][j]);   // D[n][m], as in the ring kernel
+        for (int i = 0; i < 4; ++i) acc[i][j] = Frag<TI>::mma(b[j], a[i], acc[i][j]);   // D[n][m], as in the ring kernel
       if (++slot == NST) slot = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the trailing zero-page stages included)
@@ -1656,8 +1702,8 @@ __global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_pe
               for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
             }
             uint2 pk;
-            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            pk.x = pack2<TI>(v[0], v[1]);
+            pk.y = pack2<TI>(v[2], v[3]);
             *reinterpret_cast<uint2*>(ring + (i * 16 + lc) * CP + lcol * 2) = pk;
           }
         }
@@ -1867,6 +1913,8 @@ static int dispatch_nt(const GemmDesc* descs, const GemmDesc& single, int groups
   else if (in_dtype == URSE_BF16 && out_dtype == URSE_F32) launch_nt<bf16_t, float>(descs, single, groups, max_blocks, act, st);
   else if (in_dtype == URSE_F32 && out_dtype == URSE_F32) launch_nt<float, float>(descs, single, groups, max_blocks, act, st);
   else if (in_dtype == URSE_F32 && out_dtype == URSE_BF16) launch_nt<float, bf16_t>(descs, single, groups, max_blocks, act, st);
+  else if (in_dtype == URSE_F16 && out_dtype == URSE_F16) launch_nt<f16_t, f16_t>(descs, single, groups, max_blocks, act, st);
+  else if (in_dtype == URSE_F16 && out_dtype == URSE_F32) launch_nt<f16_t, float>(descs, single, groups, max_blocks, act, st);
   else { set_error("gemm_nt: bad dtype %d/%d", in_dtype, out_dtype); return URSE_ERR_INVALID_ARG; }
   URSE_CHECK_LAUNCH("urse_gemm_nt");
   return URSE_OK;
@@ -1886,9 +1934,16 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   GemmDesc d;
   d.A = (const char*)A; d.B = (const char*)B; d.C = (char*)C; d.bias = bias; d.resid = resid;
   d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.ldr = ldr;
-  int rc = check_desc_host(d, in_dtype == URSE_BF16 ? 2 : 4, "urse_gemm_nt");
+  const bool in16 = in_dtype == URSE_BF16 || in_dtype == URSE_F16;      // 16-bit operands: the same kernels, the MFMA of the format
+  const bool f16 = in_dtype == URSE_F16;
+  URSE_CHECK_ARG(in16 || in_dtype == URSE_F32, "urse_gemm_nt: bad operand dtype %d", in_dtype);
+  URSE_CHECK_ARG(out_dtype == URSE_F32 || (out_dtype == URSE_BF16 && !f16) || (out_dtype == URSE_F16 && f16),
+                 "urse_gemm_nt: output dtype %d with operand dtype %d (16-bit outputs take the operands' format)", out_dtype, in_dtype);
+  const bool out16 = out_dtype != URSE_F32;
+  int rc = check_desc_host(d, in16 ? 2 : 4, "urse_gemm_nt");
   if (rc) return rc;
-  URSE_CHECK_ARG(!resid || act == 2 || out_dtype == URSE_F32, "urse_gemm_nt: residual epilogue writes f32");
+  URSE_CHECK_ARG(!resid || act == 2 || out_dtype == URSE_F32 || (in_dtype == URSE_F16 && out_dtype == URSE_F16 && act == 1),
+                 "urse_gemm_nt: residual epilogue writes f32 (f16 operands with act 1: the aux slot is the bf16 copy of the output)");
   URSE_CHECK_ARG(act != 2 || resid, "urse_gemm_nt: act 2 (tanh backward) needs the aux operand");
   static const bool no_dma = getenv("URSE_NT_NO_DMA") != nullptr;
   const char* bres_env = getenv("URSE_NT_BRES");
@@ -1913,7 +1968,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     URSE_CHECK_LAUNCH("urse_gemm_nt");
     return URSE_OK;
   }
-  if (bres_mode && in_dtype == URSE_BF16 && out_dtype == URSE_BF16 && !no_dma && M >= 8192 && N >= g_nt_bres_min_n && K % 32 == 0 &&
+  if (bres_mode && in16 && out16 && !no_dma && M >= 8192 && N >= g_nt_bres_min_n && K % 32 == 0 &&
       K >= 96 && K <= 224 && !resid && act != 2 && (ldc * 2) % 16 == 0 && ((uintptr_t)C % 16) == 0) {
     // weight-stationary tiles: see gemm_nt_bres_kernel
     const int tn = (int)((N + 223) / 224);
@@ -1922,12 +1977,15 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     dim3 grid((unsigned)(tn * per));
     hipStream_t st = (hipStream_t)stream;
     note_launch(URSE_KV_NT_BRES);
-    if (act == 0) hipLaunchKernelGGL(gemm_nt_bres_kernel<0>, grid, dim3(512), 0, st, d, per);
+    if (f16) {
+      if (act == 0) hipLaunchKernelGGL((gemm_nt_bres_kernel<0, f16_t>), grid, dim3(512), 0, st, d, per);
+      else hipLaunchKernelGGL((gemm_nt_bres_kernel<1, f16_t>), grid, dim3(512), 0, st, d, per);
+    } else if (act == 0) hipLaunchKernelGGL(gemm_nt_bres_kernel<0>, grid, dim3(512), 0, st, d, per);
     else hipLaunchKernelGGL(gemm_nt_bres_kernel<1>, grid, dim3(512), 0, st, d, per);
     URSE_CHECK_LAUNCH("urse_gemm_nt");
     return URSE_OK;
   }
-  if (in_dtype == URSE_BF16 && !no_dma && M >= 2048 && N >= 160 && K % 32 == 0 && K >= 96) {
+  if (in16 && !no_dma && M >= 2048 && N >= 160 && K % 32 == 0 && K >= 96 && !(f16 && act == 2)) {
     const long pad7 = (N + 223) / 224 * 224, pad8 = (N + 255) / 256 * 256;
     int ntw = pad7 <= pad8 ? 7 : 8;
     if (const char* e = getenv("URSE_NT_NTW")) ntw = atoi(e) == 8 ? 8 : 7;
@@ -1936,6 +1994,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     // 128 x 448 tiles (896-byte output row segments) for the write-bound shapes: short K, wide N
     int wide = g_nt_wide_default && K <= g_nt_wide_maxk && N >= 1792 && out_dtype == URSE_BF16 && (N + 447) / 448 * 448 <= pad7 + 64;
     if (const char* e = getenv("URSE_NT_WIDE")) wide = atoi(e) != 0 && N >= 448;
+    if (f16) { wide = 0; bmx = 256; }        // (the f16 forward mode instantiates the 256-row tile only)
     const long tl = wide ? ((M + 127) / 128) * ((N + 447) / 448) : ((M + bmx - 1) / bmx) * ((N + 32L * ntw - 1) / (32L * ntw));
     URSE_CHECK_ARG(tl < (1L << 31), "urse_gemm_nt: too many tiles");
     dim3 grid((unsigned)tl);
@@ -1953,7 +2012,12 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
 #define URSE_NT_DMA_ACT(TO_, NTW_) \
   do { if (act == 0) URSE_NT_DMA_B(TO_, NTW_, 0); else if (act == 1) URSE_NT_DMA_B(TO_, NTW_, 1); else URSE_NT_DMA_B(TO_, NTW_, 2); } while (0)
     note_launch(wide ? URSE_KV_NT_RING_WIDE : URSE_KV_NT_RING);
-    if (out_dtype == URSE_BF16) {
+    if (f16) {
+#define URSE_NT_DMA_H(TO_, NTW_, ACT_) hipLaunchKernelGGL((gemm_nt_dma_kernel<TO_, NTW_, ACT_, 256, 2, f16_t>), grid, dim3(512), 0, st, d, xtra)
+#define URSE_NT_DMA_H_ACT(TO_, NTW_) do { if (act == 0) URSE_NT_DMA_H(TO_, NTW_, 0); else URSE_NT_DMA_H(TO_, NTW_, 1); } while (0)
+      if (out_dtype == URSE_F16) { if (ntw == 7) URSE_NT_DMA_H_ACT(f16_t, 7); else URSE_NT_DMA_H_ACT(f16_t, 8); }
+      else { if (ntw == 7) URSE_NT_DMA_H_ACT(float, 7); else URSE_NT_DMA_H_ACT(float, 8); }
+    } else if (out_dtype == URSE_BF16) {
       if (ntw == 7) URSE_NT_DMA_ACT(bf16_t, 7); else URSE_NT_DMA_ACT(bf16_t, 8);
     } else {
       if (ntw == 7) URSE_NT_DMA_ACT(float, 7); else URSE_NT_DMA_ACT(float, 8);
@@ -2048,8 +2112,11 @@ extern "C" int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_des
                                       int out_dtype, int act, void* stream) {
   URSE_CHECK_ARG(descs && host_descs && groups > 0 && groups < 65536, "urse_gemm_nt_grouped_h: bad argument");
   const GemmDesc* hd = reinterpret_cast<const GemmDesc*>(host_descs);
-  const int es = in_dtype == URSE_BF16 ? 2 : 4;
-  bool dma = in_dtype == URSE_BF16 && !getenv("URSE_NT_NO_DMA") && !getenv("URSE_NT_GROUPED_NO_DMA");
+  const bool f16 = in_dtype == URSE_F16;
+  const int es = (in_dtype == URSE_BF16 || f16) ? 2 : 4;
+  URSE_CHECK_ARG(out_dtype == URSE_F32 || (out_dtype == URSE_BF16 && !f16) || (out_dtype == URSE_F16 && f16),
+                 "urse_gemm_nt_grouped_h: output dtype %d with operand dtype %d", out_dtype, in_dtype);
+  bool dma = es == 2 && !(f16 && act == 2) && !getenv("URSE_NT_NO_DMA") && !getenv("URSE_NT_GROUPED_NO_DMA");
   long t128 = 0, tdma = 0;
   const char* mm = getenv("URSE_NT_GROUPED_MIN_M");      // (tests lower it to run the ring kernel on small batches)
   const long min_m = mm ? atol(mm) : 1024;
@@ -2073,7 +2140,10 @@ extern "C" int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_des
 #define URSE_NT_G(TO_, ACT_) hipLaunchKernelGGL((gemm_nt_dma_grouped_kernel<TO_, ACT_>), grid, dim3(512), 0, st, dd)
 #define URSE_NT_G_ACT(TO_) do { if (act == 0) URSE_NT_G(TO_, 0); else if (act == 1) URSE_NT_G(TO_, 1); else URSE_NT_G(TO_, 2); } while (0)
   note_launch(URSE_KV_NT_GROUPED_RING);
-  if (out_dtype == URSE_BF16) URSE_NT_G_ACT(bf16_t);
+#define URSE_NT_GH(TO_, ACT_) hipLaunchKernelGGL((gemm_nt_dma_grouped_kernel<TO_, ACT_, f16_t>), grid, dim3(512), 0, st, dd)
+  if (f16 && out_dtype == URSE_F16) { if (act == 0) URSE_NT_GH(f16_t, 0); else URSE_NT_GH(f16_t, 1); }
+  else if (f16) { if (act == 0) URSE_NT_GH(float, 0); else URSE_NT_GH(float, 1); }
+  else if (out_dtype == URSE_BF16) URSE_NT_G_ACT(bf16_t);
   else if (out_dtype == URSE_F32) URSE_NT_G_ACT(float);
   else { set_error("urse_gemm_nt_grouped_h: bad output dtype %d", out_dtype); return URSE_ERR_INVALID_ARG; }
   URSE_CHECK_LAUNCH("urse_gemm_nt_grouped_h");

@@ -16,6 +16,8 @@
 // row(s, t) = (s / inner) * outer + (s % inner) + t * stride   maps (sequence, step) to a row of the
 // [B*T*K, .] channel-last activation matrices: time path inner=K, outer=T*K, stride=K; band path
 // inner=1, outer=K, stride=1.
+#include <type_traits>
+
 #include "urse_common.h"
 
 namespace urse {
@@ -32,6 +34,7 @@ struct LstmFwdArgs {
   void* gx; long ldg;        // [M, ldg] T: gate pre-activations (both directions, 2*4H); overwritten with activations
   const void* whh;           // fragment-ordered [2][nut][nslab][4][64][16 B]
   void* hout; long ldh;      // [M, ldh] T: h (dir 0 cols [0,H), dir 1 cols [H,2H))
+  void* hout2;               // f16 mode: the same h once more in bf16 (operand of the weight-gradient GEMMs; may be null)
   float* c;                  // [M, 2H] f32 cell state (saved when `save`)
   int H, Hp, save;
   int xcd;                   // xcd_dir_tile mapping
@@ -63,6 +66,16 @@ template <> struct Vec4<bf16_t> {
     return v;
   }
 };
+template <> struct Vec4<f16_t> {
+  typedef uint2 raw;
+  static __device__ __forceinline__ void unpack(raw v, float (&o)[4]) { unpack2<f16_t>(v.x, o[0], o[1]); unpack2<f16_t>(v.y, o[2], o[3]); }
+  static __device__ __forceinline__ raw pack(const float (&i)[4]) {
+    raw v;
+    v.x = pack2<f16_t>(i[0], i[1]);
+    v.y = pack2<f16_t>(i[2], i[3]);
+    return v;
+  }
+};
 template <> struct Vec4<float> {
   typedef float4 raw;
   static __device__ __forceinline__ void unpack(raw v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
@@ -73,9 +86,7 @@ template <typename T, int RT>
 __device__ __forceinline__ void mma_slab(const uint4 (&a)[RT], const uint4& b, f32x4_t (&acc)[RT]) {
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[rt]),
-                                                        __builtin_bit_cast(bf16x8_t, b), acc[rt], 0, 0, 0);
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16<T>(a[rt], b, acc[rt]);
   } else {
     const float bf[4] = {__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
 #pragma unroll
@@ -95,6 +106,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T), R = 16 * RT;
   typedef typename Vec4<T>::raw V4;
+  // the saved gate activations feed the BPTT, whose operands are bf16 in the f16 forward mode too (gradients need the range)
+  typedef typename std::conditional<__is_same(T, f16_t), bf16_t, T>::type TS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   int dir, tile_;
   xcd_dir_tile(p.xcd, dir, tile_);
@@ -204,9 +217,12 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
             if (rvalid[rt][r] && uvalid) {
 #endif
               hout[row * p.ldh + (long)dir * H + u] = hT;
+              if constexpr (__is_same(T, f16_t)) {
+                if (p.hout2) reinterpret_cast<bf16_t*>(p.hout2)[row * p.ldh + (long)dir * H + u] = f32_to_bf16(to_f32<T>(hT));      // (the f16 value rounded once more, as the other forward kernels' copies)
+              }
               if (p.save) {
                 const float act[4] = {iv, fv, gv, ov};
-                *reinterpret_cast<V4*>(gx + row * p.ldg + gcol0 + u * 4) = Vec4<T>::pack(act);
+                *reinterpret_cast<V4*>(gx + row * p.ldg + gcol0 + u * 4) = Vec4<TS>::pack(act);
                 p.c[row * 2 * H + (long)dir * H + u] = cv;
               }
             }
@@ -232,8 +248,12 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
 // STG: the step's gate gradients leave through the LDS tile (which holds them anyway) as 16-byte pieces along the rows, after the barrier,
 // instead of 8 bytes per lane and unit from the cell phase (32 store instructions per lane and step in the 32-row geometry): what took
 // 1.2 us per step off the N-split kernel (lstm_nsplit.hip).  bf16, single direction segment of 4H columns a multiple of 8.
-template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0, int PF = 0, int STG = 0>
+// KH = 2 (f32 operands at H > 624: the [16][4H] f32 tile of the flow model's H = 768 is 196 KB, more than a CU's LDS): the tile holds one HALF of
+// the gate-gradient columns at a time; a wave keeps the gradients of its units in registers, the recurrent product runs half by half over the
+// matching half of the k range into the same accumulators (same k order as one pass: bit-identical to a tile that would fit).
+template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0, int PF = 0, int STG = 0, int KH = 1>
 __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
+  static_assert(KH == 1 || (KH == 2 && !HC && !HPC && !PF && !STG), "the half-tile form exists for the plain variant only");
 #if URSE_BWD_PRIO
   __builtin_amdgcn_s_setprio(URSE_BWD_PRIO);   // the BPTT is on the step's critical path; the wgrad GEMMs it shares CUs with are not
 #endif
@@ -245,8 +265,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   xcd_dir_tile(p.xcd, dir, tile_);
   const int s0 = tile_ * R;
   const int H = HC ? HC : p.H, nut = (H + 15) >> 4, G4 = 4 * H;
-  const int pitch = HPC ? lds_frag_pitch(4 * HPC * ES) : lds_frag_pitch(G4 * ES);
-  const int nbuf = p.dbuf ? 2 : 1;         // double-buffered dgates tile: one barrier per step
+  const int pitch = HPC ? lds_frag_pitch(4 * HPC * ES) : lds_frag_pitch(G4 / KH * ES);
+  const int nbuf = (p.dbuf && KH == 1) ? 2 : 1;         // double-buffered dgates tile: one barrier per step
   float dcs[MAXUT][RT][4], dhr[MAXUT][RT][4], ccur[MAXUT][RT][4];
   int rowbase[RT][4];                      // negative: sequence beyond n_seq (clamped, never stored)
 #pragma unroll
@@ -302,6 +322,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   V4 gpf[PU][RT][4];
   float cpf[PU][RT][4];
   T dhpf[PU][RT][4];
+  V4 dgk[KH == 2 ? MAXUT : 1][RT][4];      // KH = 2: this wave's gate gradients of the step, until their half of the tile is due
   auto load_step = [&](int ui, int slot, int tt) {
     const int u = (w + NW * ui) * 16 + lc;
     const bool first_ = dir ? (tt == p.m.seq_len - 1) : (tt == 0);   // first step of the forward recurrence: c_{-1} = 0
@@ -388,7 +409,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
               dcs[ui][rt][r] = dct * fv;
               ccur[ui][rt][r] = cpre[rt][r];          // c_{t-1} is the next processed step's c_t
               const V4 pk = Vec4<T>::pack(dg);
-              *reinterpret_cast<V4*>(tile + (rt * 16 + lr * 4 + r) * pitch + (u * 4) * ES) = pk;
+              if constexpr (KH == 2) dgk[ui][rt][r] = pk;
+              else *reinterpret_cast<V4*>(tile + (rt * 16 + lr * 4 + r) * pitch + (u * 4) * ES) = pk;
 #ifndef BABL_NO_STORE
 #if defined(BABL_HOT_INPUTS) && BABL_HOT_INPUTS == 3
               if (rowbase[rt][r] >= 0)
@@ -404,6 +426,61 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
     }
     if constexpr (!STG) {
       if (step + 1 == p.m.seq_len) break;
+    }
+    if constexpr (KH == 2) {
+      f32x4_t accs[MAXUT][RT];
+#pragma unroll
+      for (int ui = 0; ui < MAXUT; ++ui)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) accs[ui][rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int hu = H / 2, hs = nslab / 2;             // units / k slabs per half (H % 8 == 0: a slab never straddles the halves)
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ui = 0; ui < MAXUT; ++ui) {
+          const int u = (w + NW * ui) * 16 + lc;
+          if (u < H && (u >= hu) == (half == 1)) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<V4*>(tile + (rt * 16 + lr * 4 + r) * pitch + ((u - half * hu) * 4) * ES) = dgk[ui][rt][r];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ui = 0; ui < MAXUT; ++ui) {
+          const int ut = w + NW * ui;
+          if (ut < nut) {
+            const char* wr = whhT + ((long)ut * nslab + half * hs) * 1024;
+            const char* ar = tile + lc * pitch + 16 * lr;
+            constexpr int KB = 8;
+#pragma unroll 1
+            for (int k0 = 0; k0 < hs; k0 += KB) {
+              uint4 b[KB];
+#pragma unroll
+              for (int i = 0; i < KB; ++i) b[i] = *reinterpret_cast<const uint4*>(wr + ((k0 + i < hs) ? k0 + i : hs - 1) * 1024);
+#pragma unroll
+              for (int i = 0; i < KB; ++i) {
+                if (k0 + i < hs) {
+                  uint4 a[RT];
+#pragma unroll
+                  for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const uint4*>(ar + rt * 16 * pitch + (k0 + i) * 64);
+                  mma_slab<T, RT>(a, b[i], accs[ui]);
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();                                 // the tile is free for the other half / the next step
+      }
+#pragma unroll
+      for (int ui = 0; ui < MAXUT; ++ui)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dhr[ui][rt][r] = accs[ui][rt][r];
+      continue;
     }
     if constexpr (PF == 1) load_all(dir ? t + 1 : t - 1);     // next step's inputs: in flight under the weight pass
     __syncthreads();
@@ -673,12 +750,14 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_tr_kernel(LstmBwdArgs p) {
 //  out 2: bias   [8H] f32   b_ih + b_hh, permuted
 //  out 3: whh fragments     [2][nut][nslab][4][64 lanes][16 B]   (B operand of h * W_hh^T)
 //  out 4: whhT fragments    [2][nut][nslabT][64 lanes][16 B]     (B operand of dgates * W_hh, k = unit*4+gate)
-template <typename T>
+// T: format of the forward layouts (wih_p, whh_f); TB: of the backward layouts (wihT_p, whhT_f) - the same, except bf16 under f16 forward operands
+template <typename T, typename TB = T>
 __device__ __forceinline__ void lstm_pack_dev(const float* __restrict__ wih, const float* __restrict__ whh,
                                               const float* __restrict__ bih, const float* __restrict__ bhh,
-                                              T* __restrict__ wih_p, T* __restrict__ wihT_p,
+                                              T* __restrict__ wih_p, TB* __restrict__ wihT_p,
                                               float* __restrict__ bias, T* __restrict__ whh_f,
-                                              T* __restrict__ whhT_f, int N, int Np, int H, int Hp) {
+                                              TB* __restrict__ whhT_f, int N, int Np, int H, int Hp) {
+  static_assert(sizeof(T) == sizeof(TB), "one element size per pack");
   constexpr int ES = sizeof(T), EPL = 16 / ES, SK = 64 / ES;
   const int nut = (H + 15) >> 4, G4 = 4 * H;
   const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -693,7 +772,7 @@ __device__ __forceinline__ void lstm_pack_dev(const float* __restrict__ wih, con
     for (long idx = i0; idx < (long)N * 2 * G4; idx += stride) {
       const int n = (int)(idx / (2 * G4)), rp = (int)(idx - (long)n * 2 * G4);
       const int d = rp / G4, r = rp - d * G4, u = r >> 2, g = r & 3;
-      wihT_p[idx] = from_f32<T>(wih[((long)d * G4 + g * H + u) * N + n]);
+      wihT_p[idx] = from_f32<TB>(wih[((long)d * G4 + g * H + u) * N + n]);
     }
   } else if (which == 2) {
     for (long idx = i0; idx < 2 * G4; idx += stride) {
@@ -727,24 +806,24 @@ __device__ __forceinline__ void lstm_pack_dev(const float* __restrict__ wih, con
       const int d = (int)(q / nut);
       const int n = ut * 16 + (lane & 15), kk = ks * SK + EPL * (lane >> 4) + j;
       const int up = kk >> 2, gp = kk & 3;
-      whhT_f[idx] = from_f32<T>(n < H ? whh[((long)d * G4 + gp * H + up) * H + n] : 0.f);
+      whhT_f[idx] = from_f32<TB>(n < H ? whh[((long)d * G4 + gp * H + up) * H + n] : 0.f);
     }
   }
 }
 
-template <typename T>
+template <typename T, typename TB = T>
 __global__ void __launch_bounds__(256) lstm_pack_kernel(const float* __restrict__ wih, const float* __restrict__ whh,
                                                         const float* __restrict__ bih, const float* __restrict__ bhh,
-                                                        T* __restrict__ wih_p, T* __restrict__ wihT_p,
+                                                        T* __restrict__ wih_p, TB* __restrict__ wihT_p,
                                                         float* __restrict__ bias, T* __restrict__ whh_f,
-                                                        T* __restrict__ whhT_f, int N, int Np, int H, int Hp) {
-  lstm_pack_dev<T>(wih, whh, bih, bhh, wih_p, wihT_p, bias, whh_f, whhT_f, N, Np, H, Hp);
+                                                        TB* __restrict__ whhT_f, int N, int Np, int H, int Hp) {
+  lstm_pack_dev<T, TB>(wih, whh, bih, bhh, wih_p, wihT_p, bias, whh_f, whhT_f, N, Np, H, Hp);
 }
 // all LSTMs of a model in one launch: blockIdx.z = row of the pointer table (the model re-packs its 12 LSTMs after every optimizer step)
-template <typename T>
+template <typename T, typename TB = T>
 __global__ void __launch_bounds__(256) lstm_pack_multi_kernel(const PackRow* __restrict__ tab, int N, int Np, int H, int Hp) {
   const PackRow r = tab[blockIdx.z];
-  lstm_pack_dev<T>(r.wih, r.whh, r.bih, r.bhh, (T*)r.wih_p, (T*)r.wihT_p, r.bias, (T*)r.whh_f, (T*)r.whhT_f, N, Np, H, Hp);
+  lstm_pack_dev<T, TB>(r.wih, r.whh, r.bih, r.bhh, (T*)r.wih_p, (TB*)r.wihT_p, r.bias, (T*)r.whh_f, (TB*)r.whhT_f, N, Np, H, Hp);
 }
 
 template <typename K>
@@ -782,6 +861,28 @@ template <typename T, int RT, int NW>
 static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
   constexpr int R = 16 * RT;
   size_t lds = (size_t)R * lds_frag_pitch(4 * p.H * (int)sizeof(T));
+  if constexpr (sizeof(T) == 4 && RT == 1 && NW == 16) {
+    if (lds > 160 * 1024 && p.H % 8 == 0 && (size_t)R * lds_frag_pitch(2 * p.H * 4) <= 160 * 1024) {
+      // exact-f32 mode at the flow model's H = 768: half the gate-gradient columns in LDS at a time (KH = 2)
+      LstmBwdArgs pa = p;
+      pa.dbuf = 0;
+      pa.xcd = xcd_dir_env() & 1;
+      const size_t lds2 = (size_t)R * lds_frag_pitch(2 * p.H * 4);
+      dim3 grid(ceil_div(p.m.n_seq, R), 2);
+      const int upw = ((p.H + 15) / 16 + NW - 1) / NW;
+      if (upw <= 3) {
+        static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 3, 16, 0, 0, 0, 0, 2>), true);
+        (void)once;
+        hipLaunchKernelGGL((lstm_bwd_kernel<T, 1, 3, 16, 0, 0, 0, 0, 2>), grid, dim3(NW * 64), lds2, st, pa);
+      } else {
+        static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 6, 16, 0, 0, 0, 0, 2>), true);
+        (void)once;
+        hipLaunchKernelGGL((lstm_bwd_kernel<T, 1, 6, 16, 0, 0, 0, 0, 2>), grid, dim3(NW * 64), lds2, st, pa);
+      }
+      URSE_CHECK_LAUNCH("urse_lstm_bwd");
+      return URSE_OK;
+    }
+  }
   URSE_CHECK_ARG(lds <= 160 * 1024, "urse_lstm_bwd: H %d with %d rows exceeds LDS", p.H, R);
   LstmBwdArgs pa = p;
   pa.dbuf = (2 * lds <= 150 * 1024) ? 1 : 0;
@@ -891,11 +992,15 @@ extern "C" int urse_lstm_pack(const float* wih, const float* whh, const float* b
                               void* wihT_p, float* bias, void* whh_frag, void* whhT_frag, int N, int Np, int H, int Hp,
                               int dtype, void* stream) {
   URSE_CHECK_ARG(wih && whh && bih && bhh && wih_p && wihT_p && bias && whh_frag && whhT_frag, "urse_lstm_pack: null pointer");
-  const int es = dtype == URSE_BF16 ? 2 : 4;
+  const int es = dtype == URSE_F32 ? 4 : 2;
+  URSE_CHECK_ARG(dtype == URSE_F32 || dtype == URSE_BF16 || dtype == URSE_F16, "urse_lstm_pack: bad dtype %d", dtype);
   URSE_CHECK_ARG(N > 0 && H > 0 && Np >= N && (Hp * es) % 64 == 0 && Hp >= ((H + 15) / 16) * 16 && (4 * H * es) % 64 == 0,
                  "urse_lstm_pack: bad shape N%d Np%d H%d Hp%d", N, Np, H, Hp);
   dim3 grid(256, 5), blk(256);
-  if (dtype == URSE_BF16)
+  if (dtype == URSE_F16)      // forward layouts f16, backward layouts (wihT, whhT) bf16
+    hipLaunchKernelGGL((lstm_pack_kernel<f16_t, bf16_t>), grid, blk, 0, (hipStream_t)stream, wih, whh, bih, bhh, (f16_t*)wih_p,
+                       (bf16_t*)wihT_p, bias, (f16_t*)whh_frag, (bf16_t*)whhT_frag, N, Np, H, Hp);
+  else if (dtype == URSE_BF16)
     hipLaunchKernelGGL(lstm_pack_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, wih, whh, bih, bhh, (bf16_t*)wih_p,
                        (bf16_t*)wihT_p, bias, (bf16_t*)whh_frag, (bf16_t*)whhT_frag, N, Np, H, Hp);
   else
@@ -906,11 +1011,14 @@ extern "C" int urse_lstm_pack(const float* wih, const float* whh, const float* b
 }
 
 extern "C" int urse_lstm_pack_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, int dtype, void* stream) {
-  const int es = dtype == URSE_BF16 ? 2 : 4;
+  const int es = dtype == URSE_F32 ? 4 : 2;
+  URSE_CHECK_ARG(dtype == URSE_F32 || dtype == URSE_BF16 || dtype == URSE_F16, "urse_lstm_pack_multi: bad dtype %d", dtype);
   URSE_CHECK_ARG(table && n_lstm > 0 && n_lstm < 65536 && N > 0 && H > 0 && Np >= N && (Hp * es) % 64 == 0 && Hp >= ((H + 15) / 16) * 16 &&
                      (4 * H * es) % 64 == 0, "urse_lstm_pack_multi: bad argument N%d Np%d H%d Hp%d", N, Np, H, Hp);
   dim3 grid(256, 5, (unsigned)n_lstm), blk(256);
-  if (dtype == URSE_BF16)
+  if (dtype == URSE_F16)
+    hipLaunchKernelGGL((lstm_pack_multi_kernel<f16_t, bf16_t>), grid, blk, 0, (hipStream_t)stream, (const PackRow*)table, N, Np, H, Hp);
+  else if (dtype == URSE_BF16)
     hipLaunchKernelGGL(lstm_pack_multi_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const PackRow*)table, N, Np, H, Hp);
   else
     hipLaunchKernelGGL(lstm_pack_multi_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const PackRow*)table, N, Np, H, Hp);
@@ -920,13 +1028,15 @@ extern "C" int urse_lstm_pack_multi(const void* table, int n_lstm, int N, int Np
 
 extern "C" int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void* hout, int64_t ldh, float* c, int H,
                                    int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride,
-                                   int save, int dtype, int rows16, void* stream) {
+                                   int save, int dtype, int rows16, void* hout_bf16, void* stream) {
   URSE_CHECK_ARG(gx && whh && hout && (c || !save), "urse_lstm_bidir_fwd: null pointer");
+  URSE_CHECK_ARG(dtype == URSE_F32 || dtype == URSE_BF16 || dtype == URSE_F16, "urse_lstm_bidir_fwd: bad dtype %d", dtype);
+  URSE_CHECK_ARG(!hout_bf16 || dtype == URSE_F16, "urse_lstm_bidir_fwd: the bf16 copy of h goes with f16 operands only");
   LstmFwdArgs p;
-  p.gx = gx; p.ldg = ldg; p.whh = whh; p.hout = hout; p.ldh = ldh; p.c = c; p.H = H; p.Hp = Hp; p.save = save;
+  p.gx = gx; p.ldg = ldg; p.whh = whh; p.hout = hout; p.hout2 = hout_bf16; p.ldh = ldh; p.c = c; p.H = H; p.Hp = Hp; p.save = save;
   p.xcd = (xcd_dir_env() >> 2) & 1;
   p.m.inner = inner; p.m.outer = outer; p.m.stride = stride; p.m.n_seq = n_seq; p.m.seq_len = seq_len;
-  const int es = dtype == URSE_BF16 ? 2 : 4;
+  const int es = dtype == URSE_F32 ? 4 : 2;
   int rc = check_map(p.m, H, es, "urse_lstm_bidir_fwd");
   if (rc) return rc;
   URSE_CHECK_ARG((Hp * es) % 64 == 0 && Hp >= ((H + 15) / 16) * 16, "urse_lstm_bidir_fwd: bad Hp %d for H %d", Hp, H);
@@ -937,6 +1047,7 @@ extern "C" int urse_lstm_bidir_fwd(void* gx, int64_t ldg, const void* whh, void*
   bool nw8 = (rows16 >> 4) & 1;
   if (rt == 0) { rt = 1; nw8 = false; }
   note_launch(URSE_KV_LSTM_FWD_STREAM);
+  if (dtype == URSE_F16) return launch_fwd<f16_t, 1, 16>(p, st);
   if (dtype == URSE_BF16) {
     if (nw8) {
       if (rt >= 4) return launch_fwd<bf16_t, 4, 8>(p, st);

@@ -28,6 +28,7 @@ struct ClusterArgs {
   void* gx; long ldg;
   const void* whhq;               // [2][nq][NSLAB][64][16 B] quad-ordered fragments
   void* hout; long ldh;
+  void* hout2;                    // f16 operands: h once more in bf16 for the weight-gradient GEMMs (null: not wanted)
   float* c;
   bf16_t* hx;                     // exchange [2 parity][2 dir][ncl][rows_pad][Hp]
   unsigned* cnt;                  // [2 dir][ncl] arrival counters (zeroed per launch)
@@ -75,8 +76,12 @@ __device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned of
 // pieces), between the same two barriers as the working waves, whose instruction streams and in-order vmcnt queues then hold the h gather,
 // the MFMAs, the cell update and the publication only.  (The ablation of the helper-less form priced the deferred stores at 1.7 us and the
 // staged pre-activations at 1.3 us of a 6.4 us step - at 21 GB/s per CU this kernel is bound by its step latency, not by bytes.)
-template <int NSLAB, int MAXCH, int HELP = 0>
+// TI: operand format (bf16_t | f16_t): the gate pre-activations read from gx, the resident W_hh fragments, the exchanged h and hout; the saved
+// gate activations written back into gx are bf16 in both (they feed the BPTT).  The tag bit of the hand-off (bit 14 = the exponent's MSB) is
+// clear for |h| <= 1 in either format.  H2 (f16 only): hout2 receives h in bf16 as well.
+template <int NSLAB, int MAXCH, int HELP = 0, typename TI = bf16_t, bool H2 = false>
 __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(ClusterArgs p) {
+  static_assert(!H2 || __is_same(TI, f16_t), "the bf16 copy of h exists in the f16 mode only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane >> 4, lc = lane & 15;
   const int H = p.H;
@@ -250,6 +255,7 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
   const __amdgpu_buffer_rsrc_t rs_gs = __builtin_amdgcn_make_buffer_rsrc(p.gx, 0, (int)p.g_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_hs = __builtin_amdgcn_make_buffer_rsrc(p.hout, 0, (int)p.h_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hs2 = __builtin_amdgcn_make_buffer_rsrc(H2 ? p.hout2 : p.hout, 0, (int)p.h_bytes, 0x00020000);
   const int nvu = (H - j * UW) < UW ? (H - j * UW > 0 ? H - j * UW : 0) : UW;     // valid units of this workgroup (a multiple of 8)
   __syncthreads();                                                     // rowtab
   unsigned dvo_g[2], dvo_c, dvo_h;
@@ -380,6 +386,12 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
     {
       const uint4 v = *reinterpret_cast<const uint4*>(hst + (tid < CROWS * SC ? tid : 0) * 16);
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_hs, (int)dvo_h, toff_d * ldh_i * 2, 0);
+      if constexpr (H2) {
+        float a0, a1, a2, a3, a4, a5, a6, a7;
+        unpack2<f16_t>(v.x, a0, a1); unpack2<f16_t>(v.y, a2, a3); unpack2<f16_t>(v.z, a4, a5); unpack2<f16_t>(v.w, a6, a7);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack2<bf16_t>(a0, a1), pack2<bf16_t>(a2, a3), pack2<bf16_t>(a4, a5), pack2<bf16_t>(a6, a7)},
+                                               rs_hs2, (int)dvo_h, toff_d * ldh_i * 2, 0);
+      }
     }
     if (p.save && HELP == 0) {                                           // (helper form: the helper waves store the gates and c)
 #pragma unroll
@@ -473,8 +485,7 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
       for (int ks = 0; ks < NSLAB; ++ks) {
 #ifndef CABL_NO_MFMA
         const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, breg[ks]),
-                                                      __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
+        acc = mfma16<TI>(breg[ks], a, acc);
 #else
         acc[ks & 3] += __uint_as_float(breg[ks].x);
 #endif
@@ -482,8 +493,10 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
       // acc[g] = gate g of unit ul, sequence rt*16 + rl
       const float pre[4] = {acc[0], acc[1], acc[2], acc[3]};
       const uint2 gxv = *reinterpret_cast<const uint2*>(gstage0 + (step & 1) * (CROWS * UW * 8) + (rt * 16 + rl) * (UW * 8) + (w * 4 + ul) * 8);
-      const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
-      const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
+      float x0, x1, x2, x3;
+      unpack2<TI>(gxv.x, x0, x1);
+      unpack2<TI>(gxv.y, x2, x3);
+      const float gi = pre[0] + x0, gf = pre[1] + x1, gg = pre[2] + x2, go = pre[3] + x3;
 #ifdef CABL_NO_CELL
       const float iv = gi, fv = gf, gv = gg, ov = go;
       const float cv = fv * cst[ch][rt] + iv * gv;
@@ -495,7 +508,7 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
       cst[ch][rt] = cv;
       const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
 #endif
-      if (qvalid) reinterpret_cast<bf16_t*>((step & 1) ? hstage1 : reinterpret_cast<char*>(hstage))[(rt * 16 + rl) * UW + w * 4 + ul] = f32_to_bf16(hv);
+      if (qvalid) reinterpret_cast<TI*>((step & 1) ? hstage1 : reinterpret_cast<char*>(hstage))[(rt * 16 + rl) * UW + w * 4 + ul] = from_f32<TI>(hv);
       if (p.save && qvalid) {
         uint2 gs;
         gs.x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
@@ -534,7 +547,8 @@ __global__ void __launch_bounds__(CTHR + 64 * HELP) lstm_fwd_cluster_kernel(Clus
 
 // quad-ordered recurrent weights: block (dir, quad, slab) = 64 lanes x 16 B; lane (lr, lc): unit quad*4 + (lc>>2),
 // gate lc & 3, k = slab*32 + 8*lr + j
-__device__ __forceinline__ void lstm_pack_quads_dev(const float* __restrict__ whh, bf16_t* __restrict__ out, int H, int Hp) {
+template <typename TI>
+__device__ __forceinline__ void lstm_pack_quads_dev(const float* __restrict__ whh, TI* __restrict__ out, int H, int Hp) {
   const int nq = (H + 3) >> 2, nslab = Hp / 32, G4 = 4 * H;
   const long total = (long)2 * nq * nslab * 64 * 8;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -546,15 +560,17 @@ __device__ __forceinline__ void lstm_pack_quads_dev(const float* __restrict__ wh
     const int d = (int)(r / nq);
     const int lc = lane & 15, lr = lane >> 4;
     const int u = qd * 4 + (lc >> 2), g = lc & 3, k = ks * 32 + 8 * lr + jj;
-    out[idx] = f32_to_bf16((u < H && k < H) ? whh[((long)d * G4 + g * H + u) * H + k] : 0.f);
+    out[idx] = from_f32<TI>((u < H && k < H) ? whh[((long)d * G4 + g * H + u) * H + k] : 0.f);
   }
 }
-__global__ void __launch_bounds__(256) lstm_pack_quads_kernel(const float* __restrict__ whh, bf16_t* __restrict__ out, int H, int Hp) {
-  lstm_pack_quads_dev(whh, out, H, Hp);
+template <typename TI>
+__global__ void __launch_bounds__(256) lstm_pack_quads_kernel(const float* __restrict__ whh, TI* __restrict__ out, int H, int Hp) {
+  lstm_pack_quads_dev<TI>(whh, out, H, Hp);
 }
+template <typename TI>
 __global__ void __launch_bounds__(256) lstm_pack_quads_multi_kernel(const PackRow* __restrict__ tab, int H, int Hp) {
   const PackRow r = tab[blockIdx.y];
-  if (r.whhq) lstm_pack_quads_dev(r.whh, (bf16_t*)r.whhq, H, Hp);
+  if (r.whhq) lstm_pack_quads_dev<TI>(r.whh, (TI*)r.whhq, H, Hp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -773,16 +789,19 @@ __global__ void __launch_bounds__(256) lstm_pack_bwd_quads_kernel(const float* _
 }
 
 template <int NSLAB, int MAXCH>
-static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<NSLAB, MAXCH, 2>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+static int launch_cluster(const ClusterArgs& p, int f16, hipStream_t st) {
+#define URSE_CL_ATTR(...) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+  static bool once = (URSE_CL_ATTR(NSLAB, MAXCH), URSE_CL_ATTR(NSLAB, MAXCH, 2), URSE_CL_ATTR(NSLAB, MAXCH, 2, f16_t, false),
+                      URSE_CL_ATTR(NSLAB, MAXCH, 2, f16_t, true), true);
   (void)once;
+#undef URSE_CL_ATTR
   const int helpers = getenv("URSE_CLUSTER_HELPERS") ? atoi(getenv("URSE_CLUSTER_HELPERS")) : 2;     // (A/B switch; 0 = the 14-wave form)
   const size_t lds = (size_t)CROWS * lds_frag_pitch(p.Hp * 2) + (size_t)CROWS * UW * 2 + 16 + 64 + CROWS * sizeof(int) + (size_t)CROWS * UW * 14 + (size_t)CROWS * UW * 12;
   dim3 grid(p.C * p.ncl, 2);
-  if (helpers > 0) hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH, 2>), grid, dim3(CTHR + 128), lds, st, p);
+  if (f16) {          // (the f16 forward mode exists in the helper-wave form only)
+    if (p.hout2) hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH, 2, f16_t, true>), grid, dim3(CTHR + 128), lds, st, p);
+    else hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH, 2, f16_t, false>), grid, dim3(CTHR + 128), lds, st, p);
+  } else if (helpers > 0) hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH, 2>), grid, dim3(CTHR + 128), lds, st, p);
   else hipLaunchKernelGGL((lstm_fwd_cluster_kernel<NSLAB, MAXCH>), grid, dim3(CTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_cluster_fwd");
   return URSE_OK;
@@ -792,16 +811,19 @@ static int launch_cluster(const ClusterArgs& p, hipStream_t st) {
 
 using namespace urse;
 
-extern "C" int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, void* stream) {
-  URSE_CHECK_ARG(whh && out && H > 0 && Hp % 32 == 0 && Hp >= H, "urse_lstm_pack_quads: bad argument");
-  hipLaunchKernelGGL(lstm_pack_quads_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, whh, (bf16_t*)out, H, Hp);
+extern "C" int urse_lstm_pack_quads(const float* whh, void* out, int H, int Hp, int dtype, void* stream) {
+  URSE_CHECK_ARG(whh && out && H > 0 && Hp % 32 == 0 && Hp >= H && (dtype == URSE_BF16 || dtype == URSE_F16), "urse_lstm_pack_quads: bad argument");
+  if (dtype == URSE_F16) hipLaunchKernelGGL(lstm_pack_quads_kernel<f16_t>, dim3(256), dim3(256), 0, (hipStream_t)stream, whh, (f16_t*)out, H, Hp);
+  else hipLaunchKernelGGL(lstm_pack_quads_kernel<bf16_t>, dim3(256), dim3(256), 0, (hipStream_t)stream, whh, (bf16_t*)out, H, Hp);
   URSE_CHECK_LAUNCH("urse_lstm_pack_quads");
   return URSE_OK;
 }
 
-extern "C" int urse_lstm_pack_quads_multi(const void* table, int n_lstm, int H, int Hp, void* stream) {
-  URSE_CHECK_ARG(table && n_lstm > 0 && n_lstm < 65536 && H > 0 && Hp % 32 == 0 && Hp >= H, "urse_lstm_pack_quads_multi: bad argument");
-  hipLaunchKernelGGL(lstm_pack_quads_multi_kernel, dim3(256, (unsigned)n_lstm), dim3(256), 0, (hipStream_t)stream, (const PackRow*)table, H, Hp);
+extern "C" int urse_lstm_pack_quads_multi(const void* table, int n_lstm, int H, int Hp, int dtype, void* stream) {
+  URSE_CHECK_ARG(table && n_lstm > 0 && n_lstm < 65536 && H > 0 && Hp % 32 == 0 && Hp >= H && (dtype == URSE_BF16 || dtype == URSE_F16),
+                 "urse_lstm_pack_quads_multi: bad argument");
+  if (dtype == URSE_F16) hipLaunchKernelGGL(lstm_pack_quads_multi_kernel<f16_t>, dim3(256, (unsigned)n_lstm), dim3(256), 0, (hipStream_t)stream, (const PackRow*)table, H, Hp);
+  else hipLaunchKernelGGL(lstm_pack_quads_multi_kernel<bf16_t>, dim3(256, (unsigned)n_lstm), dim3(256), 0, (hipStream_t)stream, (const PackRow*)table, H, Hp);
   URSE_CHECK_LAUNCH("urse_lstm_pack_quads_multi");
   return URSE_OK;
 }
@@ -889,8 +911,10 @@ extern "C" int urse_lstm_cluster_plan(int H, int Hp, int n_seq, int reserved_cus
 extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                                      void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len,
                                      int64_t inner, int64_t outer, int64_t stride, int save, int reserved_cus, int xcd_aware,
-                                     void* stream) {
+                                     int dtype, void* hout_bf16, void* stream) {
   URSE_CHECK_ARG(gx && whhq && hout && hx && counters && err_flag && (c || !save), "urse_lstm_cluster_fwd: null pointer");
+  URSE_CHECK_ARG(dtype == URSE_BF16 || dtype == URSE_F16, "urse_lstm_cluster_fwd: operands are bf16 or f16 (dtype %d)", dtype);
+  URSE_CHECK_ARG(!hout_bf16 || (dtype == URSE_F16 && ((uintptr_t)hout_bf16 % 16) == 0), "urse_lstm_cluster_fwd: the bf16 copy of h goes with f16 operands only");
   int64_t plan[6];
   int rc = urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus, plan);
   if (rc) return rc;
@@ -907,7 +931,7 @@ extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, vo
                    "urse_lstm_cluster_fwd: matrices of %ld rows exceed 32-bit byte offsets, or gx / c are not 16-byte aligned", rows);
     p.g_bytes = (unsigned)(rows * ldg * 2); p.c_bytes = c ? (unsigned)(rows * 2L * H * 4) : 0u; p.h_bytes = (unsigned)(rows * ldh * 2);
   }
-  p.gx = gx; p.ldg = ldg; p.whhq = whhq; p.hout = hout; p.ldh = ldh; p.c = c; p.hx = (bf16_t*)hx;
+  p.gx = gx; p.ldg = ldg; p.whhq = whhq; p.hout = hout; p.hout2 = hout_bf16; p.ldh = ldh; p.c = c; p.hx = (bf16_t*)hx;
   p.cnt = (unsigned*)counters; p.err = (unsigned*)err_flag; p.H = H; p.Hp = Hp; p.save = save;
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
   p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2]; p.rows_pad = (int)plan[3];
@@ -921,7 +945,8 @@ extern "C" int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, vo
   }
   const int nslab = Hp / 32;
   note_launch(URSE_KV_LSTM_FWD_CLUSTER);
-  if (nslab == 13) return launch_cluster<13, 1>(p, st);
-  if (nslab == 2) return launch_cluster<2, 1>(p, st);
-  return launch_cluster<1, 1>(p, st);
+  const int f16 = dtype == URSE_F16;
+  if (nslab == 13) return launch_cluster<13, 1>(p, f16, st);
+  if (nslab == 2) return launch_cluster<2, 1>(p, f16, st);
+  return launch_cluster<1, 1>(p, f16, st);
 }

@@ -39,6 +39,7 @@ struct RxArgs {
   const float* bias;              // [2][4H] f32, (unit, gate) interleaved: b_ih + b_hh
   void* gates; long ldg;          // out (save): gate activations, (unit, gate) interleaved
   void* hout; long ldh;
+  void* hout2;                    // f16 operands: h once more in bf16 for the weight-gradient GEMMs (null: not wanted)
   float* c;
   long inner, outer, stride;
   int n_seq, seq_len;
@@ -53,8 +54,11 @@ __device__ __forceinline__ void rx_glds16(const char* gsrc, unsigned dst) {
 }
 #pragma clang diagnostic pop
 
-template <int H, int HP, int NP, bool SAVE>
+// TI: operand format of both products (bf16_t | f16_t: x_n, W_ih, W_hh, the carried h and hout); the saved gate activations are bf16 in both
+// (they feed the BPTT); H2: also write hout2 (f16 only)
+template <int H, int HP, int NP, bool SAVE, typename TI = bf16_t, bool H2 = false>
 __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p) {
+  static_assert(!H2 || __is_same(TI, f16_t), "the bf16 copy of h exists in the f16 mode only");
   constexpr int NBLK = (H + 15) / 16, NSH = HP / 32, NSX = NP / 32, NS = NSH + NSX, NF = 4 * NS;   // 25 blocks, 13 + 7 slabs, 80 fragments per block
   constexpr int SF = RX_SF, SPB = NF / SF, SPS = NBLK * SPB, SLOTB = SF * 1024;              // 8 stages per block, 200 per step
   constexpr int HPITCH = lds_frag_pitch(HP * 2);
@@ -112,6 +116,7 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)p.g_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(p.hout, 0, (int)p.h_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h2 = __builtin_amdgcn_make_buffer_rsrc(H2 ? p.hout2 : p.hout, 0, (int)p.h_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xn), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, 2 * 4 * H * 4, 0x00020000);
   // per-lane byte offsets at t = 0, block 0: rows 4 lr + r (C layout: cell update, stores), row lc (A layout: x fragments)
@@ -148,12 +153,18 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
     const unsigned off = (idx < 16 * CPR && grow >= 0) ? ((unsigned)grow * (unsigned)ldh_i + (unsigned)(hcol_i + cc * 8)) * 2u : OOB;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_h, (int)(off | mask), soff, 0);
+    if constexpr (H2) {
+      float a0, a1, a2, a3, a4, a5, a6, a7;
+      unpack2<f16_t>(v.x, a0, a1); unpack2<f16_t>(v.y, a2, a3); unpack2<f16_t>(v.z, a4, a5); unpack2<f16_t>(v.w, a6, a7);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack2<bf16_t>(a0, a1), pack2<bf16_t>(a2, a3), pack2<bf16_t>(a4, a5), pack2<bf16_t>(a6, a7)},
+                                             rs_h2, (int)(off | mask), soff, 0);
+    }
   };
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  auto pack2 = [](float a, float b) -> unsigned {
+  auto pack2b = [](float a, float b) -> unsigned {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
   };
 
@@ -229,7 +240,7 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
       const float cv = __builtin_fmaf(fv, cprevp[r], __fmul_rn(iv, gv));
       const float hv = ov * tanhf_(cv);
 #endif
-      *reinterpret_cast<bf16_t*>(hs + hsoff[r] + blk * 32) = f32_to_bf16(hv);      // (units past H: the tile's k padding, finite values against zero weights)
+      *reinterpret_cast<TI*>(hs + hsoff[r] + blk * 32) = from_f32<TI>(hv);      // (units past H: the tile's k padding, finite values against zero weights)
       unsigned co = coff[r], go = goff[r];
 #ifdef RXABL_NO_STORE
       co = hv == 123.f ? co : OOB; go = hv == 123.f ? go : OOB;
@@ -244,7 +255,7 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
       }
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cv), rs_c, (int)co, sc_t + blk * 64, 0);
       if constexpr (SAVE)
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(iv, fv), pack2(gv, ov)}, rs_g, (int)go, sg_t + blk * 128, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2b(iv, fv), pack2b(gv, ov)}, rs_g, (int)go, sg_t + blk * 128, 0);
     };
 
     auto body = [&](int bo, auto first) {
@@ -269,8 +280,7 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
             const int fb = q * SF + f, ks = fb >> 2, gate = fb & 3;       // slabs 0 .. 12: h W_hh^T, 13 .. 19: x W_ih^T
             const uint4 a = ks < NSH ? hfrag[ks < NSH ? ks : 0] : xfrag[ks >= NSH ? ks - NSH : 0];
 #ifndef RXABL_NO_MFMA
-            acc[gate] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bq[fb % RX_D]),
-                                                                acc[gate], 0, 0, 0);
+            acc[gate] = mfma16<TI>(a, bq[fb % RX_D], acc[gate]);
 #else
             acc[gate][0] += __uint_as_float(a.x ^ bq[fb % RX_D].x);
 #endif
@@ -317,8 +327,9 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
 // Block-ordered weights of the fused kernel: (dir, blk, slab, gate) = 64 lanes x 16 B; lane (lr, lc): unit blk * 16 + lc;
 // slab ks < Hp / 32: W_hh[gate * H + unit][ks * 32 + 8 lr + j]; the following Np / 32 slabs: W_ih[gate * H + unit][(ks - Hp / 32) * 32 + 8 lr + j];
 // zeros past H / N.
+template <typename TI>
 __device__ __forceinline__ void lstm_pack_blocks_x_dev(const float* __restrict__ wih, const float* __restrict__ whh,
-                                                       bf16_t* __restrict__ out, int N, int Np, int H, int Hp) {
+                                                       TI* __restrict__ out, int N, int Np, int H, int Hp) {
   const int nblk = (H + 15) >> 4, nsh = Hp / 32, ns = nsh + Np / 32, G4 = 4 * H;
   const long total = (long)2 * nblk * ns * 4 * 64 * 8;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -341,16 +352,18 @@ __device__ __forceinline__ void lstm_pack_blocks_x_dev(const float* __restrict__
         if (k < N) v = wih[((long)d * G4 + g * H + u) * N + k];
       }
     }
-    out[idx] = f32_to_bf16(v);
+    out[idx] = from_f32<TI>(v);
   }
 }
+template <typename TI>
 __global__ void __launch_bounds__(256) lstm_pack_blocks_x_kernel(const float* __restrict__ wih, const float* __restrict__ whh,
-                                                                 bf16_t* __restrict__ out, int N, int Np, int H, int Hp) {
-  lstm_pack_blocks_x_dev(wih, whh, out, N, Np, H, Hp);
+                                                                 TI* __restrict__ out, int N, int Np, int H, int Hp) {
+  lstm_pack_blocks_x_dev<TI>(wih, whh, out, N, Np, H, Hp);
 }
+template <typename TI>
 __global__ void __launch_bounds__(256) lstm_pack_blocks_x_multi_kernel(const PackRow* __restrict__ tab, int N, int Np, int H, int Hp) {
   const PackRow r = tab[blockIdx.y];
-  if (r.wx) lstm_pack_blocks_x_dev(r.wih, r.whh, (bf16_t*)r.wx, N, Np, H, Hp);
+  if (r.wx) lstm_pack_blocks_x_dev<TI>(r.wih, r.whh, (TI*)r.wx, N, Np, H, Hp);
 }
 
 static bool rx_shape(int N, int Np, int H, int Hp) { return N == 196 && Np == 224 && H == 392 && Hp == 416; }
@@ -361,31 +374,37 @@ using namespace urse;
 
 extern "C" int urse_lstm_rwx_supported(int N, int Np, int H, int Hp) { return rx_shape(N, Np, H, Hp) ? 1 : 0; }
 
-extern "C" int urse_lstm_pack_blocks_x(const float* wih, const float* whh, void* out, int N, int Np, int H, int Hp, void* stream) {
-  URSE_CHECK_ARG(wih && whh && out && rx_shape(N, Np, H, Hp), "urse_lstm_pack_blocks_x: bad argument (N=%d Np=%d H=%d Hp=%d)", N, Np, H, Hp);
-  hipLaunchKernelGGL(lstm_pack_blocks_x_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, wih, whh, (bf16_t*)out, N, Np, H, Hp);
+extern "C" int urse_lstm_pack_blocks_x(const float* wih, const float* whh, void* out, int N, int Np, int H, int Hp, int dtype, void* stream) {
+  URSE_CHECK_ARG(wih && whh && out && rx_shape(N, Np, H, Hp) && (dtype == URSE_BF16 || dtype == URSE_F16),
+                 "urse_lstm_pack_blocks_x: bad argument (N=%d Np=%d H=%d Hp=%d dtype=%d)", N, Np, H, Hp, dtype);
+  if (dtype == URSE_F16) hipLaunchKernelGGL(lstm_pack_blocks_x_kernel<f16_t>, dim3(512), dim3(256), 0, (hipStream_t)stream, wih, whh, (f16_t*)out, N, Np, H, Hp);
+  else hipLaunchKernelGGL(lstm_pack_blocks_x_kernel<bf16_t>, dim3(512), dim3(256), 0, (hipStream_t)stream, wih, whh, (bf16_t*)out, N, Np, H, Hp);
   URSE_CHECK_LAUNCH("urse_lstm_pack_blocks_x");
   return URSE_OK;
 }
 
-extern "C" int urse_lstm_pack_blocks_x_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, void* stream) {
-  URSE_CHECK_ARG(table && n_lstm > 0 && n_lstm < 65536 && rx_shape(N, Np, H, Hp), "urse_lstm_pack_blocks_x_multi: bad argument (N=%d Np=%d H=%d Hp=%d)", N, Np, H, Hp);
-  hipLaunchKernelGGL(lstm_pack_blocks_x_multi_kernel, dim3(512, (unsigned)n_lstm), dim3(256), 0, (hipStream_t)stream, (const PackRow*)table, N, Np, H, Hp);
+extern "C" int urse_lstm_pack_blocks_x_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, int dtype, void* stream) {
+  URSE_CHECK_ARG(table && n_lstm > 0 && n_lstm < 65536 && rx_shape(N, Np, H, Hp) && (dtype == URSE_BF16 || dtype == URSE_F16),
+                 "urse_lstm_pack_blocks_x_multi: bad argument (N=%d Np=%d H=%d Hp=%d dtype=%d)", N, Np, H, Hp, dtype);
+  if (dtype == URSE_F16) hipLaunchKernelGGL(lstm_pack_blocks_x_multi_kernel<f16_t>, dim3(512, (unsigned)n_lstm), dim3(256), 0, (hipStream_t)stream, (const PackRow*)table, N, Np, H, Hp);
+  else hipLaunchKernelGGL(lstm_pack_blocks_x_multi_kernel<bf16_t>, dim3(512, (unsigned)n_lstm), dim3(256), 0, (hipStream_t)stream, (const PackRow*)table, N, Np, H, Hp);
   URSE_CHECK_LAUNCH("urse_lstm_pack_blocks_x_multi");
   return URSE_OK;
 }
 
 extern "C" int urse_lstm_rwx_fwd(const void* xn, int64_t ldx, const void* wx, const float* bias, void* gates, int64_t ldg, void* hout,
                                  int64_t ldh, float* c, int N, int Np, int H, int Hp, int n_seq, int seq_len, int64_t inner,
-                                 int64_t outer, int64_t stride, int save, int target_workgroups, void* stream) {
+                                 int64_t outer, int64_t stride, int save, int target_workgroups, int dtype, void* hout_bf16, void* stream) {
   URSE_CHECK_ARG(xn && wx && bias && hout && c && (gates || !save), "urse_lstm_rwx_fwd: null pointer (c is required: it carries c_{t-1})");
+  URSE_CHECK_ARG(dtype == URSE_BF16 || dtype == URSE_F16, "urse_lstm_rwx_fwd: operands are bf16 or f16 (dtype %d)", dtype);
+  URSE_CHECK_ARG(!hout_bf16 || (dtype == URSE_F16 && ((uintptr_t)hout_bf16 % 16) == 0), "urse_lstm_rwx_fwd: the bf16 copy of h goes with f16 operands only");
   URSE_CHECK_ARG(rx_shape(N, Np, H, Hp), "urse_lstm_rwx_fwd: unsupported N=%d Np=%d H=%d Hp=%d", N, Np, H, Hp);
   URSE_CHECK_ARG(n_seq > 0 && seq_len > 0 && inner > 0 && target_workgroups >= 0, "urse_lstm_rwx_fwd: bad sequence geometry");
   URSE_CHECK_ARG(ldx >= Np && ldx % 8 == 0 && ((uintptr_t)xn % 16) == 0 && ldh >= 2L * H && ldh % 8 == 0 && ((uintptr_t)hout % 16) == 0 &&
                      (!save || (ldg >= 8L * H && ldg % 4 == 0 && ((uintptr_t)gates % 8) == 0)) && ((uintptr_t)bias % 16) == 0,
                  "urse_lstm_rwx_fwd: bad leading dimension / alignment");
   RxArgs p;
-  p.xn = xn; p.ldx = ldx; p.wx = wx; p.bias = bias; p.gates = gates ? gates : hout; p.ldg = save ? ldg : 8L * H; p.hout = hout; p.ldh = ldh; p.c = c;
+  p.xn = xn; p.ldx = ldx; p.wx = wx; p.bias = bias; p.gates = gates ? gates : hout; p.ldg = save ? ldg : 8L * H; p.hout = hout; p.hout2 = hout_bf16; p.ldh = ldh; p.c = c;
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
   {
     const long rows = stride * (seq_len - 1) + ((n_seq - 1) / inner) * outer + ((n_seq - 1) % inner) + 1;
@@ -403,14 +422,20 @@ extern "C" int urse_lstm_rwx_fwd(const void* xn, int64_t ldx, const void* wx, co
   p.tiles_rem = ntile % G;
   constexpr int HPITCH = lds_frag_pitch(416 * 2);
   const size_t lds = (size_t)RX_NSLOT * RX_SF * 1024 + (size_t)RX_MAXT * 16 * HPITCH + RX_MAXT * 16 * sizeof(int);
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rwx_kernel<392, 416, 224, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rwx_kernel<392, 416, 224, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+#define URSE_RX_ATTR(...) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rwx_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+  static bool once = (URSE_RX_ATTR(392, 416, 224, true), URSE_RX_ATTR(392, 416, 224, false), URSE_RX_ATTR(392, 416, 224, true, f16_t, false),
+                      URSE_RX_ATTR(392, 416, 224, true, f16_t, true), URSE_RX_ATTR(392, 416, 224, false, f16_t, false), true);
   (void)once;
+#undef URSE_RX_ATTR
   note_launch(URSE_KV_LSTM_FWD_RWX);
-  if (save) hipLaunchKernelGGL((lstm_fwd_rwx_kernel<392, 416, 224, true>), dim3(2 * G), dim3(RX_WAVES * 64), lds, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((lstm_fwd_rwx_kernel<392, 416, 224, false>), dim3(2 * G), dim3(RX_WAVES * 64), lds, (hipStream_t)stream, p);
+  const dim3 grid(2 * G), blk(RX_WAVES * 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == URSE_F16) {
+    if (save && hout_bf16) hipLaunchKernelGGL((lstm_fwd_rwx_kernel<392, 416, 224, true, f16_t, true>), grid, blk, lds, st, p);
+    else if (save) hipLaunchKernelGGL((lstm_fwd_rwx_kernel<392, 416, 224, true, f16_t, false>), grid, blk, lds, st, p);
+    else hipLaunchKernelGGL((lstm_fwd_rwx_kernel<392, 416, 224, false, f16_t, false>), grid, blk, lds, st, p);
+  } else if (save) hipLaunchKernelGGL((lstm_fwd_rwx_kernel<392, 416, 224, true>), grid, blk, lds, st, p);
+  else hipLaunchKernelGGL((lstm_fwd_rwx_kernel<392, 416, 224, false>), grid, blk, lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_rwx_fwd");
   return URSE_OK;
 }

@@ -84,7 +84,8 @@ template <typename TO>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ add, TO* __restrict__ y, GnShape s,
-                                                       float eps) {
+                                                       float eps, bf16_t* __restrict__ y2 = nullptr) {
+  // y2 (f16 forward mode, training): the same rows once more in bf16 - the weight-gradient GEMMs multiply them with bf16 gate gradients
   const int n4 = s.Np >> 2, vpb = 256 / n4, wn = s.W / s.N;
   const int b = blockIdx.z, kg = blockIdx.y;
   const int slot = threadIdx.x / n4, c = (threadIdx.x - slot * n4) * 4;
@@ -105,18 +106,25 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   for (int i = 0; i < wk.left; ++i, wk.next()) {
     const long vec = (((long)b * s.T + wk.t) * s.Kg + kg) * wn + wk.v;
     TO o[4];
+    float of[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < s.N) {
       const float4 v = *reinterpret_cast<const float4*>(x + vec * s.N + c);
-      o[0] = from_f32<TO>((v.x - mean) * rstd * g[0] + be[0] + ad[0]);      // (same arithmetic as ever: results unchanged)
-      o[1] = from_f32<TO>((v.y - mean) * rstd * g[1] + be[1] + ad[1]);
-      o[2] = from_f32<TO>((v.z - mean) * rstd * g[2] + be[2] + ad[2]);
-      o[3] = from_f32<TO>((v.w - mean) * rstd * g[3] + be[3] + ad[3]);
-    } else {
-      o[0] = o[1] = o[2] = o[3] = from_f32<TO>(0.f);
+      of[0] = (v.x - mean) * rstd * g[0] + be[0] + ad[0];      // (same arithmetic as ever: results unchanged)
+      of[1] = (v.y - mean) * rstd * g[1] + be[1] + ad[1];
+      of[2] = (v.z - mean) * rstd * g[2] + be[2] + ad[2];
+      of[3] = (v.w - mean) * rstd * g[3] + be[3] + ad[3];
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = from_f32<TO>(of[j]);
     TO* dst = y + vec * s.Np + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) dst[j] = o[j];
+    if (y2) {
+      uint2 pk;
+      pk.x = pack2<bf16_t>(of[0], of[1]);
+      pk.y = pack2<bf16_t>(of[2], of[3]);
+      *reinterpret_cast<uint2*>(y2 + vec * s.Np + c) = pk;
+    }
   }
 }
 
@@ -338,10 +346,23 @@ static int make_shape(GnShape* s, int B, int T, int Kg, int W, int N, int Np, in
   return URSE_OK;
 }
 
+static int launch_gn_apply(dim3 grid_a, hipStream_t st, const float* x, const double* stats, const float* gamma, const float* beta,
+                           const float* add, void* y, void* y_bf16, const GnShape& s, float eps, int out_dtype, const char* who) {
+  URSE_CHECK_ARG(!y_bf16 || (out_dtype == URSE_F16 && ((uintptr_t)y_bf16 % 8) == 0), "%s: the bf16 copy goes with f16 output only", who);
+  if (out_dtype == URSE_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (bf16_t*)y, s, eps, (bf16_t*)nullptr);
+  else if (out_dtype == URSE_F16)
+    hipLaunchKernelGGL(gn_apply_kernel<f16_t>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (f16_t*)y, s, eps, (bf16_t*)y_bf16);
+  else if (out_dtype == URSE_F32)
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (float*)y, s, eps, (bf16_t*)nullptr);
+  else { set_error("%s: bad output dtype %d", who, out_dtype); return URSE_ERR_INVALID_ARG; }
+  return URSE_OK;
+}
+
 extern "C" int urse_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* add, void* y,
                                   double* stats,
                                   int B, int T, int Kg, int W, int N, int Np, int gstride, float eps, int out_dtype,
-                                  void* stream) {
+                                  void* y_bf16, void* stream) {
   GnShape s;
   int rc = make_shape(&s, B, T, Kg, W, N, Np, gstride, "urse_groupnorm_fwd");
   if (rc) return rc;
@@ -356,10 +377,8 @@ extern "C" int urse_groupnorm_fwd(const float* x, const float* gamma, const floa
   URSE_CHECK_ARG(Np / 4 <= 256, "urse_groupnorm_fwd: Np %d too wide", Np);
   const int vpb_f = 256 / (Np / 4);
   dim3 grid_a(ceil_div((long)T * (W / N), (long)vpb_f * GN_ITER), Kg, B);
-  if (out_dtype == URSE_BF16)
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (bf16_t*)y, s, eps);
-  else
-    hipLaunchKernelGGL(gn_apply_kernel<float>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (float*)y, s, eps);
+  rc = launch_gn_apply(grid_a, st, x, stats, gamma, beta, add, y, y_bf16, s, eps, out_dtype, "urse_groupnorm_fwd");
+  if (rc) return rc;
   URSE_CHECK_LAUNCH("urse_groupnorm_fwd");
   return URSE_OK;
 }
@@ -381,7 +400,7 @@ extern "C" int urse_groupnorm_stats(const float* x, double* stats, int B, int T,
 
 extern "C" int urse_groupnorm_apply(const float* x, const float* gamma, const float* beta, const float* add, void* y,
                                     const double* stats, int B, int T, int Kg, int W, int N, int Np, int gstride, float eps,
-                                    int out_dtype, void* stream) {
+                                    int out_dtype, void* y_bf16, void* stream) {
   GnShape s;
   int rc = make_shape(&s, B, T, Kg, W, N, Np, gstride, "urse_groupnorm_apply");
   if (rc) return rc;
@@ -389,10 +408,8 @@ extern "C" int urse_groupnorm_apply(const float* x, const float* gamma, const fl
   hipStream_t st = (hipStream_t)stream;
   const int vpb_f = 256 / (Np / 4);
   dim3 grid_a(ceil_div((long)T * (W / N), (long)vpb_f * GN_ITER), Kg, B);
-  if (out_dtype == URSE_BF16)
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (bf16_t*)y, s, eps);
-  else
-    hipLaunchKernelGGL(gn_apply_kernel<float>, grid_a, dim3(256), 0, st, x, stats, gamma, beta, add, (float*)y, s, eps);
+  rc = launch_gn_apply(grid_a, st, x, stats, gamma, beta, add, y, y_bf16, s, eps, out_dtype, "urse_groupnorm_apply");
+  if (rc) return rc;
   URSE_CHECK_LAUNCH("urse_groupnorm_apply");
   return URSE_OK;
 }
@@ -469,6 +486,12 @@ extern "C" int urse_pack2d(const void* in, int64_t ldi, int in_dtype, void* out,
   else if (in_dtype == URSE_BF16 && out_dtype == URSE_F32)
     hipLaunchKernelGGL((pack2d_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)in, (long)ldi, (float*)out,
                        (long)ldo, rows, cols, out_rows, out_cols, transpose);
+  else if (in_dtype == URSE_F32 && out_dtype == URSE_F16)
+    hipLaunchKernelGGL((pack2d_kernel<float, f16_t>), g, b, 0, st, (const float*)in, (long)ldi, (f16_t*)out,
+                       (long)ldo, rows, cols, out_rows, out_cols, transpose);
+  else if (in_dtype == URSE_F16 && out_dtype == URSE_F32)
+    hipLaunchKernelGGL((pack2d_kernel<f16_t, float>), g, b, 0, st, (const f16_t*)in, (long)ldi, (float*)out,
+                       (long)ldo, rows, cols, out_rows, out_cols, transpose);
   else { set_error("urse_pack2d: bad dtype"); return URSE_ERR_INVALID_ARG; }
   URSE_CHECK_LAUNCH("urse_pack2d");
   return URSE_OK;
@@ -504,6 +527,9 @@ extern "C" int urse_pack_segments(const float* in, void* out, const void* segs, 
   dim3 g(blocks_per_seg, nseg), b(256);
   if (out_dtype == URSE_BF16)
     hipLaunchKernelGGL(urse::pack_seg_kernel<urse::bf16_t>, g, b, 0, (hipStream_t)stream, in, (urse::bf16_t*)out,
+                       (const urse::PackSeg*)segs, transpose);
+  else if (out_dtype == URSE_F16)
+    hipLaunchKernelGGL(urse::pack_seg_kernel<urse::f16_t>, g, b, 0, (hipStream_t)stream, in, (urse::f16_t*)out,
                        (const urse::PackSeg*)segs, transpose);
   else
     hipLaunchKernelGGL(urse::pack_seg_kernel<float>, g, b, 0, (hipStream_t)stream, in, (float*)out,

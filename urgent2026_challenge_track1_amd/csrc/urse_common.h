@@ -35,6 +35,10 @@ void note_launch(int variant);
   } while (0)
 
 typedef unsigned short bf16_t;  // raw bf16 bits
+// IEEE half (11 significant bits): the operand format of the f16 FORWARD mode (compute_dtype "f16": same bytes and MFMA rate as bf16,
+// v_mfma_f32_16x16x32_f16; 8x smaller operand rounding - what north_star's 1e-3 on the enhanced waveform needs).
+// Gradients stay bf16 (range), so every backward operand is bf16 in that mode too.
+typedef _Float16 f16_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
@@ -49,6 +53,41 @@ template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return b
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return (float)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }      // round-to-nearest-even, NaN stays NaN, overflow -> inf
+
+// two f32 -> one dword of two 16-bit values (low half = a), and back
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<bf16_t>(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{a, b}, bf16x2_));
+}
+template <> __device__ __forceinline__ unsigned pack2<f16_t>(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{a, b}, f16x2_));
+}
+template <typename T> __device__ __forceinline__ void unpack2(unsigned v, float& a, float& b);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(unsigned v, float& a, float& b) {
+  a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16_t>(unsigned v, float& a, float& b) {
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  const f16x2_ h = __builtin_bit_cast(f16x2_, v);
+  a = (float)h[0]; b = (float)h[1];
+}
+// the 16 x 16 x 32 MFMA of a 16-bit operand format on raw fragment registers (4 dwords = 8 elements each)
+template <typename T> __device__ __forceinline__ float __attribute__((ext_vector_type(4)))
+mfma16(const uint4& a, const uint4& b, float __attribute__((ext_vector_type(4))) c) {
+  if constexpr (__is_same(T, f16_t)) {
+    typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_, a), __builtin_bit_cast(f16x8_, b), c, 0, 0, 0);
+  } else {
+    typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
+  }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -11,7 +11,10 @@ from . import ops
 from .bsrnn import BSRNN_SE
 from .config import Config
 
-_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "float32": torch.float32}
+# "f16" = IEEE-half operands in the forward contractions (bf16's bytes and MFMA rate, 11 significant bits: the enhanced waveform then meets
+# north_star's 1e-3 against the f32 reference arithmetic), bf16 operands in the backward (bsrnn.BSRNNCore.__init__)
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "float32": torch.float32,
+           "f16": torch.float16, "float16": torch.float16, "f16fwd": torch.float16}
 
 
 class StepLR:

@@ -33,6 +33,8 @@ class FlowBSRNNCore(BSRNNCore):
     band_groups = ("bsx", "bsy", "gdm", "gdr")
 
     def __init__(self, input_dim=769, num_channel=384, num_layer=6, compute_dtype=torch.bfloat16):
+        if compute_dtype == torch.float16:
+            raise NotImplementedError("the f16 forward mode covers the discriminative BSRNN (BSRNN_SE); the flow DNN runs bf16 or f32")
         super().__init__(input_dim, num_channel, num_layer, 48000, False, 1, compute_dtype)
         self._pf = None
 

@@ -11,7 +11,14 @@ from . import _lib
 from ._lib import call, require_cuda, stream_ptr
 
 WIN_RECT, WIN_HANN = 0, 1
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2       # include/urse.h: URSE_F32 / URSE_BF16 / URSE_F16
+HALF_TYPES = (torch.bfloat16, torch.float16)   # 16-bit operand formats: same kernels, layouts and padding; f16 is the FORWARD-only format
+
+
+def bwd_dtype(dtype):
+    """operand type of the backward kernels for a forward operand type: gradients need bf16's range, so the f16 forward mode
+    (compute_dtype "f16": 11 significant bits, what north_star's 1e-3 on the enhanced waveform needs) keeps bf16 backward operands."""
+    return torch.bfloat16 if dtype == torch.float16 else dtype
 
 # Optional per-kernel HIP-event timing (bench.py): name -> [(start_event, end_event), ...]
 _timing = None
@@ -131,11 +138,19 @@ def _dt(t):
         return BF16
     if t.dtype == torch.float32:
         return F32
-    raise TypeError("URSE GEMM operands are bf16 or f32, got %s" % t.dtype)
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError("URSE GEMM operands are bf16, f16 or f32, got %s" % t.dtype)
+
+
+def dtype_code(dtype):
+    """URSE_* code of a torch dtype."""
+    return {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[dtype]
 
 
 def gemm_nt(A, W, bias=None, resid=None, act=0, out=None, out_dtype=None, N=None, gn_rows=0):
     """out[M, N] = act(A[M, K] @ W[N, K]^T + bias) (+ resid).  A, W: 2-D, unit inner stride, same dtype.
+    f16 operands with act = 1 and a 16-bit output: `resid` (a bf16 tensor shaped like `out`) receives the same values in bf16.
     gn_rows > 0 (f32 dense output): also returns the GroupNorm statistics of `out` per group of gn_rows rows, f64 [M / gn_rows, 2]
     (sum, sum of squares) as `groupnorm_fwd(..., stats=)` takes them -> (out, stats)."""
     require_cuda(A, W)
@@ -222,8 +237,8 @@ def pad_to(n, m):
 
 
 def kpad(n, dtype):
-    """zero-padded contraction length the MFMA GEMMs need: multiple of 32 (bf16) / 16 (f32)."""
-    return pad_to(n, 32 if dtype == torch.bfloat16 else 16)
+    """zero-padded contraction length the MFMA GEMMs need: multiple of 32 (bf16 / f16) / 16 (f32)."""
+    return pad_to(n, 32 if dtype in HALF_TYPES else 16)
 
 
 def pack2d(inp, out_rows, out_cols, dtype, transpose=False, out=None):
@@ -238,18 +253,22 @@ def pack2d(inp, out_rows, out_cols, dtype, transpose=False, out=None):
     return out
 
 
-def groupnorm_fwd(x, gamma, beta, B, T, Kg, W, N, Np, gstride, dtype, eps=1e-5, add=None, stats=None):
+def groupnorm_fwd(x, gamma, beta, B, T, Kg, W, N, Np, gstride, dtype, eps=1e-5, add=None, stats=None, bf16_copy=False):
     """x f32 [B,T,Kg,W] -> (y [B*T*Kg*(W/N), Np] dtype, stats f64 [B*Kg*2]).  stats: the statistics of x where its producer
-    computed them already (`gemm_nt(..., gn_rows=)`): only the normalisation runs."""
+    computed them already (`gemm_nt(..., gn_rows=)`): only the normalisation runs.
+    bf16_copy (dtype f16, training): -> (y, stats, y_bf16), the rows once more in bf16 for the weight-gradient GEMMs."""
     require_cuda(x)
     y = torch.empty(B * T * Kg * (W // N), Np, device=x.device, dtype=dtype)
+    y2 = torch.empty_like(y, dtype=torch.bfloat16) if (bf16_copy and dtype == torch.float16) else None
     if stats is not None:
         assert stats.numel() == B * Kg * 2 and stats.dtype == torch.float64
-        call("groupnorm_apply", x, gamma, beta, add, y, stats, B, T, Kg, W, N, Np, gstride, float(eps), _dt(y), stream_ptr())
-        return y, stats
-    stats = torch.empty(B * Kg * 2, device=x.device, dtype=torch.float64)
-    call("groupnorm_fwd", x, gamma, beta, add, y, stats, B, T, Kg, W, N, Np, gstride, float(eps), _dt(y), stream_ptr())
-    return y, stats
+        call("groupnorm_apply", x, gamma, beta, add, y, stats, B, T, Kg, W, N, Np, gstride, float(eps), _dt(y), y2, stream_ptr())
+    else:
+        stats = torch.empty(B * Kg * 2, device=x.device, dtype=torch.float64)
+        call("groupnorm_fwd", x, gamma, beta, add, y, stats, B, T, Kg, W, N, Np, gstride, float(eps), _dt(y), y2, stream_ptr())
+    if bf16_copy is None:            # (callers that always unpack three: the third is the backward's operand, y itself without a copy)
+        return y, stats, y
+    return (y, stats, (y2 if y2 is not None else y)) if bf16_copy else (y, stats)
 
 
 def groupnorm_bwd(x, dy, stats, gamma, dres, dgamma, dbeta, B, T, Kg, W, N, gstride, eps=1e-5, pack_ld=0, sums=None):
@@ -315,19 +334,30 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None, layouts=None):
     dev = wih.device
     Np, Hp = kpad(N, dtype), kpad(pad_to(H, 16), dtype)
     nu = pad_to(H, 16)
+    bdt = bwd_dtype(dtype)        # dtype f16: the forward layouts (wih, whh, whhq, wx) are f16, the backward ones (wihT, whhT) bf16
     if out is None:
             out = dict(wih=torch.empty(8 * H, Np, device=dev, dtype=dtype),
-                   wihT=torch.empty(N, 8 * H, device=dev, dtype=dtype),
+                   wihT=torch.empty(N, 8 * H, device=dev, dtype=bdt),
                    bias=torch.empty(8 * H, device=dev, dtype=torch.float32),
                    whh=torch.empty(2 * nu * 4 * Hp, device=dev, dtype=dtype),
-                   whhT=torch.empty(2 * nu * 4 * H, device=dev, dtype=dtype), Np=Np, Hp=Hp)
+                   whhT=torch.empty(2 * nu * 4 * H, device=dev, dtype=bdt), Np=Np, Hp=Hp)
     call("lstm_pack", wih, whh, bih, bhh, out["wih"], out["wihT"], out["bias"], out["whh"], out["whhT"], N, Np, H, Hp,
          _dt(out["wih"]), stream_ptr())
+    if dtype == torch.float16 and Hp % 32 == 0:
+        # the f16 forward mode has the kernels of the benchmarked dispatch: cluster forward (whhq) and fused row-wave forward (wx)
+        if want("whhq"):
+            if "whhq" not in out:
+                out["whhq"] = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=dtype)
+            call("lstm_pack_quads", whh, out["whhq"], H, Hp, F16, stream_ptr())
+        if want("wx") and _lib.load().urse_lstm_rwx_supported(N, Np, H, Hp):
+            if "wx" not in out:
+                out["wx"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32 + Np // 32) * 4 * 512, device=dev, dtype=dtype)
+            call("lstm_pack_blocks_x", wih, whh, out["wx"], N, Np, H, Hp, F16, stream_ptr())
     if dtype == torch.bfloat16 and Hp % 32 == 0:
         if want("whhq"):
             if "whhq" not in out:
                 out["whhq"] = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=dtype)
-            call("lstm_pack_quads", whh, out["whhq"], H, Hp, stream_ptr())
+            call("lstm_pack_quads", whh, out["whhq"], H, Hp, BF16, stream_ptr())
         if want("whhb") and _lib.load().urse_lstm_wide_supported(H, Hp):
             if "whhb" not in out:
                 out["whhb"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32) * 4 * 512, device=dev, dtype=dtype)
@@ -339,7 +369,7 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None, layouts=None):
         if want("wx") and _lib.load().urse_lstm_rwx_supported(N, Np, H, Hp):
             if "wx" not in out:
                 out["wx"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32 + Np // 32) * 4 * 512, device=dev, dtype=dtype)
-            call("lstm_pack_blocks_x", wih, whh, out["wx"], N, Np, H, Hp, stream_ptr())
+            call("lstm_pack_blocks_x", wih, whh, out["wx"], N, Np, H, Hp, BF16, stream_ptr())
         if want("whhTq") and H % 8 == 0:
             C = ((H + 3) // 4 + 13) // 14
             if "whhTq" not in out:
@@ -363,13 +393,15 @@ def lstm_pack_multi(entries, N, H, dtype, table=None):
     if table is None or table[1] != rows:
         table = (upload(torch.tensor(rows, dtype=torch.int64), dev, cached=True), rows)
     n = len(rows)
-    call("lstm_pack_multi", table[0], n, N, Np, H, Hp, _dt(first["wih"]), stream_ptr())
+    fdt = _dt(first["wih"])
+    call("lstm_pack_multi", table[0], n, N, Np, H, Hp, fdt, stream_ptr())
     if any(r[9] for r in rows):
-        call("lstm_pack_quads_multi", table[0], n, H, Hp, stream_ptr())
+        call("lstm_pack_quads_multi", table[0], n, H, Hp, fdt, stream_ptr())
     if any(r[10] for r in rows):
+        assert fdt == BF16
         call("lstm_pack_blocks_multi", table[0], n, H, Hp, stream_ptr())
     if any(r[11] for r in rows):
-        call("lstm_pack_blocks_x_multi", table[0], n, N, Np, H, Hp, stream_ptr())
+        call("lstm_pack_blocks_x_multi", table[0], n, N, Np, H, Hp, fdt, stream_ptr())
     return table
 
 
@@ -404,9 +436,9 @@ def poll_kernel_errors(device, sync=False):
                              "(URSE_LSTM_CLUSTER=0 selects the streaming kernels)")
 
 
-def _hout_buffer(M, ldh, H, like):
+def _hout_buffer(M, ldh, H, like, dtype=None):
     """hidden-state matrix [M, ldh]: the kernels write every row's 2H columns, only the K padding needs zeros."""
-    hout = torch.empty(M, ldh, device=like.device, dtype=like.dtype)
+    hout = torch.empty(M, ldh, device=like.device, dtype=dtype or like.dtype)
     if ldh > 2 * H:
         hout[:, 2 * H:].zero_()
     return hout
@@ -497,8 +529,9 @@ def lstm_cluster_plan(H, Hp, n_seq):
 CLUSTER_XCD_AWARE = os.environ.get("URSE_LSTM_CLUSTER_XCD", "1") != "0"
 
 
-def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, xcd_aware=None):
-    """persistent cluster LSTM forward (bf16): see csrc/lstm_cluster.hip."""
+def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, xcd_aware=None, bf16_copy=False):
+    """persistent cluster LSTM forward (bf16 | f16 operands): see csrc/lstm_cluster.hip.  With save the gx buffer comes back holding the gate
+    ACTIVATIONS in bf16 (also under f16 operands: read it as gx.view(torch.bfloat16)).  bf16_copy (f16): -> (hout, c, err, hout_bf16)."""
     xcd_aware = CLUSTER_XCD_AWARE if xcd_aware is None else xcd_aware
     plan = lstm_cluster_plan(H, Hp, n_seq)
     M, dev = gx.shape[0], gx.device
@@ -510,10 +543,12 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
     hx, cnt, err = _cluster_ws[key]
     ldh = kpad(2 * H, gx.dtype)
     hout = _hout_buffer(M, ldh, H, gx)
+    hout2 = _hout_buffer(M, ldh, H, gx, torch.bfloat16) if (bf16_copy and gx.dtype == torch.float16) else None
     c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster_fwd", gx, gx.stride(0), whhq, hout, ldh,
-               c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), reserved_cus(), int(bool(xcd_aware)), stream_ptr())
-    return hout, c, err
+               c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), reserved_cus(), int(bool(xcd_aware)), _dt(gx), hout2,
+               stream_ptr())
+    return (hout, c, err, hout2 if hout2 is not None else hout) if bf16_copy else (hout, c, err)
 
 
 # which hidden sizes take the generalised cluster kernel: "768" by default (H = 392 keeps lstm_cluster.hip unless asked)
@@ -577,15 +612,17 @@ def lstm_fwd_cluster2(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, sav
     return hout, c, err
 
 
-def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, rows16=0):
-    """gx [M, 8H] (overwritten by gate activations if save) -> (hout [M, kpad(2H)], c [M, 2H] f32)."""
+def lstm_fwd(gx, whh, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, rows16=0, bf16_copy=False):
+    """gx [M, 8H] (overwritten by gate activations if save - in bf16 also under f16 operands) -> (hout [M, kpad(2H)], c [M, 2H] f32);
+    bf16_copy (f16): -> (hout, c, hout_bf16)."""
     M = gx.shape[0]
     ldh = kpad(2 * H, gx.dtype)
     hout = _hout_buffer(M, ldh, H, gx)
+    hout2 = _hout_buffer(M, ldh, H, gx, torch.bfloat16) if (bf16_copy and gx.dtype == torch.float16) else None
     c = torch.empty(M, 2 * H, device=gx.device, dtype=torch.float32) if save else None
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_bidir_fwd", gx, gx.stride(0), whh, hout, ldh,
-               c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), _dt(gx), rows16, stream_ptr())
-    return hout, c
+               c, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), _dt(gx), rows16, hout2, stream_ptr())
+    return (hout, c, hout2 if hout2 is not None else hout) if bf16_copy else (hout, c)
 
 
 USE_WIDE_LSTM = os.environ.get("URSE_LSTM_WIDE", "1") != "0"
@@ -687,15 +724,19 @@ def lstm_rwx_supported(N, Np, H, Hp):
     return bool(_lib.load().urse_lstm_rwx_supported(N, Np, H, Hp))
 
 
-def lstm_fwd_rwx(xn, wx, bias, N, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, target_wgs=0):
-    """row-wave LSTM forward with the input projection fused: xn [M, Np] bf16 -> (gates [M, 8H] activations or None, hout, c)."""
+def lstm_fwd_rwx(xn, wx, bias, N, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, target_wgs=0, bf16_copy=False):
+    """row-wave LSTM forward with the input projection fused: xn [M, Np] bf16 | f16 -> (gates [M, 8H] bf16 activations or None, hout, c);
+    bf16_copy (f16): -> (gates, hout, c, hout_bf16)."""
     M, Np = xn.shape[0], xn.shape[1]
     ldh = kpad(2 * H, xn.dtype)
     hout = _hout_buffer(M, ldh, H, xn)
+    hout2 = _hout_buffer(M, ldh, H, xn, torch.bfloat16) if (bf16_copy and xn.dtype == torch.float16 and save) else None
     c = torch.empty(M, 2 * H, device=xn.device, dtype=torch.float32)
-    gates = torch.empty(M, 8 * H, device=xn.device, dtype=xn.dtype) if save else None
+    gates = torch.empty(M, 8 * H, device=xn.device, dtype=torch.bfloat16) if save else None
     timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_rwx_fwd", xn, xn.stride(0), wx, bias, gates, 8 * H, hout, ldh, c,
-               N, Np, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), int(target_wgs), stream_ptr())
+               N, Np, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), int(target_wgs), _dt(xn), hout2, stream_ptr())
+    if bf16_copy:
+        return gates, hout, (c if save else None), (hout2 if hout2 is not None else hout)
     return gates, hout, (c if save else None)
 
 
