@@ -260,5 +260,6 @@ def test_full_length_gradients_match_f32_oracle(lib, monkeypatch):
     print("C2 full length (B8 x 4 s): loss %.2e, wav rel. L2 %.2e, worst grad rel. L2 %.2e (%s), all grads %.2e" % (e_loss, l2, worst, wn, (num / den) ** 0.5), per_group)
     parity_log.record("bf16_full_length_gradients_vs_f32_oracle", shape="B8 x 4 s @ 48 kHz (401 steps), N=196, L=6", loss_rel=e_loss, wav_rel_l2=l2,
                       worst_grad_rel_l2=worst, worst_grad=wn, all_grads_rel_l2=(num / den) ** 0.5, worst_by_module=per_group)
-    # bf16 operands (8 significant bits) through 6 layers x 401 steps: bounds = 2x observed (profiles/r05_c2_parity*.json)
-    assert e_loss <= 1e-3 and l2 <= 1e-2 and worst <= 6e-2, (e_loss, l2, worst, wn)
+    # bf16 operands (8 significant bits) through 6 layers x 401 steps: bounds = 2x observed (profiles/r05_c2_parity_v1.json: loss 2.3e-5, waveform 4.3e-3,
+    # worst gradient 7.8e-3 rel. L2 - a band-split GroupNorm weight -, all gradients together 2.5e-3): the gradients at 401 steps are no worse than at 101
+    assert e_loss <= 1e-4 and l2 <= 8.7e-3 and worst <= 1.6e-2 and (num / den) ** 0.5 <= 5e-3, (e_loss, l2, worst, wn)

@@ -116,5 +116,6 @@ def test_c4_full_width_bf16_dispatch_bounded(lib, c4_oracle):
     # the kernels `bench.py --model flow` times: H = 768 cluster forward (time path: one launch, band path: row-block launches) and the split BPTT
     assert counts["lstm_fwd_cluster2"] > 0 and counts["lstm_bwd_split"] > 0, counts
     assert counts["lstm_fwd_stream"] == 0, counts
-    # 8-bit operand mantissas through 6 layers; bounds = 2x the figures observed on the GPU (recorded in profiles/r05_c2_parity*.json)
-    assert fig["out_rel_l2"] <= 2e-2 and fig["loss_rel"] <= 5e-3 and fig["worst_grad_rel_l2"] <= 8e-2, fig
+    # 8-bit operand mantissas through 6 layers; bounds = 2x the figures observed on the GPU (profiles/r05_c2_parity_v1.json: output 4.7e-3 rel. L2 /
+    # 4.6e-3 of the peak, loss 5e-6, worst gradient 1.14e-2 rel. L2)
+    assert fig["out_rel_l2"] <= 9.4e-3 and fig["out_max_over_peak"] <= 9.2e-3 and fig["loss_rel"] <= 1e-4 and fig["worst_grad_rel_l2"] <= 2.3e-2, fig

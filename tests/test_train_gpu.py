@@ -121,7 +121,7 @@ def test_single_rank_rccl_carries_the_gradient_buckets():
     arithmetic is covered over gloo above.)"""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NCCL_MAX_NCHANNELS")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--pretouch-gib", "0",
             "--batch", "2", "--seconds", "1", "--channels", "32", "--layers", "2", "--no-flow", "--no-metrics", "--no-cpu-baseline"]

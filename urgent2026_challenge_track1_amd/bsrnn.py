@@ -818,6 +818,7 @@ class BSRNNCore(nn.Module):
                 torch.cuda.current_stream().wait_stream(self._side)
         self._deferred, self._inflight, self._grad_pack = [], None, None     # nothing survives an aborted backward
         ops.CO_RESIDENT_WGS = 0       # (an aborted backward may have left the second queue's reservation set: ADVICE r3)
+        ops.COMM_RESERVED_CUS = 0     # (... or RCCL's: GradBucketReducer.finish() never ran; nothing of it is in flight once a new forward starts)
         spec_ri = spec_ri.contiguous().float()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not train:

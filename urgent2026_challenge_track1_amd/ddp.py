@@ -46,9 +46,9 @@ class GradBucketReducer:
             return
         self.launched += 1
         if self.on_gpu:
-            # from the first bucket until finish() an all-reduce kernel may sit on up to RCCL_MAX_CHANNELS CUs: cooperative recurrences
+            # from the first bucket until finish() an all-reduce kernel may sit on up to NCCL_MAX_NCHANNELS CUs: cooperative recurrences
             # launched meanwhile (flow model: split BPTT) are planned on the rest, or refused (ops.reserved_cus)
-            ops.COMM_RESERVED_CUS = ops.RCCL_MAX_CHANNELS
+            ops.COMM_RESERVED_CUS = ops.rccl_reserved_cus()      # (the effective NCCL_MAX_NCHANNELS, not our default)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)

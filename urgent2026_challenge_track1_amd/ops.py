@@ -473,9 +473,21 @@ COOP_REFUSALS = 0                # cooperative plans refused because of reserved
 
 
 def cap_rccl_channels():
-    """call BEFORE the first collective creates the RCCL communicator: bounds the workgroups an all-reduce can occupy to what
-    reserved_cus() sets aside for it."""
+    """call BEFORE the first collective creates the RCCL communicator: bounds the workgroups an all-reduce can occupy (a value the
+    user has set stays - and is what rccl_reserved_cus() then sets aside).  Returns the effective cap."""
     os.environ.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_MAX_CHANNELS))
+    return rccl_reserved_cus()
+
+
+def rccl_reserved_cus():
+    """CUs to leave to RCCL while a bucket is in flight = the EFFECTIVE channel cap: NCCL_MAX_NCHANNELS as the communicator saw it (ADVICE r4:
+    a user-set value above our default stayed in force while the reservation assumed 32 - the cooperative recurrences were then planned on
+    CUs RCCL held).  Unset (cap_rccl_channels never ran) or unparsable: RCCL's own maximum of 64 channels, the safe side."""
+    v = os.environ.get("NCCL_MAX_NCHANNELS")
+    try:
+        return max(1, int(v)) if v is not None else 64
+    except ValueError:
+        return 64
 
 
 def reserved_cus():
@@ -670,7 +682,9 @@ TN_JOIN_LAG = int(os.environ.get("URSE_TN_JOIN_LAG", "2"))   # same-box: 176.7 (
 TN_BAND_PARTS = int(os.environ.get("URSE_TN_BAND_PARTS", "-1"))
 TN_BAND_PARTS = None if TN_BAND_PARTS < 0 else TN_BAND_PARTS
 TN_OVERLAP_TAIL = os.environ.get("URSE_TN_OVERLAP_TAIL", "0") != "0"     # the last half layer's weight gradients beside the band split's backward (measured: 132.95 / 134.61 ms per step off, 135.01 / 134.19 on - no gain, off)
-DEFER_MASKDEC_WGRADS = os.environ.get("URSE_DEFER_MASKDEC_WGRADS", "1") != "0"   # the mask decoder's grouped weight gradients on the second queue
+# the mask decoder's grouped weight gradients on the second queue: measured neutral once the A/B's order bias was removed (profiles/r04_ab_order_bias_v1.log),
+# it delays the 'md' bucket of the DDP reducer by TN_JOIN_LAG joins and its launch is not sized to the CUs the second queue declares: off
+DEFER_MASKDEC_WGRADS = os.environ.get("URSE_DEFER_MASKDEC_WGRADS", "0") != "0"
 TN_OVERLAP_BAND = os.environ.get("URSE_TN_OVERLAP_BAND", "1") != "0"   # also start deferred wgrads beside the band path's BPTT
 # the wide kernel wins once there are enough 64-sequence workgroups to fill the chip in both directions
 WIDE_MIN_SEQ = int(os.environ.get("URSE_LSTM_WIDE_MIN_SEQ", str(64 * 128)))
@@ -820,17 +834,23 @@ USE_NSPLIT_LSTM_BWD = os.environ.get("URSE_LSTM_NSPLIT_BWD", "1") != "0"
 NSPLIT_MAX_SEQ = int(os.environ.get("URSE_LSTM_NSPLIT_MAX_SEQ", "2304"))       # beyond that the 32-sequence streaming geometry has the rows it needs
 
 
+# ranks that share THIS device (bench.py / train_se set it when a non-RCCL backend puts several processes on one GPU): two processes with a
+# persistent pair-spinning grid each can keep each other's partners off the chip until the spin bound trips - the N-split is not planned then
+SHARED_GPU_RANKS = 1
+
+
 def _nsplit_reserved():
     """CUs the N-split plan must leave alone.  Its workgroups wait for ONE partner each, not for the whole grid: a member whose partner has
-    not started yet spins until any other workgroup on the chip retires.  Work that is finite and independent of this launch - the second
-    queue's weight-gradient GEMMs, RCCL's all-reduce kernels, the prefetcher's simulator kernels - therefore only delays a pair, it cannot
-    starve it (unlike the cluster / split kernels, whose every workgroup waits for all the others of its cluster): nothing is reserved, the
-    plan only checks that the grid itself fits the chip."""
-    return 0
+    not started yet spins until any other workgroup on the chip retires.  The second queue's weight-gradient GEMMs are finite work SIZED beside
+    this launch (TN_SHADOW_WGS_NSPLIT), so they only delay a pair and are not reserved for; RCCL's all-reduce kernels and the prefetcher's
+    simulator kernels are declared by others and honoured here: the grid must fit beside them."""
+    return int(COMM_RESERVED_CUS) + int(PREFETCH_RESERVED_CUS)
 
 
 def lstm_nsplit_plan(H, n_seq):
     import ctypes
+    if SHARED_GPU_RANKS > 1:
+        return None
     plan = (ctypes.c_int64 * 3)()
     if _lib.load().urse_lstm_nsplit_plan(H, n_seq, _nsplit_reserved(), plan) != 0:
         return None

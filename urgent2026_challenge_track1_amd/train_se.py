@@ -179,7 +179,9 @@ def fit(cfg, max_steps=None, log_every=50):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("URSE_DIST_BACKEND", "nccl") != "nccl":
-        local %= max(1, torch.cuda.device_count())
+        ndev = max(1, torch.cuda.device_count())
+        ops.SHARED_GPU_RANKS = -(-world // ndev)      # ranks per device: pair-spinning grids of two processes on one GPU are not planned (ops.lstm_nsplit_plan)
+        local %= ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 and not dist.is_initialized():
@@ -235,10 +237,16 @@ def fit(cfg, max_steps=None, log_every=50):
             hit = bool(skipped)
             if policy == "raise" and world > 1:
                 # every rank must leave the loop in the same step: a rank that raised alone would leave its peers in the next
-                # step's bucket all-reduce until the collective times out - agree on the flag first
-                flag = torch.tensor([1.0 if hit else 0.0], device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                hit = bool(flag.item() > 0)
+                # step's bucket all-reduce until the collective times out - agree on the flag first.  The agreement is a blocking
+                # collective + a host read (it drains the queue: no prefetch / second-queue overlap across it), so it runs when the log line is due,
+                # not every step: under DDP the raise policy stops within log_every steps of the first unsupported draw, on every rank
+                # at the same step
+                if step % log_every == 0:
+                    flag = torch.tensor([1.0 if hit else 0.0], device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                    hit = bool(flag.item() > 0)
+                else:
+                    hit = False
             if hit and not warned and policy != "count":
                 warned = True
                 msg = ("dynamic mixing drew an augmentation the device simulator does not apply (%s): it is skipped for that "
