@@ -84,9 +84,10 @@ const char* urse_last_error(void);
 #define URSE_KV_ISTFT_GENERIC 21
 #define URSE_KV_ISTFT960 22
 #define URSE_KV_LSTM_FWD_RW 23     /* lstm_fwd_rw_kernel: 16 sequences per wave, weights shared through an LDS-DMA ring */
-#define URSE_KV_LSTM_BWD_RW 24     /* lstm_bwd_rw_kernel */
+/* (24: unused - a row-wave BPTT was priced in round 4 and round 5 and not built: DESIGN.md) */
 #define URSE_KV_LSTM_FWD_RWX 25    /* lstm_fwd_rwx_kernel: row-wave forward with the input projection fused */
 #define URSE_KV_LSTM_BWD_NSPLIT 26 /* lstm_bwd_nsplit_kernel: pairs of workgroups split the output columns of the recurrent product */
+#define URSE_KV_LSTM_FWD_CLUSTERX 27 /* lstm_fwd_cluster_kernel<.., NSX = 7>: cluster forward with the input projection fused */
 #define URSE_KV_COUNT 32
 int urse_launch_count(int variant);
 int urse_launch_counts_reset(void);
@@ -242,6 +243,18 @@ int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, i
                           void* counters, void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner,
                           int64_t outer, int64_t stride, int save, int reserved_cus, int xcd_aware, int dtype, void* hout_bf16,
                           void* stream);
+/* Cluster forward with the INPUT PROJECTION FUSED (round 5; the time path of BSRNN at C2: espnet2 BSRNN's rnn_time, reference twin
+ * baseline_code/models/bsrnn_flowse.py:296-299): nn.LSTM(bidirectional)'s x W_ih^T + b_ih + h W_hh^T + b_hh in ONE call - no gate-projection GEMM,
+ * no [M, 8H] pre-activation matrix written and read back.  xn [M, ldx >= Np] 16-bit normalised input rows (zero K padding); wihq from
+ * urse_lstm_pack_quads_x (2 * ceil(H/4) * (Np/32) * 512 elements); bias [2*4H] f32 from urse_lstm_pack; whhq from urse_lstm_pack_quads; gates
+ * [M, ldg >= 8H] RECEIVES the bf16 gate activations (save != 0; NULL otherwise); plan / hx / counters / err_flag / reserved_cus / xcd_aware / dtype /
+ * hout_bf16 as urse_lstm_cluster_fwd.  urse_lstm_clusterx_supported: Np == 224, Hp == 416 (N = 196, H = 392). */
+int urse_lstm_clusterx_supported(int N, int Np, int H, int Hp);
+int urse_lstm_pack_quads_x(const float* wih, void* out, int N, int Np, int H, int dtype, void* stream);
+int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* wihq, const float* bias, const void* whhq, void* gates, int64_t ldg, void* hout,
+                           int64_t ldh, float* c, void* hx, void* counters, void* err_flag, int N, int Np, int H, int Hp, int n_seq, int seq_len,
+                           int64_t inner, int64_t outer, int64_t stride, int save, int reserved_cus, int xcd_aware, int dtype, void* hout_bf16,
+                           void* stream);
 /* Generalised cluster forward (csrc/lstm_cluster2.hip): same protocol and arguments, geometry chosen per hidden size
  * (H = 768, the flow model: 24 workgroups per cluster; H = 392: 7).  plan = {C, clusters per direction, rows per cluster,
  * hx bf16 elements}; hx is zeroed by the call; whhq from urse_lstm_pack_quads. */
@@ -286,10 +299,11 @@ int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* hout, int64_
  * from the two-kernel form by bf16 rounding of gx (closer to the f32 reference).  urse_lstm_rwx_supported: N = 196, H = 392. */
 /* The pack entry points for ALL LSTMs of a model in one launch each (the model re-packs its 12 BLSTMs after every optimizer step:
  * espnet2 BSRNN keeps nn.LSTM's own layout, here the kernels' fragment orders have to follow the f32 master weights).  table = device array of
- * n_lstm rows of 12 pointers {wih, whh, bih, bhh, wih_p, wihT_p, bias, whh_frag, whhT_frag, whhq, whhb, wx}: the operands of urse_lstm_pack,
- * then the destinations of urse_lstm_pack_quads / _blocks / _blocks_x (NULL = that LSTM does not use the layout).  Same shapes for all rows. */
+ * n_lstm rows of 13 pointers {wih, whh, bih, bhh, wih_p, wihT_p, bias, whh_frag, whhT_frag, whhq, whhb, wx, wihq}: the operands of urse_lstm_pack,
+ * then the destinations of urse_lstm_pack_quads / _blocks / _blocks_x / _quads_x (NULL = that LSTM does not use the layout).  Same shapes for all rows. */
 int urse_lstm_pack_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, int dtype, void* stream);
 int urse_lstm_pack_quads_multi(const void* table, int n_lstm, int H, int Hp, int dtype, void* stream);
+int urse_lstm_pack_quads_x_multi(const void* table, int n_lstm, int N, int Np, int H, int dtype, void* stream);
 int urse_lstm_pack_blocks_multi(const void* table, int n_lstm, int H, int Hp, void* stream);
 int urse_lstm_pack_blocks_x_multi(const void* table, int n_lstm, int N, int Np, int H, int Hp, int dtype, void* stream);
 int urse_lstm_rwx_supported(int N, int Np, int H, int Hp);

@@ -1,4 +1,5 @@
-"""Band-path BPTT (12,832 x 34): gate gradients stored per lane from the cell phase against 16-byte row pieces from the LDS tile."""
+"""Band-path BPTT (12,832 x 34): the shipped 32-row / 8-wave kernel (variant 0) against variants of URSE_BWD_VARIANT
+(7: two-slot pipelined input loads; 8: 48 rows on four waves, one per SIMD - round 5).  python scripts/exp_bwd_band.py [variants...]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
@@ -28,8 +29,8 @@ for _ in range(5):
     ops.lstm_bwd(dh, g, c, pk["whhT"], H, **sm); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
 print("%%.3f ms (min of 5: %%s)" %% (min(ts), " ".join("%%.3f" %% v for v in ts)))
 ''' % ROOT
-for v in ("1", "7", "1", "7"):
-    env = dict(os.environ, URSE_BWD_STAGED_STORES="1", URSE_BWD_VARIANT=("7" if v == "7" else "0"))
+for v in (sys.argv[1:] or ["0", "8", "0", "8"]):
+    env = dict(os.environ, URSE_BWD_STAGED_STORES="1", URSE_BWD_VARIANT=v)
     r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
     print("variant=%s" % v, r.stdout.strip().replace("\n", " | "), r.stderr[-300:] if r.returncode else "", flush=True)
 

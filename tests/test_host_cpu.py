@@ -194,3 +194,25 @@ def test_bench_weight_stream_bound_arithmetic():
     b = bench.l2_port_roofline("lstm_bwd_band", 4.3, B, T, K, H)
     assert b["workgroups"] == 2 * -(-B * T // 32) == 802 and b["cus"] == 256 and b["frac"] < t["frac"]
     assert bench.l2_port_roofline("lstm_fwd_time", 3.5, B, T, K, H) is None
+
+
+def test_flow_split_bptt_plan_does_not_depend_on_the_nsplit_shadow_size(monkeypatch):
+    """VERDICT r4 item 5 (the 87.8 -> 104.3 ms regression of the flow train step): the second queue's sizing beside the N-split BPTT
+    (TN_SHADOW_WGS_NSPLIT) must not reach the flow model, whose cooperative split BPTT is planned on the CUs the second queue leaves.  The
+    plan queries need no GPU (256 CUs assumed)."""
+    import torch
+    from urgent2026_challenge_track1_amd import _lib, ops
+    _lib.load()
+    sm_flow = dict(n_seq=96, seq_len=501, inner=48, outer=501 * 48, stride=48)           # C4 time path: B 2 x 48 bands, 501 frames
+    sm_c2 = dict(n_seq=1088, seq_len=401, inner=34, outer=401 * 34, stride=34)
+    plans = set()
+    for v in (84, 98, 112, 140):
+        monkeypatch.setattr(ops, "TN_SHADOW_WGS_NSPLIT", v)
+        assert ops.use_nsplit_bwd(768, 768, torch.bfloat16, "t", sm_flow) is False         # H = 768 has no N-split kernel
+        target = ops.wgrad_shadow_wgs("t", False)
+        assert target == ops.TN_SHADOW_WGS
+        with ops.reserve_cus(co_resident=target):
+            plans.add(tuple(ops.lstm_split_plan(768, sm_flow["n_seq"])))
+        assert ops.use_nsplit_bwd(392, 416, torch.bfloat16, "t", sm_c2) is True and ops.wgrad_shadow_wgs("t", True) == v
+        assert ops.wgrad_shadow_wgs("f", True) == ops.TN_SHADOW_WGS_BAND
+    assert len(plans) == 1 and next(iter(plans))[0] == 12, plans                             # the 12-way split of the benchmarked flow step

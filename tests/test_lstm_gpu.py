@@ -533,3 +533,48 @@ def test_multi_pack_equals_per_lstm_pack(lib):
         for k, v in ref.items():
             if torch.is_tensor(v):
                 assert torch.equal(out[k], v), k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,K,path", [(2, 9, 20, "time"), (3, 7, 34, "time"), (2, 40, 34, "time"), (2, 40, 34, "band"), (32, 25, 34, "time")])
+def test_cluster_forward_with_fused_projection_matches_two_kernel_form(lib, dtype, B, T, K, path):
+    """csrc/lstm_clusterx.hip (round 5): x W_ih^T + b + h W_hh^T in ONE kernel on the cluster geometry (7 waves x 2 unit quads) against the gate GEMM +
+    lstm_cluster.hip.  Same rounding points (the projection is rounded to the 16-bit operand format before the recurrent product is added), so h, c
+    and the saved gate activations agree to a 16-bit ulp where the summation order inside an MFMA chain differs; also against nn.LSTM in f32."""
+    from urgent2026_challenge_track1_amd import ops
+    N, H, dev = 196, 392, "cuda"
+    torch.manual_seed(5)
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    assert pk.get("wihq") is not None and ops.lstm_clusterx_supported(N, pk["Np"], H, pk["Hp"])
+    M = B * T * K
+    x = torch.randn(B, T, K, N)
+    if path == "time":
+        sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+        y = lstm(x.permute(0, 2, 1, 3).reshape(B * K, T, N))[0].detach().reshape(B, K, T, 2 * H).permute(0, 2, 1, 3).reshape(-1, 2 * H)
+    else:
+        sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+        y = lstm(x.reshape(B * T, K, N))[0].detach().reshape(-1, 2 * H)
+    assert ops.lstm_cluster_plan(H, pk["Hp"], sm["n_seq"]) is not None
+    xr = ops.pack2d(x.reshape(M, N).to(dev), M, pk["Np"], dtype)
+    gx = ops.gemm_nt(xr, pk["wih"], pk["bias"])
+    h1, c1, e1 = ops.lstm_fwd_cluster(gx, pk["whhq"], H, pk["Hp"], **sm)
+    g1 = gx.view(torch.bfloat16)
+    ops.launch_counts(reset=True)
+    g2, h2, c2, e2, h2b = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], bf16_copy=True, **sm)
+    assert ops.launch_counts()["lstm_fwd_clusterx"] == 1
+    assert int(e1.item()) == 0 and int(e2.item()) == 0
+    tol = 2e-2 if dtype == torch.bfloat16 else 2.5e-3
+    assert (h2[:, :2 * H].float().cpu() - y).abs().max().item() <= tol
+    ulp = 8e-3 if dtype == torch.bfloat16 else 1e-3
+    dh, dc, dg = (h1.float() - h2.float()).abs(), (c1 - c2).abs(), (g1.float() - g2.float()).abs()
+    print("fused vs two-kernel (%s): h max %.2e mean %.2e, c max %.2e, gates max %.2e" % (dtype, dh.max().item(), dh.mean().item(), dc.max().item(), dg.max().item()))
+    assert dh.max().item() <= 2 * ulp and dh.mean().item() <= 1e-4 and dc.max().item() <= 4 * ulp and dg.max().item() <= 2e-2
+    assert torch.all(h2[:, 2 * H:] == 0) and g2.dtype == torch.bfloat16
+    if dtype == torch.float16:
+        assert torch.equal(h2b[:, :2 * H], h2[:, :2 * H].float().to(torch.bfloat16)) and torch.all(h2b[:, 2 * H:] == 0)
+    # inference form: nothing saved
+    g3, h3, c3, e3 = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], save=False, **sm)
+    assert g3 is None and c3 is None and torch.equal(h3, h2)

@@ -370,8 +370,8 @@ class BSRNNCore(nn.Module):
         srcs = {p: (self._p(p + "wih", 8 * H * N), self._p(p + "whh", 8 * H * H), self._p(p + "bih", 8 * H), self._p(p + "bhh", 8 * H))
                 for p in names}
         multi = (ops.PACK_MULTI and self._flat.is_cuda and all(p in self._lstm_bufs for p in names) and
-                 all(set(k for k in ("whhq", "whhb", "wx", "whhb_rw", "whhTq") if self._lstm_bufs[p].get(k) is not None) ==
-                     self._lstm_layouts(p[-2]) <= {"whhq", "whhb", "wx"} for p in names))
+                 all(set(k for k in ("whhq", "whhb", "wx", "whhb_rw", "whhTq", "wihq") if self._lstm_bufs[p].get(k) is not None) ==
+                     self._lstm_layouts(p[-2]) <= {"whhq", "whhb", "wx", "wihq"} for p in names))
         if multi:
             # the buffers exist (every step after the first): one launch per layout for all 12 LSTMs instead of three to five per LSTM
             self._lstm_bufs["table"] = ops.lstm_pack_multi([srcs[p] + (self._lstm_bufs[p],) for p in names], N, H, dtype,
@@ -385,6 +385,7 @@ class BSRNNCore(nn.Module):
                 pk[p + "wih"], pk[p + "wihT"], pk[p + "bias"] = lp["wih"], lp["wihT"], lp["bias"]
                 pk[p + "whh"], pk[p + "whhT"] = lp["whh"], lp["whhT"]
                 pk[p + "whhq"], pk[p + "whhTq"] = lp.get("whhq"), lp.get("whhTq")
+                pk[p + "wihq"] = lp.get("wihq")
                 pk[p + "whhb"] = lp.get("whhb")
                 pk[p + "whhb_rw"] = lp.get("whhb_rw")
                 pk[p + "wx"] = lp.get("wx")
@@ -397,6 +398,9 @@ class BSRNNCore(nn.Module):
         lay = ops.model_lstm_layouts()
         if self.H == 392 and path == "t":
             lay -= {"wx", "whhb_rw"}
+        d = self._dims
+        if (self.H == 392 and path == "f") or not ops.lstm_clusterx_supported(self.N, d["Np"], self.H, d["Hp"]):
+            lay -= {"wihq"}          # (the fused cluster forward serves the time path; other shapes have no such kernel)
         return lay
 
     def _band_tables(self, F, dtype, device):
@@ -518,9 +522,18 @@ class BSRNNCore(nn.Module):
                  sm["n_seq"] >= ops.RW_MIN_SEQ and not (ops.USE_CLUSTER_LSTM and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
                                                       ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None))
         # (fused: the input projection runs inside the recurrence kernel - no gate GEMM, no [M, 8H] pre-activation matrix)
-        gx = None if fused else ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
+        fused_c = (not fused and ops.USE_CLUSTERX_LSTM and ops.USE_CLUSTER_LSTM and dt in ops.HALF_TYPES and pk.get(p + "wihq") is not None and
+                   pk.get(p + "whhq") is not None and H not in ops.CLUSTER2_H and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
+                   ops.lstm_clusterx_supported(N, d["Np"], H, d["Hp"]) and ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None)
+        gx = None if (fused or fused_c) else ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
         hout_b = None
-        if fused:
+        if fused_c:
+            # the cluster forward with the projection fused (the time path at C2)
+            gx, hout, c, self._cluster_err, hout_b = ops.lstm_fwd_clusterx(xn, pk[p + "wihq"], pk[p + "whhq"], pk[p + "bias"], N, H, d["Hp"], save=save,
+                                                                            bf16_copy=True, **sm)
+            if not two:
+                hout_b = None
+        elif fused:
             gx, hout, c, hout_b = ops.lstm_fwd_rwx(xn, pk[p + "wx"], pk[p + "bias"], N, H, d["Hp"], save=save, bf16_copy=True, **sm)
         elif dt == torch.float16:
             # f16 operands: the cluster forward where its plan fits (the time path at C2), else the streaming kernel
@@ -575,16 +588,12 @@ class BSRNNCore(nn.Module):
         ops.gemm_nt(doT, pk[p + "wfcT"], out=dh, N=2 * H)
         sm = self._seqmap(path, B, T, K)
         overlap = ops.TN_OVERLAP and skip.is_cuda
-        use_nsplit = (not (ops.USE_CLUSTER_LSTM_BWD and pk.get(p + "whhTq") is not None and ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None) and
-                      not ((ops.USE_SPLIT_LSTM_BWD or H >= ops.SPLIT_BWD_MIN_H) and dt == torch.bfloat16 and ops.lstm_split_chunks(H, **sm) is not None) and
-                      ops.USE_NSPLIT_LSTM_BWD and dt == torch.bfloat16 and path not in ops.BWD_ROWS16 and sm["n_seq"] <= ops.NSPLIT_MAX_SEQ and
-                      sm["n_seq"] * sm["seq_len"] >= 4096 and ops.lstm_nsplit_plan(H, sm["n_seq"]) is not None)
+        use_nsplit = ops.use_nsplit_bwd(H, d["Hp"], dt, path, sm, pk.get(p + "whhTq") is not None)
         if overlap and (path == "t" or ops.TN_OVERLAP_BAND):
             # the time path's BPTT occupies 136 of the 256 CUs for ~7 ms (and the band path's last round of workgroups
             # leaves most CUs idle): the weight-gradient GEMMs deferred by the previous half layers run beside it on a
             # second stream (they only feed the optimizer / all-reduce)
-            self._run_deferred_wgrads(skip.device, (ops.TN_SHADOW_WGS_NSPLIT if use_nsplit else ops.TN_SHADOW_WGS) if path == "t" else ops.TN_SHADOW_WGS_BAND,
-                                      None if path == "t" else ops.TN_BAND_PARTS)
+            self._run_deferred_wgrads(skip.device, ops.wgrad_shadow_wgs(path, use_nsplit), None if path == "t" else ops.TN_BAND_PARTS)
         if ops.USE_CLUSTER_LSTM_BWD and pk.get(p + "whhTq") is not None and \
                 ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
             dg, self._cluster_err = ops.lstm_bwd_cluster(dh, gates, c, pk[p + "whhTq"], H, d["Hp"], **sm)

@@ -1131,6 +1131,25 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
   };
   // two stages per barrier on four slots: at the wait of iteration kt the stages kt, kt + 1 were issued a whole iteration ago; after
   // the barrier the slots of stages kt - 2, kt - 1 are free and take kt + 2, kt + 3, which have two stage times to land
+  if (p.pad_[0] == 3) {
+    // THREE stages (108 KB) in flight, one barrier per stage: at the top of iteration kt the stages kt .. kt + 2 are outstanding; the counted
+    // wait leaves the two younger ones in flight (this wave's own DMAs: 5 per stage for waves 0-3, 4 for the others), the barrier makes stage kt
+    // whole and retires the slot of stage kt - 1, which takes stage kt + 3.  (The two-stages-per-barrier form below drains to ZERO in flight every
+    // second stage and has 72 KB in flight at best: at ~1.3 us per stage it is bound by what a CU keeps in flight against the latency of its operands.)
+    issue(0);
+    issue(1);
+    issue(2);
+    int slot = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      if (w < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue((slot + 3) & 3);
+      compute(slot);
+      slot = (slot + 1) & 3;
+    }
+  } else {
   issue(0);
   issue(1);
   int slot = 0;
@@ -1143,6 +1162,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
 #pragma unroll 1
     for (int h = 0; h < nh; ++h) compute(slot + h);
     slot ^= 2;
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (zero page) DMAs must not outlive the workgroup
 
@@ -2288,6 +2308,13 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
       slices = (R + rps - 1) / rps;
       p.rows_per_slice = rps;
       p.nt1 = 0;
+      {
+        // A/B switch, read per call: 3 = three stages in flight and one barrier per stage, 2 = two stages per barrier with the queue drained.
+        // 1.14 -> 1.12 ms alone (profiles/r05_exp_tn224_depth_v1.log), -1.4 ms per train step same-box in both orders (141.11 / 140.99 against
+        // 139.90 / 139.38, profiles/r05_ab_tn224_depth_v1.log): beside a BPTT kernel the DMA queue that never drains is worth more than alone
+        const char* e = getenv("URSE_TN224_DEPTH");
+        p.pad_[0] = e ? atol(e) : 3;
+      }
       note_launch(URSE_KV_TN_DUAL);
       hipLaunchKernelGGL(gemm_tn_dual224_kernel, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
       URSE_CHECK_LAUNCH("urse_gemm_tn_dual");

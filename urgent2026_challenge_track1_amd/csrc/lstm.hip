@@ -534,7 +534,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #define URSE_BWD_KB2_STG 25   // the staged-store form of the 32-sequence geometry has the registers for 49 = 25 + 24 fragments in flight (246 VGPRs, no
                               // spill): 3.69 -> 3.61 ms per launch, same bits (scripts/diag/kb2_sweep.sh; 19 and 21 leave ragged last batches and lose)
 #endif
-        constexpr int KB = (sizeof(T) == 2) ? (RT >= 2 ? (PF == 3 ? URSE_BWD_KB2_PF3 : (STG ? URSE_BWD_KB2_STG : URSE_BWD_KB2)) : (NW == 8 ? URSE_BWD_KB8 : (PF == 1 ? (NW == 12 ? URSE_BWD_KBPF12 : URSE_BWD_KBPF16) : URSE_BWD_KB))) : 8;
+#ifndef URSE_BWD_KB3
+#define URSE_BWD_KB3 13   // 48 rows on four waves (512 registers per wave): what the per-row state of 7 x 3 tiles leaves for fragments in flight
+#endif
+        constexpr int KB = (sizeof(T) == 2) ? (RT >= 3 ? URSE_BWD_KB3 : RT >= 2 ? (PF == 3 ? URSE_BWD_KB2_PF3 : (STG ? URSE_BWD_KB2_STG : URSE_BWD_KB2)) : (NW == 8 ? URSE_BWD_KB8 : (PF == 1 ? (NW == 12 ? URSE_BWD_KBPF12 : URSE_BWD_KBPF16) : URSE_BWD_KB))) : 8;
         #pragma unroll 1
         for (int k0 = 0; k0 < nslab; k0 += KB) {
           uint4 b[KB];
@@ -917,6 +920,16 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
       return URSE_OK;
     }
   }
+  if constexpr (sizeof(T) == 2 && NW == 4 && RT == 3) {
+    // 48 sequences per workgroup on FOUR waves (one per SIMD: the 512-register budget holds 7 unit tiles x 3 row tiles of per-row state,
+    // which spilled at the 256 of two waves per SIMD, profiles/r04_exp_bwd_band_rows48_v1.log): 1.5x the rows per pass over W_hh^T
+    static bool once = (allow_big_lds(lstm_bwd_kernel<T, 3, 7, 4, 0, 392, 0, 1>), true);
+    (void)once;
+    pa.dbuf = 0;
+    hipLaunchKernelGGL((lstm_bwd_kernel<T, 3, 7, 4, 0, 392, 0, 1>), grid, dim3(NW * 64), (size_t)R * lds_frag_pitch(4 * p.H * 2) + R * sizeof(int), st, pa);
+    URSE_CHECK_LAUNCH("urse_lstm_bwd");
+    return URSE_OK;
+  } else {
   if constexpr (sizeof(T) == 2 && NW == 8 && RT == 1) {
     if (p.H == 392 && bwd_variant() == 6) {     // transposed accumulator layout: wide loads / stores
       static bool once = (allow_big_lds(lstm_bwd_tr_kernel<1, 4, 8, 392>), true);
@@ -974,6 +987,7 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
 #undef URSE_LB
   URSE_CHECK_LAUNCH("urse_lstm_bwd");
   return URSE_OK;
+  }
 }
 
 }  // namespace urse
@@ -1085,6 +1099,11 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
     nw8 = many && fits2;
   }
   if (rt == 1 && (bwd_variant() == 2 || bwd_variant() == 6)) nw8 = true;
+  const bool fits3 = (size_t)48 * lds_frag_pitch(8 * H) + 48 * sizeof(int) <= 160 * 1024;
+  if (dtype == URSE_BF16 && H == 392 && rt == 2 && fits3 && bwd_variant() == 8 && (ldg * 2) % 16 == 0 && ((uintptr_t)gates % 16) == 0) {
+    note_launch(URSE_KV_LSTM_BWD_STREAM32);
+    return launch_bwd<bf16_t, 3, 4>(p, st);
+  }
   note_launch(dtype == URSE_BF16 && rt >= 2 && fits2 ? URSE_KV_LSTM_BWD_STREAM32 : URSE_KV_LSTM_BWD_STREAM16);
   if (dtype == URSE_BF16) {
     if (nw8) return (rt >= 2 && fits2) ? launch_bwd<bf16_t, 2, 8>(p, st) : launch_bwd<bf16_t, 1, 8>(p, st);

@@ -441,7 +441,9 @@ extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, in
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   note_launch(URSE_KV_LSTM_BWD_NSPLIT);
-  const int helpers = getenv("URSE_NSPLIT_HELPERS") ? atoi(getenv("URSE_NSPLIT_HELPERS")) : 3;
+  // A/B switch.  The helper-wave form (3) is 0.07 ms faster alone and SLOWER in the step beside the second queue's GEMMs: same-box A/B in both
+  // orders, 140.83 / 139.49 ms per step with helpers against 139.10 / 138.94 without (profiles/r05_ab_nsplit_helpers_v1.log): the 13-wave form ships.
+  const int helpers = getenv("URSE_NSPLIT_HELPERS") ? atoi(getenv("URSE_NSPLIT_HELPERS")) : 0;
   if (helpers > 0) hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 3>), dim3((unsigned)plan[1]), dim3((NSW + 3) * 64), lds, st, p);
   else hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 0>), dim3((unsigned)plan[1]), dim3(NSTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_nsplit_bwd");

@@ -161,6 +161,7 @@ struct PackRow {
   const float* wih; const float* whh; const float* bih; const float* bhh;
   void* wih_p; void* wihT_p; float* bias; void* whh_f; void* whhT_f;
   void* whhq; void* whhb; void* wx;
+  void* wihq;          // quad-ordered W_ih fragments of the fused cluster forward (urse_lstm_pack_quads_x)
 };
 
 }  // namespace urse

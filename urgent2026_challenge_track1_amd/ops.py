@@ -50,7 +50,8 @@ def timed_call(tname, name, *args):
 KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_ring", "nt_grouped_128", "tn_ring", "tn_ring_t",
                    "tn_dual", "tn_128", "tn_grouped", "lstm_fwd_stream", "lstm_fwd_wide", "lstm_fwd_cluster",
                    "lstm_fwd_cluster2", "lstm_bwd_stream16", "lstm_bwd_stream32", "lstm_bwd_cluster", "lstm_bwd_split",
-                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "lstm_bwd_rw", "lstm_fwd_rwx", "lstm_bwd_nsplit")
+                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "_unused24", "lstm_fwd_rwx", "lstm_bwd_nsplit",
+                   "lstm_fwd_clusterx")
 
 
 _PAGEABLE_UPLOADS = os.environ.get("URSE_PAGEABLE_UPLOADS", "0") == "1"
@@ -316,6 +317,8 @@ def model_lstm_layouts():
     lay = set()
     if USE_CLUSTER_LSTM:
         lay.add("whhq")
+        if USE_CLUSTERX_LSTM:
+            lay.add("wihq")
     if USE_CLUSTER_LSTM_BWD:
         lay.add("whhTq")
     if USE_RW_LSTM and USE_RWX_LSTM:
@@ -329,7 +332,7 @@ def model_lstm_layouts():
 
 def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None, layouts=None):
     """f32 nn.LSTM weights (fwd+reverse concatenated) -> dict of kernel-layout operands (see urse_lstm_pack).
-    layouts: which of the optional layouts to produce ({"whhq", "whhTq", "whhb", "whhb_rw", "wx"}; None = all the shape supports)."""
+    layouts: which of the optional layouts to produce ({"whhq", "whhTq", "whhb", "whhb_rw", "wx", "wihq"}; None = all the shape supports)."""
     want = lambda name: layouts is None or name in layouts
     dev = wih.device
     Np, Hp = kpad(N, dtype), kpad(pad_to(H, 16), dtype)
@@ -349,6 +352,10 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None, layouts=None):
             if "whhq" not in out:
                 out["whhq"] = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=dtype)
             call("lstm_pack_quads", whh, out["whhq"], H, Hp, F16, stream_ptr())
+        if want("wihq") and _lib.load().urse_lstm_clusterx_supported(N, Np, H, Hp):
+            if "wihq" not in out:
+                out["wihq"] = torch.empty(2 * ((H + 3) // 4) * (Np // 32) * 512, device=dev, dtype=dtype)
+            call("lstm_pack_quads_x", wih, out["wihq"], N, Np, H, F16, stream_ptr())
         if want("wx") and _lib.load().urse_lstm_rwx_supported(N, Np, H, Hp):
             if "wx" not in out:
                 out["wx"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32 + Np // 32) * 4 * 512, device=dev, dtype=dtype)
@@ -358,6 +365,10 @@ def lstm_pack(wih, whh, bih, bhh, N, H, dtype, out=None, layouts=None):
             if "whhq" not in out:
                 out["whhq"] = torch.empty(2 * ((H + 3) // 4) * (Hp // 32) * 512, device=dev, dtype=dtype)
             call("lstm_pack_quads", whh, out["whhq"], H, Hp, BF16, stream_ptr())
+        if want("wihq") and _lib.load().urse_lstm_clusterx_supported(N, Np, H, Hp):
+            if "wihq" not in out:
+                out["wihq"] = torch.empty(2 * ((H + 3) // 4) * (Np // 32) * 512, device=dev, dtype=dtype)
+            call("lstm_pack_quads_x", wih, out["wihq"], N, Np, H, BF16, stream_ptr())
         if want("whhb") and _lib.load().urse_lstm_wide_supported(H, Hp):
             if "whhb" not in out:
                 out["whhb"] = torch.empty(2 * ((H + 15) // 16) * (Hp // 32) * 4 * 512, device=dev, dtype=dtype)
@@ -389,7 +400,7 @@ def lstm_pack_multi(entries, N, H, dtype, table=None):
     dev = entries[0][0].device
     ptr = lambda t: 0 if t is None else t.data_ptr()
     rows = [[ptr(wih), ptr(whh), ptr(bih), ptr(bhh), ptr(o["wih"]), ptr(o["wihT"]), ptr(o["bias"]), ptr(o["whh"]), ptr(o["whhT"]),
-             ptr(o.get("whhq")), ptr(o.get("whhb")), ptr(o.get("wx"))] for wih, whh, bih, bhh, o in entries]
+             ptr(o.get("whhq")), ptr(o.get("whhb")), ptr(o.get("wx")), ptr(o.get("wihq"))] for wih, whh, bih, bhh, o in entries]
     if table is None or table[1] != rows:
         table = (upload(torch.tensor(rows, dtype=torch.int64), dev, cached=True), rows)
     n = len(rows)
@@ -402,6 +413,8 @@ def lstm_pack_multi(entries, N, H, dtype, table=None):
         call("lstm_pack_blocks_multi", table[0], n, H, Hp, stream_ptr())
     if any(r[11] for r in rows):
         call("lstm_pack_blocks_x_multi", table[0], n, N, Np, H, Hp, fdt, stream_ptr())
+    if any(r[12] for r in rows):
+        call("lstm_pack_quads_x_multi", table[0], n, N, Np, H, fdt, stream_ptr())
     return table
 
 
@@ -561,6 +574,39 @@ def lstm_fwd_cluster(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save
                c, hx, cnt, err, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), reserved_cus(), int(bool(xcd_aware)), _dt(gx), hout2,
                stream_ptr())
     return (hout, c, err, hout2 if hout2 is not None else hout) if bf16_copy else (hout, c, err)
+
+
+# the cluster forward with the input projection fused (csrc/lstm_clusterx.hip, round 5): no gate-projection GEMM on the time path, no gx matrix
+USE_CLUSTERX_LSTM = os.environ.get("URSE_LSTM_CLUSTERX", "1") != "0"
+
+
+def lstm_clusterx_supported(N, Np, H, Hp):
+    return bool(_lib.load().urse_lstm_clusterx_supported(N, Np, H, Hp))
+
+
+def lstm_fwd_clusterx(xn, wihq, whhq, bias, N, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, xcd_aware=None, bf16_copy=False):
+    """cluster LSTM forward with the input projection fused (bf16 | f16 operands): xn [M, Np] -> (gates [M, 8H] bf16 activations or None, hout, c, err);
+    bf16_copy (f16): one more element, hout_bf16.  The plan and the workspaces are lstm_fwd_cluster's."""
+    xcd_aware = CLUSTER_XCD_AWARE if xcd_aware is None else xcd_aware
+    plan = lstm_cluster_plan(H, Hp, n_seq)
+    M, Np, dev = xn.shape[0], xn.shape[1], xn.device
+    key = (dev, H, Hp, n_seq, plan[4], plan[5])
+    if key not in _cluster_ws:
+        _cluster_ws[key] = (torch.zeros(plan[4], device=dev, dtype=torch.bfloat16),
+                            torch.zeros(plan[5], device=dev, dtype=torch.int32),
+                            kernel_error_flag(dev))
+    hx, cnt, err = _cluster_ws[key]
+    ldh = kpad(2 * H, xn.dtype)
+    hout = _hout_buffer(M, ldh, H, xn)
+    hout2 = _hout_buffer(M, ldh, H, xn, torch.bfloat16) if (bf16_copy and xn.dtype == torch.float16 and save) else None
+    c = torch.empty(M, 2 * H, device=dev, dtype=torch.float32) if save else None
+    gates = torch.empty(M, 8 * H, device=dev, dtype=torch.bfloat16) if save else None
+    timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_clusterx_fwd", xn, xn.stride(0), wihq, bias, whhq, gates, 8 * H, hout, ldh, c,
+               hx, cnt, err, N, Np, H, Hp, n_seq, seq_len, inner, outer, stride, int(save), reserved_cus(), int(bool(xcd_aware)), _dt(xn), hout2,
+               stream_ptr())
+    if bf16_copy:
+        return gates, hout, c, err, (hout2 if hout2 is not None else hout)
+    return gates, hout, c, err
 
 
 # which hidden sizes take the generalised cluster kernel: "768" by default (H = 392 keeps lstm_cluster.hip unless asked)
@@ -855,6 +901,24 @@ def lstm_nsplit_plan(H, n_seq):
     if _lib.load().urse_lstm_nsplit_plan(H, n_seq, _nsplit_reserved(), plan) != 0:
         return None
     return list(plan)
+
+
+def use_nsplit_bwd(H, Hp, dt, path, sm, has_whhTq=False):
+    """does this half layer's BPTT run on the N-split kernel (bsrnn.dualpath_bwd's dispatch: after the opt-in cluster BPTT and the split BPTT of
+    big hidden sizes, before the streaming kernel)?  Only where the library has an N-split kernel for H (392)."""
+    return (not (USE_CLUSTER_LSTM_BWD and has_whhTq and lstm_cluster_plan(H, Hp, sm["n_seq"]) is not None) and
+            not ((USE_SPLIT_LSTM_BWD or H >= SPLIT_BWD_MIN_H) and dt == torch.bfloat16 and lstm_split_chunks(H, **sm) is not None) and
+            USE_NSPLIT_LSTM_BWD and dt == torch.bfloat16 and path not in BWD_ROWS16 and sm["n_seq"] <= NSPLIT_MAX_SEQ and
+            sm["n_seq"] * sm["seq_len"] >= 4096 and lstm_nsplit_plan(H, sm["n_seq"]) is not None)
+
+
+def wgrad_shadow_wgs(path, nsplit):
+    """workgroups the second queue's weight-gradient launches are sized to beside this half layer's BPTT.  TN_SHADOW_WGS_NSPLIT applies ONLY
+    beside the N-split kernel: every other time-path BPTT - the flow model's cooperative split BPTT among them, whose plan is made on the CUs
+    this number leaves - keeps TN_SHADOW_WGS (one number for both cost the flow train step 87.8 -> 104.3 ms in round 4; tests/test_host_cpu.py)."""
+    if path != "t":
+        return TN_SHADOW_WGS_BAND
+    return TN_SHADOW_WGS_NSPLIT if nsplit else TN_SHADOW_WGS
 
 
 def lstm_bwd_nsplit(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
