@@ -21,7 +21,7 @@ from tests import parity_log
 pytestmark = pytest.mark.gpu
 
 N, B, FS, SECONDS = 196, 6, 48000, 1.0
-C2_KERNELS = ("stft960", "nt_bres", "nt_ring", "lstm_fwd_cluster", "lstm_fwd_rwx", "lstm_bwd_nsplit", "lstm_bwd_stream32",
+C2_KERNELS = ("stft960", "nt_bres", "nt_ring", "lstm_fwd_clusterx", "lstm_fwd_rwx", "lstm_bwd_nsplit", "lstm_bwd_stream32",
               "tn_dual", "tn_ring_t", "nt_grouped_ring", "tn_grouped")
 
 
@@ -207,4 +207,4 @@ def test_bf16_c2_train_step_matches_oracle(lib, c2_dispatch):
         flipped += int(((d_m - d_r).abs() > 5e-4).sum())
     assert flipped <= 2e-2 * tot, (flipped, tot)
     counts = ops.launch_counts()
-    assert counts["tn_dual"] > 0 and counts["lstm_fwd_cluster"] > 0 and counts["lstm_bwd_stream32"] > 0, counts
+    assert counts["tn_dual"] > 0 and counts["lstm_fwd_clusterx"] > 0 and counts["lstm_bwd_stream32"] > 0, counts

@@ -200,7 +200,7 @@ def test_f16_c2_kernel_set_forward_and_gradients(lib, monkeypatch, fs):
     model.se_model.core._flush_deferred_wgrads()
     torch.cuda.synchronize()
     counts = ops.launch_counts()
-    for k in ("nt_bres", "nt_ring", "lstm_fwd_cluster", "lstm_fwd_rwx", "nt_grouped_ring", "lstm_bwd_nsplit"):
+    for k in ("nt_bres", "nt_ring", "lstm_fwd_clusterx", "lstm_fwd_rwx", "nt_grouped_ring", "lstm_bwd_nsplit"):
         assert counts[k] > 0, (k, counts)
     assert counts["tn_dual"] > 0 or fs != 48000, counts       # (K = 27 bands at 16 kHz: the dual weight-gradient kernel's whole-block condition does not hold)
     assert counts["lstm_fwd_stream"] == 0 and counts["nt_128"] == 0, counts
