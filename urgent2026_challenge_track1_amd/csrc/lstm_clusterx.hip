@@ -6,18 +6,32 @@
 // THAT kernel fails on its budgets, measured in round 5: its 14 working waves have 128 registers each (16 waves per workgroup), the working path
 // uses 106, and the seven k-slabs of W_ih are 28 more plus 16 for accumulators that must survive the h gather - 161, spilled (round 2 saw the same:
 // 65 spills, 6.8 vs 4.6 ms); its LDS is full (156 of 160 KB).  So this kernel re-cuts the SAME cluster: SEVEN working waves per workgroup, each with
-// TWO unit quads (8 hidden units x 4 gates), plus ONE helper wave - 8 waves = two per SIMD = a 256-register budget: 104 registers of W_hh + 56 of
+// TWO unit quads (8 hidden units x 4 gates), plus ONE helper wave - 8 waves = two per SIMD = a 256-register budget: 104 registers of W_hh + 48 of
 // W_ih fragments per wave.  Per step:
-//   0. x_t W_ih^T + b for the 64 rows x this wave's 32 gate columns - independent of h, issued while the first loads of the h gather are in flight;
-//   1. h_{t-1} of the cluster's 64 sequences -> LDS (tag-in-data hand-off, exactly lstm_cluster.hip's), barrier 1;
-//   2. + h_{t-1} W_hh^T (an A fragment read from LDS feeds both quads: half the LDS read traffic of the 14-wave form), cell update, barrier 2;
-//   3. h_t -> exchange buffer (tagged); hout / saved gates / c_t leave in the NEXT step (deferred 16-byte row pieces).
-// The helper wave brings x_{t+1} (64 rows x 448 bytes) by LDS-DMA into the staging tile of that step's parity - two rows per instruction at the
-// bank-conflict-free pitch of 480 bytes - and stores the previous step's saved gates and c_t.  The x tile doubles as the saved-gates staging tile:
-// every wave has multiplied x_t before barrier 1, the gate activations are written behind it.
-// Same math / layouts / protocol as lstm_cluster.hip, and the same rounding points as the two-kernel form: x W_ih^T + b is rounded to the 16-bit
-// operand format before h W_hh^T is added to it (there: the gx matrix; here: the register pairs that wait for the gather) - equal to it up to the
-// summation order inside the MFMAs.  N = 196 (Np 224), H = 392 (Hp 416).
+//   0. x_t W_ih^T + b for the 64 rows x this wave's 32 gate columns - independent of h, issued while the loads of the h gather are in flight (six of
+//      the seven k-slabs of W_ih: the seventh - input channels 192 .. 195 + padding - sits in the K padding of W_hh's last slab and the h tile's
+//      chunk 49 carries x_t[192 .. 199], so it costs no register, no MFMA and no LDS read of its own);
+//   1. h_{t-1} of the cluster's 64 sequences -> LDS (tag-in-data hand-off, lstm_cluster.hip's protocol), barrier 1;
+//   2. + h_{t-1} W_hh^T (an A fragment read from LDS feeds both quads), cell update, barrier 2;
+//   3. h_t -> exchange buffer (tagged); hout leaves in the NEXT step (deferred 16-byte row pieces).
+// Every wave brings four of the step's 32 LDS-DMA instructions of x_{t+1} (two 448-byte rows each, at the bank-conflict-free pitch of 480 bytes)
+// right behind barrier 1; the helper wave copies x[192 .. 199] into the h tile and stores the step's saved gates and c_t behind barrier 2.  The x
+// tile doubles as the saved-gates staging tile: every wave has multiplied x_t before barrier 1, the gate activations are written behind it.
+// What the in-kernel cycle stamps (XSTAMP, scripts/abl_clusterx.py) and the ablations decided, in the order found:
+//   * addresses: every LDS / exchange offset is the lane id (made opaque once per step and per phase, against loop-invariant hoisting -> spills)
+//     times a constant + an instruction's immediate; the exchange planes keep rows at the LDS tile's pitch and the chunk walk is "nine rows of 49
+//     chunks per pass" so that a pass is an immediate too: 730 -> 470 vector instructions per wave and step;
+//   * the hand-off waits per WAVE, not per lane (one ballot per round), and looks at the gather once in the middle of the projection;
+//   * A fragments are read three (h tile) / four (x tile) ahead of their MFMAs: written as read -> MFMA -> MFMA the compiler kept that order and
+//     every k-slab waited out an LDS round trip;
+//   * the helper wave alone issuing the 32 DMAs took 9,000 of a step's 15,700 cycles (an LDS-DMA instruction costs its wave 100 - 300 cycles) and
+//     the working waves waited 3,400 cycles at barrier 2 for x_{t+1}: the DMAs are spread over all eight waves;
+//   * a 16-byte buffer store reads its data registers some time after it has issued: an LDS read a few instructions behind it into the same
+//     registers can land first (first dword of the stored piece replaced, in the waves that issue last) - the registers stay occupied until the
+//     MFMA block behind the store has issued (deferred_hout).
+// Same math / layouts / protocol as lstm_cluster.hip, and the same rounding points as the two-kernel form for 192 of the 196 input channels:
+// x W_ih^T + b is rounded to the 16-bit operand format before h W_hh^T is added to it (there: the gx matrix; here: the register pairs that wait for
+// the gather); the last four channels are added unrounded.  N = 196 (Np 224), H = 392 (Hp 416).
 #include "urse_common.h"
 
 namespace urse {
@@ -30,6 +44,23 @@ constexpr int XTHR = XW * 64;      // 448 working threads
 constexpr int XROWS = 64;          // sequences per cluster
 constexpr int XUW = XW * XQ * 4;   // hidden units per workgroup (56)
 constexpr int XNSH = 13, XNSX = 7; // k-slabs of W_hh (Hp = 416) and W_ih (Np = 224)
+constexpr int XNSP = 6;            // k-slabs of W_ih the PROJECTION multiplies: the seventh (input channels 192 .. 195 + padding) rides in the free k positions
+                                   // 392 .. 399 of the recurrent product's last slab (eight resident registers and eight MFMAs per wave and step less)
+#ifndef XFETCH_POS
+#define XFETCH_POS 0
+#endif
+#ifndef XHSLEEP
+#define XHSLEEP 24                 // s_sleep units the helper waits behind barrier 2 before its 44 stores (the publication of h_t goes first)
+#endif
+#ifndef XAD
+#define XAD 3                      // A fragments of the h tile in flight ahead of their MFMAs
+#endif
+#ifndef XMIDPOLL
+#define XMIDPOLL 0x2               // behind which row tiles of the projection the wave looks at the gather (bit rt)
+#endif
+#ifndef XPD
+#define XPD 4                      // A fragments of the x tile read ahead in the projection (registers: 4 each)
+#endif
 
 struct ClusterXArgs {
   const void* xn; long ldx;       // [M, ldx] 16-bit normalised input rows, K padding zero
@@ -40,7 +71,7 @@ struct ClusterXArgs {
   void* hout; long ldh;
   void* hout2;                    // f16 operands: h once more in bf16 (null: not wanted)
   float* c;
-  bf16_t* hx;                     // exchange [2 parity][2 dir][ncl][rows_pad][Hp]
+  bf16_t* hx;                     // exchange [2 parity][2 dir][ncl][rows_pad][432 = the LDS tile's pitch]
   unsigned* err;
   int H, save;
   long inner, outer, stride;
@@ -64,6 +95,13 @@ __device__ __forceinline__ uint4 xload_sc1(__amdgpu_buffer_rsrc_t rs, unsigned o
   return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+#ifdef XSTAMP      // timing diagnostics: cycle stamps of workgroup (XSTAMP_WG, 0): slots 0 .. 7 working wave 0, 8 .. 11 the helper wave, [step][16]
+__device__ unsigned long long g_xstamps[512 * 16];
+#define XST(slot) do { if (stamp_on && step < 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_xstamps[step * 16 + (slot)] = t_; } } while (0)
+#else
+#define XST(slot) do { } while (0)
+#endif
+
 template <typename TI, bool H2, bool SAVE>
 __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXArgs p) {
   static_assert(!H2 || __is_same(TI, f16_t), "the bf16 copy of h exists in the f16 mode only");
@@ -71,6 +109,9 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H;
+#ifdef XSTAMP
+  const bool stamp_on = blockIdx.x == XSTAMP && blockIdx.y == 0 && (w == 0 || w == XW);
+#endif
   constexpr int Hp = XNSH * 32, pitch = lds_frag_pitch(Hp * 2);          // h tile row pitch (864)
   constexpr int GP = lds_frag_pitch(XNSX * 64);                           // x / gates tile row pitch (480): conflict-free A fragment reads
   constexpr int GPC = GP / 16;                                            // 30 pieces of 16 bytes per tile row (28 carry data)
@@ -83,6 +124,8 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   int* rowtab = reinterpret_cast<int*>(bias_s + XUW * 4);                 // [64] row of (sequence, t = 0)
   int* xs = rowtab + XROWS;                                               // [12] broadcast of the cluster assignment, [12] dead flag
   unsigned* deadflag = reinterpret_cast<unsigned*>(xs + 12);
+  unsigned* xrow = reinterpret_cast<unsigned*>(xs + 32);                  // [64] byte offset of the x row of (sequence, t = 0), out of range for a dead row
+  unsigned* hrow = xrow + XROWS;                                          // [448] byte offset of the working thread's h piece in hout at t = 0
 
   // ---- which cluster, which member, which sequences (lstm_cluster.hip: static or XCD-aware formation; placement decides speed, never correctness)
   int dir = blockIdx.y, cl = blockIdx.x / p.C, j = blockIdx.x - cl * p.C;
@@ -146,7 +189,16 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   if (tid < XROWS) {
     int seq = seq0 + tid;
     if (seq >= p.n_seq) seq = p.n_seq - 1;
-    rowtab[tid] = (int)((seq / p.inner) * p.outer + (seq % p.inner));
+    const int r0 = (int)((seq / p.inner) * p.outer + (seq % p.inner));
+    rowtab[tid] = r0;
+    xrow[tid] = tid < nrows ? (unsigned)r0 * (unsigned)((int)p.ldx * 2) : 0xFFFFF000u;
+  }
+  if (tid < XTHR) {                                                       // (the h piece of working thread tid: row tid / 7, units 8 (tid % 7) ..)
+    const int sr = tid / (XUW * 2 / 16), sc = tid - sr * (XUW * 2 / 16), ucol = j * XUW + sc * 8;
+    int seq = seq0 + sr;
+    if (seq >= p.n_seq) seq = p.n_seq - 1;
+    const int r0 = (int)((seq / p.inner) * p.outer + (seq % p.inner));
+    hrow[tid] = (sr < nrows && ucol < H) ? ((unsigned)r0 * (unsigned)ldh_i + (unsigned)(hcol_i + ucol)) * 2u : 0xFFFFF000u;
   }
   for (int i = tid; i < XUW * 4; i += XTHR + 64) {
     const int u = j * XUW + (i >> 2);
@@ -160,8 +212,40 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   const __amdgpu_buffer_rsrc_t rs_gs = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)p.g_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
 
+  // ---- x rows by LDS-DMA: one instruction brings TWO rows - lanes 0 .. 27 the 28 pieces of row 2 i, lanes 30 .. 57 those of row 2 i + 1 (the destination
+  // is lane-linear: lane 30 lands at byte 480 = the tile's pitch), the other lanes are masked off.  EVERY wave issues four of the 32 instructions of a
+  // step (rows 8 w .. 8 w + 7) right behind barrier 1: issued by the helper wave alone they took 9,000 cycles of a 15,700-cycle step (in-kernel stamps,
+  // profiles/r05_abl_clusterx_v9_stamps.log: an LDS-DMA instruction costs its wave 100 - 300 cycles of issue) and the working waves waited 3,400 cycles
+  // at barrier 2 for x_{t+1} to land.  The byte offsets of the 64 rows at t = 0 sit in an LDS table.
+  const int ldx2 = (int)p.ldx * 2;
+  typedef int rsrc4 __attribute__((ext_vector_type(4)));
+  const unsigned long gbx = (unsigned long)p.xn;
+  const rsrc4 rg = rsrc4{(int)(unsigned)gbx, (int)(unsigned)((gbx >> 32) & 0xffffu), (int)p.x_bytes, 0x00020000};
+  const unsigned lds_g0 = (unsigned)(size_t)gstage0;
+  auto fetch4 = [&](int par, int toff_, int lane_) __attribute__((always_inline)) {
+    const unsigned soff = (unsigned)(toff_ * ldx2);
+    const bool xact = lane_ < 28 || (lane_ >= 30 && lane_ < 58);
+    const unsigned xpiece = (unsigned)((lane_ < 30 ? lane_ : lane_ - 30) * 16);
+#pragma unroll
+    for (int i = 0; i < XROWS / 2 / (XW + 1); ++i) {
+      const int pr = w * (XROWS / 2 / (XW + 1)) + i;                       // row pair
+      const unsigned vo = xrow[2 * pr + (lane_ < 30 ? 0 : 1)] + xpiece;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_g0 + (unsigned)(par * (XROWS * GP) + 2 * pr * GP));
+#ifndef XABL_NO_DMA      // timing diagnostics (wrong results): XABL_NO_DMA, XABL_NO_HSTORE, XABL_NO_PROJ, XABL_NO_REC, XABL_NO_AREAD (no A fragment reads), XABL_NO_CELL, XABL_NO_GATHER, XABL_NO_XSTORE, XABL_NO_HOUT
+      if (xact) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vo), "s"(rg), "s"(soff), "s"(dst) : "memory");
+      }
+#else
+      asm volatile("" :: "v"(vo), "s"(dst), "s"(soff));
+#endif
+    }
+  };
+  fetch4(0, (dir ? p.seq_len - 1 : 0) * stride_i, lane);                 // x_0 -> tile 0 (every wave its rows; B0 below)
+
   if (w == XW) {
-    // ================= helper wave: x_{t+1} in, saved gates / c_t of step t - 1 out; the working waves' two barriers per step =================
+    // ================= helper wave: saved gates / c_t of every step out; the working waves' two barriers per step =================
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int NG = XROWS * GPC / 64, NC = XROWS * (XUW * 4 / 16) / 64;     // 30 gates pieces, 14 c pieces per lane and step
     constexpr int GC = XUW * 8 / 16, CC = XUW * 4 / 16;
@@ -176,43 +260,19 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       const int idx = lane + i * 64, row = idx / CC, cc = idx - row * CC;
       oc[i] = (row < nrows && cc * 4 < nvu) ? ((unsigned)rowtab[row] * (unsigned)ldc_i + (unsigned)(hcol_i + j * XUW + cc * 4)) * 4u : COOB;
     }
-    // x rows: lane l holds the byte offset of row l at t = 0; one LDS-DMA instruction brings TWO rows - lanes 0 .. 27 the 28 pieces of row 2 i, lanes
-    // 30 .. 57 those of row 2 i + 1 (the destination is lane-linear: lane 30 lands at byte 480 = the tile's pitch), the other lanes are masked off
-    const int ldx2 = (int)p.ldx * 2;
-    const unsigned xoff_row = lane < nrows ? (unsigned)rowtab[lane] * (unsigned)ldx2 : COOB;
-    const bool xact = lane < 28 || (lane >= 30 && lane < 58);
-    const unsigned xpiece = (unsigned)((lane < 30 ? lane : lane - 30) * 16);
-    const unsigned long gb = (unsigned long)p.xn;
-    typedef int rsrc4 __attribute__((ext_vector_type(4)));
-    const rsrc4 rg = rsrc4{(int)(unsigned)gb, (int)(unsigned)((gb >> 32) & 0xffffu), (int)p.x_bytes, 0x00020000};
-    const unsigned lds_g0 = (unsigned)(size_t)gstage0;
-    auto fetch = [&](int par, int toff_) {
-      const unsigned soff = (unsigned)(toff_ * ldx2);
-#pragma unroll
-      for (int i = 0; i < XROWS / 2; ++i) {
-        const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)xoff_row, 2 * i), r1 = (unsigned)__builtin_amdgcn_readlane((int)xoff_row, 2 * i + 1);
-        const unsigned vo = (lane < 30 ? r0 : r1) + xpiece;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_g0 + (unsigned)(par * (XROWS * GP) + 2 * i * GP));
-#ifndef XABL_NO_DMA      // timing diagnostics (wrong results): XABL_NO_DMA, XABL_NO_HSTORE, XABL_NO_PROJ, XABL_NO_REC, XABL_NO_CELL, XABL_NO_GATHER, XABL_NO_XSTORE, XABL_NO_HOUT
-        if (xact) {
-          unsigned keep;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep) : "v"(vo), "s"(rg), "s"(soff), "s"(dst) : "memory");
-        }
-#else
-        asm volatile("" :: "v"(vo), "s"(dst), "s"(soff));
-#endif
-      }
-    };
     uint4 vg[NG], vc[NC];
-    fetch(0, (dir ? p.seq_len - 1 : 0) * stride_i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // B0: x_0 is in tile 0
-    // The helper's work is split over the two halves of a step so that it is never the last to arrive at a barrier: between barrier 1 and barrier 2
-    // (the working waves multiply h W_hh^T and update the cells) it reads the PREVIOUS step's staged pieces into registers and issues the DMAs of
-    // x_{t+1} into the tile they came from; between barrier 2 and the next barrier 1 (the working waves project x_{t+1} and gather h_t) it stores the
-    // pieces.  (All of it between barrier 1 and barrier 2 - 32 DMAs + 44 LDS reads + 44 stores, ~3.3 us - made the working waves wait there.)
-    bool have = false;
+    // x_t[192 .. 199] (16 bytes per row: bytes 384 .. 399 of the x row) -> chunk 49 of the h tile's row, where the recurrent product's last k-slab picks
+    // it up (XNSP); lane = row.  The h tile's chunk 49 is touched by nobody else: the gather writes chunks 0 .. 48.
+    auto copy_x49 = [&](int par) {
+      const uint4 v = *reinterpret_cast<const uint4*>(gstage0 + par * (XROWS * GP) + lane * GP + XNSP * 64);
+      *reinterpret_cast<uint4*>(htile + lane * pitch + (Hp - 32 + 8) * 2) = v;
+    };
+    copy_x49(0);
+    // Between barrier 1 and barrier 2 (the working waves multiply and update the cells) the helper issues its four DMAs of x_{t+1} and waits for them;
+    // behind barrier 2 (the working waves publish h_t, project x_{t+1}, gather) it reads the step's staged gate activations and c_t into registers and
+    // stores them - the tile is free again when it arrives at the next barrier 1, which is when x_{t+2} may overwrite it.
     int toff_st = 0;
     auto store_pieces = [&]() {
 #ifndef XABL_NO_HSTORE
@@ -232,28 +292,27 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #pragma unroll
       for (int i = 0; i < NC; ++i) vc[i] = *reinterpret_cast<const uint4*>(cst_ + (lane + i * 64) * 16);
     };
-    int toff_prev = 0;
     for (int step = 0; step < p.seq_len; ++step) {
       const int t = dir ? (p.seq_len - 1 - step) : step;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the stores issued behind the previous barrier 2 are done: their data registers may be rewritten
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // (chunk 49 is written)
+      XST(8);
       __builtin_amdgcn_s_barrier();                                       // barrier 1 of the step
-      const int pp = (step + 1) & 1;                                      // parity of the previous step = of the next one
-      have = p.save && step > 0;
-      if (have) read_pieces(pp);                                          // the previous step's tiles are complete behind ITS barrier 2
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the tile is in registers: x_{t+1} may overwrite it
-      if (step + 1 < p.seq_len) fetch(pp, (dir ? t - 1 : t + 1) * stride_i);
-      toff_st = toff_prev;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // x_{t+1} has landed: the working waves multiply it right behind barrier 2
+      XST(9);
+      if (step + 1 < p.seq_len) fetch4((step + 1) & 1, (dir ? t - 1 : t + 1) * stride_i, lane);
+      XST(10);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // its rows of x_{t+1} have landed (and the previous step's stores are done:
+      XST(11);                                                            //  their data registers may be rewritten)
       __builtin_amdgcn_s_barrier();                                       // barrier 2 of the step
-      if (have) store_pieces();
-      toff_prev = t * stride_i;
-    }
-    if (p.save) {                                                         // the last step's tiles
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      read_pieces((p.seq_len + 1) & 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      toff_st = toff_prev;
-      store_pieces();
+      copy_x49((step + 1) & 1);                                           // (x_{t+1} is whole behind barrier 2; read by the MFMAs behind barrier 1 of step t + 1)
+      if (p.save) {
+#if XHSLEEP > 0
+        __builtin_amdgcn_s_sleep(XHSLEEP);                                // (the working waves' publication of h_t first: one store the cluster waits for)
+#endif
+        read_pieces(step & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        toff_st = t * stride_i;
+        store_pieces();
+      }
     }
     return;
   }
@@ -261,100 +320,185 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   // ================= working waves =================
   // operands swapped as in lstm_cluster.hip: A = the resident weight fragment (rows = the quad's 16 gate columns), B = the h / x fragment (columns =
   // sequences): lane (lr, lc) then holds the FOUR GATES of unit lr of the quad for sequence lc of the row tile
-  const int ul = lr, rl = lc;
-  uint4 breg[XQ][XNSH], wreg[XQ][XNSX];
-  int lu[XQ];                                                             // unit index inside the workgroup (0 .. 55); H % 56 == 0: every quad and unit is valid
+  uint4 breg[XQ][XNSH], wreg[XQ][XNSP];
+  const int lu0 = w * XQ * 4 + lr;                                        // unit index inside the workgroup of quad 0 (quad 1: + 4); H % 56 == 0: all valid
+  (void)lu0;
 #pragma unroll
   for (int q = 0; q < XQ; ++q) {
     const int qd = j * (XW * XQ) + w * XQ + q;
-    lu[q] = (w * XQ + q) * 4 + ul;
     const char* sh = reinterpret_cast<const char*>(p.whhq) + (((long)dir * nq + qd) * XNSH) * 1024 + lane * 16;
     const char* sx = reinterpret_cast<const char*>(p.wihq) + (((long)dir * nq + qd) * XNSX) * 1024 + lane * 16;
 #pragma unroll
     for (int ks = 0; ks < XNSH; ++ks) breg[q][ks] = *reinterpret_cast<const uint4*>(sh + ks * 1024);
 #pragma unroll
-    for (int ks = 0; ks < XNSX; ++ks) wreg[q][ks] = *reinterpret_cast<const uint4*>(sx + ks * 1024);
+    for (int ks = 0; ks < XNSP; ++ks) wreg[q][ks] = *reinterpret_cast<const uint4*>(sx + ks * 1024);
+    // the last slab of W_hh holds k = 384 .. 415, of which 392 .. 415 are padding (zero columns): lanes lr = 1 (k = 392 .. 399) take the seventh slab
+    // of W_ih's lr = 0 lanes (input channels 192 .. 199, of which 196 .. 199 are padding) - the h tile's chunk 49 carries x_t[192 .. 199] (helper wave)
+    const uint4 w6 = *reinterpret_cast<const uint4*>(sx + (XNSX - 1) * 1024);
+    const int src = ((lane - 16) & 63) * 4;
+    const uint4 w6s = make_uint4((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)w6.x), (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)w6.y),
+                                 (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)w6.z), (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)w6.w));
+    if (lr == 1) breg[q][XNSH - 1] = w6s;
   }
   // c_{t-1} is read back from the previous step's c staging tile (LDS, written every step), not carried in registers: the budget is 256 and the
   // resident weights take 160
   for (int i = tid; i < 2 * XROWS * XUW; i += XTHR) reinterpret_cast<float*>(cstage0)[i] = 0.f;
 
-  const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * p.rows_pad * Hp * 2);
-  const unsigned cl_bytes = (unsigned)((long)clx * p.rows_pad * Hp * 2);
+  // exchange planes: rows at the LDS tile's pitch (864 B), so that a chunk sits at the same byte offset of the plane AND of the tile, and a chunk walk whose
+  // offsets are the lane's base + a compile-time multiple of the pass: pass i of thread tid < 441 takes chunk tid % 49 of row 9 i + tid / 49 (nine rows of
+  // 49 data chunks per pass, 7 passes = 63 rows), the seven threads left over (441 .. 447, all in wave 6) share row 63, seven chunks per pass.  One per-lane
+  // offset, everything else an instruction's immediate or a scalar (round 5: the step's vector ALU work, not its memory, is what this kernel waits for -
+  // two working waves per SIMD issued ~730 vector instructions per step each, 40 % of them integer address arithmetic)
+  const unsigned plane_bytes = (unsigned)((long)2 * p.ncl * p.rows_pad * pitch);
+  const unsigned cl_bytes = (unsigned)((long)clx * p.rows_pad * pitch);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2u * plane_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_hs = __builtin_amdgcn_make_buffer_rsrc(p.hout, 0, (int)p.h_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_hs2 = __builtin_amdgcn_make_buffer_rsrc(H2 ? p.hout2 : p.hout, 0, (int)p.h_bytes, 0x00020000);
-  const int hchunks = H / 8;                                              // 49 data chunks of 16 B per h row (H % 8 == 0)
-  constexpr int HL = 7;                                                   // chunks per working thread: 64 rows x 49 = 7 x 448 (H = 392)
-  static_assert(XTHR == 9 * 49 + 7, "chunk walk below: 448 = 9 rows of 49 chunks + 7");
-  const int hrow0_o = tid / 49, hcc0_o = tid - hrow0_o * 49;              // chunk i of this thread: linear index tid + 448 i = (row, chunk), see hpos
+  constexpr int HL = 7, HCH = 49, HRP = 9;                                // chunks per working thread, data chunks per row, rows per pass
+  static_assert(XTHR == HRP * HCH + 7 && HRP * HL + 1 == XROWS && HL * 7 == HCH, "chunk walk below");
+  const bool tailw = w == XW - 1;                                         // the wave with the seven left-over threads (uniform)
+  const bool tailt = tid >= HRP * HCH;
+  constexpr int GCORR = HRP * pitch - 7 * 16;                             // their pass stride is 7 chunks instead of 9 rows
+  // Rows are published and gathered in whole passes: nact = ceil(nrows / 9) passes of nine rows (a cluster with fewer than 64 sequences - the mixed
+  // clusters of the XCD-aware formation have 32 - moves 36 rows, not 64; the rows past its last sequence compute on zero inputs and are stored nowhere),
+  // so that "which chunks does this thread wait for" is a scalar, not a per-lane mask.  With fewer than 64 rows the seven left-over threads
+  // duplicate threads 0 .. 6 (same loads, same LDS writes) instead of taking row 63.
+  const int nact = nrows >= XROWS ? HL : (nrows + HRP - 1) / HRP;
+  const bool full = nrows >= XROWS;
+  (void)tailt;
   constexpr unsigned TAGM = 0x40004000u;                                  // bit 14 of both 16-bit halves: clear in |h| <= 1 (bf16 and f16)
   // the one (row, 16-byte piece) of the staged h tile this thread publishes / stores per step: 64 rows x 7 pieces = 448 = one per working thread
   constexpr int SC = XUW * 2 / 16;
   const int st_row = tid / SC, st_cc = tid - st_row * SC;
-  unsigned dvo_h;
-  {
-    const int ucol = j * XUW + st_cc * 8;
-    dvo_h = (st_row < nrows && ucol < H) ? ((unsigned)rowtab[st_row] * (unsigned)ldh_i + (unsigned)(hcol_i + ucol)) * 2u : COOB;
-  }
+  // LDS regions as byte offsets from smem
+  constexpr int H0 = XROWS * pitch, HS = XROWS * XUW * 2;                  // h staging [2]
+  constexpr int G0 = H0 + 2 * HS, GS = XROWS * GP;                         // x / gates tiles [2]
+  constexpr int C0 = G0 + 2 * GS, CS = XROWS * XUW * 4;                    // c staging [2]
+  constexpr int B0 = C0 + 2 * CS;                                          // bias
+  // per-lane byte offsets, derived inside the step from the (opaque) lane id: lane (lr, lc), unit lu0 = w * 8 + lr of the workgroup (quad 1: + 4)
+  //   A fragment of the h tile   lc * pitch + 16 lr              + rt * 16 * pitch + ks * 64
+  //   A fragment of the x tile   G0 + lc * GP + 16 lr            + par * GS + rt * 16 * GP + ks * 64
+  //   c staging of (lc, lu0)     C0 + lc * XUW * 4 + lu0 * 4     + par * CS + rt * 16 * XUW * 4 + q * 16      (h staging: H0 + half of the lane part)
+  //   gate activations           G0 + lc * GP + lu0 * 8          + par * GS + rt * 16 * GP + q * 32
+  //   bias of unit lu0           B0 + lu0 * 16                   + q * 64
+  //   gather chunk / staged piece  tid * 16
   int toff_d = 0;
   bool have_d = false;
-  auto deferred_hout = [&](int par) {
+  // (returns the registers the stores read: a 16-byte buffer store fetches its data some time AFTER it has issued, and an LDS read that the compiler
+  //  places a few instructions behind it into the same registers can land first - seen here as the first dword of a piece replaced in the waves that
+  //  issue last, and in lstm_cluster.hip's helper waves in round 4; the caller keeps the registers occupied until the MFMA block behind has issued)
+  auto deferred_hout = [&](int par, int tv, uint4& keep0, uint4& keep1) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const uint4 v = *reinterpret_cast<const uint4*>(hstage0 + par * (XROWS * XUW * 2) + tid * 16);
+    const unsigned dvo_h = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(hrow) + (tv >> 2));      // (a table, not a register held for 401 steps)
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + H0 + par * HS + tv);
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_hs, (int)dvo_h, toff_d * ldh_i * 2, 0);
+    keep0 = v;
     if constexpr (H2) {
       float a0, a1, a2, a3, a4, a5, a6, a7;
       unpack2<f16_t>(v.x, a0, a1); unpack2<f16_t>(v.y, a2, a3); unpack2<f16_t>(v.z, a4, a5); unpack2<f16_t>(v.w, a6, a7);
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack2<bf16_t>(a0, a1), pack2<bf16_t>(a2, a3), pack2<bf16_t>(a4, a5), pack2<bf16_t>(a6, a7)},
-                                             rs_hs2, (int)dvo_h, toff_d * ldh_i * 2, 0);
+      const uint4 vb = make_uint4(pack2<bf16_t>(a0, a1), pack2<bf16_t>(a2, a3), pack2<bf16_t>(a4, a5), pack2<bf16_t>(a6, a7));
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{vb.x, vb.y, vb.z, vb.w}, rs_hs2, (int)dvo_h, toff_d * ldh_i * 2, 0);
+      keep1 = vb;
     }
   };
-  __builtin_amdgcn_s_barrier();                                           // B0: x_0 is in tile 0 (the helper's first fetch)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                           // B0: x_0 is in tile 0 (every wave fetched its rows)
 
-  const int lr_o = lr, lc_o = lc, lu0_o = lu[0], lu1_o = lu[1];
+  int lane_v = lane;
+  bool dead = false;
+  volatile __attribute__((address_space(3))) unsigned* dead_lds = (volatile __attribute__((address_space(3))) unsigned*)deadflag;
   for (int step = 0; step < p.seq_len; ++step) {
-    // The lane's index registers are made opaque once per step: every LDS / exchange address below is then recomputed from them inside the step (a
-    // few dozen integer instructions) instead of being hoisted out of the time loop as ~60 loop-invariant registers - which the 256-register budget
-    // (160 of it resident weights) turned into scratch spills, and a scratch reload is a vector memory operation IN FRONT of which the in-order vmcnt
-    // queue waits for every gather load issued before it: the seven loads of the h gather ran as seven serial round trips.
-    int lr = lr_o, lc = lc_o, hrow0 = hrow0_o, hcc0 = hcc0_o;
-    int lu[XQ] = {lu0_o, lu1_o};
-    asm volatile("" : "+v"(lr), "+v"(lc), "+v"(hrow0), "+v"(hcc0), "+v"(lu[0]), "+v"(lu[1]));
-    const int ul = lr, rl = lc;
-    (void)ul;
-    auto hpos = [&](int i, int& row, int& cc) {
-      const int c = hcc0 + 7 * i, wrap = c >= 49 ? 1 : 0;
-      row = hrow0 + 9 * i + wrap;
-      cc = c - 49 * wrap;
-    };
+    // The lane's indices are made opaque per step (and again per phase): left visible as loop invariants the compiler hoists every address derived
+    // from them out of the time loop (~60 registers), the 256-register budget (160 of it resident weights) turns those into scratch, and a scratch
+    // reload is a vector memory operation IN FRONT of which the in-order vmcnt queue waits for every gather load issued before it (the gather ran as
+    // serial round trips).  Each phase derives its few base offsets from the lane id (a handful of integer instructions); everything else is an
+    // instruction's immediate or a scalar.  (In place: no second copy of the registers stays live.)
+    XST(0);
+    asm volatile("" : "+v"(lane_v));
+    // the thread's chunk walk base: (tid / 49) * pitch + (tid % 49) * 16 = 16 tid + (pitch - 49 * 16) * (tid / 49), tid / 49 = tid * 1338 >> 16 for tid < 448;
+    // the seven left-over threads (wave 6, lanes 57 .. 63): row 63 of a full cluster, else they duplicate threads 0 .. 6
+    int gb;
+    {
+      const int tid_v = w * 64 + lane_v;
+      gb = tid_v * 16 + (pitch - HCH * 16) * ((tid_v * 1338) >> 16);
+      if (tailw) gb = lane_v >= 64 - 7 ? (full ? (XROWS - 1) * pitch : 0) + (lane_v - (64 - 7)) * 16 : gb;
+    }
     const int t = dir ? (p.seq_len - 1 - step) : step;
     const int toff = t * stride_i;
     const int par = step & 1;
     const unsigned pprev = (unsigned)((step + 1) & 1), pcur = (unsigned)par;
     const unsigned tag_cur = (((unsigned)step >> 1) & 1u) ^ 1u;
     const unsigned tag_prev = (((unsigned)(step - 1) >> 1) & 1u) ^ 1u;
-    char* xg = gstage0 + par * (XROWS * GP);
-    // ---- 0. x_t W_ih^T + b (independent of h) + 1. the h gather.  The gather's first round of loads is issued in front of the projection.
+    const int xg = G0 + par * GS + (lane_v & 15) * GP + (lane_v >> 4) * 16;
+    const int bq = B0 + w * (XQ * 64) + (lane_v >> 4) * 16;
+    // ---- 0. x_t W_ih^T + b (independent of h) + 1. the h gather.  The gather's loads are issued in front of the projection.
     // (the projection's sums wait for the gather as 16-bit pairs of the operand format - what the two-kernel form stores in gx - : 16 registers
     //  instead of 32 across barrier 1)
     uint2 accp[4][XQ];
-    auto project = [&]() {
+    {
+      // the thread's chunks of the cluster's h_{t-1}, all of them in flight at once.  Which chunks are still awaited is kept per WAVE (a scalar mask:
+      // a chunk index is re-requested for the whole wave while any of its lanes misses a tag - re-reading a piece that has arrived is harmless, the plane
+      // is not rewritten before every member has passed this step), so the loop carries no per-lane bookkeeping
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      uint4 hn[HL];
+      bool live = step > 0 && !dead && nact > 0;                          // (dead: this wave has seen a hand-off time out - it stops waiting;
+                                                                          //  nact == 0: a cluster the XCD-aware formation left without sequences)
+#ifdef XABL_NO_GATHER
+      live = false;
+#endif
+      const unsigned sbase = pprev * plane_bytes + cl_bytes;
+      const int gcorr = (tailw && full && lane_v >= 64 - 7) ? GCORR : 0;
+      // (all seven loads of a round are unconditional: a pass past the cluster's last row - clusters with fewer than 64 sequences - re-reads pass 0,
+      //  a scalar select of the offset; per-chunk branches around the loads made the compiler keep two generations of the 28 registers alive)
+      auto load_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+          const int so = (int)(sbase + (unsigned)(i < nact ? HRP * pitch * i : 0));
+          const u32x4 r = tailw ? __builtin_amdgcn_raw_buffer_load_b128(rs, i < nact ? gb - i * gcorr : gb, so, 16)
+                                : __builtin_amdgcn_raw_buffer_load_b128(rs, gb, so, 16);
+          hn[i] = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+      };
+      if (live) load_all();
+      else {
+#pragma unroll
+        for (int i = 0; i < HL; ++i) hn[i] = make_uint4(0, 0, 0, 0);
+      }
+      unsigned pendu = live ? 1u : 0u;
+      // a chunk has arrived when all eight tags are the previous step's: AND / OR trees over the round's chunks, one ballot per round
+      auto check = [&]() __attribute__((always_inline)) {
+        unsigned acc_and = hn[0].x & hn[0].y & hn[0].z & hn[0].w, acc_or = hn[0].x | hn[0].y | hn[0].z | hn[0].w;
+#pragma unroll
+        for (int i = 1; i < HL; ++i) {
+          acc_and &= hn[i].x & hn[i].y & hn[i].z & hn[i].w;
+          acc_or |= hn[i].x | hn[i].y | hn[i].z | hn[i].w;
+        }
+        const bool miss = tag_prev ? ((acc_and & TAGM) != TAGM) : ((acc_or & TAGM) != 0u);
+        if (__builtin_amdgcn_ballot_w64(miss) == 0ull) pendu = 0u;
+      };
+      auto reissue = [&]() __attribute__((always_inline)) { load_all(); };
+      // ---- the projection, behind the loads: A fragments of the x tile (4 row tiles x 7 k-slabs) read XPD ahead through a rotating set of registers.
+      // Between row tiles the wave looks at what has arrived and asks again for what has not: the members of a cluster publish within a few hundred
+      // cycles of each other, so the first request usually comes back with the old tags, and a wave that only looked again after the whole projection
+      // (4,100 cycles, in-kernel stamps) found out 2,600 cycles late.
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         f32x4_t accx[XQ];
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) accx[q] = *reinterpret_cast<const f32x4_t*>(bias_s + lu[q] * 4);
-        const char* xr = xg + (rt * 16 + lc) * GP + 16 * lr;
+        for (int q = 0; q < XQ; ++q) accx[q] = *reinterpret_cast<const f32x4_t*>(smem + bq + q * 64);
 #pragma unroll
-        for (int k0 = 0; k0 < XNSX; k0 += 4) {
-          uint4 a[4];
+        for (int k0 = 0; k0 < XNSP; k0 += XPD) {
+          uint4 a[XPD];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (k0 + i < XNSX) a[i] = *reinterpret_cast<const uint4*>(xr + (k0 + i) * 64);
+          for (int i = 0; i < XPD; ++i)
+#ifndef XABL_NO_AREAD
+            if (k0 + i < XNSP) a[i] = *reinterpret_cast<const uint4*>(smem + xg + rt * 16 * GP + (k0 + i) * 64);
+#else
+            if (k0 + i < XNSP) a[i] = make_uint4(xg, rt, k0, i);
+#endif
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (k0 + i < XNSX) {
+          for (int i = 0; i < XPD; ++i)
+            if (k0 + i < XNSP) {
 #pragma unroll
 #ifndef XABL_NO_PROJ
               for (int q = 0; q < XQ; ++q) accx[q] = mfma16<TI>(wreg[q][k0 + i], a[i], accx[q]);
@@ -365,69 +509,71 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         }
 #pragma unroll
         for (int q = 0; q < XQ; ++q) accp[rt][q] = make_uint2(pack2<TI>(accx[q][0], accx[q][1]), pack2<TI>(accx[q][2], accx[q][3]));
-      }
-    };
-    const unsigned want = tag_prev ? TAGM : 0u;
-    bool dead = *reinterpret_cast<volatile unsigned*>(deadflag) != 0u;
-    {
-      // the thread's chunks of the cluster's h_{t-1}: only the H / 8 data chunks of a row are walked (64 rows x 49 = 7 per working thread), all of
-      // them in flight at once; the tile's K padding (chunks 49 .. 51) was zeroed once
-      uint4 hn[HL];
-      unsigned pend = 0u;
-#pragma unroll
-      for (int i = 0; i < HL; ++i) {
-        hn[i] = make_uint4(0, 0, 0, 0);
-#ifndef XABL_NO_GATHER
-        int row, cc;
-        hpos(i, row, cc);
-        if (step > 0 && row < nrows && !dead) pend |= 1u << i;
+#ifndef XNO_MIDPOLL
+        if (((XMIDPOLL >> rt) & 1) && pendu) {
+          check();
+          if (pendu) reissue();
+        }
 #endif
       }
-      auto issue = [&]() {
-#pragma unroll
-        for (int i = 0; i < HL; ++i)
-          if (pend & (1u << i)) {
-            int row, cc;
-            hpos(i, row, cc);
-            hn[i] = xload_sc1(rs, pprev * plane_bytes + cl_bytes + (unsigned)(row * Hp * 2 + cc * 16));
-          }
-      };
-      issue();
-      project();                                                          // (behind the first round of loads)
-      unsigned spins = 0;
-      while (pend) {
-#pragma unroll
-        for (int i = 0; i < HL; ++i) {
-          if (pend & (1u << i)) {
-            const uint4 v = hn[i];
-            if ((v.x & TAGM) == want && (v.y & TAGM) == want && (v.z & TAGM) == want && (v.w & TAGM) == want) pend &= ~(1u << i);
-          }
-        }
-        if (pend) {
+      XST(1);
+      if (pendu) {
+        unsigned spins = 0;
+        while (true) {
+          check();
+          if (!pendu) break;
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 20)) { atomicExch(p.err, 1u); *reinterpret_cast<volatile unsigned*>(deadflag) = 1u; pend = 0u; dead = true; }
-          issue();
+          ++spins;
+          if ((spins & 1023u) == 0u && dead_lds[0] != 0u) { dead = true; break; }      // another wave of the workgroup has given up
+          if (spins > (1u << 20)) { atomicExch(p.err, 1u); dead_lds[0] = 1u; dead = true; break; }
+          reissue();
         }
       }
+      XST(2);
+      if (live && tag_prev) {                                             // (tags of the other parity are zero bits: nothing to clear)
 #pragma unroll
-      for (int i = 0; i < HL; ++i) {
-        uint4 v = hn[i];
-        v.x &= ~TAGM; v.y &= ~TAGM; v.z &= ~TAGM; v.w &= ~TAGM;
-        int row, cc;
-        hpos(i, row, cc);
-        if (row < XROWS) *reinterpret_cast<uint4*>(htile + row * pitch + cc * 16) = v;
+        for (int i = 0; i < HL; ++i) { hn[i].x &= ~TAGM; hn[i].y &= ~TAGM; hn[i].z &= ~TAGM; hn[i].w &= ~TAGM; }
+      }
+      if (!tailw) {
+#pragma unroll
+        for (int i = 0; i < HL; ++i) *reinterpret_cast<uint4*>(smem + gb + HRP * pitch * i) = hn[i];      // (a dead pass wrote a copy of pass 0 into rows nobody stores)
+      } else {
+#pragma unroll
+        for (int i = 0; i < HL; ++i) *reinterpret_cast<uint4*>(smem + gb - i * gcorr + HRP * pitch * i) = hn[i];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    XST(3);
     __builtin_amdgcn_s_barrier();                                         // barrier 1: the h tile is whole; every wave has read x_t
-#ifndef XABL_NO_HOUT
-    if (have_d) deferred_hout(par ^ 1);                                   // the previous step's h rows -> hout, under this step's MFMAs
+    XST(4);
+    asm volatile("" : "+v"(lane_v));
+#if XFETCH_POS == 0
+    if (step + 1 < p.seq_len) fetch4(par ^ 1, (dir ? t - 1 : t + 1) * stride_i, lane_v);      // this wave's rows of x_{t+1} (the tile's previous contents left before barrier 1)
 #endif
-    // ---- 2. + h_{t-1} W_hh^T, cell update - as a software pipeline inside the wave: the 26 MFMAs of row tile rt + 1 are issued among the ~130 vector
+    const int tv = w * 1024 + lane_v * 16;
+    uint4 keep0 = make_uint4(0, 0, 0, 0), keep1 = keep0;
+#ifndef XABL_NO_HOUT
+    if (have_d) deferred_hout(par ^ 1, tv, keep0, keep1);                 // the previous step's h rows -> hout, under this step's MFMAs
+#endif
+    // ---- 2. + h_{t-1} W_hh^T, cell update - as a software pipeline inside the wave: the 26 MFMAs of row tile rt + 1 are issued among the vector
     // instructions of the cell update of row tile rt (one straight-line block: every quad and unit of this geometry is valid, the save switch is a
-    // template parameter; the scheduler is told the interleave).  With two waves per SIMD that leave barrier 1 together, MFMA blocks and cell updates
-    // otherwise alternate in lockstep on both and the matrix pipe idles while the vector ALU is the bottleneck (ablation: 4.7 us of a 7.1 us step
-    // with every memory access switched off, profiles/r05_abl_clusterx_v1.log).
+    // template parameter).
+    const int a_off = (lane_v & 15) * pitch + (lane_v >> 4) * 16;
+    const int cq = (lane_v & 15) * (XUW * 4) + (lane_v >> 4) * 4 + w * (XQ * 16);
+    const int c_prev = cq + C0 + (par ^ 1) * CS, c_cur = cq + C0 + par * CS, h_cur = (cq >> 1) + H0 + par * HS;
+    const int g_cur = G0 + par * GS + (lane_v & 15) * GP + (lane_v >> 4) * 8 + w * (XQ * 32);
+    // The A fragments of the h tile (4 row tiles x 13 k-slabs) are read XAD ahead of their MFMAs through a rotating set of registers, across row-tile
+    // boundaries: written as read -> MFMA -> MFMA the compiler kept that order and every k-slab waited out an LDS round trip (13 per row tile).
+    uint4 ab[XAD];
+    auto rd = [&](int idx) __attribute__((always_inline)) {
+#ifndef XABL_NO_AREAD
+      return *reinterpret_cast<const uint4*>(smem + a_off + (idx / XNSH) * 16 * pitch + (idx % XNSH) * 64);
+#else
+      return make_uint4(a_off, idx, 0, 0);
+#endif
+    };
+#pragma unroll
+    for (int i = 0; i < XAD; ++i) ab[i] = rd(i);
     auto mm = [&](int rt, f32x4_t (&acc)[XQ]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < XQ; ++q) {
@@ -436,10 +582,11 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         unpack2<TI>(accp[rt][q].y, a2, a3);
         acc[q] = f32x4_t{a0, a1, a2, a3};
       }
-      const char* ar = htile + (rt * 16 + lc) * pitch + 16 * lr;
 #pragma unroll
       for (int ks = 0; ks < XNSH; ++ks) {
-        const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
+        const int idx = rt * XNSH + ks;
+        const uint4 a = ab[idx % XAD];
+        if (idx + XAD < 4 * XNSH) ab[idx % XAD] = rd(idx + XAD);
 #pragma unroll
 #ifndef XABL_NO_REC
         for (int q = 0; q < XQ; ++q) acc[q] = mfma16<TI>(breg[q][ks], a, acc[q]);
@@ -449,26 +596,25 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       }
     };
     auto cell = [&](int rt, const f32x4_t (&acc)[XQ]) __attribute__((always_inline)) {
-      const int row = rt * 16 + rl;
 #pragma unroll
       for (int q = 0; q < XQ; ++q) {
-        const float cprev = *reinterpret_cast<const float*>(cstage0 + (par ^ 1) * (XROWS * XUW * 4) + row * (XUW * 4) + lu[q] * 4);
+        const float cprev = *reinterpret_cast<const float*>(smem + c_prev + rt * 16 * XUW * 4 + q * 16);
 #ifndef XABL_NO_CELL
         const float iv = sigmoidf_(acc[q][0]), fv = sigmoidf_(acc[q][1]), gv = tanhf_(acc[q][2]), ov = sigmoidf_(acc[q][3]);
-        const float cv = fv * cprev + iv * gv;
-        const float hv = ov * tanhf_(cv);
+        const float cv = __builtin_fmaf(fv, cprev, __fmul_rn(iv, gv));    // (spelled out: left to the compiler, the eight instances of a step and the
+        const float hv = ov * tanhf_(cv);                                  //  template variants did not all contract the same way - 1 ulp apart)
 #else
         const float iv = acc[q][0], fv = acc[q][1], gv = acc[q][2], ov = acc[q][3];
         const float cv = fv * cprev + iv * gv;
         const float hv = ov * cv;
 #endif
-        reinterpret_cast<TI*>(hstage0 + par * (XROWS * XUW * 2))[row * XUW + lu[q]] = from_f32<TI>(hv);
-        *reinterpret_cast<float*>(cstage0 + par * (XROWS * XUW * 4) + row * (XUW * 4) + lu[q] * 4) = cv;      // (also the next step's c_{t-1})
+        *reinterpret_cast<TI*>(smem + h_cur + rt * 16 * XUW * 2 + q * 8) = from_f32<TI>(hv);
+        *reinterpret_cast<float*>(smem + c_cur + rt * 16 * XUW * 4 + q * 16) = cv;      // (also the next step's c_{t-1})
         if constexpr (SAVE) {
           uint2 gs;
           gs.x = pack2<bf16_t>(iv, fv);
           gs.y = pack2<bf16_t>(gv, ov);
-          *reinterpret_cast<uint2*>(xg + row * GP + lu[q] * 8) = gs;
+          *reinterpret_cast<uint2*>(smem + g_cur + rt * 16 * GP + q * 32) = gs;
         }
       }
     };
@@ -476,8 +622,15 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       f32x4_t accA[XQ], accB[XQ];
       mm(0, accA);
       mm(1, accB);
+#ifndef XNO_KEEP
+      asm volatile("" :: "v"(keep0.x), "v"(keep0.y), "v"(keep0.z), "v"(keep0.w));      // (see deferred_hout)
+      if constexpr (H2) asm volatile("" :: "v"(keep1.x), "v"(keep1.y), "v"(keep1.z), "v"(keep1.w));
+#endif
+#if XFETCH_POS == 1
+      if (step + 1 < p.seq_len) fetch4(par ^ 1, (dir ? t - 1 : t + 1) * stride_i, lane_v);
+#endif
       cell(0, accA);
-#ifndef XNO_SCHED
+#ifdef XSCHED
 #pragma unroll
       for (int i = 0; i < XNSH; ++i) {      // one A fragment read + its two MFMAs per ~10 vector instructions of the cell update
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -487,7 +640,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #endif
       mm(2, accA);
       cell(1, accB);
-#ifndef XNO_SCHED
+#ifdef XSCHED
 #pragma unroll
       for (int i = 0; i < XNSH; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
@@ -497,7 +650,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #endif
       mm(3, accB);
       cell(2, accA);
-#ifndef XNO_SCHED
+#ifdef XSCHED
 #pragma unroll
       for (int i = 0; i < XNSH; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
@@ -507,28 +660,36 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #endif
       cell(3, accB);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         // (its rows of x_{t+1} have landed)
+    XST(5);
     __builtin_amdgcn_s_barrier();                                         // barrier 2
+    XST(6);
     // ---- 3. h_t of this workgroup's units -> exchange buffer (tagged)
-    {
+    if (step + 1 < p.seq_len) {
       const unsigned tagv = tag_cur ? TAGM : 0u;
-      const int ucol = j * XUW + st_cc * 8;
-      if (st_row < nrows && ucol < H && step + 1 < p.seq_len) {
-        const uint4 v = *reinterpret_cast<const uint4*>(hstage0 + par * (XROWS * XUW * 2) + tid * 16);
-        const uint4 vt = make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv);
-        const unsigned xo = pcur * plane_bytes + cl_bytes + (unsigned)(st_row * Hp * 2 + ucol * 2);
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + H0 + par * HS + tv);
+      const uint4 vt = make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv);
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef XABL_NO_XSTORE
-        if (local) xstore_plain(rs, xo, vt);
-        else xstore_sc1(rs, xo, vt);
+      // its place in the exchange plane: row tid / 7 at the tile's pitch, piece tid % 7 of this workgroup's seventh: 16 tid + (pitch - 112) (tid / 7) + 112 j,
+      // tid / 7 = tid * 9363 >> 16 for tid < 448; rows past the last whole pass of a cluster with fewer than 64 sequences are not published
+      const int srow = ((tv >> 4) * 9363) >> 16;
+      unsigned xo = (unsigned)(tv + (pitch - XUW * 2) * srow + j * (XUW * 2));
+      if (!full) xo = srow < nact * HRP ? xo : COOB;
+      if (local) __builtin_amdgcn_raw_buffer_store_b128(u32x4{vt.x, vt.y, vt.z, vt.w}, rs, (int)xo, (int)(pcur * plane_bytes + cl_bytes), 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(u32x4{vt.x, vt.y, vt.z, vt.w}, rs, (int)xo, (int)(pcur * plane_bytes + cl_bytes), 16);
 #else
-        asm volatile("" :: "v"(vt.x), "v"(xo));
+      asm volatile("" :: "v"(vt.x));
 #endif
-      }
     }
+    XST(7);
     toff_d = toff;
     have_d = true;
   }
-  if (have_d) deferred_hout((p.seq_len + 1) & 1);
+  {
+    uint4 k0, k1;
+    if (have_d) deferred_hout((p.seq_len + 1) & 1, w * 1024 + lane * 16, k0, k1);
+  }
 }
 
 // quad-ordered fragments of W_ih: block (dir, quad, slab) = 64 lanes x 16 B; lane (lr, lc): unit quad * 4 + (lc >> 2), gate lc & 3, k = slab * 32 + 8 lr + j
@@ -561,7 +722,7 @@ __global__ void __launch_bounds__(256) lstm_pack_quads_x_multi_kernel(const Pack
 
 constexpr size_t clusterx_lds() {
   return (size_t)XROWS * lds_frag_pitch(XNSH * 64) + 2 * (size_t)XROWS * XUW * 2 + 2 * (size_t)XROWS * lds_frag_pitch(XNSX * 64) + 2 * (size_t)XROWS * XUW * 4 +
-         (size_t)XUW * 16 + XROWS * sizeof(int) + 32 * sizeof(int);
+         (size_t)XUW * 16 + XROWS * sizeof(int) + 32 * sizeof(int) + (XROWS + XTHR) * sizeof(unsigned);
 }
 
 }  // namespace urse
@@ -585,8 +746,24 @@ extern "C" int urse_lstm_pack_quads_x_multi(const void* table, int n_lstm, int N
   return URSE_OK;
 }
 
+#ifdef XSTAMP
+extern "C" int urse_diag_clusterx_stamps(void* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_xstamps), sizeof(unsigned long long) * 512 * 16);
+}
+#endif
+
 extern "C" int urse_lstm_clusterx_supported(int N, int Np, int H, int Hp) {
   return (N > 0 && N <= 224 && Np == 224 && Hp == 416 && H > 0 && H % XUW == 0 && H <= 416) ? 1 : 0;      // (whole workgroups of 56 units: H = 392)
+}
+
+extern "C" int urse_lstm_clusterx_hx_elems(int H, int Hp, int n_seq, int reserved_cus, int64_t* elems) {
+  URSE_CHECK_ARG(elems, "urse_lstm_clusterx_hx_elems: null pointer");
+  URSE_CHECK_ARG(urse_lstm_clusterx_supported(196, 224, H, Hp), "urse_lstm_clusterx_hx_elems: unsupported H=%d Hp=%d", H, Hp);
+  int64_t plan[6];
+  const int rc = urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus, plan);
+  if (rc) return rc;
+  *elems = (int64_t)2 * 2 * plan[1] * plan[3] * (lds_frag_pitch(XNSH * 64) / 2);
+  return URSE_OK;
 }
 
 extern "C" int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* wihq, const float* bias, const void* whhq, void* gates, int64_t ldg,
@@ -618,7 +795,8 @@ extern "C" int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* w
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
   p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2]; p.rows_pad = (int)plan[3];
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(hx, 0, sizeof(bf16_t) * plan[4], st);            // the exchange planes start with every tag bit clear
+  // the exchange planes start with every tag bit clear; their rows sit at the LDS tile's pitch: plan[4] * 27 / 26 elements (urse_lstm_clusterx_hx_elems)
+  (void)hipMemsetAsync(hx, 0, (size_t)2 * 2 * plan[1] * plan[3] * lds_frag_pitch(XNSH * 64), st);
   p.xws = nullptr;
   if (xcd_aware && plan[5] >= 9) {
     (void)hipMemsetAsync(counters, 0, sizeof(unsigned) * plan[5], st);

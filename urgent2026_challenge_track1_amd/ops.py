@@ -590,9 +590,14 @@ def lstm_fwd_clusterx(xn, wihq, whhq, bias, N, H, Hp, n_seq, seq_len, inner, out
     xcd_aware = CLUSTER_XCD_AWARE if xcd_aware is None else xcd_aware
     plan = lstm_cluster_plan(H, Hp, n_seq)
     M, Np, dev = xn.shape[0], xn.shape[1], xn.device
-    key = (dev, H, Hp, n_seq, plan[4], plan[5])
+    import ctypes
+    n_hx_ = ctypes.c_int64()
+    if _lib.load().urse_lstm_clusterx_hx_elems(H, Hp, n_seq, reserved_cus(), ctypes.byref(n_hx_)) != 0:
+        raise RuntimeError("lstm_fwd_clusterx: no cluster plan for H=%d n_seq=%d" % (H, n_seq))
+    n_hx = int(n_hx_.value)
+    key = ("x", dev, H, Hp, n_seq, n_hx, plan[5])
     if key not in _cluster_ws:
-        _cluster_ws[key] = (torch.zeros(plan[4], device=dev, dtype=torch.bfloat16),
+        _cluster_ws[key] = (torch.zeros(n_hx, device=dev, dtype=torch.bfloat16),
                             torch.zeros(plan[5], device=dev, dtype=torch.int32),
                             kernel_error_flag(dev))
     hx, cnt, err = _cluster_ws[key]
