@@ -7,8 +7,8 @@ names = sys.argv[1:] or ["base", "NO_DMA_WAIT", "NO_DMA", "NO_MFMA", "NO_CELL", 
                          "NO_STORE+NO_CLOAD+NO_DMA_WAIT", "NO_MFMA+CHEAP_CELL", "NO_MFMA+CHEAP_CELL+NO_DMA", "NO_STORE+NO_CLOAD+NO_CELL", "NO_STORE+NO_CLOAD+NO_CELL+NO_DMA_WAIT"]
 libs = {}
 for name in names:
-    fl = [] if name == "base" else ["-DRXABL_" + x for x in name.split("+")]
-    so = "/tmp/ablrwx_%s.so" % name.replace("+", "_")
+    fl = [] if name == "base" else [("-D" + x[2:]) if x.startswith("D:") else ("-DRXABL_" + x) for x in name.split("+")]      # D:MACRO=v passes a plain define
+    so = "/tmp/ablrwx_%s.so" % name.replace("+", "_").replace(":", "_").replace("=", "_")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-w", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", *fl,
                            os.path.join(CS, "lstm_rwx.hip"), os.path.join(CS, "api.hip"), "-o", so])
     libs[name] = ctypes.CDLL(so)

@@ -32,6 +32,12 @@ constexpr int RX_SF = 10;         // fragments per stage
 constexpr int RX_UB = 5;          // blocks per unrolled body
 constexpr int RX_D = 4;           // fragments read ahead
 constexpr int RX_PD = 3;          // blocks c_{t-1} / the bias are fetched ahead
+#ifndef RX_LOADER
+#define RX_LOADER 0                // 0: the loader wave feeds the ring by LDS-DMA, 1: through registers (global load + LDS store) - measured equal, see below
+#endif
+#ifndef RX_NIF
+#define RX_NIF 4                   // stages (10 fragments each) the loader keeps in flight in registers
+#endif
 
 struct RxArgs {
   const void* xn; long ldx;       // [M, ldx] bf16 normalised input, K padding zero
@@ -77,6 +83,49 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
     // loader: stage s -> slot s % 6.  Invariant at barrier A_k: stages <= k + 1 have landed, the compute waves are done with stages <= k - 1;
     // after A_k stage k + 5 goes into the slot stage k - 1 has left; four stages (40 KB) in flight.
     const char* wsrc = reinterpret_cast<const char*>(p.wx) + (long)dir * NBLK * NF * 1024 + lane * 16;
+#if RX_LOADER == 1
+    // Round 5 experiment (off): the ring fed through REGISTERS - global_load_dwordx4 into a rotating set of 4 x 10 fragments, ds_write_b128 into the slot
+    // just in time.  The question it answered: one wave issues 2,000 LDS-DMA instructions per step, and the in-kernel stamps of lstm_clusterx.hip priced
+    // such an instruction at 100 - 300 cycles of its wave - 2,000 x 100 cycles IS the 87 us step; is this launch bound by the loader's issue rate rather
+    // than by the CU's memory path (round 4's reading)?  No: a load + an LDS store cost the wave ~25 cycles per fragment and the launch takes the same
+    // 3.07 ms (profiles/r05_abl_rwx_loader_v2.log).  Bytes through the CU, whoever issues them.
+    // Invariant at barrier A_k as before: stages <= k + 1 are in LDS, the compute waves are done with stages <= k - 1.
+    static_assert(SPS % RX_NIF == 0 && RX_NIF * SF <= 60 && RX_NIF + 2 <= RX_NSLOT + 2, "loader geometry");
+    static_assert(RX_NIF == 4 && SF == 10, "the loader's rotation below is written out for four stages of ten fragments in flight");
+    // (named registers, written out: as an array indexed through unrolled loops inside lambdas the buffer stayed in scratch memory)
+#define RX_F10(M, s) M(s, 0) M(s, 1) M(s, 2) M(s, 3) M(s, 4) M(s, 5) M(s, 6) M(s, 7) M(s, 8) M(s, 9)
+#define RX_DECL(s, f) uint4 fb_##s##_##f;
+    RX_F10(RX_DECL, 0) RX_F10(RX_DECL, 1) RX_F10(RX_DECL, 2) RX_F10(RX_DECL, 3)
+    int sm = 0;                                                          // stage (within the step) the next loads fetch
+    const char* src_;
+    char* dst_;
+#define RX_LD1(s, f) fb_##s##_##f = *reinterpret_cast<const uint4*>(src_ + (f) * 1024);
+#define RX_ST1(s, f) *reinterpret_cast<uint4*>(dst_ + (f) * 1024) = fb_##s##_##f;
+#define RX_GLOAD(s) do { src_ = wsrc + (long)sm * SLOTB; RX_F10(RX_LD1, s) sm = (sm + 1 == SPS) ? 0 : sm + 1; } while (0)
+#define RX_LWRITE(s, slot_) do { dst_ = ring + (slot_) * SLOTB + lane * 16; RX_F10(RX_ST1, s) } while (0)
+    // prologue: stages 0, 1 into LDS; stages 2 .. 5 in flight
+    RX_GLOAD(0); RX_GLOAD(1);
+    RX_LWRITE(0, 0); RX_LWRITE(1, 1);
+    RX_GLOAD(0); RX_GLOAD(1); RX_GLOAD(2); RX_GLOAD(3);                 // fb_i <- stage 2 + i
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // A_0
+    int slot = 2;                                                        // slot of stage k + 2
+    // k: stage k + 2 sits in fb_s -> its slot (the compiler waits for exactly these ten loads: the younger ones stay in flight), then stage k + 2 + NIF is
+    // requested into the same registers (past the end: wraps into the weights again, harmless)
+#define RX_TURN(s) do { RX_LWRITE(s, slot); slot = (slot + 1 == RX_NSLOT) ? 0 : slot + 1; RX_GLOAD(s); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+                        __builtin_amdgcn_s_barrier(); } while (0)
+    for (long k0 = 0; k0 < total_stages; k0 += RX_NIF) {
+      RX_TURN(0); RX_TURN(1); RX_TURN(2); RX_TURN(3);
+    }
+#undef RX_TURN
+#undef RX_GLOAD
+#undef RX_LWRITE
+#undef RX_LD1
+#undef RX_ST1
+#undef RX_DECL
+#undef RX_F10
+    return;
+#else
     const unsigned ring0 = (unsigned)(size_t)ring;
     int sm = 0, slot = 0;
     auto issue = [&]() {
@@ -102,6 +151,7 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
+#endif
   }
   if (w >= ntl) return;
 
