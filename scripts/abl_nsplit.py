@@ -6,8 +6,8 @@ CS = os.path.join(ROOT, "urgent2026_challenge_track1_amd", "csrc")
 names = sys.argv[1:] or ["base", "PUB=0", "PUB=2", "NO_STORE", "NO_POLL", "NO_LOAD"]
 libs = {}
 for name in names:
-    fl = [] if name == "base" else [("-DNS_" + x) if x.startswith("PUB") else ("-DNSABL_" + x) for x in name.split("+")]
-    so = "/tmp/ablns_%s.so" % name.replace("+", "_").replace("=", "")
+    fl = [] if name == "base" else [("-DNS_" + x) if x.startswith("PUB") else ("-D" + x[2:]) if x.startswith("D:") else ("-DNSABL_" + x) for x in name.split("+") if x != "WIDE"]
+    so = "/tmp/ablns_%s.so" % name.replace("+", "_").replace("=", "").replace(":", "")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-w", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", *fl,
                            os.path.join(CS, "lstm_nsplit.hip"), os.path.join(CS, "api.hip"), "-o", so])
     libs[name] = ctypes.CDLL(so)
@@ -29,6 +29,7 @@ def bwd(lib, g):
     assert rc == 0, rc
 g = g0.clone()
 for name, lib in libs.items():
+    os.environ["URSE_NSPLIT_WIDE"] = "1" if "WIDE" in name.split("+") else "0"      # the seven-wave / two-tile kernel of the same entry point
     bwd(lib, g); torch.cuda.synchronize()
     ts = []
     for _ in range(3):

@@ -544,6 +544,18 @@ def test_nsplit_bptt_matches_streaming_kernel(lib, B, T, K):
         else:
             os.environ["URSE_NSPLIT_HELPERS"] = prev
     assert torch.equal(g2.view(torch.int16), g3.view(torch.int16))
+    # the seven-wave form with two unit tiles per wave (round 5 experiment, opt-in): the same sums in the same order, bit for bit
+    prevw = os.environ.get("URSE_NSPLIT_WIDE")
+    try:
+        os.environ["URSE_NSPLIT_WIDE"] = "1"
+        g4 = gx.clone()
+        _, err4 = ops.lstm_bwd_nsplit(dh, g4, c, pk["whhT"], H, **sm)
+    finally:
+        if prevw is None:
+            os.environ.pop("URSE_NSPLIT_WIDE", None)
+        else:
+            os.environ["URSE_NSPLIT_WIDE"] = prevw
+    assert int(err4.item()) == 0 and torch.equal(g4.view(torch.int16), g3.view(torch.int16))
 
 
 def test_multi_pack_equals_per_lstm_pack(lib):

@@ -47,7 +47,7 @@ struct NsplitArgs {
   unsigned* err;
   long inner, outer, stride;
   int n_seq, seq_len, npairs;
-  unsigned g_bytes;
+  unsigned g_bytes, c_bytes, d_bytes;
 };
 
 // HELP > 0: that many HELPER waves beside the 13 compute waves.  The helpers own the hand-off: after the barrier that completes the own
@@ -395,6 +395,277 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Round 5 EXPERIMENT (opt-in, URSE_NSPLIT_WIDE=1): the same pair protocol with SEVEN waves of TWO unit tiles each (8-wave budget: 256 registers).
+// The question: three kernels looked like one law - the 16-wave streaming BPTT keeps 16 x 13 KB of weight fragments in flight and streams at 110 GB/s,
+// the 13-wave kernel above 13 x 9 KB at 62 GB/s, the three-member kernel (lstm_nsplit3.hip) 9 x 11 KB at 52 GB/s: bytes in flight / 1.9 us every time -
+// is the weight stream bound by what the waves can keep IN FLIGHT, i.e. by registers?  This form keeps two streams of NSW_KB fragments per wave in
+// flight (7 x 2 x 14 KB = 196 KB), reads one A fragment from LDS for both tiles, takes the cell-phase inputs through 32-bit buffer offsets and moves
+// 16-byte pieces with a fixed row per thread.  ANSWER: no.  Bit-identical gate gradients, 5.77 ms against 5.08 per launch; 7, 10 or 14 fragments
+// in flight per tile take the same time (profiles/r05_abl_nsplit_wide_v1.log); with everything but the weight stream switched off the step is
+// 9.4 us = 640 KB at 68 GB/s - the rate at which ONE CU reads its L2, whatever is in flight.  The N-split is bound by bytes through the CU.
+constexpr int NSW_W = 7;            // waves per workgroup
+constexpr int NSW_THR = NSW_W * 64;
+#ifndef NSW_KB
+#define NSW_KB 14                   // weight fragments in flight per wave AND tile
+#endif
+
+template <int H>
+__global__ void __launch_bounds__(NSW_THR) lstm_bwd_nsplitw_kernel(NsplitArgs p) {
+  constexpr int NUT = (H + 15) / 16, G4 = 4 * H, NSLAB = G4 * 2 / 64, UT0 = (NUT + 1) / 2;     // 25 tiles, 49 slabs, member 0 owns 13 tiles
+  static_assert(UT0 <= 2 * NSW_W, "two unit tiles per wave");
+  constexpr int PITCH = lds_frag_pitch(G4 * 2);
+  constexpr int TPR = NSW_THR / 32;                                    // 14 threads per row move the row's 16-byte pieces
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                                   // [32][PITCH] gate gradients of the step, all units (MFMA A operand)
+  unsigned* lsync = reinterpret_cast<unsigned*>(smem + 32 * PITCH);    // [0] waves whose stores are complete (monotonic), [1] dead flag, [2] same XCD
+  int* rowtab = reinterpret_cast<int*>(lsync + 4);
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lin = blockIdx.x, m = (lin >> 3) & 1, P = (lin >> 4) * 8 + (lin & 7);
+  const int dir = P & 1, pair = P >> 1;
+  if (pair >= p.npairs) return;
+  const int ut_lo = m ? UT0 : 0, ut_hi = m ? NUT : UT0;                 // owned unit tiles
+  const int ut0 = ut_lo + 2 * w;                                        // this wave's tiles: ut0, ut0 + 1
+  const int ntile = ut0 + 1 < ut_hi ? 2 : (ut0 < ut_hi ? 1 : 0);
+  const int ob0 = ut_lo * 128, ob1 = (ut_hi * 128 < G4 * 2) ? ut_hi * 128 : G4 * 2;
+  const int ks_own0 = 2 * ut_lo, ks_own1 = (2 * ut_hi < NSLAB) ? 2 * ut_hi : NSLAB;
+  int ucol[2];
+  bool uval[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int u = (ut0 + tt) * 16 + lc;
+    uval[tt] = tt < ntile && u < H;
+    ucol[tt] = uval[tt] ? u : H - 1;
+  }
+  if (tid < 3) lsync[tid] = 0u;
+  const int s0 = pair * 32;
+  const int ldg_i = (int)p.ldg, ldd_i = (int)p.ldd, ldc_i = 2 * H, stride_i = (int)p.stride;
+  const int gcol_i = dir * G4, hcol_i = dir * H, prev_i = dir ? stride_i : -stride_i;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c), 0, (int)p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dh), 0, (int)p.d_bytes, 0x00020000);
+  unsigned rowq[2][4];                                                  // row of (sequence, t = 0) of the lane's rows in the C layout (clamped beyond n_seq)
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int seq = s0 + rt * 16 + lr * 4 + r;
+      if (seq >= p.n_seq) seq = p.n_seq - 1;
+      rowq[rt][r] = (unsigned)((seq / p.inner) * p.outer + (seq % p.inner));
+    }
+  const unsigned ldg2 = (unsigned)ldg_i * 2u, ldc4 = (unsigned)ldc_i * 4u, ldd2 = (unsigned)ldd_i * 2u;      // (< 2^24, as the rows: checked by the host)
+  const char* whhT0 = reinterpret_cast<const char*>(p.whhT) + ((long)dir * NUT * NSLAB + (long)(ntile > 0 ? ut0 : ut_lo) * NSLAB) * 1024 + lane * 16;
+  const char* whhT1 = whhT0 + (ntile > 1 ? (long)NSLAB * 1024 : 0);
+  unsigned* my_flag = p.flags + ((dir * p.npairs + pair) * 2 + m);
+  unsigned* partner_flag = p.flags + ((dir * p.npairs + pair) * 2 + (m ^ 1));
+  if (tid < 32) {
+    const int seq = s0 + tid;
+    rowtab[tid] = seq < p.n_seq ? (int)((seq / p.inner) * p.outer + (seq % p.inner)) : -1;
+  }
+  for (int i = tid; i < 32 * PITCH / 16; i += NSW_THR) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
+
+  float dcs[2][2][4], dhr[2][2][4], ccur[2][2][4];
+  {
+    const int toff0 = (dir ? 0 : p.seq_len - 1) * stride_i;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dcs[tt][rt][r] = 0.f;
+          dhr[tt][rt][r] = 0.f;
+          ccur[tt][rt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)(__umul24(rowq[rt][r], ldc4) + (unsigned)(hcol_i + ucol[tt]) * 4u), toff0 * ldc_i * 4, 0));
+        }
+  }
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 7u;      // HW_REG_XCC_ID
+    unsigned* xw = p.flags + 2 * 2 * p.npairs + ((dir * p.npairs + pair) * 2);
+    __hip_atomic_store(xw + m, xcc | 0x100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned v = 0u, spins = 0;
+    while ((v = __hip_atomic_load(xw + (m ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) { atomicExch(p.err, 1u); break; }
+    }
+    lsync[2] = (v == (xcc | 0x100u)) ? 1u : 0u;
+  }
+  __syncthreads();
+  const bool local = lsync[2] != 0u;
+  bool dead = false;
+  // the thread's row of the tile for the 16-byte pieces it moves (own half out, the partner's half in): row tid / 14, pieces tid % 14 + 14 j
+  const int mv_row = tid / TPR, mv_c0 = tid - mv_row * TPR;
+  const int mv_grow = rowtab[mv_row];
+  const unsigned mv_lds = (unsigned)(mv_row * PITCH + mv_c0 * 16);
+  const unsigned mv_glb = mv_grow >= 0 ? (unsigned)(((long)mv_grow * ldg_i + gcol_i) * 2 + mv_c0 * 16) : 0xFFFFF000u;      // (a row past n_seq: loads return zeros, stores are dropped)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int MAXP = (UT0 * 128 / 16 + TPR - 1) / TPR;                // 8 rounds of 14 pieces cover the wider half (104 pieces)
+  const int pb0 = m ? 0 : UT0 * 128, pb1 = m ? UT0 * 128 : G4 * 2;      // the partner's bytes of a row
+
+  for (int step = 0; step < p.seq_len; ++step) {
+    const int t = dir ? step : (p.seq_len - 1 - step);
+    const int toff = t * stride_i;
+    const bool first_ = dir ? (t == p.seq_len - 1) : (t == 0);          // first step of the forward recurrence: c_{-1} = 0
+    const bool last = step + 1 == p.seq_len;
+    // (the row registers are made opaque per step: visible as loop invariants, the offsets derived from them are hoisted out of the time loop and spilled)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) asm volatile("" : "+v"(rowq[rt][0]), "+v"(rowq[rt][1]), "+v"(rowq[rt][2]), "+v"(rowq[rt][3]));
+    // ---- 1. gate gradients of the owned units -> LDS tile (own columns)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      if (tt < ntile) {
+        const unsigned gbase = (unsigned)(gcol_i + ucol[tt] * 4) * 2u, cbase = (unsigned)(hcol_i + ucol[tt]) * 4u, dbase = (unsigned)(hcol_i + ucol[tt]) * 2u;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          uint2 gpre[4];
+          float cpre[4];
+          bf16_t dhpre[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#ifdef NSABL_NO_LOAD
+            gpre[r] = make_uint2(rowq[rt][r], 0x3f003f00u); cpre[r] = (float)(toff & 3); dhpre[r] = (bf16_t)(0x3c00 + (toff & 7));
+#else
+            const u32x2 gv2 = __builtin_amdgcn_raw_buffer_load_b64(rs_g, (int)(__umul24(rowq[rt][r], ldg2) + gbase), toff * ldg_i * 2, 0);
+            gpre[r] = make_uint2(gv2[0], gv2[1]);
+            cpre[r] = first_ ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)(__umul24(rowq[rt][r], ldc4) + cbase), (toff + prev_i) * ldc_i * 4, 0));
+            dhpre[r] = (bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_d, (int)(__umul24(rowq[rt][r], ldd2) + dbase), toff * ldd_i * 2, 0);
+#endif
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float iv = __uint_as_float(gpre[r].x << 16), fv = __uint_as_float(gpre[r].x & 0xffff0000u);
+            const float gv = __uint_as_float(gpre[r].y << 16), ov = __uint_as_float(gpre[r].y & 0xffff0000u);
+            const float dht = bf16_to_f32(dhpre[r]) + dhr[tt][rt][r];
+            const float tc = tanhf_(ccur[tt][rt][r]);
+            const float dct = dcs[tt][rt][r] + dht * ov * (1.f - tc * tc);
+            const float d0 = dct * gv * iv * (1.f - iv), d1 = dct * cpre[r] * fv * (1.f - fv);
+            const float d2 = dct * iv * (1.f - gv * gv), d3 = dht * tc * ov * (1.f - ov);
+            dcs[tt][rt][r] = dct * fv;
+            ccur[tt][rt][r] = cpre[r];                                   // c_{t-1} is the next processed step's c_t
+            if (uval[tt]) {
+              uint2 pk;
+              pk.x = (unsigned)f32_to_bf16(d0) | ((unsigned)f32_to_bf16(d1) << 16);
+              pk.y = (unsigned)f32_to_bf16(d2) | ((unsigned)f32_to_bf16(d3) << 16);
+              *reinterpret_cast<uint2*>(tile + (rt * 16 + lr * 4 + r) * PITCH + ((ut0 + tt) * 16 + lc) * 8) = pk;     // (columns past 4H stay zero)
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                        // the own half of the tile is complete
+    // the own half of the tile -> the gates output, 16 bytes per lane along the rows
+    const unsigned step_off = (unsigned)((long)toff * ldg_i * 2);
+#ifndef NSABL_NO_STORE
+#pragma unroll
+    for (int jj = 0; jj < MAXP; ++jj) {
+      const int cb = ob0 + (mv_c0 + TPR * jj) * 16;
+      if (cb < ob1) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + mv_lds + ob0 + TPR * 16 * jj);
+        if (local) __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_g, (int)(mv_glb + (unsigned)(ob0 + TPR * 16 * jj)), (int)step_off, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_g, (int)(mv_glb + (unsigned)(ob0 + TPR * 16 * jj)), (int)step_off, 16);
+      }
+    }
+#endif
+    if (last) break;
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) acc[tt][rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const char* ar = tile + lc * PITCH + 16 * lr;
+    // k-slabs [k0, k1) of this wave's unit tiles against the tile in LDS: NSW_KB fragments of EACH tile in flight; `publish`: behind the second batch of
+    // fragment loads wait for this wave's stores (older in the in-order vmcnt queue) and count the wave in
+    auto product = [&](int k0, int k1, bool publish) {
+#pragma unroll 1
+      for (int kb = k0; kb < k1; kb += NSW_KB) {
+        uint4 b0[NSW_KB], b1[NSW_KB];
+#pragma unroll
+        for (int i = 0; i < NSW_KB; ++i) {
+          const int ks = (kb + i < k1) ? kb + i : k1 - 1;
+          b0[i] = *reinterpret_cast<const uint4*>(whhT0 + (long)ks * 1024);
+          b1[i] = *reinterpret_cast<const uint4*>(whhT1 + (long)ks * 1024);
+        }
+        if (publish && (kb == k0 + NSW_KB || (kb == k0 && k0 + NSW_KB >= k1))) {
+          asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NSW_KB) : "memory");
+          if (lane == 0) {
+            const unsigned n = __hip_atomic_fetch_add(&lsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+            if (n == (unsigned)NSW_W * (unsigned)(step + 1))             // every wave of this member has waited for its stores
+              __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+#ifndef NSABL_NO_MM
+#pragma unroll
+        for (int i = 0; i < NSW_KB; ++i) {
+          if (kb + i < k1) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+              const uint4 a = *reinterpret_cast<const uint4*>(ar + rt * 16 * PITCH + (kb + i) * 64);
+              acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b0[i]), acc[0][rt], 0, 0, 0);
+              acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b1[i]), acc[1][rt], 0, 0, 0);
+            }
+          }
+        }
+#else
+        acc[0][0][0] += __uint_as_float(b0[0].x ^ b1[0].x);
+#endif
+      }
+    };
+    static_assert(2 * NSW_KB <= 63, "counted vmcnt");
+    // ---- 2. the own K range (in LDS already); the hand-off to the partner travels meanwhile
+    if (ntile > 0) {
+      product(ks_own0, ks_own1, true);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const unsigned n = __hip_atomic_fetch_add(&lsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+        if (n == (unsigned)NSW_W * (unsigned)(step + 1)) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // ---- 3. the partner's half: wait for its flag, copy its columns of the 32 rows from the gates output into the tile
+    if (w == 0 && lane == 0) {
+      unsigned spins = 0;
+#ifndef NSABL_NO_POLL
+      while (!dead && __hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(step + 1)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 22)) { dead = true; atomicExch(p.err, 1u); lsync[1] = 1u; }
+      }
+#endif
+    }
+    __syncthreads();
+#ifndef NSABL_NO_COPY
+    {
+      u32x4 v[MAXP];
+#pragma unroll
+      for (int jj = 0; jj < MAXP; ++jj) {
+        const int cb = pb0 + (mv_c0 + TPR * jj) * 16;
+        v[jj] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)(cb < pb1 ? mv_glb + (unsigned)(pb0 + TPR * 16 * jj) : 0xFFFFF000u), (int)step_off, 16);      // sc1: L1-bypassing
+      }
+#pragma unroll
+      for (int jj = 0; jj < MAXP; ++jj) {
+        const int cb = pb0 + (mv_c0 + TPR * jj) * 16;
+        if (cb < pb1) *reinterpret_cast<uint4*>(tile + mv_lds + pb0 + TPR * 16 * jj) = make_uint4(v[jj][0], v[jj][1], v[jj][2], v[jj][3]);
+      }
+    }
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- 4. the other K range
+    if (ntile > 0) {
+      if (m) product(0, ks_own0, false);
+      else product(ks_own1, NSLAB, false);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dhr[tt][rt][r] = acc[tt][rt][r];
+    }
+  }
+}
+
 }  // namespace urse
 
 using namespace urse;
@@ -431,20 +702,26 @@ extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, in
   NsplitArgs p;
   p.dh = dh; p.ldd = ldd; p.gates = gates; p.ldg = ldg; p.c = c; p.whhT = whhT; p.flags = (unsigned*)flags; p.err = (unsigned*)err_flag;
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len; p.npairs = (int)plan[0];
-  p.g_bytes = (unsigned)(rows * ldg * 2);
+  p.g_bytes = (unsigned)(rows * ldg * 2); p.c_bytes = (unsigned)(rows * 2L * H * 4); p.d_bytes = (unsigned)(rows * ldd * 2);
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(flags, 0, sizeof(unsigned) * plan[2], st);
   const size_t lds = (size_t)32 * lds_frag_pitch(4 * 392 * 2) + 16 + 32 * sizeof(int);
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 0>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 3>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplitw_kernel<392>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   note_launch(URSE_KV_LSTM_BWD_NSPLIT);
   // A/B switch.  The helper-wave form (3) is 0.07 ms faster alone and SLOWER in the step beside the second queue's GEMMs: same-box A/B in both
   // orders, 140.83 / 139.49 ms per step with helpers against 139.10 / 138.94 without (profiles/r05_ab_nsplit_helpers_v1.log): the 13-wave form ships.
   const int helpers = getenv("URSE_NSPLIT_HELPERS") ? atoi(getenv("URSE_NSPLIT_HELPERS")) : 0;
-  if (helpers > 0) hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 3>), dim3((unsigned)plan[1]), dim3((NSW + 3) * 64), lds, st, p);
+  // URSE_NSPLIT_WIDE: the seven-wave form with two unit tiles per wave (twice the weight fragments in flight)
+  const int wide = getenv("URSE_NSPLIT_WIDE") ? atoi(getenv("URSE_NSPLIT_WIDE")) : 0;
+  const bool wide_ok = wide && rows < (1L << 24) && ldg * 2 < (1L << 24) && ldd * 2 < (1L << 24) && rows * 2L * H * 4 < 0xFFFFF000L && rows * ldd * 2 < 0xFFFFF000L;
+  if (wide_ok) hipLaunchKernelGGL((lstm_bwd_nsplitw_kernel<392>), dim3((unsigned)plan[1]), dim3(NSW_THR), lds, st, p);
+  else if (helpers > 0) hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 3>), dim3((unsigned)plan[1]), dim3((NSW + 3) * 64), lds, st, p);
   else hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 0>), dim3((unsigned)plan[1]), dim3(NSTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_nsplit_bwd");
   return URSE_OK;
