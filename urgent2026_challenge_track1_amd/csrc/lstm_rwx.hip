@@ -90,12 +90,18 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
     // than by the CU's memory path (round 4's reading)?  No: a load + an LDS store cost the wave ~25 cycles per fragment and the launch takes the same
     // 3.07 ms (profiles/r05_abl_rwx_loader_v2.log).  Bytes through the CU, whoever issues them.
     // Invariant at barrier A_k as before: stages <= k + 1 are in LDS, the compute waves are done with stages <= k - 1.
-    static_assert(SPS % RX_NIF == 0 && RX_NIF * SF <= 60 && RX_NIF + 2 <= RX_NSLOT + 2, "loader geometry");
-    static_assert(RX_NIF == 4 && SF == 10, "the loader's rotation below is written out for four stages of ten fragments in flight");
+    static_assert(RX_NIF * SF <= 60, "counted waits");
+    static_assert(RX_NIF >= 4 && RX_NIF <= 6 && SF == 10, "the loader's rotation below is written out for four to six stages of ten fragments in flight");
     // (named registers, written out: as an array indexed through unrolled loops inside lambdas the buffer stayed in scratch memory)
 #define RX_F10(M, s) M(s, 0) M(s, 1) M(s, 2) M(s, 3) M(s, 4) M(s, 5) M(s, 6) M(s, 7) M(s, 8) M(s, 9)
 #define RX_DECL(s, f) uint4 fb_##s##_##f;
     RX_F10(RX_DECL, 0) RX_F10(RX_DECL, 1) RX_F10(RX_DECL, 2) RX_F10(RX_DECL, 3)
+#if RX_NIF > 4
+    RX_F10(RX_DECL, 4)
+#endif
+#if RX_NIF > 5
+    RX_F10(RX_DECL, 5)
+#endif
     int sm = 0;                                                          // stage (within the step) the next loads fetch
     const char* src_;
     char* dst_;
@@ -103,10 +109,16 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
 #define RX_ST1(s, f) *reinterpret_cast<uint4*>(dst_ + (f) * 1024) = fb_##s##_##f;
 #define RX_GLOAD(s) do { src_ = wsrc + (long)sm * SLOTB; RX_F10(RX_LD1, s) sm = (sm + 1 == SPS) ? 0 : sm + 1; } while (0)
 #define RX_LWRITE(s, slot_) do { dst_ = ring + (slot_) * SLOTB + lane * 16; RX_F10(RX_ST1, s) } while (0)
-    // prologue: stages 0, 1 into LDS; stages 2 .. 5 in flight
+    // prologue: stages 0, 1 into LDS; stages 2 .. 1 + NIF in flight
     RX_GLOAD(0); RX_GLOAD(1);
     RX_LWRITE(0, 0); RX_LWRITE(1, 1);
     RX_GLOAD(0); RX_GLOAD(1); RX_GLOAD(2); RX_GLOAD(3);                 // fb_i <- stage 2 + i
+#if RX_NIF > 4
+    RX_GLOAD(4);
+#endif
+#if RX_NIF > 5
+    RX_GLOAD(5);
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                       // A_0
     int slot = 2;                                                        // slot of stage k + 2
@@ -114,8 +126,25 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
     // requested into the same registers (past the end: wraps into the weights again, harmless)
 #define RX_TURN(s) do { RX_LWRITE(s, slot); slot = (slot + 1 == RX_NSLOT) ? 0 : slot + 1; RX_GLOAD(s); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                         __builtin_amdgcn_s_barrier(); } while (0)
-    for (long k0 = 0; k0 < total_stages; k0 += RX_NIF) {
+    long k0 = 0;
+    for (; k0 + RX_NIF <= total_stages; k0 += RX_NIF) {
       RX_TURN(0); RX_TURN(1); RX_TURN(2); RX_TURN(3);
+#if RX_NIF > 4
+      RX_TURN(4);
+#endif
+#if RX_NIF > 5
+      RX_TURN(5);
+#endif
+    }
+    {                                                                    // the remaining total_stages % NIF turns
+      const int left = (int)(total_stages - k0);
+      if (left > 0) RX_TURN(0);
+      if (left > 1) RX_TURN(1);
+      if (left > 2) RX_TURN(2);
+      if (left > 3) RX_TURN(3);
+#if RX_NIF > 5
+      if (left > 4) RX_TURN(4);
+#endif
     }
 #undef RX_TURN
 #undef RX_GLOAD
