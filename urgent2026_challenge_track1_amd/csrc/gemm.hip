@@ -947,6 +947,10 @@ __device__ __forceinline__ void glds16u(const char* gsrc, unsigned dst) {
 }
 #pragma clang diagnostic pop
 
+template <int DEPTH>      // stages in flight: 2 (two stages per barrier) or 3 (one barrier per stage).  A template, not a run-time switch: with both loops in one kernel
+                          // the register allocation of BOTH got worse (9 spilled registers where round 4's kernel had none) and the second queue's
+                          // weight gradients ran 16 % longer - 5.7 ms per train step that hid the round's other gains until a round-over-round A/B
+                          // on one box (profiles/r05_ab_round_v2.log)
 __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
   constexpr int BMX = 224, BNX = 320, NST = 4, STAGE = 36864, MT = 7, NT = 5;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
@@ -1131,7 +1135,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
   };
   // two stages per barrier on four slots: at the wait of iteration kt the stages kt, kt + 1 were issued a whole iteration ago; after
   // the barrier the slots of stages kt - 2, kt - 1 are free and take kt + 2, kt + 3, which have two stage times to land
-  if (p.pad_[0] == 3) {
+  if constexpr (DEPTH == 3) {
     // THREE stages (108 KB) in flight, one barrier per stage: at the top of iteration kt the stages kt .. kt + 2 are outstanding; the counted
     // wait leaves the two younger ones in flight (this wave's own DMAs: 5 per stage for waves 0-3, 4 for the others), the barrier makes stage kt
     // whole and retires the slot of stage kt - 1, which takes stage kt + 3.  (The two-stages-per-barrier form below drains to ZERO in flight every
@@ -2309,14 +2313,16 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
       p.rows_per_slice = rps;
       p.nt1 = 0;
       {
-        // A/B switch, read per call: 3 = three stages in flight and one barrier per stage, 2 = two stages per barrier with the queue drained.
-        // 1.14 -> 1.12 ms alone (profiles/r05_exp_tn224_depth_v1.log), -1.4 ms per train step same-box in both orders (141.11 / 140.99 against
-        // 139.90 / 139.38, profiles/r05_ab_tn224_depth_v1.log): beside a BPTT kernel the DMA queue that never drains is worth more than alone
+        // A/B switch, read per call: 2 = two stages per barrier with the queue drained (default), 3 = three stages in flight and one barrier per stage.
+        // Alone the deeper form is 2 % faster (profiles/r05_exp_tn224_depth_v1.log); in the train step it LOSES 2.1 ms, same box, both orders
+        // (130.38 / 130.73 against 132.91 / 132.47, profiles/r05_ab_tn224_depth_v3.log).  An earlier A/B had said the opposite - on a binary that held
+        // both loops in one kernel behind a run-time branch and spilled nine registers in either (see the template note at the kernel).
         const char* e = getenv("URSE_TN224_DEPTH");
-        p.pad_[0] = e ? atol(e) : 3;
+        p.pad_[0] = e ? atol(e) : 2;
       }
       note_launch(URSE_KV_TN_DUAL);
-      hipLaunchKernelGGL(gemm_tn_dual224_kernel, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+      if (p.pad_[0] == 3) hipLaunchKernelGGL(gemm_tn_dual224_kernel<3>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+      else hipLaunchKernelGGL(gemm_tn_dual224_kernel<2>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
       URSE_CHECK_LAUNCH("urse_gemm_tn_dual");
       return URSE_OK;
     }
