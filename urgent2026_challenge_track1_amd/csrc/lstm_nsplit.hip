@@ -714,8 +714,9 @@ extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, in
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   note_launch(URSE_KV_LSTM_BWD_NSPLIT);
-  // A/B switch.  The helper-wave form (3) is 0.07 ms faster alone and SLOWER in the step beside the second queue's GEMMs: same-box A/B in both
-  // orders, 140.83 / 139.49 ms per step with helpers against 139.10 / 138.94 without (profiles/r05_ab_nsplit_helpers_v1.log): the 13-wave form ships.
+  // A/B switch.  The helper-wave form (3) is 0.07 ms faster alone and no faster in the step beside the second queue's GEMMs: same-box A/B in both
+  // orders, 133.09 / 130.96 ms per step with helpers against 131.70 / 131.63 without (profiles/r05_ab_nsplit_helpers_v3.log; v1 of that log, 140.83 /
+  // 139.49 against 139.10 / 138.94, was taken while the weight-gradient GEMM spilled): the 13-wave form ships.
   const int helpers = getenv("URSE_NSPLIT_HELPERS") ? atoi(getenv("URSE_NSPLIT_HELPERS")) : 0;
   // URSE_NSPLIT_WIDE: the seven-wave form with two unit tiles per wave (twice the weight fragments in flight)
   const int wide = getenv("URSE_NSPLIT_WIDE") ? atoi(getenv("URSE_NSPLIT_WIDE")) : 0;
