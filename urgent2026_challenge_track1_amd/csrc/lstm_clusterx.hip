@@ -401,6 +401,18 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       keep1 = vb;
     }
   };
+  // The resident weight fragments are USED once here, in front of the time loop: the compiler's wait-count bookkeeping then knows their loads are done.
+  // Without this the loads of the last fragments count as outstanding at the loop's entry, the merge with the back edge keeps that state for every
+  // iteration, and the first MFMAs that read those registers carry `s_waitcnt vmcnt(4) ... vmcnt(0)` - which, from the second step on, wait for the
+  // seven loads of the h GATHER issued just before: the projection ran BEHIND the gather's round trip instead of under it (found in the ISA after the
+  // stamps put 2,900 - 3,250 cycles on a projection whose MFMAs need 1,500).
+#pragma unroll
+  for (int q = 0; q < XQ; ++q) {
+#pragma unroll
+    for (int ks = 0; ks < XNSH; ++ks) asm volatile("" :: "v"(breg[q][ks].x), "v"(breg[q][ks].y), "v"(breg[q][ks].z), "v"(breg[q][ks].w));
+#pragma unroll
+    for (int ks = 0; ks < XNSP; ++ks) asm volatile("" :: "v"(wreg[q][ks].x), "v"(wreg[q][ks].y), "v"(wreg[q][ks].z), "v"(wreg[q][ks].w));
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                           // B0: x_0 is in tile 0 (every wave fetched its rows)
 
