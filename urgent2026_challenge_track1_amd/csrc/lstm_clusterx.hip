@@ -55,6 +55,9 @@ constexpr int XNSP = 6;            // k-slabs of W_ih the PROJECTION multiplies:
 #ifndef XAD
 #define XAD 3                      // A fragments of the h tile in flight ahead of their MFMAs
 #endif
+#ifndef XDW
+#define XDW 2                      // LDS-DMA instructions of x_{t+1} per working wave and step, the helper takes the other 18 (in the step: 14.70 ms of cluster forward per train step with 2, 14.84 with 3, 15.16 with 4, profiles/r05_ab_xdw_v1.log)
+#endif
 #ifndef XMIDPOLL
 #define XMIDPOLL 0x2               // behind which row tiles of the projection the wave looks at the gather (bit rt)
 #endif
@@ -213,8 +216,8 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
 
   // ---- x rows by LDS-DMA: one instruction brings TWO rows - lanes 0 .. 27 the 28 pieces of row 2 i, lanes 30 .. 57 those of row 2 i + 1 (the destination
-  // is lane-linear: lane 30 lands at byte 480 = the tile's pitch), the other lanes are masked off.  EVERY wave issues four of the 32 instructions of a
-  // step (rows 8 w .. 8 w + 7) right behind barrier 1: issued by the helper wave alone they took 9,000 cycles of a 15,700-cycle step (in-kernel stamps,
+  // is lane-linear: lane 30 lands at byte 480 = the tile's pitch), the other lanes are masked off.  EVERY wave issues some of the 32 instructions of a
+  // step (XDW per working wave, the rest the helper) right behind barrier 1: issued by the helper wave alone they took 9,000 cycles of a 15,700-cycle step (in-kernel stamps,
   // profiles/r05_abl_clusterx_v9_stamps.log: an LDS-DMA instruction costs its wave 100 - 300 cycles of issue) and the working waves waited 3,400 cycles
   // at barrier 2 for x_{t+1} to land.  The byte offsets of the 64 rows at t = 0 sit in an LDS table.
   const int ldx2 = (int)p.ldx * 2;
@@ -226,9 +229,14 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     const unsigned soff = (unsigned)(toff_ * ldx2);
     const bool xact = lane_ < 28 || (lane_ >= 30 && lane_ < 58);
     const unsigned xpiece = (unsigned)((lane_ < 30 ? lane_ : lane_ - 30) * 16);
+    // (XDW instructions per working wave, the other 32 - 7 XDW by the helper, which has the time: it reaches barrier 2 ~1,700 cycles before the working
+    //  waves when all eight take four)
+    constexpr int HDW = XROWS / 2 - XW * XDW;
+    static_assert(HDW >= 0, "DMA split");
 #pragma unroll
-    for (int i = 0; i < XROWS / 2 / (XW + 1); ++i) {
-      const int pr = w * (XROWS / 2 / (XW + 1)) + i;                       // row pair
+    for (int i = 0; i < (XDW > HDW ? XDW : HDW); ++i) {
+      if (i >= (w == XW ? HDW : XDW)) continue;
+      const int pr = (w == XW ? XW * XDW : w * XDW) + i;                   // row pair
       const unsigned vo = xrow[2 * pr + (lane_ < 30 ? 0 : 1)] + xpiece;
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds_g0 + (unsigned)(par * (XROWS * GP) + 2 * pr * GP));
 #ifndef XABL_NO_DMA      // timing diagnostics (wrong results): XABL_NO_DMA, XABL_NO_HSTORE, XABL_NO_PROJ, XABL_NO_REC, XABL_NO_AREAD (no A fragment reads), XABL_NO_CELL, XABL_NO_GATHER, XABL_NO_XSTORE, XABL_NO_HOUT
