@@ -50,7 +50,7 @@ constexpr int XNSP = 6;            // k-slabs of W_ih the PROJECTION multiplies:
 #define XFETCH_POS 0
 #endif
 #ifndef XHSLEEP
-#define XHSLEEP 24                 // s_sleep units the helper waits behind barrier 2 before its 44 stores (the publication of h_t goes first)
+#define XHSLEEP 48                 // s_sleep units (64 cycles) the helper waits behind barrier 2 before it reads and stores the step's gates and c_t: the publication of h_t and the gather go first (in the step: 14.9 ms of kernel per train step with 24, 14.3 with 48, 14.4 with 64, 14.9 with 80, 16.1 with 100; profiles/r05_ab_clusterx_params_v2.log)
 #endif
 #ifndef XAD
 #define XAD 3                      // A fragments of the h tile in flight ahead of their MFMAs
