@@ -37,6 +37,9 @@ constexpr int NSTHR = NSW * 64;
 #define NS_PUB 1                  // the batch of the own-range product in front of which the wave publishes (0 .. 2)
 #endif
 constexpr int NS_KB = 9;           // weight fragments in flight per wave (13 waves: 128-VGPR cap)
+#ifndef NS_RES
+#define NS_RES 4                  // weight fragments per wave that stay in LDS for the whole launch (the first slabs of the partner's K range): the 60 KB
+#endif                            // the tile leaves free take 8 % of the weight stream off the CU's L2 port
 
 struct NsplitArgs {
   const void* dh; long ldd;
@@ -110,6 +113,13 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
     rowtab[tid] = seq < p.n_seq ? (int)((seq / p.inner) * p.outer + (seq % p.inner)) : -1;
   }
   for (int i = tid; i < 32 * PITCH / 16; i += NTHR_ALL) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
+  // resident weight fragments: the first NS_RES k-slabs of the PARTNER's K range of this wave's unit tile, read from LDS every step
+  char* resw = smem + 32 * PITCH + 256 + (w < NSW ? w : 0) * (NS_RES * 1024) + lane * 16;
+  if (NS_RES > 0 && active) {
+    const int k0o = m ? 0 : ks_own1;
+#pragma unroll
+    for (int i = 0; i < NS_RES; ++i) *reinterpret_cast<uint4*>(resw + i * 1024) = *reinterpret_cast<const uint4*>(whhT + (long)(k0o + i) * 1024);
+  }
 
   float dcs[2][4], dhr[2][4], ccur[2][4];
   {
@@ -383,8 +393,22 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
     }
     // ---- 4. the other K range
     if (active) {
-      if (m) product(0, ks_own0, false);
-      else product(ks_own1, NSLAB, false);
+      // the first NS_RES k-slabs of the partner's range come from LDS (resident for the whole launch), the rest is streamed
+      const int k0o = m ? 0 : ks_own1, k1o = m ? ks_own0 : NSLAB;
+#if NS_RES > 0
+#ifndef NSABL_NO_MM
+#pragma unroll
+      for (int i = 0; i < NS_RES; ++i) {
+        const uint4 bw = *reinterpret_cast<const uint4*>(resw + i * 1024);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const uint4 a = *reinterpret_cast<const uint4*>(ar + rt * 16 * PITCH + (k0o + i) * 64);
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bw), acc[rt], 0, 0, 0);
+        }
+      }
+#endif
+#endif
+      product(k0o + NS_RES, k1o, false);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -705,7 +729,7 @@ extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, in
   p.g_bytes = (unsigned)(rows * ldg * 2); p.c_bytes = (unsigned)(rows * 2L * H * 4); p.d_bytes = (unsigned)(rows * ldd * 2);
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(flags, 0, sizeof(unsigned) * plan[2], st);
-  const size_t lds = (size_t)32 * lds_frag_pitch(4 * 392 * 2) + 16 + 32 * sizeof(int);
+  const size_t lds = (size_t)32 * lds_frag_pitch(4 * 392 * 2) + 256 + (size_t)NSW * NS_RES * 1024;      // tile, flags + row table, resident fragments
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 0>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 3>),
