@@ -36,3 +36,20 @@ for name, lib in libs.items():
         g.copy_(g0); torch.cuda.synchronize()
         t0 = time.perf_counter(); bwd(lib, g); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
     print("%-44s %.3f ms  (%.2f us per step)  err %d" % (name, min(ts), min(ts) * 1e3 / T, int(err.item())), flush=True)
+
+# in-kernel cycle stamps (variants built with D:NSSTAMP=<workgroup>): median cycles between the stamps of waves 0 and 6
+import numpy as np
+for name, lib in libs.items():
+    if "NSSTAMP" not in name:
+        continue
+    os.environ["URSE_NSPLIT_WIDE"] = "0"
+    g.copy_(g0); bwd(lib, g); torch.cuda.synchronize()
+    buf = np.zeros(512 * 16, dtype=np.uint64)
+    assert lib.urse_diag_nsplit_stamps(buf.ctypes.data_as(P)) == 0
+    sa = buf.reshape(512, 2, 8)[5:T - 3].astype(np.int64); nx = buf.reshape(512, 2, 8)[6:T - 2].astype(np.int64)
+    lab = ["top", "cell phase done", "barrier 1 passed", "own half stored (issued)", "own product done", "partner flag + sync", "copy + barrier", "other product done"]
+    for wv, wn in ((0, "wave 0"), (1, "wave 6")):
+        print(name, wn, "median shader-clock cycles:")
+        for i in range(1, 8):
+            print("   %-26s -> %-26s %8.0f" % (lab[i - 1], lab[i], np.median(sa[:, wv, i] - sa[:, wv, i - 1])))
+        print("   step %8.0f" % np.median(nx[:, wv, 0] - sa[:, wv, 0]))

@@ -39,6 +39,12 @@ def case(B, T, K, time_runs=0):
     os.environ["URSE_NSPLIT_WIDE"] = "0"
     print("  seven waves x two tiles: err flag %d, == 13-wave form bit for bit: %s, max |d| vs streaming / scale %.2e" % (
         int(err5.item()), torch.equal(g5, g3), (g1.float() - g5.float()).abs().max().item() / scale), flush=True)
+    os.environ["URSE_NSPLIT_TOUCH"] = "1"
+    g6 = gx.clone()
+    _, err6 = ops.lstm_bwd_nsplit(dh, g6, c, pk["whhT"], H, **sm)
+    torch.cuda.synchronize()
+    os.environ["URSE_NSPLIT_TOUCH"] = "0"
+    print("  with the touch wave: err flag %d, == 13-wave form bit for bit: %s" % (int(err6.item()), torch.equal(g6, g3)), flush=True)
     ops.NSPLIT_MEMBERS = 3
     g4 = gx.clone()
     _, err3 = ops.lstm_bwd_nsplit(dh, g4, c, pk["whhT"], H, **sm)
@@ -47,13 +53,17 @@ def case(B, T, K, time_runs=0):
     d3 = (g1.float() - g4.float()).abs()
     print("  three members x 48 rows: err flag %d, max |d| / scale %.2e, mean %.2e, vs two members max %.2e, finite %s" % (
         int(err3.item()), d3.max().item() / scale, d3.mean().item() / scale, (g4.float() - g3.float()).abs().max().item() / scale, bool(torch.isfinite(g4.float()).all())), flush=True)
-    for name in (("stream16", "nsplit0", "wide", "members3") * 2 if time_runs else ()):
+    for name in (("stream16", "nsplit0", "touch", "wide", "members3") * 2 if time_runs else ()):
         ts = []
         for _ in range(time_runs):
             g2.copy_(gx); torch.cuda.synchronize()
             t0 = time.perf_counter()
             if name == "stream16":
                 ops.lstm_bwd(dh, g2, c, pk["whhT"], H, rows16=1, **sm)
+            elif name == "touch":
+                os.environ["URSE_NSPLIT_HELPERS"] = "0"; os.environ["URSE_NSPLIT_TOUCH"] = "1"
+                ops.lstm_bwd_nsplit(dh, g2, c, pk["whhT"], H, **sm)
+                os.environ["URSE_NSPLIT_TOUCH"] = "0"
             elif name == "wide":
                 os.environ["URSE_NSPLIT_HELPERS"] = "0"; os.environ["URSE_NSPLIT_WIDE"] = "1"
                 ops.lstm_bwd_nsplit(dh, g2, c, pk["whhT"], H, **sm)

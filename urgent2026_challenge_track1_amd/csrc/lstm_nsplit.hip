@@ -58,9 +58,23 @@ struct NsplitArgs {
 // partner's half into the tile - all of it WHILE the compute waves multiply the own K range, which then starts on a vmcnt queue with no
 // store in it.  The ablation of the helper-less form (profiles/r04_abl_nsplit_v4.log) priced the own-half stores at 1.2 us and the copy at
 // 1.2 us of a 12.7 us step, both in series with the products; 16 waves = 4 per SIMD, the 128-VGPR cap the 13-wave form already had.
-template <int H, int HELP>
-__global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(NsplitArgs p) {
-  constexpr int NTHR_ALL = (NSW + HELP) * 64;
+#ifdef NSSTAMP      // timing diagnostics: cycle stamps of workgroup NSSTAMP, waves 0 and 6: [step][2][8] (scripts/abl_nsplit.py)
+__device__ unsigned long long g_nsstamps[512 * 16];
+#define NST_(slot) do { if (stamp_on && step < 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_nsstamps[step * 16 + (w ? 8 : 0) + (slot)] = t_; } } while (0)
+#else
+#define NST_(slot) do { } while (0)
+#endif
+
+// TCH = 1: one more wave that does nothing but TOUCH the next step's input rows (one dword per 64-byte sector of the gates / c / dh segments the
+// member's cell phase will read), so that those loads find their lines in the XCD's L2: the in-kernel stamps (profiles/r05_abl_nsplit_stamps_v1.log) put
+// 6,000 of a step's 30,400 cycles on the cell phase - one exposed HBM round trip per step - and 2,500 - 4,400 more on the barrier behind it.  The loads
+// have to come from a wave of their own: in a compute wave's in-order vmcnt queue an HBM-latency load holds back every younger L2 load.
+// MEASURED (opt-in, URSE_NSPLIT_TOUCH=1; profiles/r05_exp_nsplit_touch_v1.log): bit-identical and 6.41 against 5.07 ms - the touches are 94 KB more per step
+// through the SAME CU's memory path (830 -> 924 KB), which is what the step is made of; a warm L2 does not pay for them.  (Round 3 had priced the same idea
+// for the streaming kernel at -4 % with the lines warmed for free.)
+template <int H, int HELP, int TCH = 0>
+__global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kernel(NsplitArgs p) {
+  constexpr int NTHR_ALL = (NSW + HELP + TCH) * 64;
   constexpr int NUT = (H + 15) / 16, G4 = 4 * H, NSLAB = G4 * 2 / 64, UT0 = (NUT + 1) / 2;     // 25 tiles, 49 slabs, member 0 owns 13 tiles
   constexpr int PITCH = lds_frag_pitch(G4 * 2);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -72,6 +86,9 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
   const int lin = blockIdx.x, m = (lin >> 3) & 1, P = (lin >> 4) * 8 + (lin & 7);
   const int dir = P & 1, pair = P >> 1;
   if (pair >= p.npairs) return;
+#ifdef NSSTAMP
+  const bool stamp_on = blockIdx.x == NSSTAMP && (w == 0 || w == 6);
+#endif
   const int ut_lo = m ? UT0 : 0, ut_hi = m ? NUT : UT0;                 // owned unit tiles
   const int ut = ut_lo + w;
   const bool active = ut < ut_hi;
@@ -229,11 +246,48 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
     }
   }
 
+  if constexpr (TCH > 0) {
+    if (w == NSW + HELP) {
+      // sectors of a row: the member's own bytes of the gates segment, of c and of dh
+      const int ob0t = m ? UT0 * 128 : 0, obnt = (m ? G4 * 2 : UT0 * 128) - ob0t;                     // gates: bytes [ob0t, ob0t + obnt)
+      const int ngs = (obnt + 63) / 64, ncs = (obnt / 2 + 63) / 64, nds = (obnt / 4 + 63) / 64, nsec = ngs + ncs + nds;      // (c: 4 B per unit, dh: 2 B: obnt / 8 units)
+      const char* gbase = reinterpret_cast<const char*>(p.gates) + (long)gcol_i * 2 + ob0t;
+      const char* cbase = reinterpret_cast<const char*>(p.c) + ((long)hcol_i + ob0t / 8) * 4;
+      const char* dbase = reinterpret_cast<const char*>(p.dh) + ((long)hcol_i + ob0t / 8) * 2;
+      unsigned sink = 0u;      // ONE register that every touch load writes, kept live to the end: the loads land whenever they land, and a register the compiler
+                               // believed free (an address, say) must not be what they land in
+      for (int step = 0; step < p.seq_len; ++step) {
+        __builtin_amdgcn_s_barrier();                                    // (the compute waves' barrier behind the cell phase)
+        if (step + 1 == p.seq_len) break;
+        if (step + 2 <= p.seq_len) {
+          const int tn = dir ? step + 1 : (p.seq_len - 2 - step);        // the NEXT step's time index
+          const long toffn = (long)tn * stride_i;
+          const bool firstn = dir ? (tn == p.seq_len - 1) : (tn == 0);     // (that step reads no c_{t-1})
+          for (int idx = lane; idx < 32 * nsec; idx += 64) {
+            const int row = idx / nsec, sec = idx - row * nsec;
+            const int grow = rowtab[row];
+            if (grow < 0) continue;
+            const char* a;
+            if (sec < ngs) a = gbase + (grow + toffn) * ldg_i * 2 + sec * 64;
+            else if (sec < ngs + ncs) { if (firstn) continue; a = cbase + (grow + toffn + prev_i) * (long)ldc_i * 4 + (sec - ngs) * 64; }
+            else a = dbase + (grow + toffn) * ldd_i * 2 + (sec - ngs - ncs) * 64;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a) : "memory");      // never waited for: the line is what is wanted
+          }
+        }
+        __builtin_amdgcn_s_barrier();                                    // (behind the poll: the compute waves' __syncthreads; raw here - a fence would wait for the touches)
+        __builtin_amdgcn_s_barrier();                                    // (behind the copy)
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" :: "v"(sink));
+      return;
+    }
+  }
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? step : (p.seq_len - 1 - step);
     const int toff = t * stride_i;
     const bool first_ = dir ? (t == p.seq_len - 1) : (t == 0);          // first step of the forward recurrence: c_{-1} = 0
     const bool last = step + 1 == p.seq_len;
+    NST_(0);
     // ---- 1. gate gradients of the owned units: LDS tile (own columns) + the gates output (write-through: the partner reads them)
     if (active) {
       uint2 gpre[2][4];
@@ -275,7 +329,9 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
     }
     // (raw barriers: __syncthreads() would also drain the write-through stores above - their latency belongs behind the weight stream)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NST_(1);
     __builtin_amdgcn_s_barrier();                                        // the own half of the tile is complete
+    NST_(2);
     // the own half of the tile -> the gates output, 16 bytes per lane along the rows (write-through).  (Stored from the cell phase,
     // 8 bytes per lane and unit, the same bytes cost 3 us per step: an sc1 store of 8 bytes per lane moves at a third of the 16-byte
     // form's rate per byte, MI355X_MICROARCH.md "stores of each flavour"; profiles/r04_abl_nsplit_v1.log.)
@@ -297,6 +353,7 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
         else __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_g, (int)off, 0, 16);           // sc1: write-through
       }
     }
+    NST_(3);
     if (last) break;                                                     // (the last step's gradients are stored; nothing waits for them)
     f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
     const char* ar = tile + lc * PITCH + 16 * lr;
@@ -360,6 +417,7 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
         if (n == (unsigned)NSW * (unsigned)(step + 1)) __hip_atomic_store(my_flag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    NST_(4);
     // ---- 3. the partner's half: wait for its flag, copy its columns of the 32 rows from the gates output into the tile
     if (w == 0) {
       unsigned spins = 0;
@@ -375,6 +433,7 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
       }
     }
     __syncthreads();
+    NST_(5);
 #ifdef NSABL_NO_COPY
     for (int idx = tid; idx < 0 * pcpr; idx += NSTHR) {
 #else
@@ -391,6 +450,7 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     }
+    NST_(6);
     // ---- 4. the other K range
     if (active) {
       // the first NS_RES k-slabs of the partner's range come from LDS (resident for the whole launch), the rest is streamed
@@ -414,6 +474,7 @@ __global__ void __launch_bounds__((NSW + HELP) * 64) lstm_bwd_nsplit_kernel(Nspl
 #pragma unroll
         for (int r = 0; r < 4; ++r) dhr[rt][r] = acc[rt][r];
     }
+    NST_(7);
     // no barrier here: the next step's cell phase rewrites the OWN columns, whose last readers (this step's own-range product) sit
     // behind two barriers; the next copy rewrites the PARTNER's columns behind the next step's two barriers
   }
@@ -696,6 +757,12 @@ using namespace urse;
 
 // -> plan {pairs per direction, workgroups, flag words}; < 0 (URSE_ERR_UNSUPPORTED) if the shape has no kernel or the pairs would not
 // be co-resident beside the reserved CUs
+#ifdef NSSTAMP
+extern "C" int urse_diag_nsplit_stamps(void* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nsstamps), sizeof(unsigned long long) * 512 * 16);
+}
+#endif
+
 extern "C" int urse_lstm_nsplit_plan(int H, int n_seq, int reserved_cus, int64_t* plan) {
   URSE_CHECK_ARG(plan && n_seq > 0 && reserved_cus >= 0, "urse_lstm_nsplit_plan: bad argument");
   if (H != 392) {
@@ -735,6 +802,8 @@ extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, in
                       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 3>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplitw_kernel<392>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 0, 1>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   note_launch(URSE_KV_LSTM_BWD_NSPLIT);
@@ -745,7 +814,9 @@ extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, in
   // URSE_NSPLIT_WIDE: the seven-wave form with two unit tiles per wave (twice the weight fragments in flight)
   const int wide = getenv("URSE_NSPLIT_WIDE") ? atoi(getenv("URSE_NSPLIT_WIDE")) : 0;
   const bool wide_ok = wide && rows < (1L << 24) && ldg * 2 < (1L << 24) && ldd * 2 < (1L << 24) && rows * 2L * H * 4 < 0xFFFFF000L && rows * ldd * 2 < 0xFFFFF000L;
+  const int touch = getenv("URSE_NSPLIT_TOUCH") ? atoi(getenv("URSE_NSPLIT_TOUCH")) : 0;
   if (wide_ok) hipLaunchKernelGGL((lstm_bwd_nsplitw_kernel<392>), dim3((unsigned)plan[1]), dim3(NSW_THR), lds, st, p);
+  else if (touch > 0 && helpers == 0) hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 0, 1>), dim3((unsigned)plan[1]), dim3(NSTHR + 64), lds, st, p);
   else if (helpers > 0) hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 3>), dim3((unsigned)plan[1]), dim3((NSW + 3) * 64), lds, st, p);
   else hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 0>), dim3((unsigned)plan[1]), dim3(NSTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_nsplit_bwd");
