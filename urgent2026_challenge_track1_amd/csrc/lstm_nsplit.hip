@@ -490,10 +490,16 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
 // 16-byte pieces with a fixed row per thread.  ANSWER: no.  Bit-identical gate gradients, 5.77 ms against 5.08 per launch; 7, 10 or 14 fragments
 // in flight per tile take the same time (profiles/r05_abl_nsplit_wide_v1.log); with everything but the weight stream switched off the step is
 // 9.4 us = 640 KB at 68 GB/s - the rate at which ONE CU reads its L2, whatever is in flight.  The N-split is bound by bytes through the CU.
+// Second question (the stamps of the 13-wave kernel put 30 % of a step on the exposed round trip of the input rows): with 256 registers the NEXT step's
+// inputs fit beside the weights - requested behind this step's last weight fragments (NSW_PFX; in front of them they would hold every younger load back in
+// the in-order vmcnt queue).  ANSWER: bit-identical, 5.93 ms - no gain: "behind the last fragments" is 300 cycles before the cell phase, not a step.
 constexpr int NSW_W = 7;            // waves per workgroup
 constexpr int NSW_THR = NSW_W * 64;
 #ifndef NSW_KB
-#define NSW_KB 14                   // weight fragments in flight per wave AND tile
+#define NSW_KB 5                    // weight fragments in flight per wave AND tile (7, 10, 14 measured equal; 5 leaves the registers the prefetched inputs need)
+#endif
+#ifndef NSW_PFX
+#define NSW_PFX 1                   // the next step's input rows requested a step ahead
 #endif
 
 template <int H>
@@ -589,6 +595,33 @@ __global__ void __launch_bounds__(NSW_THR) lstm_bwd_nsplitw_kernel(NsplitArgs p)
   constexpr int MAXP = (UT0 * 128 / 16 + TPR - 1) / TPR;                // 8 rounds of 14 pieces cover the wider half (104 pieces)
   const int pb0 = m ? 0 : UT0 * 128, pb1 = m ? UT0 * 128 : G4 * 2;      // the partner's bytes of a row
 
+  // the step's input rows (saved gate activations, c_{t-1}, dh) of the lane's 2 tiles x 2 x 4 rows: ALL requested at once (one round trip, not one per
+  // tile and row group), and with NSW_PFX a step ahead - behind the last weight fragments of the previous step, where they are the youngest entries of the
+  // in-order vmcnt queue and hold nothing back; the 13-wave kernel has no registers for this (124 of 128), this one has
+  uint2 gpre[2][2][4];
+  float cpre[2][2][4];
+  bf16_t dhpre[2][2][4];
+  auto load_inputs = [&](int toff_, bool first__) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const unsigned gbase = (unsigned)(gcol_i + ucol[tt] * 4) * 2u, cbase = (unsigned)(hcol_i + ucol[tt]) * 4u, dbase = (unsigned)(hcol_i + ucol[tt]) * 2u;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#ifdef NSABL_NO_LOAD
+          gpre[tt][rt][r] = make_uint2(rowq[rt][r], 0x3f003f00u); cpre[tt][rt][r] = (float)(toff_ & 3); dhpre[tt][rt][r] = (bf16_t)(0x3c00 + (toff_ & 7));
+#else
+          if (tt < ntile) {
+            const u32x2 gv2 = __builtin_amdgcn_raw_buffer_load_b64(rs_g, (int)(__umul24(rowq[rt][r], ldg2) + gbase), toff_ * ldg_i * 2, 0);
+            gpre[tt][rt][r] = make_uint2(gv2[0], gv2[1]);
+            cpre[tt][rt][r] = first__ ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)(__umul24(rowq[rt][r], ldc4) + cbase), (toff_ + prev_i) * ldc_i * 4, 0));
+            dhpre[tt][rt][r] = (bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_d, (int)(__umul24(rowq[rt][r], ldd2) + dbase), toff_ * ldd_i * 2, 0);
+          }
+#endif
+        }
+    }
+  };
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? step : (p.seq_len - 1 - step);
     const int toff = t * stride_i;
@@ -598,37 +631,29 @@ __global__ void __launch_bounds__(NSW_THR) lstm_bwd_nsplitw_kernel(NsplitArgs p)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) asm volatile("" : "+v"(rowq[rt][0]), "+v"(rowq[rt][1]), "+v"(rowq[rt][2]), "+v"(rowq[rt][3]));
     // ---- 1. gate gradients of the owned units -> LDS tile (own columns)
+#if NSW_PFX == 0
+    load_inputs(toff, first_);
+#else
+    if (step == 0) load_inputs(toff, first_);                            // (later steps: requested behind the last weight fragments of the previous step)
+#endif
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       if (tt < ntile) {
-        const unsigned gbase = (unsigned)(gcol_i + ucol[tt] * 4) * 2u, cbase = (unsigned)(hcol_i + ucol[tt]) * 4u, dbase = (unsigned)(hcol_i + ucol[tt]) * 2u;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          uint2 gpre[4];
-          float cpre[4];
-          bf16_t dhpre[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-#ifdef NSABL_NO_LOAD
-            gpre[r] = make_uint2(rowq[rt][r], 0x3f003f00u); cpre[r] = (float)(toff & 3); dhpre[r] = (bf16_t)(0x3c00 + (toff & 7));
-#else
-            const u32x2 gv2 = __builtin_amdgcn_raw_buffer_load_b64(rs_g, (int)(__umul24(rowq[rt][r], ldg2) + gbase), toff * ldg_i * 2, 0);
-            gpre[r] = make_uint2(gv2[0], gv2[1]);
-            cpre[r] = first_ ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)(__umul24(rowq[rt][r], ldc4) + cbase), (toff + prev_i) * ldc_i * 4, 0));
-            dhpre[r] = (bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_d, (int)(__umul24(rowq[rt][r], ldd2) + dbase), toff * ldd_i * 2, 0);
-#endif
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float iv = __uint_as_float(gpre[r].x << 16), fv = __uint_as_float(gpre[r].x & 0xffff0000u);
-            const float gv = __uint_as_float(gpre[r].y << 16), ov = __uint_as_float(gpre[r].y & 0xffff0000u);
-            const float dht = bf16_to_f32(dhpre[r]) + dhr[tt][rt][r];
+            const uint2 gp = gpre[tt][rt][r];
+            const float cp = cpre[tt][rt][r];
+            const float iv = __uint_as_float(gp.x << 16), fv = __uint_as_float(gp.x & 0xffff0000u);
+            const float gv = __uint_as_float(gp.y << 16), ov = __uint_as_float(gp.y & 0xffff0000u);
+            const float dht = bf16_to_f32(dhpre[tt][rt][r]) + dhr[tt][rt][r];
             const float tc = tanhf_(ccur[tt][rt][r]);
             const float dct = dcs[tt][rt][r] + dht * ov * (1.f - tc * tc);
-            const float d0 = dct * gv * iv * (1.f - iv), d1 = dct * cpre[r] * fv * (1.f - fv);
+            const float d0 = dct * gv * iv * (1.f - iv), d1 = dct * cp * fv * (1.f - fv);
             const float d2 = dct * iv * (1.f - gv * gv), d3 = dht * tc * ov * (1.f - ov);
             dcs[tt][rt][r] = dct * fv;
-            ccur[tt][rt][r] = cpre[r];                                   // c_{t-1} is the next processed step's c_t
+            ccur[tt][rt][r] = cp;                                        // c_{t-1} is the next processed step's c_t
             if (uval[tt]) {
               uint2 pk;
               pk.x = (unsigned)f32_to_bf16(d0) | ((unsigned)f32_to_bf16(d1) << 16);
@@ -739,8 +764,41 @@ __global__ void __launch_bounds__(NSW_THR) lstm_bwd_nsplitw_kernel(NsplitArgs p)
     __builtin_amdgcn_s_barrier();
     // ---- 4. the other K range
     if (ntile > 0) {
-      if (m) product(0, ks_own0, false);
-      else product(ks_own1, NSLAB, false);
+      const int k0o = m ? 0 : ks_own1, k1o = m ? ks_own0 : NSLAB;
+#if NSW_PFX > 0
+      // all batches but the last in the loop; the last one written out, so that the NEXT step's input rows can be requested between its weight loads and
+      // its MFMAs in straight-line code (inside the loop, behind a condition, the 64 input registers doubled through the loop's merges)
+      const int klast = k0o + ((k1o - k0o - 1) / NSW_KB) * NSW_KB;
+      product(k0o, klast, false);
+      {
+        uint4 b0[NSW_KB], b1[NSW_KB];
+#pragma unroll
+        for (int i = 0; i < NSW_KB; ++i) {
+          const int ks = (klast + i < k1o) ? klast + i : k1o - 1;
+          b0[i] = *reinterpret_cast<const uint4*>(whhT0 + (long)ks * 1024);
+          b1[i] = *reinterpret_cast<const uint4*>(whhT1 + (long)ks * 1024);
+        }
+        {
+          const int tn = dir ? step + 1 : (p.seq_len - 2 - step);
+          load_inputs(tn * stride_i, dir ? (tn == p.seq_len - 1) : (tn == 0));
+        }
+#ifndef NSABL_NO_MM
+#pragma unroll
+        for (int i = 0; i < NSW_KB; ++i) {
+          if (klast + i < k1o) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+              const uint4 a = *reinterpret_cast<const uint4*>(ar + rt * 16 * PITCH + (klast + i) * 64);
+              acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b0[i]), acc[0][rt], 0, 0, 0);
+              acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b1[i]), acc[1][rt], 0, 0, 0);
+            }
+          }
+        }
+#endif
+      }
+#else
+      product(k0o, k1o, false);
+#endif
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
