@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -532,6 +533,37 @@ def parity_block(model, batch, args, dev):
     return out
 
 
+def single_rank_rccl_leg(args, plain_ms, timeout=420):
+    """What ONE rank of a DDP job runs, timed on this box: the same step as ONE rank of an RCCL (`nccl`) process group -
+    weight broadcast, every gradient bucket all-reduced on the reducer's stream beside the backward, the N-split BPTT planned on the CUs
+    the all-reduce channels leave (ops.rccl_reserved_cus).  `reserved_step_ms` / the plain step = the per-rank cost of the reservation and the
+    bucket traffic, i.e. the ceiling of weak-scaling efficiency before a byte crosses xGMI.  Runs as a child process with a timeout."""
+    here = os.path.abspath(__file__)
+    cmd = [sys.executable, here, "--gpus", "1", "--single-rank-collectives", "--dist-backend", "nccl", "--steps", str(args.steps),
+           "--warmup", str(max(2, min(args.warmup, 3))), "--batch", str(args.batch), "--seconds", str(args.seconds),
+           "--channels", str(args.channels), "--layers", str(args.layers), "--dtype", args.dtype, "--pretouch-gib", "0",
+           "--no-flow", "--no-metrics", "--no-cpu-baseline", "--no-f32-mode"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"world_size": 1, "error": "single-rank RCCL leg failed (rc %d): %s" % (r.returncode, r.stderr[-300:])}
+        d = json.loads(lines[-1])
+        res = dict(d["config"]["dist"] or {})
+        res.update({"note": "this run itself used no process group; the figures below are the same step re-run as ONE rank of an RCCL group "
+                            "(child process, same box): every bucket all-reduced beside the backward, cooperative kernels planned on the CUs RCCL leaves",
+                    "reserved_step_ms": d["ms_per_step"], "plain_step_ms": plain_ms, "reserved_vs_plain": d["ms_per_step"] / plain_ms,
+                    "gradient_buckets": d.get("gradient_buckets"), "final_loss": d.get("final_loss"),
+                    "ranks_hold_identical_weights": d.get("ranks_hold_identical_weights"),
+                    "kernels_ms_per_step": d.get("kernels_ms_per_step")})
+        res.update(d.get("cooperative_kernels_beside_rccl") or {})
+        return res
+    except Exception as e:
+        return {"world_size": 1, "error": repr(e)[:300]}
+
+
 def f32_mode_step(args, dev, rank, steps=3, dtype="f32"):
     """ms per optimisation step of the SAME workload in the exact-f32 MFMA mode - the arithmetic that meets north_star's 1e-3 on
     every output (waveform, loss, gradients); the headline `value` is the bf16 mode's.  dtype "f16": the f16-forward mode (waveform and loss
@@ -601,6 +633,8 @@ def main():
                     help="with one rank: still create the process group on --dist-backend (nccl = RCCL) and send every gradient bucket, "
                          "the weight broadcast, the barriers and the checksum reductions through it - the N > 1 code path with a "
                          "communicator of size 1 (a 1-GPU box cannot hold two RCCL ranks)")
+    ap.add_argument("--no-dist-leg", action="store_true",
+                    help="skip the extra leg that re-runs the step as ONE rank of an RCCL process group (`config.dist.reserved_step_ms`)")
     ap.add_argument("--dynamic-mix", action="store_true",
                     help="config C3's feed: every step draws B recipes (DynamicMixingDataset) and simulates the batch on the GPU "
                          "inside the timed region")
@@ -712,9 +746,13 @@ def main():
         def feed():
             return next(staged)
 
+    dist_seen = {"reserved_cus_during_backward": 0, "refusals_before": ops.COOP_REFUSALS}
+
     def step():
         loss = model.training_step(feed() if feed is not None else batch)
         loss.backward()
+        if reducer is not None:      # set by the first bucket of this backward, cleared by finish() inside optimizer_step
+            dist_seen["reserved_cus_during_backward"] = max(dist_seen["reserved_cus_during_backward"], int(ops.COMM_RESERVED_CUS))
         model.optimizer_step(opt, reducer)
         return loss
 
@@ -820,8 +858,20 @@ def main():
     if reducer is not None:
         out["gradient_buckets"] = {"buckets": len(reducer.buckets), "collectives_issued": reducer.launched,
                                    "bucket_MB": [round((hi - lo) * 4 / 1e6, 1) for _, lo, hi in reducer.buckets]}
+    if reducer is not None:
+        # what a DDP rank's backward really dispatched beside the in-flight buckets: the cooperative kernels planned on
+        # the CUs RCCL leaves, every refusal counted, the device-side error flag of the bounded spins
+        out["cooperative_kernels_beside_rccl"] = {
+            "kernel_error_flag": int(ops.kernel_error_flag(dev).item()),
+            "reserved_cus_during_backward": dist_seen["reserved_cus_during_backward"],
+            "reserved_cus_after_step": int(ops.COMM_RESERVED_CUS),
+            "plans_refused": ops.COOP_REFUSALS - dist_seen["refusals_before"],
+            "tn_shadow_wgs": {"nsplit": ops.TN_SHADOW_WGS_NSPLIT, "band": ops.TN_SHADOW_WGS_BAND},
+            "launch_counts": {k: v for k, v in ops.launch_counts().items() if v and k.startswith("lstm_")}}
     if args.dynamic_mix:
         out["dynamic_mix"] = {"augmentations_drawn_but_not_applied": skipped}
+    if rank == 0 and world == 1 and not use_dist and not args.no_dist_leg and not args.dynamic_mix:
+        out["config"]["dist"] = single_rank_rccl_leg(args, out["ms_per_step"])
     want_f32 = args.dtype == "bf16" and not args.no_f32_mode and not args.dynamic_mix and not use_dist
     if rank == 0 and world == 1 and (want_f32 or not args.no_flow):
         del model, opt, batch, clean, noisy

@@ -6,7 +6,7 @@ var=$1; shift
 vals=("$@")
 run() {
   echo -n "$var=$1: "
-  env $var=$1 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-metrics --no-flow --no-f32-mode 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['kernels_ms_per_step'].items()})"
+  env $var=$1 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-metrics --no-flow --no-f32-mode --no-dist-leg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['kernels_ms_per_step'].items()})"
 }
 for v in "${vals[@]}"; do run $v; done
 for ((i=${#vals[@]}-1; i>=0; i--)); do run ${vals[$i]}; done

@@ -11,7 +11,7 @@ for f in $CS/*.hip; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/altlib/liburse_generic.so /tmp/altlib/*.o
-B="python $R/bench.py --no-flow --no-f32-mode --no-metrics --no-cpu-baseline --steps 8 --warmup 3"
+B="python $R/bench.py --no-flow --no-f32-mode --no-dist-leg --no-metrics --no-cpu-baseline --steps 8 --warmup 3"
 for i in 1 2 3; do
   echo "lean:    $($B | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"])')"
   echo "generic: $(URSE_LIB_PATH=/tmp/altlib/liburse_generic.so $B | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"])')"

@@ -8,7 +8,7 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp
 rocprofv3 -L > $O/counters.txt 2>&1
-B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-metrics --pretouch-gib 0"
+B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-metrics --no-dist-leg --pretouch-gib 0"
 run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- $B > $O/$name.log 2>&1; echo "$name rc=$?"; }
 run a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS
 run b SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU

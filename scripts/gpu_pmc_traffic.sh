@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp
-B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-metrics --no-flow --no-f32-mode --pretouch-gib 0"
+B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-metrics --no-flow --no-f32-mode --no-dist-leg --pretouch-gib 0"
 C="python3 $R/scripts/pmc_calibrate.py"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1; echo "fetch rc=$?"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B > $O/write.log 2>&1; echo "write rc=$?"

@@ -124,7 +124,7 @@ def test_single_rank_rccl_carries_the_gradient_buckets():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NCCL_MAX_NCHANNELS")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--pretouch-gib", "0",
-            "--batch", "2", "--seconds", "1", "--channels", "32", "--layers", "2", "--no-flow", "--no-metrics", "--no-cpu-baseline"]
+            "--batch", "2", "--seconds", "1", "--channels", "32", "--layers", "2", "--no-flow", "--no-metrics", "--no-cpu-baseline", "--no-dist-leg"]
     lines = []
     for extra in ([], ["--single-rank-collectives", "--dist-backend", "nccl"]):
         r = subprocess.run(base + extra, cwd=root, env=env, capture_output=True, text=True, timeout=900)
@@ -163,3 +163,44 @@ def test_cooperative_bptt_beside_rccl_buckets_leaves_the_collective_its_cus():
     lc = co["launch_counts"]
     assert lc.get("lstm_bwd_split", 0) + lc.get("lstm_bwd_stream16", 0) + lc.get("lstm_bwd_stream32", 0) > 0, co
     assert fb["final_loss"] == fb["final_loss"]
+
+
+@pytest.mark.gpu
+def test_full_size_c2_step_as_one_rccl_rank_runs_the_cooperative_kernels_beside_the_buckets():
+    """VERDICT r5 item 1 (reference `baseline_code/train_se.py:74-83`, Lightning DDP): what ONE rank of a DDP job runs, at the size
+    bench.py times (B 32 x 4 s @ 48 kHz, N 196, 6 layers) - the step as the only rank of an RCCL process group.  Every gradient bucket is
+    all-reduced on the reducer's stream beside the backward; from the first bucket to finish() `ops.COMM_RESERVED_CUS` = the RCCL
+    channel cap, and the N-split BPTT (H 392; pairs of workgroups that spin for each other) is planned on the CUs that leaves, next
+    to the second queue's weight-gradient workgroups.  The fused cluster forward runs outside that window (no bucket in flight).
+    Asserted: both cooperative kernels ran (or every missing one is explained by a counted refusal), the bounded spins never tripped
+    the device error flag, one collective per bucket and step, and the loss after the steps is the plain run's."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NCCL_MAX_NCHANNELS")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--pretouch-gib", "0",
+            "--no-flow", "--no-metrics", "--no-cpu-baseline", "--no-f32-mode", "--no-dist-leg"]
+    lines = []
+    for extra in ([], ["--single-rank-collectives", "--dist-backend", "nccl"]):
+        r = subprocess.run(base + extra, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+        lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    plain, rccl = lines
+    assert "B32 x 4 s" in rccl["config"]["workload"] and "N=196 L=6" in rccl["config"]["workload"]
+    assert rccl["config"]["dist"]["backend"] == "nccl" and rccl["config"]["dist"]["world_size"] == 1
+    co = rccl["cooperative_kernels_beside_rccl"]
+    lc = co["launch_counts"]
+    assert co["kernel_error_flag"] == 0, co
+    assert co["reserved_cus_during_backward"] == rccl["config"]["dist"]["comm_reserved_cus"] == 32 and co["reserved_cus_after_step"] == 0, co
+    # 6 layers x 2 directions are one launch each: 6 per step, 4 steps (1 warm-up + 3 timed) - or a counted refusal per missing launch
+    assert lc.get("lstm_fwd_clusterx", 0) == 24, co                      # forward: no bucket in flight, nothing reserved
+    assert lc.get("lstm_bwd_nsplit", 0) + co["plans_refused"] >= 24 and lc.get("lstm_bwd_nsplit", 0) > 0, co
+    gb = rccl["gradient_buckets"]
+    assert gb["buckets"] >= 4 and gb["collectives_issued"] == gb["buckets"] * 4, gb
+    assert rccl["ranks_hold_identical_weights"] is True
+    assert abs(rccl["final_loss"] - plain["final_loss"]) <= 1e-3 * abs(plain["final_loss"]), (rccl["final_loss"], plain["final_loss"])
+    os.makedirs(os.path.join(root, "gpurun_out", "parity"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "parity", "c2_one_rccl_rank.json"), "w") as f:
+        json.dump({"plain_ms_per_step": plain["ms_per_step"], "rccl_rank_ms_per_step": rccl["ms_per_step"],
+                   "plain_final_loss": plain["final_loss"], "rccl_final_loss": rccl["final_loss"],
+                   "gradient_buckets": gb, "cooperative_kernels_beside_rccl": co, "dist": rccl["config"]["dist"]}, f, indent=1)

@@ -422,134 +422,153 @@ __global__ void __launch_bounds__(URSE_STFT960_NFF_THREADS) stft960_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 960-point forward STFT, "slim" variant of stft960_kernel<0>: the same 32 x 30 register FFT per half-wave, but every trip through
-// LDS carries the real and the imaginary parts one after the other through ONE 992-float slice per half-wave (4 KB instead of 8),
-// and the half-wave also splits its own spectrum into the two real frames' spectra and stores them: no workgroup barrier after the
-// twiddle table is in place, 39 KB of LDS per workgroup -> four workgroups (16 waves) per CU instead of two (round 3: the kernel
-// was bound by two resident workgroups per CU running load -> DFT -> LDS -> DFT -> LDS -> store back to back).
-__global__ void __launch_bounds__(256, 3) stft960s_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
+// 960-point STFT at hop 480, PIPELINED (round 6; replaces the "slim" experiment of round 3, which lost in the step).
+// The arithmetic is stft960_kernel's (32 x 30 register FFT per half-wave, one complex transform = two real frames); what changes is
+// the order in which a CU touches memory.  stft960_kernel runs load -> DFT -> LDS -> DFT -> LDS -> barrier -> store once per workgroup,
+// two workgroups per CU started together: the CU's memory pipe idles while it computes and its VALUs idle while it loads (ablation,
+// round 3: loads + LDS passes alone 24.9 of 36.4 us).  Here
+//  (i)  a half-wave owns PP frame pairs one after the other and REQUESTS pair i + 1's samples before it transforms pair i (48 registers);
+//  (ii) the half-wave splits its own complex spectrum into the two real frames' spectra and stores them: the only workgroup barrier is
+//       the one behind the twiddle table, waves drift apart, one wave's loads and stores travel under another wave's DFTs;
+//  (iii) samples come through a buffer descriptor over the utterance: frame a = rows 0..31, frame b = rows 16..47 of ONE 48 x 30 matrix of
+//       consecutive samples (hop 480 = 16 rows), one voffset + immediates; only pairs that touch an end of the utterance take the
+//       per-element path (reflect padding, MODE 0; zero padding, MODE 1).
+// MODE as stft960_kernel.
+template <int MODE, int PP>
+__global__ void __launch_bounds__(256, 2) stft960p_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
                                                           float2* __restrict__ out, int L, int T, int hann,
                                                           const float2* __restrict__ tw_g) {
-  constexpr int N = 960, F = 481, NFF = 8, NTH = 256, HOP = 480;
-  constexpr int ZS = 992;                                   // 32 rows of pitch 31 (pass 1 -> 2), 960 natural-order bins (pass 2 -> split)
-  __shared__ float zf[NFF][ZS];
+  constexpr int N = 960, F = 481, NFF = 8, NTH = 256, HOP = 480, ZS = 1000, NR = 48;
+  constexpr int OOB = 0x7ffffff0;                           // an offset every descriptor here answers with 0 (loads) / drops (stores)
+  __shared__ float2 zbuf[NFF][ZS];
   __shared__ float2 tw[N];
-  const int tid = threadIdx.x, lane = tid & 63, l = lane & 31;
-  const int f = 2 * (tid >> 6) + (lane >> 5);
+  const int tid = threadIdx.x, l = tid & 31, f = tid >> 5;
   const int b = blockIdx.y;
-  const int ta = blockIdx.x * 2 * NFF + 2 * f;
-  for (int i = tid; i < N; i += NTH) tw[i] = tw_g[i];
-  const float* xb = x + (size_t)b * L;
-  const int tac = ta < T ? ta : T - 1, tbc = ta + 1 < T ? ta + 1 : T - 1;
-  const float ma = ta < T ? 1.f : 0.f, mb = ta + 1 < T ? 1.f : 0.f;
-  const int lq = l < 30 ? l : 29;
-  const int pa0 = tac * HOP - N / 2 + lq, pb0 = tbc * HOP - N / 2 + lq;
-  // samples straight into the FFT's registers: v[n1].x = frame a row n1, v[n1].y = frame b row n1; with hop 480 = 16 rows, frame
-  // b's rows 0..15 are frame a's rows 16..31 (copied below, before the window touches them)
-  float2 v[32];
-  const bool shared_rows = tbc == tac + 1;
+  const int lq = l < 30 ? l : 29;                           // lanes 30 / 31 run pass 1 on a copy of lane 29's column and write it to spare slots
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)b * L, 0, (int)((unsigned)L * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro =
+      __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * T * F, 0, (int)((unsigned)T * F * 8u), 0x00020000);
+  float s[NR];
+  auto request = [&](int p) {
+    const int q0 = 2 * p * HOP - N / 2;                     // position of the pair's first sample
+    // wave-uniform choice (a wave's two half-waves own neighbouring pairs): the per-element form is the identity on inside positions
+    if (__all(q0 >= 0 && q0 + NR * 30 <= L)) {
+      const int vo = (q0 + lq) * 4;
 #pragma unroll
-  for (int n1 = 0; n1 < 32; ++n1) {
-    int qa = pa0 + 30 * n1;
-    qa = qa < 0 ? -qa : qa;
-    qa = qa >= L ? 2 * (L - 1) - qa : qa;
-    v[n1].x = xb[qa];
-  }
+      for (int r = 0; r < NR; ++r) s[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo + r * 120, 0, 0));
+    } else {
 #pragma unroll
-  for (int n1 = 16; n1 < 32; ++n1) {
-    int qb = pb0 + 30 * n1;
-    qb = qb < 0 ? -qb : qb;
-    qb = qb >= L ? 2 * (L - 1) - qb : qb;
-    v[n1].y = xb[qb];
-  }
-  if (!shared_rows) {
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-      int qb = pb0 + 30 * n1;
-      qb = qb < 0 ? -qb : qb;
-      qb = qb >= L ? 2 * (L - 1) - qb : qb;
-      v[n1].y = xb[qb];
+      for (int r = 0; r < NR; ++r) {
+        int q = q0 + lq + 30 * r;
+        if (MODE == 0) {                                    // reflect; pairs past the last frame are masked below, their addresses only kept inside
+          q = q < 0 ? -q : q;
+          q = q >= L ? 2 * (L - 1) - q : q;
+        }
+        // outside [0, L): the descriptor's bounds check answers 0 (= zero padding, MODE 1)
+        s[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (q >= 0 && q < L) ? q * 4 : OOB, 0, 0));
+      }
     }
-  }
-  __syncthreads();                                          // twiddle table complete (the only workgroup barrier)
-  float* z = zf[f];
-  float2 u[30];
-  {
-    constexpr int BREV[32] = {0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30,
-                              1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31};
-    if (l < 30) {
+  };
+  const int p0 = blockIdx.x * (NFF * PP) + f;
+  request(p0);                                              // in flight under the twiddle table's load
+  for (int i = tid; i < N; i += NTH) tw[i] = tw_g[i];
+  int olen = T;
+  if (lens != nullptr) olen = lens[b] / HOP + 1;
+  __syncthreads();
+  float2* zf = zbuf[f];
+#pragma unroll 1
+  for (int it = 0; it < PP; ++it) {
+    const int p = p0 + it * NFF, ta = 2 * p;
+    const float ma = ta < T ? 1.f : 0.f, mb = ta + 1 < T ? 1.f : 0.f;
+    // the window and twiddle reads do not depend on the pair: left visible, the compiler hoists them out of the loop and spills;
+    // an opaque zero in the index keeps them where they are
+    int opq = 0;
+    asm volatile("" : "+v"(opq));
+    const float2* twl = tw + opq;
+    if (MODE == 1) {
+      // divide by the OLA envelope.  It belongs to the sample's padded position m = t * 480 + i (frames m / 480 with window sample r and
+      // m / 480 - 1 with r + 480), not to the frame: rows 16..31 are frame a's second half AND frame b's first - one division per row
 #pragma unroll
-      for (int n1 = 0; n1 < 16; ++n1) {
-        const float w = hann ? 0.5f - 0.5f * tw[30 * n1 + l].x : 1.0f;
-        const float rawb = shared_rows ? v[n1 + 16].x : v[n1].y;
-        v[n1] = make_float2(v[n1].x * w * ma, rawb * w * mb);
+      for (int r = 0; r < NR; ++r) {
+        const int rr = 30 * (r & 15) + lq, j = ta + (r >> 4);
+        const float w0 = hann ? 0.5f - 0.5f * twl[rr].x : 1.0f, w1 = hann ? 0.5f - 0.5f * twl[rr + 480].x : 1.0f;
+        const float e = (j < T ? w0 * w0 : 0.f) + (j >= 1 ? w1 * w1 : 0.f);
+        s[r] = s[r] != 0.f ? s[r] / e : 0.f;
       }
+    }
+    float2 v[32];
 #pragma unroll
-      for (int n1 = 16; n1 < 32; ++n1) {
-        const float w = hann ? 0.5f - 0.5f * tw[30 * n1 + l].x : 1.0f;
-        v[n1] = make_float2(v[n1].x * w * ma, v[n1].y * w * mb);
-      }
-      dft32_dif(v);
+    for (int n1 = 0; n1 < 32; ++n1) {
+      const float w = hann ? 0.5f - 0.5f * twl[30 * n1 + lq].x : 1.0f;
+      v[n1] = make_float2(s[n1] * w * ma, s[n1 + 16] * w * mb);
+    }
+    if (it + 1 < PP) request(p + NFF);                      // the next pair's samples travel under this pair's transforms
+    dft32_dif(v);
+    {
+      constexpr int BREV[32] = {0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30,
+                                1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31};
+      float2* zw = zf + (l < 30 ? l : 992 - 30 + l);        // row pitch 31; lanes 30 / 31: slots 992.. behind the 32 rows
+      const int zstep = l < 30 ? 31 : 2;
 #pragma unroll
       for (int k1 = 0; k1 < 32; ++k1) {
         const float2 a = v[BREV[k1]];
-        const float2 w = tw[l * k1];
-        v[BREV[k1]] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+        const float2 w = twl[lq * k1];                      // W_960^(n2 k1), n2 k1 <= 899
+        zw[(k1 & (l < 30 ? 31 : 3)) * zstep] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
       }
-#pragma unroll
-      for (int k1 = 0; k1 < 32; ++k1) z[k1 * 31 + l] = v[BREV[k1]].x;
     }
-    // a wave's LDS accesses execute in order, so the half-wave may read what its other lanes wrote without a workgroup barrier -
-    // but only if the wave IS converged between the two: lanes 30 / 31 skip the `if` above, and without a convergent operation
-    // here the compiler threads the two identical `l < 30` tests into one branch whose other side reads before this side wrote.
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();                        // LDS runs a wave's accesses in order; the wave must be converged between them (stft960_kernel)
+    {
+      float2 u[30];
 #pragma unroll
-    for (int n2 = 0; n2 < 30; ++n2) u[n2].x = z[l * 31 + n2];
-    __builtin_amdgcn_wave_barrier();
-    if (l < 30) {
+      for (int n2 = 0; n2 < 30; ++n2) u[n2] = zf[l * 31 + n2];
+      dft30_pfa(u);
+      __builtin_amdgcn_wave_barrier();                      // (all rows read before natural-order bins overwrite them)
 #pragma unroll
-      for (int k1 = 0; k1 < 32; ++k1) z[k1 * 31 + l] = v[BREV[k1]].y;
+      for (int k2 = 0; k2 < 30; ++k2) zf[l + 32 * k2] = u[k2];
     }
     __builtin_amdgcn_wave_barrier();
+    // split: frame a = (Z[k] + conj Z[N - k]) / 2, frame b = -i (Z[k] - conj Z[N - k]) / 2; 32 consecutive bins per instruction,
+    // through a descriptor over the utterance's spectra: frames past T / the lanes past bin 480 store to an offset it drops
+    const int oa = (ta < T) ? (ta * F + l) * 8 : OOB, ob = (ta + 1 < T) ? ((ta + 1) * F + l) * 8 : OOB;
+    const float keep_a = ta < olen ? 1.f : 0.f, keep_b = ta + 1 < olen ? 1.f : 0.f;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int n2 = 0; n2 < 30; ++n2) u[n2].y = z[l * 31 + n2];
-    __builtin_amdgcn_wave_barrier();
-  }
-  dft30_pfa(u);
-  // split: Xa[k] = (Z[k] + conj Z[N - k]) / 2, Xb[k] = -i (Z[k] - conj Z[N - k]) / 2, k = l + 32 j (16 bins per lane, 481 in all)
-  float zr[16], zcr[16];
-#pragma unroll
-  for (int k2 = 0; k2 < 30; ++k2) z[l + 32 * k2] = u[k2].x;
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int k = l + 32 * j;
-    const int kc = k == 0 ? 0 : N - k;
-    zr[j] = k < F ? z[k] : 0.f;
-    zcr[j] = k < F ? z[kc] : 0.f;
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int k2 = 0; k2 < 30; ++k2) z[l + 32 * k2] = u[k2].y;
-  __builtin_amdgcn_wave_barrier();
-  int olen = T;
-  if (lens != nullptr) olen = lens[b] / HOP + 1;
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  float2* oa = out + ((size_t)b * T + ta) * F;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int k = l + 32 * j;
-    if (k < F) {
-      const int kc = k == 0 ? 0 : N - k;
-      const float zi = z[k], zci = z[kc];
-      const f32x2_t va = {0.5f * (zr[j] + zcr[j]), 0.5f * (zi - zci)};
-      const f32x2_t vb = {0.5f * (zi + zci), -0.5f * (zr[j] - zcr[j])};
-      const f32x2_t zero = {0.f, 0.f};
-      if (ta < T) __builtin_nontemporal_store(ta < olen ? va : zero, reinterpret_cast<f32x2_t*>(oa + k));
-      if (ta + 1 < T) __builtin_nontemporal_store(ta + 1 < olen ? vb : zero, reinterpret_cast<f32x2_t*>(oa + F + k));
+    for (int j = 0; j < 16; ++j) {
+      const int k = j * 32 + l;
+      const int kk = (j < 15 || l == 0) ? k : 0;
+      const float2 zk = zf[kk];
+      const float2 zc = zf[kk == 0 ? 0 : N - kk];
+      float2 xa = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+      float2 xbv = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+      if (MODE == 1) {
+        const bool edge = kk == 0 || kk == N / 2;
+        const float sc = edge ? 1.0f / (float)N : 2.0f / (float)N;
+        xa.x *= sc; xbv.x *= sc;
+        xa.y = edge ? 0.f : xa.y * sc;
+        xbv.y = edge ? 0.f : xbv.y * sc;
+      }
+      const bool live = j < 15 || l == 0;
+      __builtin_amdgcn_raw_buffer_store_b64(f32x2_t{xa.x * keep_a, xa.y * keep_a}, ro, live ? oa + j * 256 : OOB, 0, 2);     // aux 2 = nt
+      __builtin_amdgcn_raw_buffer_store_b64(f32x2_t{xbv.x * keep_b, xbv.y * keep_b}, ro, live ? ob + j * 256 : OOB, 0, 2);
     }
+    __builtin_amdgcn_wave_barrier();                        // the split's reads sit in front of the next pair's pass-1 writes
   }
 }
+
+template <int MODE>
+static void launch_stft960p(const float* x, const int32_t* lens, float2* out, int B, int L, int T, int hann, const float2* tw, hipStream_t st) {
+  static const int pp = [] { const char* e = getenv("URSE_STFT960_PP"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }();
+  const int npairs = (T + 1) / 2;
+  const dim3 grid(ceil_div(npairs, 8 * pp), B);
+  switch (pp) {
+    case 1: hipLaunchKernelGGL((stft960p_kernel<MODE, 1>), grid, dim3(256), 0, st, x, lens, out, L, T, hann, tw); break;
+    case 3: hipLaunchKernelGGL((stft960p_kernel<MODE, 3>), grid, dim3(256), 0, st, x, lens, out, L, T, hann, tw); break;
+    case 4: hipLaunchKernelGGL((stft960p_kernel<MODE, 4>), grid, dim3(256), 0, st, x, lens, out, L, T, hann, tw); break;
+    default: hipLaunchKernelGGL((stft960p_kernel<MODE, 2>), grid, dim3(256), 0, st, x, lens, out, L, T, hann, tw); break;
+  }
+}
+
 
 // iSTFT: each workgroup owns C*hop consecutive positions of the padded OLA axis and transforms
 // the 2*NF frames that cover them (halo frames are recomputed, nothing is accumulated in HBM).
@@ -743,13 +762,10 @@ extern "C" int urse_stft_fwd(const float* wav, const int32_t* lens, float* spec,
   static const bool no960 = getenv("URSE_STFT_GENERIC") != nullptr;
   if (n_fft == 960 && !no960) {
     note_launch(URSE_KV_STFT960);
-    // stft960s_kernel: faster in a cold-cache microbenchmark (34.5 vs 37.9 us, scripts/exp_stft.py) but SLOWER where it counts, as the
-    // first kernel of a train step (48.6 vs 39-40 us between HIP events, 36.7 vs 33.8 us under rocprofv3, profiles/r03_bench_20steps_v2.json):
-    // opt-in (URSE_STFT960_SLIM=1)
-    static const bool slim = getenv("URSE_STFT960_SLIM") != nullptr && atoi(getenv("URSE_STFT960_SLIM")) != 0;
-    if (slim && hop == 480)
-      hipLaunchKernelGGL(stft960s_kernel, dim3(ceil_div(T, 16), B), dim3(256), 0, (hipStream_t)stream, wav, lens,
-                         reinterpret_cast<float2*>(spec), L, T, window == URSE_WIN_HANN ? 1 : 0, tb.tw);
+    // hop 480 (the C2 front end): the pipelined kernel; URSE_STFT960_PIPE=0 keeps the round-2 kernel (A/B switch); other hops: round-2 kernel
+    static const bool pipe = !(getenv("URSE_STFT960_PIPE") != nullptr && atoi(getenv("URSE_STFT960_PIPE")) == 0);
+    if (pipe && hop == 480 && (long)L * 4 < (1L << 31))
+      launch_stft960p<0>(wav, lens, reinterpret_cast<float2*>(spec), B, L, T, window == URSE_WIN_HANN ? 1 : 0, tb.tw, (hipStream_t)stream);
     else
     hipLaunchKernelGGL(stft960_kernel<0>, dim3(ceil_div(T, 2 * URSE_STFT960_NFF), B), dim3(URSE_STFT960_NFF_THREADS), 0, (hipStream_t)stream, wav, lens,
                        reinterpret_cast<float2*>(spec), L, T, hop, window == URSE_WIN_HANN ? 1 : 0, tb.tw);
@@ -776,6 +792,10 @@ extern "C" int urse_istft_bwd(const float* grad_wav, float* grad_spec, int B, in
   static const bool no960 = getenv("URSE_STFT_GENERIC") != nullptr;
   if (n_fft == 960 && hop == 480 && L_out > 480 && (window == URSE_WIN_RECT || window == URSE_WIN_HANN) && !no960) {
     note_launch(URSE_KV_STFT960);
+    static const bool pipe = !(getenv("URSE_STFT960_PIPE") != nullptr && atoi(getenv("URSE_STFT960_PIPE")) == 0);
+    if (pipe && (long)L_out * 4 < (1L << 31))
+      launch_stft960p<1>(grad_wav, nullptr, reinterpret_cast<float2*>(grad_spec), B, L_out, T, window == URSE_WIN_HANN ? 1 : 0, tb.tw, (hipStream_t)stream);
+    else
     hipLaunchKernelGGL(stft960_kernel<1>, dim3(ceil_div(T, 2 * URSE_STFT960_NFF), B), dim3(URSE_STFT960_NFF_THREADS), 0, (hipStream_t)stream,
                        grad_wav, (const int32_t*)nullptr, reinterpret_cast<float2*>(grad_spec), L_out, T, hop,
                        window == URSE_WIN_HANN ? 1 : 0, tb.tw);
