@@ -49,6 +49,9 @@ extern "C" {
 #define URSE_F32 0
 #define URSE_BF16 1
 #define URSE_F16 2            /* IEEE half operands (forward kernels only: gradients stay bf16) */
+#define URSE_BF16_ACT_F16 3   /* urse_gemm_tn / urse_gemm_tn_dual only: A (gradients) bf16, B / B2 (the forward's activations) IEEE half,
+                                 converted to bf16 in registers behind the LDS fragment read - the weight gradients of an f16-forward step read
+                                 x_n and h where the forward left them, no second bf16 copy is written (shapes: urse_gemm_tn_act_f16_supported) */
 
 #define URSE_WIN_RECT 0
 #define URSE_WIN_HANN 1
@@ -158,6 +161,9 @@ int urse_gemm_nt_grouped_h(const void* descs, const int64_t* host_descs, int gro
 int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
                  int64_t R, int64_t Mo, int64_t No, int64_t shift, int64_t inner, int64_t period,
                  int64_t invalid_step, int64_t perm_h, int dtype, int target_workgroups, void* stream);
+/* 1 if the URSE_BF16_ACT_F16 form of urse_gemm_tn (No2 == 0; the wide-and-short fc gradient, needs colsum) / urse_gemm_tn_dual (No2 > 0) serves
+ * the shape - `d_model.py:61-89`'s backward in an f16-forward step (nn.Linear / nn.LSTM weight gradients, `bsrnn_flowse.py:296-307`). */
+int urse_gemm_tn_act_f16_supported(int64_t R, int64_t Mo, int64_t No, int64_t No2, int with_colsum);
 /* Two weight gradients that share their A operand in one pass over A (the two wgrads of one LSTM direction):
  * C[Mo,No] += A^T B (+ colsum) and C2[Mo,No2] += A^T B2', B2' = B2 shifted / masked as in urse_gemm_tn. */
 int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,

@@ -50,6 +50,7 @@ def object_kernels(obj):
         _run(os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
              "--targets=" + TARGET, "--output=" + co)
         notes = _run(os.path.join(LLVM, "llvm-readelf"), "--notes", co)
+        in_loop = scratch_in_loops(_run(os.path.join(LLVM, "llvm-objdump"), "-d", co))
     kernels = []
     cur = None
     for line in notes.splitlines():
@@ -67,7 +68,46 @@ def object_kernels(obj):
             cur["name"] = val
         elif key in FIELDS:
             cur[key] = int(val)
+    for k in kernels:
+        if "name" in k:
+            k["scratch_ops"], k["scratch_ops_in_loops"], k["scratch_ops_in_mfma_loops"] = in_loop.get(k["name"], (0, 0, 0))
     return [(k.pop("name"), k) for k in kernels if "name" in k]
+
+
+def scratch_in_loops(disasm):
+    """{kernel symbol: (scratch instructions, those inside a loop, those inside a loop that also holds MFMAs)} from `llvm-objdump -d` of a code
+    object.  A spill that is stored and reloaded in a kernel's prologue costs nothing per iteration; one inside a time / K loop serialises the loads
+    queued in front of it (the +5.7 ms of round 5).  Loop = [target, branch] of every backward branch of the function; the loops with
+    matrix instructions are the hot ones of the GEMM / recurrence kernels (set-up loops - cluster formation spins, table fills - have none)."""
+    out, sym, start, insts = {}, None, 0, []
+
+    def close():
+        if sym is None:
+            return
+        loops = [(t, a) for a, m, t in insts if t is not None and t <= a]
+        sc = [a for a, m, t in insts if m.startswith("scratch_")]
+        mf = [a for a, m, t in insts if m.startswith("v_mfma")]
+        hot = [(lo, hi) for lo, hi in loops if any(lo <= a <= hi for a in mf)]
+        out[sym] = (len(sc), sum(1 for a in sc if any(lo <= a <= hi for lo, hi in loops)),
+                    sum(1 for a in sc if any(lo <= a <= hi for lo, hi in hot)))
+
+    for line in disasm.splitlines():
+        m = re.match(r"^([0-9a-f]{16}) <(\S+)>:", line)
+        if m:
+            close()
+            sym, start, insts = m.group(2), int(m.group(1), 16), []
+            continue
+        m = re.match(r"^\s+(\S+)\s.*//\s*([0-9A-F]{12}):", line)
+        if not m or sym is None:
+            continue
+        mn, addr = m.group(1), int(m.group(2), 16)
+        tgt = None
+        if mn.startswith("s_cbranch") or mn == "s_branch":
+            t = re.search(r"<%s\+0x([0-9a-f]+)>" % re.escape(sym), line)
+            tgt = start + int(t.group(1), 16) if t else (start if ("<%s>" % sym) in line else None)
+        insts.append((addr, mn, tgt))
+    close()
+    return out
 
 
 def short(name):

@@ -497,7 +497,19 @@ __device__ __forceinline__ void blds16(unsigned voff, rsrc_v4i_t rsrc, unsigned 
 // rows q and 8 + q on the same banks: every fragment read was a 2-way conflict.)
 __device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <int NTW, int CSM>
+// f16 -> bf16 on a fragment in registers (URSE_BF16_ACT_F16: the weight-gradient GEMMs of an f16-forward training step read the forward's f16
+// activations against bf16 gradients; a mixed-operand MFMA does not exist).  v_cvt_f32_f16 (+ sdwa for the high halves) and v_cvt_pk_bf16_f32:
+// 12 vector instructions per fragment, issued under the MFMAs - the kernel waits for bytes, not for the vector ALU.  The values differ from the
+// bf16 copy the forward kernels used to write beside the f16 one only by double rounding (f32 -> f16 -> bf16 instead of f32 -> bf16).
+__device__ __forceinline__ short8_t frag_f16_to_bf16(short8_t v) {
+  typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
+  typedef float f32x8_ __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(short8_t, __builtin_convertvector(__builtin_convertvector(__builtin_bit_cast(f16x8_, v), f32x8_), bf16x8_));
+}
+
+// CVT: 0 both operands bf16; 1 the A operand is IEEE half (the transposed fc gradient: A = h); 2 the B operand is
+template <int NTW, int CSM, int CVT = 0>
 __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   constexpr int BMX = 256, BNX = 32 * NTW, NST = URSE_TN_NST, STAGE = 32768;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
@@ -671,6 +683,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
   const int off0 = row0 * 512 + pp * 8, off1 = (row0 + 4) * 512 + pp * 8;
   const int sw0 = tn_swz(row0), sw1 = tn_swz(row0 + 4);     // swizzle keys of the two rows
 
+  static_assert(CVT == 0 || (URSE_TN_PIPE == 2 && NST == 5), "mixed operands: default loop form only");
   if constexpr (URSE_TN_PIPE == 4 && NST == 5) {
   // as variant 2, but a stage's DMA issue (address selects, phase update: ~50 VALU instructions per wave) sits BETWEEN
   // the two halves of a stage's MFMAs instead of right behind the barrier, where all eight waves did it at once with the
@@ -759,6 +772,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
     slot = slot + 2 >= NST ? slot + 2 - NST : slot + 2;
   }
   } else if constexpr (URSE_TN_PIPE == 2 && NST == 5) {
+  // (the only loop form the mixed-operand variants are built for: CVT != 0 is instantiated under the shipping switches)
   // two stages per barrier: the per-k-step barrier cost 200 of 1,000 ns (scripts/abl_tn_parts.py).  At the wait of
   // iteration kt the stages 0 .. kt+2 have been issued and only the youngest may be outstanding (4 DMAs per wave);
   // after the barrier the slots of stages kt-2, kt-1 are free and take stages kt+3, kt+4.
@@ -783,6 +797,14 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
       short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (__attribute__((address_space(3))) short4_t*)(Bs + off1 + ((S ^ sw1) << 5)));
       b[j] = short8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+    if constexpr (CVT == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = frag_f16_to_bf16(a[i]);
+    }
+    if constexpr (CVT == 2) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) b[j] = frag_f16_to_bf16(b[j]);
     }
 #if URSE_TN_SETPRIO
     __builtin_amdgcn_s_setprio(1);
@@ -932,6 +954,9 @@ __global__ void __launch_bounds__(512) gemm_tn_dma_kernel(TnArgs p) {
 #define URSE_O64 URSE_O16, URSE_O16, URSE_O16, URSE_O16
 __device__ __attribute__((aligned(1024))) unsigned g_tn_ones_page[256] = {URSE_O64, URSE_O64, URSE_O64, URSE_O64};
 #undef URSE_O4
+#define URSE_O4 0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u
+__device__ __attribute__((aligned(1024))) unsigned g_tn_ones_page_h[256] = {URSE_O64, URSE_O64, URSE_O64, URSE_O64};   // 1.0 in IEEE half (BH)
+#undef URSE_O4
 #undef URSE_O16
 #undef URSE_O64
 // swizzle key of the 128-byte-pitch image (four 32-byte segments per row): the eight rows of a 32-lane read group (q, 8 + q) alternate
@@ -947,7 +972,8 @@ __device__ __forceinline__ void glds16u(const char* gsrc, unsigned dst) {
 }
 #pragma clang diagnostic pop
 
-template <int DEPTH>      // stages in flight: 2 (two stages per barrier) or 3 (one barrier per stage).  A template, not a run-time switch: with both loops in one kernel
+// BH: the right-hand operands [B | B2 | ones] are IEEE half (the forward's f16 activations), converted to bf16 behind the fragment read
+template <int DEPTH, bool BH = false>      // stages in flight: 2 (two stages per barrier) or 3 (one barrier per stage).  A template, not a run-time switch: with both loops in one kernel
                           // the register allocation of BOTH got worse (9 spilled registers where round 4's kernel had none) and the second queue's
                           // weight gradients ran 16 % longer - 5.7 ms per train step that hid the round's other gains until a round-over-round A/B
                           // on one box (profiles/r05_ab_round_v2.log)
@@ -977,7 +1003,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
   // invalid_step, tracked per row group.  Rows outside the matrix only occur on masked rows (checked on the host: shift = -/+ inner
   // with the first / last step masked), stages past the slice end are issued from the zero page by a wave-uniform branch.
   const char* zsrc = reinterpret_cast<const char*>(g_tn_zero_page) + lane * 16;
-  const char* osrc = reinterpret_cast<const char*>(g_tn_ones_page) + lane * 16;
+  const char* osrc = reinterpret_cast<const char*>(BH ? g_tn_ones_page_h : g_tn_ones_page) + lane * 16;
   const unsigned inner_u = (unsigned)p.inner, per_u = (unsigned)p.period, inval_u = (unsigned)p.invalid_step;
   const unsigned step_q = (32u / inner_u) % per_u, step_r = 32u % inner_u;
   struct Row { unsigned ph, rm; };                         // (row / inner) % period, row % inner of a DMA row group
@@ -1115,6 +1141,10 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
       for (int j = 1; j < NT; ++j) b[j] = frag((bb0 ^ ((unsigned)(j - 1) << 5)) + st, (bb1 ^ ((unsigned)(j - 1) << 5)) + st);
 #endif
     }
+    if constexpr (BH) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = frag_f16_to_bf16(b[j]);
+    }
 #ifdef T224_NO_MFMA
 #pragma unroll
     for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(b[j]));
@@ -1190,7 +1220,8 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-static void launch_tn_dma(int ntw, int csm, dim3 grid, hipStream_t st, const TnArgs& p) {
+static void launch_tn_dma(int ntw, int csm, dim3 grid, hipStream_t st, const TnArgs& p, int cvt = 0) {
+  if (cvt == 1) { hipLaunchKernelGGL((gemm_tn_dma_kernel<7, 2, 1>), grid, dim3(512), 0, st, p); return; }     // (the one mixed instance: fc gradient, transposed)
 #define URSE_TN_L(N_, C_) hipLaunchKernelGGL((gemm_tn_dma_kernel<N_, C_>), grid, dim3(512), 0, st, p)
   if (ntw == 7) { if (csm == 0) URSE_TN_L(7, 0); else if (csm == 1) URSE_TN_L(7, 1); else URSE_TN_L(7, 2); }
   else { if (csm == 0) URSE_TN_L(8, 0); else if (csm == 1) URSE_TN_L(8, 1); else URSE_TN_L(8, 2); }
@@ -1360,7 +1391,10 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
   // GNB: group means / rstds of the (at most two) groups of this tile, the thread's four gammas, per-channel partial sums
   float gnb_m[2] = {0.f, 0.f}, gnb_r[2] = {0.f, 0.f}, gnb_ga[4] = {0.f, 0.f, 0.f, 0.f}, gnb_dg[4] = {0.f, 0.f, 0.f, 0.f}, gnb_db[4] = {0.f, 0.f, 0.f, 0.f};
   long gnb_g0 = 0, gnb_bound = 0;
-  float4 gnb_xpre[GNB ? (RPP + NTHR / CPR - 1) / (NTHR / CPR) : 1];
+  // x rows of a pass: the first GXA requested in front of the staging (their HBM latency hides behind it), the rest behind the barrier, in front
+  // of the sweep that consumes the first ones - all XI at once sat on top of the second pass's 112 live accumulators: 6 registers to scratch
+  constexpr int GXI = GNB ? (RPP + NTHR / CPR - 1) / (NTHR / CPR) : 1, GXA = GXI < 8 ? GXI : 8;
+  float4 gnb_xpre[GXI];
   if constexpr (GNB) {
     gnb_g0 = m0 / xt->rpg;
     gnb_bound = (gnb_g0 + 1) * xt->rpg;
@@ -1388,8 +1422,9 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
       constexpr int SLOTS = NTHR / CPR, XI = (RPP + SLOTS - 1) / SLOTS;
       const int slot = tid / CPR, chf = tid - slot * CPR;
       const long col = n0 + chf * EPC;
+      static_assert(XI == GXI, "prefetch array");
 #pragma unroll
-      for (int i = 0; i < XI; ++i) {
+      for (int i = 0; i < GXA; ++i) {
         const int lr_ = slot + i * SLOTS;
         const long row = m0 + pass * RPP + lr_;
         const bool ok = slot < SLOTS && col < d.N && lr_ < RPP && row < d.M;
@@ -1453,6 +1488,13 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDesc& d, double* gsta
       constexpr int SLOTS = NTHR / CPR, XI = (RPP + SLOTS - 1) / SLOTS;
       const int slot = tid / CPR, chf = tid - slot * CPR;
       const long col = n0 + chf * EPC;
+#pragma unroll
+      for (int i = GXA; i < XI; ++i) {
+        const int lr_ = slot + i * SLOTS;
+        const long row = m0 + pass * RPP + lr_;
+        const bool ok = slot < SLOTS && col < d.N && lr_ < RPP && row < d.M;
+        gnb_xpre[i] = ok ? *reinterpret_cast<const float4*>(xt->gnb_x + row * d.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (slot < SLOTS && col < d.N) {
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
@@ -2184,6 +2226,14 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
                             void* stream) {
   URSE_CHECK_ARG(A && B && C && R > 0 && Mo > 0 && No > 0 && target_workgroups >= 0, "urse_gemm_tn: bad argument");
   const long g_tn_target_wgs = target_workgroups > 0 ? target_workgroups : 256;
+  const bool act_f16 = dtype == URSE_BF16_ACT_F16;       // A = bf16 gradients, B = the forward's f16 activations (converted in registers)
+  if (act_f16) {
+    if (!urse_gemm_tn_act_f16_supported(R, Mo, No, 0, colsum != nullptr) || perm_h != 0 || shift != 0 || period != 0) {
+      set_error("urse_gemm_tn: URSE_BF16_ACT_F16 serves the shapes urse_gemm_tn_act_f16_supported accepts (R%ld Mo%ld No%ld)", (long)R, (long)Mo, (long)No);
+      return URSE_ERR_UNSUPPORTED;
+    }
+    dtype = URSE_BF16;
+  }
   const int es = dtype == URSE_BF16 ? 2 : 4;
   URSE_CHECK_ARG((lda * es) % 16 == 0 && (ldb * es) % 16 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
                  "urse_gemm_tn: operands must be 16-byte aligned with 16-byte-multiple row pitch");
@@ -2214,7 +2264,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     q.rows_per_slice = rps;
     dim3 grid((unsigned)(tl * slices));
     note_launch(URSE_KV_TN_RING_T);
-    launch_tn_dma(ntw, colsum ? 2 : 0, grid, (hipStream_t)stream, q);
+    launch_tn_dma(ntw, colsum ? 2 : 0, grid, (hipStream_t)stream, q, act_f16 ? 1 : 0);
     URSE_CHECK_LAUNCH("urse_gemm_tn");
     return URSE_OK;
   }
@@ -2271,6 +2321,19 @@ extern "C" int urse_gemm_tn_grouped(const void* descs, int groups, int max_block
   return URSE_OK;
 }
 
+// which weight-gradient shapes have a mixed-operand (URSE_BF16_ACT_F16) kernel: No2 == 0: urse_gemm_tn's transposed ring kernel with column sums
+// (the fc gradient [196, 784]); No2 > 0: urse_gemm_tn_dual's 224 x 320 kernel (row / mask conditions are checked by the call itself)
+extern "C" int urse_gemm_tn_act_f16_supported(int64_t R, int64_t Mo, int64_t No, int64_t No2, int with_colsum) {
+  static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr, no224 = getenv("URSE_TN_NO_224") != nullptr;
+  if (no_dma || R < 16384 || R >= (1L << 30)) return 0;
+  if (No2 == 0) {
+    const long pad7 = (Mo + 223) / 224 * 224, pad8 = (Mo + 255) / 256 * 256;        // (transposed: the kernel's column tiles run over Mo)
+    return (with_colsum && Mo < 512 && Mo >= 160 && No >= 512 && pad7 < pad8) ? 1 : 0;
+  }
+  const long No8 = (No + 7) & ~7L, V = No8 + No2 + (with_colsum ? 1 : 0);
+  return (!no224 && Mo >= 512 && Mo % 224 == 0 && No2 % 8 == 0 && R % 32 == 0 && V <= 640) ? 1 : 0;
+}
+
 // dW1[Mo, No] += A^T B (+ colsum),  dW2[Mo, No2] += A^T B2' (B2' = B2 shifted / masked as in urse_gemm_tn) in ONE pass
 // over A: the two weight gradients of one LSTM direction (A = dgates [M, 4H], B = layer input, B2 = h_{t-1}).
 extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
@@ -2281,9 +2344,18 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
                  "urse_gemm_tn_dual: bad argument");
   const long g_tn_target_wgs = target_workgroups > 0 ? target_workgroups : 256;
   static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr;
+  const bool act_f16 = dtype == URSE_BF16_ACT_F16;       // A = bf16 gradients, B / B2 = the forward's f16 activations
+  if (act_f16) {
+    if (!urse_gemm_tn_act_f16_supported(R, Mo, No, No2, colsum != nullptr)) {
+      set_error("urse_gemm_tn_dual: URSE_BF16_ACT_F16 serves the shapes urse_gemm_tn_act_f16_supported accepts (R%ld Mo%ld No%ld No2%ld)", (long)R, (long)Mo, (long)No, (long)No2);
+      return URSE_ERR_UNSUPPORTED;
+    }
+    dtype = URSE_BF16;
+  }
   const bool big = dtype == URSE_BF16 && !no_dma && Mo >= 512 && R >= 16384 && R < (1L << 30) && shift > -(1L << 30) && shift < (1L << 30) && period < (1L << 31) && inner < (1L << 31) &&
                    (lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && (ldb2 * 2) % 16 == 0 && ((uintptr_t)A % 16) == 0 &&
                    ((uintptr_t)B % 16) == 0 && ((uintptr_t)B2 % 16) == 0;
+  if (!big && act_f16) { set_error("urse_gemm_tn_dual: URSE_BF16_ACT_F16 needs 16-byte aligned operands"); return URSE_ERR_UNSUPPORTED; }
   if (!big) {
     int rc = urse_gemm_tn(A, lda, B, ldb, C, ldc, colsum, R, Mo, No, 0, 1, 0, 0, perm_h, dtype, target_workgroups, stream);
     if (rc) return rc;
@@ -2321,12 +2393,14 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
         p.pad_[0] = e ? atol(e) : 2;
       }
       note_launch(URSE_KV_TN_DUAL);
-      if (p.pad_[0] == 3) hipLaunchKernelGGL(gemm_tn_dual224_kernel<3>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+      if (act_f16) hipLaunchKernelGGL((gemm_tn_dual224_kernel<2, true>), dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+      else if (p.pad_[0] == 3) hipLaunchKernelGGL(gemm_tn_dual224_kernel<3>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
       else hipLaunchKernelGGL(gemm_tn_dual224_kernel<2>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
       URSE_CHECK_LAUNCH("urse_gemm_tn_dual");
       return URSE_OK;
     }
   }
+  if (act_f16) { set_error("urse_gemm_tn_dual: URSE_BF16_ACT_F16: rows / step mask outside what the 224 x 320 kernel takes"); return URSE_ERR_UNSUPPORTED; }
   const long bnx = 224;                                   // 7 column tiles per wave: 196 -> 224, 392 -> 448
   p.nt1 = (No + bnx - 1) / bnx;
   const long tl = ((Mo + 255) / 256) * (p.nt1 + (No2 + bnx - 1) / bnx);
