@@ -665,7 +665,8 @@ def main():
         ndev = max(1, torch.cuda.device_count())
         local %= ndev                                     # (debug: several ranks on one device)
         from urgent2026_challenge_track1_amd import ops as _ops0
-        _ops0.SHARED_GPU_RANKS = -(-world // ndev)       # (ranks per device: the pair-spinning N-split BPTT is not planned on a shared GPU)
+        # ranks per device on THIS node (LOCAL_WORLD_SIZE, set by torch.distributed.run): cooperative grids are not planned on a shared GPU
+        _ops0.SHARED_GPU_RANKS = -(-int(os.environ.get("LOCAL_WORLD_SIZE", world)) // ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.pretouch_gib > 0:

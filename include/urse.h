@@ -87,7 +87,7 @@ const char* urse_last_error(void);
 #define URSE_KV_ISTFT_GENERIC 21
 #define URSE_KV_ISTFT960 22
 #define URSE_KV_LSTM_FWD_RW 23     /* lstm_fwd_rw_kernel: 16 sequences per wave, weights shared through an LDS-DMA ring */
-/* (24: unused - a row-wave BPTT was priced in round 4 and round 5 and not built: DESIGN.md) */
+#define URSE_KV_TN_ACT_F16 24      /* a weight-gradient launch (ring-T or dual) in its URSE_BF16_ACT_F16 form: counted besides its own slot */
 #define URSE_KV_LSTM_FWD_RWX 25    /* lstm_fwd_rwx_kernel: row-wave forward with the input projection fused */
 #define URSE_KV_LSTM_BWD_NSPLIT 26 /* lstm_bwd_nsplit_kernel: pairs of workgroups split the output columns of the recurrent product */
 #define URSE_KV_LSTM_FWD_CLUSTERX 27 /* lstm_fwd_clusterx_kernel: cluster forward with the input projection fused */
@@ -163,7 +163,7 @@ int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
                  int64_t invalid_step, int64_t perm_h, int dtype, int target_workgroups, void* stream);
 /* 1 if the URSE_BF16_ACT_F16 form of urse_gemm_tn (No2 == 0; the wide-and-short fc gradient, needs colsum) / urse_gemm_tn_dual (No2 > 0) serves
  * the shape - `d_model.py:61-89`'s backward in an f16-forward step (nn.Linear / nn.LSTM weight gradients, `bsrnn_flowse.py:296-307`). */
-int urse_gemm_tn_act_f16_supported(int64_t R, int64_t Mo, int64_t No, int64_t No2, int with_colsum);
+int urse_gemm_tn_act_f16_supported(int64_t R, int64_t Mo, int64_t No, int64_t No2, int with_colsum, int64_t inner, int64_t period);
 /* Two weight gradients that share their A operand in one pass over A (the two wgrads of one LSTM direction):
  * C[Mo,No] += A^T B (+ colsum) and C2[Mo,No2] += A^T B2', B2' = B2 shifted / masked as in urse_gemm_tn. */
 int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
@@ -271,7 +271,7 @@ int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* wihq, const 
 int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int reserved_cus, int64_t* plan);
 int urse_lstm_cluster2_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx, void* err_flag,
                            int H, int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride, int save,
-                           int reserved_cus, void* stream);
+                           int reserved_cus, int dtype, void* stream);      /* dtype: URSE_BF16 | URSE_F16 (gx, whhq, hout; saved gates bf16) */
 /* Cluster BPTT (bf16), same protocol: whhTq from urse_lstm_pack_bwd_quads(whh, out [2*C*4*(H/8)*512 bf16], H, C);
  * dgx = exchange buffer of 2*2*ncl*64*4H bf16 elements. */
 int urse_lstm_pack_bwd_quads(const float* whh, void* out, int H, int C, void* stream);

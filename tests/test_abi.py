@@ -26,6 +26,23 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     assert rc == -1
 
 
+def test_shape_queries_refuse_what_the_kernels_cannot_run(lib):
+    """ADVICE r5: the fused cluster forward is written for N <= 200 input channels (six slabs of W_ih + the folded seventh) and H = 392;
+    the query used to accept N up to 224 (channels 200 .. 223 silently dropped) and any multiple of 56 below 392 (a gather that waits for
+    chunks nobody publishes).  Round 6: the mixed-operand weight-gradient GEMMs answer for their own shapes."""
+    assert lib.urse_lstm_clusterx_supported(196, 224, 392, 416) == 1
+    assert lib.urse_lstm_clusterx_supported(200, 224, 392, 416) == 1
+    assert lib.urse_lstm_clusterx_supported(208, 224, 392, 416) == 0
+    assert lib.urse_lstm_clusterx_supported(196, 224, 336, 416) == 0
+    assert lib.urse_lstm_clusterx_supported(196, 224, 392, 448) == 0
+    assert lib.urse_gemm_tn_act_f16_supported(436288, 196, 784, 0, 1, 1, 0) == 1           # fc gradient at C2
+    assert lib.urse_gemm_tn_act_f16_supported(436288, 1568, 196, 392, 1, 34, 401) == 1     # dual gradient, time path
+    assert lib.urse_gemm_tn_act_f16_supported(436288, 1568, 196, 392, 1, 1, 34) == 1       # band path
+    assert lib.urse_gemm_tn_act_f16_supported(20604, 1568, 196, 392, 1, 34, 101) == 0      # rows not whole 32-row stages
+    assert lib.urse_gemm_tn_act_f16_supported(436288, 3072, 384, 768, 1, 1, 48) == 0       # H = 768: no 224-row tiles
+    assert lib.urse_gemm_tn_act_f16_supported(436288, 196, 784, 0, 0, 1, 0) == 0           # the transposed instance carries the column sums
+
+
 def test_grouped_gemm_validates_the_host_mirror_before_launching(lib):
     """urse_gemm_nt_grouped_h reads the host copy of the per-band records: a bad one is an error code, not a launch"""
     import numpy as np

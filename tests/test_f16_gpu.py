@@ -171,8 +171,8 @@ def _c2_models(L, dtype, seed=0, N=196):
     return ref, model.cuda()
 
 
-@pytest.mark.parametrize("fs", [48000, 16000])
-def test_f16_c2_kernel_set_forward_and_gradients(lib, monkeypatch, fs):
+@pytest.mark.parametrize("fs,B,Ls", [(48000, 6, 48000), (16000, 6, 16000), (48000, 8, 48480)])
+def test_f16_c2_kernel_set_forward_and_gradients(lib, monkeypatch, fs, B, Ls):
     """N = 196, L = 6, B 6 x 1 s, the C2 dispatch (thresholds on the NUMBER of band-path sequences lowered as in tests/test_c2_parity_gpu.py):
     f16 forward against the f32 oracle within north_star's 1e-3 on waveform and loss; gradients (bf16 backward on the f16 forward's state)
     no worse than the bf16 mode's bound."""
@@ -185,7 +185,9 @@ def test_f16_c2_kernel_set_forward_and_gradients(lib, monkeypatch, fs):
     monkeypatch.setattr(ops, "BWD_ROWS16", {"f": 2 | 16})
     ref, model = _c2_models(6, "f16")
     g = torch.Generator().manual_seed(1)
-    B, Ls = 6, fs
+    # B 8 x 1.01 s (T = 102 frames, M = B T K = 27,744 rows = whole 32-row stages): the weight gradients take the MIXED-operand kernels (round 6:
+    # bf16 gradients against the forward's f16 x_n / h, no second bf16 copy); B 6 x 1 s (M = 20,604): the two-copy form
+    mixed = (B, Ls) == (8, 48480)
     clean = 0.3 * torch.randn(B, Ls, generator=g)
     noisy = clean + 0.1 * torch.randn(B, Ls, generator=g)
     lens = torch.full((B,), Ls, dtype=torch.int32)
@@ -203,6 +205,8 @@ def test_f16_c2_kernel_set_forward_and_gradients(lib, monkeypatch, fs):
     for k in ("nt_bres", "nt_ring", "lstm_fwd_clusterx", "lstm_fwd_rwx", "nt_grouped_ring", "lstm_bwd_nsplit"):
         assert counts[k] > 0, (k, counts)
     assert counts["tn_dual"] > 0 or fs != 48000, counts       # (K = 27 bands at 16 kHz: the dual weight-gradient kernel's whole-block condition does not hold)
+    # 12 half layers x (2 dual launches + 1 fc gradient) in the mixed form, or none of them
+    assert counts["tn_act_f16"] == (36 if mixed else 0), counts
     assert counts["lstm_fwd_stream"] == 0 and counts["nt_128"] == 0, counts
     wc, wr = wav.detach().cpu(), wav_r.detach()
     l2 = float((wc - wr).norm() / wr.norm())
@@ -218,7 +222,7 @@ def test_f16_c2_kernel_set_forward_and_gradients(lib, monkeypatch, fs):
         if r > worst:
             worst, wn = r, n
     print("f16 C2 kernel set @ %d Hz: wav rel. L2 %.2e, max / peak %.2e, loss %.2e, worst grad rel. L2 %.2e (%s)" % (fs, l2, mx, el, worst, wn))
-    parity_log.record("f16_c2_kernel_set_L6_fs%d" % fs, shape="B6 x 1 s, N=196", wav_rel_l2=l2, wav_max_over_peak=mx, loss_rel=el, worst_grad_rel_l2=worst,
+    parity_log.record("f16_c2_kernel_set_L6_fs%d%s" % (fs, "_mixed_wgrad" if mixed else ""), shape="B%d x %.2f s, N=196" % (B, Ls / fs), wav_rel_l2=l2, wav_max_over_peak=mx, loss_rel=el, worst_grad_rel_l2=worst,
                       worst_grad=wn)
     assert l2 <= 1e-3 and mx <= 1e-3 and el <= 1e-3, (l2, mx, el)
     assert worst <= 2.1e-2, (worst, wn)

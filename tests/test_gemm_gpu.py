@@ -426,3 +426,67 @@ def test_gemm_operand_slices_at_the_end_of_their_allocation_with_poison_behind(l
     outp = torch.full((M + 2, N + 8), float("nan"), device="cuda", dtype=odt)
     ops.gemm_nt(A, W, bias, out=outp[2:, 8:])
     assert torch.equal(outp[2:, 8:], ref) and torch.isnan(outp[:2].float()).all() and torch.isnan(outp[:, :8].float()).all()
+
+
+@pytest.mark.parametrize("inner,period,rev", [(34, 25, False), (34, 25, True), (1, 34, False), (1, 34, True)])
+def test_gemm_tn_dual_bf16_gradients_against_f16_activations(lib, inner, period, rev):
+    """URSE_BF16_ACT_F16 (round 6; the nn.LSTM weight gradients of `d_model.py:61-89`'s backward in an f16-forward step): A = bf16 gate
+    gradients, B / B2 = the forward's IEEE-half x_n / h, converted to bf16 in registers behind the LDS fragment read.  Exactly the product of
+    A with the bf16-ROUNDED activations: equal to the all-bf16 kernel fed `B.float().bfloat16()` up to the order of the f32 atomics, and
+    within bf16 rounding of the float64 product with the unrounded f16 values."""
+    from urgent2026_challenge_track1_amd import ops
+    H, N = 392, 196
+    R = inner * period * (32 if inner > 1 else 640)
+    assert R % 32 == 0 and ops.tn_act_f16_supported(R, 4 * H, N, H, True, inner, period)
+    A = (_mk((R, 4 * H), torch.float32, 50) * 0.3).bfloat16().cuda()
+    X = torch.zeros(R, 224, dtype=torch.float16)
+    X[:, :N] = _mk((R, N), torch.float32, 51).half()
+    Hh = torch.zeros(R, 416, dtype=torch.float16)
+    Hh[:, :H] = torch.tanh(_mk((R, H), torch.float32, 52)).half()
+    X, Hh = X.cuda(), Hh.cuda()
+    sh, inv = (inner, period - 1) if rev else (-inner, 0)
+    c1, c2, cs = torch.zeros(4 * H, N, device="cuda"), torch.zeros(4 * H, H, device="cuda"), torch.zeros(4 * H, device="cuda")
+    r1, r2, rs = torch.zeros_like(c1), torch.zeros_like(c2), torch.zeros_like(cs)
+    ops.launch_counts(reset=True)
+    ops.gemm_tn_dual(A, X, c1, cs, Hh, c2, 4 * H, N, H, sh, inner, period, inv, perm_h=H)
+    assert ops.launch_counts()["tn_dual"] == 1
+    ops.gemm_tn_dual(A, X.float().bfloat16(), r1, rs, Hh.float().bfloat16(), r2, 4 * H, N, H, sh, inner, period, inv, perm_h=H)
+    for got, ref in ((c1, r1), (c2, r2), (cs, rs)):
+        assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # float64 of the same contraction with the f16 values themselves (un-permuted rows: perm_h maps (unit, gate) -> (gate, unit))
+    c1p = torch.zeros(4 * H, N, device="cuda")
+    ops.gemm_tn_dual(A, X, c1p, None, Hh, torch.zeros_like(c2), 4 * H, N, H, sh, inner, period, inv, perm_h=0)
+    ref = (A.double().T @ X.double()[:, :N])
+    assert ((c1p.double() - ref).norm() / ref.norm()).item() < 3e-3
+
+
+def test_gemm_tn_fc_gradient_bf16_against_f16_h(lib):
+    """the wide-and-short fc weight gradient [196, 784] (transposed ring kernel, column sums of the gradient operand) with h in IEEE half."""
+    from urgent2026_challenge_track1_amd import ops
+    R, N, H2 = 34 * 640, 196, 784
+    assert ops.tn_act_f16_supported(R, N, H2, 0, True)
+    dO = torch.zeros(R, 224, dtype=torch.bfloat16)
+    dO[:, :N] = (_mk((R, N), torch.float32, 60) * 0.2).bfloat16()
+    Hh = torch.zeros(R, 800, dtype=torch.float16)
+    Hh[:, :H2] = torch.tanh(_mk((R, H2), torch.float32, 61)).half()
+    dO, Hh = dO.cuda(), Hh.cuda()
+    c, cs = torch.zeros(N, H2, device="cuda"), torch.zeros(N, device="cuda")
+    r, rs = torch.zeros_like(c), torch.zeros_like(cs)
+    ops.launch_counts(reset=True)
+    ops.gemm_tn(dO, Hh, c, colsum=cs, Mo=N, No=H2)
+    assert ops.launch_counts()["tn_ring_t"] == 1
+    ops.gemm_tn(dO, Hh.float().bfloat16(), r, colsum=rs, Mo=N, No=H2)
+    for got, ref in ((c, r), (cs, rs)):
+        assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    ref = dO.double()[:, :N].T @ Hh.double()[:, :H2]
+    assert ((c.double() - ref).norm() / ref.norm()).item() < 3e-3
+
+
+def test_gemm_tn_mixed_operands_refuse_shapes_without_a_kernel(lib):
+    from urgent2026_challenge_track1_amd import ops
+    from urgent2026_challenge_track1_amd._lib import UrseError
+    A = torch.zeros(64, 224, dtype=torch.bfloat16, device="cuda")
+    Bm = torch.zeros(64, 64, dtype=torch.float16, device="cuda")
+    assert not ops.tn_act_f16_supported(64, 224, 64, 0, True)
+    with pytest.raises(UrseError):
+        ops.gemm_tn(A, Bm, torch.zeros(224, 64, device="cuda"), Mo=224, No=64)

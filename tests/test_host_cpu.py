@@ -216,3 +216,16 @@ def test_flow_split_bptt_plan_does_not_depend_on_the_nsplit_shadow_size(monkeypa
         assert ops.use_nsplit_bwd(392, 416, torch.bfloat16, "t", sm_c2) is True and ops.wgrad_shadow_wgs("t", True) == v
         assert ops.wgrad_shadow_wgs("f", True) == ops.TN_SHADOW_WGS_BAND
     assert len(plans) == 1 and next(iter(plans))[0] == 12, plans                             # the 12-way split of the benchmarked flow step
+
+
+def test_no_cooperative_plan_when_ranks_share_a_gpu(monkeypatch):
+    """two processes on one GPU (the gloo test path) must not each bring a cooperative grid - clusters that spin until every member
+    has arrived cannot be co-resident with another process's.  With ops.SHARED_GPU_RANKS > 1 every cooperative plan (cluster, cluster2, split,
+    N-split) is refused and the streaming kernels run; alone on the device the C2 / C4 plans exist.  The plan queries need no GPU."""
+    from urgent2026_challenge_track1_amd import _lib, ops
+    _lib.load()
+    assert ops.lstm_cluster_plan(392, 416, 1088) is not None and ops.lstm_nsplit_plan(392, 1088) is not None
+    assert ops.lstm_cluster2_plan(768, 768, 48) is not None and ops.lstm_split_plan(768, 96) is not None
+    monkeypatch.setattr(ops, "SHARED_GPU_RANKS", 2)
+    assert ops.lstm_cluster_plan(392, 416, 1088) is None and ops.lstm_nsplit_plan(392, 1088) is None
+    assert ops.lstm_cluster2_plan(768, 768, 48) is None and ops.lstm_split_plan(768, 96) is None

@@ -14,11 +14,12 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 # What a C2 train step launches (profiles/r05_trainstep_v5_kernel_stats.csv, every kernel above 0.02 % of the step + the STFT family) and
 # the forward kernels of the f16 mode / inference.  Names as scripts/kernel_regs.py prints them (demangled, without the parameter list).
 C2_STEP = [
-    "gemm_tn_dual224_kernel<2>",
+    "gemm_tn_dual224_kernel<2, false>",
     "urse::lstm_bwd_nsplit_kernel<392, 0, 0>",
     "urse::lstm_bwd_kernel<unsigned short, 2, 4, 8, 0, 392, 0, 1, 1>",
     "urse::lstm_fwd_rwx_kernel<392, 416, 224, true, unsigned short, false>",
-    "gemm_tn_dma_kernel<7, 2>",
+    "gemm_tn_dma_kernel<7, 2, 0>",
+    "gemm_tn_dma_kernel<7, 2, 1>",          # f16-forward training: fc gradient against the f16 h (round 6)
     "gemm_nt_dma_gnb_kernel",
     "gemm_nt_dma_kernel<float, 7, 0, 256, 2, unsigned short>",
     "gemm_nt_bres_kernel<0, unsigned short>",
@@ -47,8 +48,9 @@ C2_STEP = [
 ]
 # C4 (BSRNN-Flow, H = 768): the cluster forward and the other kernels of its step that C2 does not launch
 C4_STEP = [
-    "urse::lstm_fwd_cluster2_kernel<24, 8, 1>",
-    "gemm_tn_dma_kernel<8, 2>",
+    "urse::lstm_fwd_cluster2_kernel<24, 8, 1, unsigned short>",
+    "_ZN4urse24lstm_fwd_cluster2_kernelILi24ELi8ELi1EDF16_EEvNS_12Cluster2ArgsE",      # its f16 instance (this c++filt does not know DF16_)
+    "gemm_tn_dma_kernel<8, 2, 0>",
 ]
 # Spills that exist, where they sit, and the bound they are held to (a regression of any of them fails this test):
 #  * the fused cluster forward allocates all 256 registers (160 of them resident weights); ONE register (a lane predicate of the prologue's x
@@ -60,6 +62,8 @@ KNOWN = {
     "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true>": dict(vgpr_spill_count=1, scratch_ops_in_mfma_loops=0),
     "urse::lstm_fwd_clusterx_kernel<unsigned short, false, false>": dict(vgpr_spill_count=1, scratch_ops_in_mfma_loops=0),
     "urse::lstm_bwd_split_kernel<2, 3>": dict(vgpr_spill_count=50, scratch_ops_in_mfma_loops=88),
+    #  * the mixed-operand dual weight-gradient GEMM (f16-forward training): two registers of its set-up are parked in scratch before the K loop
+    "gemm_tn_dual224_kernel<2, true>": dict(vgpr_spill_count=2, scratch_ops_in_mfma_loops=0),
 }
 
 

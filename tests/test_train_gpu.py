@@ -204,3 +204,52 @@ def test_full_size_c2_step_as_one_rccl_rank_runs_the_cooperative_kernels_beside_
         json.dump({"plain_ms_per_step": plain["ms_per_step"], "rccl_rank_ms_per_step": rccl["ms_per_step"],
                    "plain_final_loss": plain["final_loss"], "rccl_final_loss": rccl["final_loss"],
                    "gradient_buckets": gb, "cooperative_kernels_beside_rccl": co, "dist": rccl["config"]["dist"]}, f, indent=1)
+
+
+def test_inference_half_default_on_a_trained_checkpoint_validated_and_with_a_way_back(lib, tmp_path, monkeypatch):
+    """`inference.load_from_checkpoint` enhances a bf16-trained checkpoint with IEEE-half operands by default.
+    (a) on a checkpoint that HAS been trained (40 optimisation steps in bf16 through train_se.fit: weights that left their initialisation)
+    the f16 waveform stays within 1e-3 of the f32-mode waveform of the same checkpoint, the bf16 one does not need to;
+    (b) an unknown URSE_INFER_DTYPE is a ValueError that names the choices, not a KeyError;
+    (c) half has a range of 65504: a checkpoint whose activations leave it (weights scaled up here) gives a non-finite waveform, which
+    enhance_file notices and answers by re-running the utterance in the checkpoint's own operand type, with a warning."""
+    import warnings
+    from urgent2026_challenge_track1_amd import inference, train_se
+    from urgent2026_challenge_track1_amd.dataset import SyntheticPairDataset
+    os.chdir(tmp_path)
+    cfg = _cfg(train_tag="h", train_name="n", compute_dtype="bf16", model_configs={"num_channel": 32, "num_layer": 2},
+               train_set_path="synthetic:16", val_check_interval=40, num_train_epochs=5)
+    model, steps = train_se.fit(cfg, max_steps=40, log_every=20)
+    assert steps == 40
+    ck = [f for f in os.listdir(train_se.ckpt_dir(cfg)) if "val_loss" in f]
+    path = os.path.join(train_se.ckpt_dir(cfg), ck[0])
+    _, noisy, fs, L = SyntheticPairDataset(1, fs_list=(48000,), seconds=1.0)[0]
+    outs = {}
+    for want in ("f32", "f16", "bf16"):
+        monkeypatch.setenv("URSE_INFER_DTYPE", want)
+        m = inference.load_from_checkpoint(path)
+        m.eval()
+        assert m._ckpt_dtype == torch.bfloat16
+        outs[want] = inference.enhance_file(m, noisy[0], fs, "cuda").cpu()
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    print("trained checkpoint, 1 s @ 48 kHz: f16 vs f32 mode %.2e, bf16 vs f32 mode %.2e" % (rel(outs["f16"], outs["f32"]), rel(outs["bf16"], outs["f32"])))
+    assert rel(outs["f16"], outs["f32"]) <= 1e-3
+    assert rel(outs["f16"], outs["f32"]) < rel(outs["bf16"], outs["f32"])
+    monkeypatch.setenv("URSE_INFER_DTYPE", "fp16")
+    with pytest.raises(ValueError, match="bf16, f16, f32"):
+        inference.load_from_checkpoint(path)
+    monkeypatch.delenv("URSE_INFER_DTYPE")
+    m = inference.load_from_checkpoint(path)
+    m.eval()
+    core = m.se_model.core
+    assert core.compute_dtype == torch.float16
+    with torch.no_grad():
+        for n, p in m.se_model.named_parameters():
+            if "fc" in n and "band_split" in n and n.endswith("weight"):
+                p.mul_(3e5)                     # band-split outputs ~1e5 x their trained scale: beyond half's range, far inside bf16's
+        core.param_version += 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = inference.enhance_file(m, noisy[0], fs, "cuda")
+    assert any("checkpoint's own operand type" in str(x.message) for x in w), [str(x.message) for x in w]
+    assert core.compute_dtype == torch.bfloat16 and bool(torch.isfinite(y).all())

@@ -396,6 +396,8 @@ class BSRNNCore(nn.Module):
         """optional weight layouts this half layer's dispatch can reach (ops.model_lstm_layouts, narrowed by the path where the kernels are
         path-specific at this hidden size: the fused row-wave forward and its unfused fallbacks serve many short sequences, i.e. the band path)."""
         lay = ops.model_lstm_layouts()
+        if self.compute_dtype == torch.float16:
+            lay &= {"whhq", "wihq", "wx"}          # what ops.lstm_pack produces for f16 operands (ADVICE r5: the set never matched, 12 LSTMs were re-packed one by one)
         if self.H == 392 and path == "t":
             lay -= {"wx", "whhb_rw"}
         d = self._dims
@@ -514,10 +516,16 @@ class BSRNNCore(nn.Module):
         pre = self._gn_stats[1] if (self._gn_stats is not None and self._gn_stats[0].data_ptr() == skip.data_ptr() and
                                     self._gn_stats[0].shape == skip.shape) else None
         self._gn_stats = None
-        two = save and dt == torch.float16        # f16 forward with a backward to follow: x_n and h also in bf16 (operands of the weight-gradient GEMMs)
+        sm = self._seqmap(path, B, T, K)
+        # f16 forward with a backward to follow: x_n and h are operands of the weight-gradient GEMMs, whose other operand (the gate / output
+        # gradients) is bf16.  Where the library has the mixed-operand kernels for this half layer's shapes (round 6: f16 -> bf16 in registers
+        # behind the fragment read) the backward reads the f16 tensors themselves; otherwise the producing kernels write them once more in bf16.
+        two = save and dt == torch.float16
+        if two and ops.tn_act_f16_supported(M, N, 2 * H, 0, True) and \
+                ops.tn_act_f16_supported(M, 4 * H, N, H, True, sm["stride"], sm["seq_len"]):
+            two = False
         xn, stats, xn_b = ops.groupnorm_fwd(skip, self._p(p + "gamma", N), self._p(p + "beta", N), B, T, 1, K * N, N,
                                             d["Np"], 0, dt, GN_EPS, add=temb, stats=pre, bf16_copy=two or None)
-        sm = self._seqmap(path, B, T, K)
         fused = (ops.USE_RWX_LSTM and ops.USE_RW_LSTM and dt in ops.HALF_TYPES and pk.get(p + "wx") is not None and
                  sm["n_seq"] >= ops.RW_MIN_SEQ and not (ops.USE_CLUSTER_LSTM and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
                                                       ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None))
@@ -529,15 +537,20 @@ class BSRNNCore(nn.Module):
         hout_b = None
         if fused_c:
             # the cluster forward with the projection fused (the time path at C2)
-            gx, hout, c, self._cluster_err, hout_b = ops.lstm_fwd_clusterx(xn, pk[p + "wihq"], pk[p + "whhq"], pk[p + "bias"], N, H, d["Hp"], save=save,
-                                                                            bf16_copy=True, **sm)
-            if not two:
-                hout_b = None
+            r = ops.lstm_fwd_clusterx(xn, pk[p + "wihq"], pk[p + "whhq"], pk[p + "bias"], N, H, d["Hp"], save=save, bf16_copy=two, **sm)
+            gx, hout, c, self._cluster_err = r[:4]
+            hout_b = r[4] if two else None
         elif fused:
-            gx, hout, c, hout_b = ops.lstm_fwd_rwx(xn, pk[p + "wx"], pk[p + "bias"], N, H, d["Hp"], save=save, bf16_copy=True, **sm)
+            r = ops.lstm_fwd_rwx(xn, pk[p + "wx"], pk[p + "bias"], N, H, d["Hp"], save=save, bf16_copy=two, **sm)
+            gx, hout, c = r[:3]
+            hout_b = r[3] if two else None
         elif dt == torch.float16:
-            # f16 operands: the cluster forward where its plan fits (the time path at C2), else the streaming kernel
-            if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H not in ops.CLUSTER2_H and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and \
+            # f16 operands: the cluster forward where its plan fits (the time path at C2; H = 768, the flow DNN, forward only), else the streaming kernel
+            if ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H in ops.CLUSTER2_H and not two and \
+                    ops.lstm_cluster2_chunks(H, d["Hp"], **sm) is not None:
+                r = ops.lstm_fwd_cluster2(gx, pk[p + "whhq"], H, d["Hp"], save=save, **sm)
+                hout, c, self._cluster_err = r
+            elif ops.USE_CLUSTER_LSTM and pk.get(p + "whhq") is not None and H not in ops.CLUSTER2_H and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and \
                     ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None:
                 r = ops.lstm_fwd_cluster(gx, pk[p + "whhq"], H, d["Hp"], save=save, bf16_copy=two, **sm)
                 hout, c, self._cluster_err = r[:3]

@@ -1141,10 +1141,6 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
       for (int j = 1; j < NT; ++j) b[j] = frag((bb0 ^ ((unsigned)(j - 1) << 5)) + st, (bb1 ^ ((unsigned)(j - 1) << 5)) + st);
 #endif
     }
-    if constexpr (BH) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = frag_f16_to_bf16(b[j]);
-    }
 #ifdef T224_NO_MFMA
 #pragma unroll
     for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(b[j]));
@@ -1155,9 +1151,12 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
     __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j) {
+      // BH: one fragment at a time, right in front of its seven MFMAs (all five converted up front held ten more registers live: 2 spills)
+      const short8_t bj = BH ? frag_f16_to_bf16(b[j]) : b[j];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+      for (int i = 0; i < MT; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], bj, acc[i][j]);
+    }
 #if URSE_TN_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -2228,7 +2227,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
   const long g_tn_target_wgs = target_workgroups > 0 ? target_workgroups : 256;
   const bool act_f16 = dtype == URSE_BF16_ACT_F16;       // A = bf16 gradients, B = the forward's f16 activations (converted in registers)
   if (act_f16) {
-    if (!urse_gemm_tn_act_f16_supported(R, Mo, No, 0, colsum != nullptr) || perm_h != 0 || shift != 0 || period != 0) {
+    if (!urse_gemm_tn_act_f16_supported(R, Mo, No, 0, colsum != nullptr, 1, 0) || perm_h != 0 || shift != 0 || period != 0) {
       set_error("urse_gemm_tn: URSE_BF16_ACT_F16 serves the shapes urse_gemm_tn_act_f16_supported accepts (R%ld Mo%ld No%ld)", (long)R, (long)Mo, (long)No);
       return URSE_ERR_UNSUPPORTED;
     }
@@ -2264,6 +2263,7 @@ extern "C" int urse_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     q.rows_per_slice = rps;
     dim3 grid((unsigned)(tl * slices));
     note_launch(URSE_KV_TN_RING_T);
+    if (act_f16) note_launch(URSE_KV_TN_ACT_F16);
     launch_tn_dma(ntw, colsum ? 2 : 0, grid, (hipStream_t)stream, q, act_f16 ? 1 : 0);
     URSE_CHECK_LAUNCH("urse_gemm_tn");
     return URSE_OK;
@@ -2323,7 +2323,7 @@ extern "C" int urse_gemm_tn_grouped(const void* descs, int groups, int max_block
 
 // which weight-gradient shapes have a mixed-operand (URSE_BF16_ACT_F16) kernel: No2 == 0: urse_gemm_tn's transposed ring kernel with column sums
 // (the fc gradient [196, 784]); No2 > 0: urse_gemm_tn_dual's 224 x 320 kernel (row / mask conditions are checked by the call itself)
-extern "C" int urse_gemm_tn_act_f16_supported(int64_t R, int64_t Mo, int64_t No, int64_t No2, int with_colsum) {
+extern "C" int urse_gemm_tn_act_f16_supported(int64_t R, int64_t Mo, int64_t No, int64_t No2, int with_colsum, int64_t inner, int64_t period) {
   static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr, no224 = getenv("URSE_TN_NO_224") != nullptr;
   if (no_dma || R < 16384 || R >= (1L << 30)) return 0;
   if (No2 == 0) {
@@ -2331,7 +2331,10 @@ extern "C" int urse_gemm_tn_act_f16_supported(int64_t R, int64_t Mo, int64_t No,
     return (with_colsum && Mo < 512 && Mo >= 160 && No >= 512 && pad7 < pad8) ? 1 : 0;
   }
   const long No8 = (No + 7) & ~7L, V = No8 + No2 + (with_colsum ? 1 : 0);
-  return (!no224 && Mo >= 512 && Mo % 224 == 0 && No2 % 8 == 0 && R % 32 == 0 && V <= 640) ? 1 : 0;
+  if (inner < 1) inner = 1;
+  // (the shifted operand's step mask must cover the rows the shift reaches: whole sequences of `period` steps, shift = -/+ inner)
+  return (!no224 && Mo >= 512 && Mo % 224 == 0 && No2 % 8 == 0 && R % 32 == 0 && V <= 640 && period > 0 && period < (1L << 31) && inner < (1L << 31) &&
+          R % (inner * period) == 0 && (Mo / 224) * ((V + 319) / 320) <= 256) ? 1 : 0;
 }
 
 // dW1[Mo, No] += A^T B (+ colsum),  dW2[Mo, No2] += A^T B2' (B2' = B2 shifted / masked as in urse_gemm_tn) in ONE pass
@@ -2346,7 +2349,7 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
   static const bool no_dma = getenv("URSE_TN_NO_DMA") != nullptr;
   const bool act_f16 = dtype == URSE_BF16_ACT_F16;       // A = bf16 gradients, B / B2 = the forward's f16 activations
   if (act_f16) {
-    if (!urse_gemm_tn_act_f16_supported(R, Mo, No, No2, colsum != nullptr)) {
+    if (!urse_gemm_tn_act_f16_supported(R, Mo, No, No2, colsum != nullptr, inner, period)) {
       set_error("urse_gemm_tn_dual: URSE_BF16_ACT_F16 serves the shapes urse_gemm_tn_act_f16_supported accepts (R%ld Mo%ld No%ld No2%ld)", (long)R, (long)Mo, (long)No, (long)No2);
       return URSE_ERR_UNSUPPORTED;
     }
@@ -2393,6 +2396,7 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
         p.pad_[0] = e ? atol(e) : 2;
       }
       note_launch(URSE_KV_TN_DUAL);
+      if (act_f16) note_launch(URSE_KV_TN_ACT_F16);
       if (act_f16) hipLaunchKernelGGL((gemm_tn_dual224_kernel<2, true>), dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
       else if (p.pad_[0] == 3) hipLaunchKernelGGL(gemm_tn_dual224_kernel<3>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
       else hipLaunchKernelGGL(gemm_tn_dual224_kernel<2>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);

@@ -1,10 +1,13 @@
-// Generalised persistent cluster LSTM forward (bf16): the protocol and math of lstm_cluster.hip's forward kernel with the
+// Generalised persistent cluster LSTM forward (bf16 | f16 operands): the protocol and math of lstm_cluster.hip's forward kernel with the
 // geometry as template parameters, so that other hidden sizes fit the register file:
 //   NW waves per workgroup, QPW unit quads (4 units x 4 gates = one MFMA column tile) per wave, NSLAB = Hp / 32 K slabs;
 //   a wave keeps QPW x NSLAB B fragments resident and one A read from the LDS h tile feeds QPW MFMAs.
 // Instantiated for the flow model (H = 768: <24, 8, 1>, 24 workgroups per cluster, 4.7 MB of W_hh per direction spread
 // over their registers -- its 48..96 time-path sequences otherwise keep 3..6 streaming workgroups busy for 501 steps) and,
 // as a variant, for H = 392 (<13, 8, 2>).  Hand-off: tag in data, see lstm_cluster.hip.
+// TI (round 6): the operand format - the gate pre-activations read from gx, the resident W_hh fragments, the exchanged h and hout; bf16_t or f16_t
+// (IEEE half: the flow DNN's forward inside north_star's 1e-3, same MFMA rate).  The tag bit (bit 14 = the exponent's top bit) is clear for
+// |h| <= 1 in either format; the saved gate activations are bf16 in both.
 #include "urse_common.h"
 
 namespace urse {
@@ -56,7 +59,7 @@ __device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned of
 
 }  // namespace c2
 
-template <int NSLAB, int NW, int QPW>
+template <int NSLAB, int NW, int QPW, typename TI = bf16_t>
 __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args p) {
   using namespace c2;
   constexpr int NTHR = NW * 64, UW = NW * QPW * 4, HPB = NSLAB * 64;       // units per workgroup, bytes per h row
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
   const int H = p.H;
   constexpr int pitch = lds_frag_pitch(HPB);
   char* htile = smem;                                                        // [64][pitch]
-  bf16_t* hstage = reinterpret_cast<bf16_t*>(smem + C2ROWS * pitch);         // [64][UW]
+  TI* hstage = reinterpret_cast<TI*>(smem + C2ROWS * pitch);                 // [64][UW]
   unsigned* deadflag = reinterpret_cast<unsigned*>(smem + C2ROWS * pitch + C2ROWS * UW * 2);
   const int nq = (H + 3) >> 2;
   // operands of the recurrent product swapped as in lstm_cluster.hip (A = resident W_hh fragment, B = h fragment: same register contents):
@@ -226,8 +229,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
         const uint4 a = *reinterpret_cast<const uint4*>(ar + ks * 64);
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi)
-          acc[qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, breg[qi][ks]),
-                                                            __builtin_bit_cast(bf16x8_t, a), acc[qi], 0, 0, 0);
+          acc[qi] = mfma16<TI>(breg[qi][ks], a, acc[qi]);
       }
 #pragma unroll
       for (int qi = 0; qi < QPW; ++qi) {
@@ -237,13 +239,15 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
         // acc[g] = gate g of unit ul of the quad, sequence rt*16 + rl
         const float pre[4] = {acc[qi][0], acc[qi][1], acc[qi][2], acc[qi][3]};
         const uint2 gxv = gxc[qi][rt];
-        const float gi = pre[0] + __uint_as_float(gxv.x << 16), gf = pre[1] + __uint_as_float(gxv.x & 0xffff0000u);
-        const float gg = pre[2] + __uint_as_float(gxv.y << 16), go = pre[3] + __uint_as_float(gxv.y & 0xffff0000u);
+        float x0, x1, x2, x3;
+        unpack2<TI>(gxv.x, x0, x1);
+        unpack2<TI>(gxv.y, x2, x3);
+        const float gi = pre[0] + x0, gf = pre[1] + x1, gg = pre[2] + x2, go = pre[3] + x3;
         const float iv = sigmoidf_(gi), fv = sigmoidf_(gf), gv = tanhf_(gg), ov = sigmoidf_(go);
         const float cv = fv * cst[qi][rt] + iv * gv;
         cst[qi][rt] = cv;
         const float hv = uvalid ? ov * tanhf_(cv) : 0.f;
-        if (qvalid) hstage[(rt * 16 + rl) * UW + (w * QPW + qi) * 4 + ul] = f32_to_bf16(hv);
+        if (qvalid) hstage[(rt * 16 + rl) * UW + (w * QPW + qi) * 4 + ul] = from_f32<TI>(hv);
         gsave[qi][rt].x = (unsigned)f32_to_bf16(iv) | ((unsigned)f32_to_bf16(fv) << 16);
         gsave[qi][rt].y = (unsigned)f32_to_bf16(gv) | ((unsigned)f32_to_bf16(ov) << 16);
         csave[qi][rt] = cv;
@@ -280,12 +284,15 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
 }
 
 template <int NSLAB, int NW, int QPW>
-static int launch_cluster2(const Cluster2Args& p, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster2_kernel<NSLAB, NW, QPW>),
+static int launch_cluster2(const Cluster2Args& p, int f16, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, bf16_t>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, f16_t>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   const size_t lds = (size_t)C2ROWS * lds_frag_pitch(NSLAB * 64) + (size_t)C2ROWS * NW * QPW * 4 * 2 + 16;
-  hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<NSLAB, NW, QPW>), dim3(p.C * p.ncl, 2), dim3(NW * 64), lds, st, p);
+  if (f16) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, f16_t>), dim3(p.C * p.ncl, 2), dim3(NW * 64), lds, st, p);
+  else hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, bf16_t>), dim3(p.C * p.ncl, 2), dim3(NW * 64), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_cluster2_fwd");
   return URSE_OK;
 }
@@ -326,8 +333,9 @@ extern "C" int urse_lstm_cluster2_plan(int H, int Hp, int n_seq, int reserved_cu
 
 extern "C" int urse_lstm_cluster2_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, int64_t ldh, float* c, void* hx,
                                       void* err_flag, int H, int Hp, int n_seq, int seq_len, int64_t inner, int64_t outer,
-                                      int64_t stride, int save, int reserved_cus, void* stream) {
+                                      int64_t stride, int save, int reserved_cus, int dtype, void* stream) {
   URSE_CHECK_ARG(gx && whhq && hout && hx && err_flag && (c || !save), "urse_lstm_cluster2_fwd: null pointer");
+  URSE_CHECK_ARG(dtype == URSE_BF16 || dtype == URSE_F16, "urse_lstm_cluster2_fwd: operands are bf16 or f16 (dtype %d)", dtype);
   int64_t plan[4];
   int rc = urse_lstm_cluster2_plan(H, Hp, n_seq, reserved_cus, plan);
   if (rc) return rc;
@@ -343,6 +351,6 @@ extern "C" int urse_lstm_cluster2_fwd(void* gx, int64_t ldg, const void* whhq, v
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(hx, 0, sizeof(bf16_t) * plan[3], st);      // every tag bit starts clear
   note_launch(URSE_KV_LSTM_FWD_CLUSTER2);
-  if (Hp / 32 == 24) return launch_cluster2<24, 8, 1>(p, st);
-  return launch_cluster2<13, 8, 2>(p, st);
+  if (Hp / 32 == 24) return launch_cluster2<24, 8, 1>(p, dtype == URSE_F16, st);
+  return launch_cluster2<13, 8, 2>(p, dtype == URSE_F16, st);
 }

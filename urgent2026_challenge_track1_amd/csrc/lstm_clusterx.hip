@@ -773,7 +773,10 @@ extern "C" int urse_diag_clusterx_stamps(void* host_out) {
 #endif
 
 extern "C" int urse_lstm_clusterx_supported(int N, int Np, int H, int Hp) {
-  return (N > 0 && N <= 224 && Np == 224 && Hp == 416 && H > 0 && H % XUW == 0 && H <= 416) ? 1 : 0;      // (whole workgroups of 56 units: H = 392)
+  // the projection multiplies input channels 0 .. 199 (six slabs of W_ih + the lr = 0 lanes of the seventh, carried in chunk 49 of the h
+  // tile): N in 201 .. 224 would silently lose channels; the 49-chunk gather, XNSH and XUW are written for H = 392 (7 workgroups x 56 units): a smaller
+  // multiple of 56 would wait for chunks nobody publishes.  The model's shape is N = 196, H = 392.
+  return (N > 0 && N <= 200 && Np == 224 && H == 392 && Hp == 416) ? 1 : 0;
 }
 
 extern "C" int urse_lstm_clusterx_hx_elems(int H, int Hp, int n_seq, int reserved_cus, int64_t* elems) {

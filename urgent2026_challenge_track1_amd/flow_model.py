@@ -33,8 +33,9 @@ class FlowBSRNNCore(BSRNNCore):
     band_groups = ("bsx", "bsy", "gdm", "gdr")
 
     def __init__(self, input_dim=769, num_channel=384, num_layer=6, compute_dtype=torch.bfloat16):
-        if compute_dtype == torch.float16:
-            raise NotImplementedError("the f16 forward mode covers the discriminative BSRNN (BSRNN_SE); the flow DNN runs bf16 or f32")
+        # compute_dtype f16 (round 6): the FORWARD of the flow DNN with IEEE-half operands - what the Euler sampler chains 15 times; the enhanced
+        # waveform then stays inside north_star's 1e-3 of the f32 oracle at bf16's speed (tests/test_c4_fullsize_gpu.py).  Training keeps bf16 / f32:
+        # forward() refuses a gradient-recording pass in f16 (the flow decoder's backward has no mixed-operand form).
         super().__init__(input_dim, num_channel, num_layer, 48000, False, 1, compute_dtype)
         self._pf = None
 
@@ -101,7 +102,7 @@ class FlowBSRNNCore(BSRNNCore):
                 self._packed[key] = _view(bf, hd).view(-1)
 
     # ---- forward pieces ---------------------------------------------------------------------------------------
-    def front_fwd(self, x, y):
+    def front_fwd(self, x, y, save=True):
         """two band splits -> concat on channels -> condition_fc  (bsrnn_flowse.py:283-287)."""
         B, T, F, _ = x.shape
         dt, dev, N, pk = self.compute_dtype, x.device, self.N, self._packed
@@ -109,8 +110,8 @@ class FlowBSRNNCore(BSRNNCore):
         W2 = ops.kpad(2 * N, dt)
         cat = torch.zeros(B, T, K, W2, dtype=dt, device=dev) if W2 != 2 * N else \
             torch.empty(B, T, K, W2, dtype=dt, device=dev)
-        _, sx = self.bandsplit_fwd(x, "bsx", cat, W2, 0)
-        _, sy = self.bandsplit_fwd(y, "bsy", cat, W2, N)
+        _, sx = self.bandsplit_fwd(x, "bsx", cat, W2, 0, save=save)
+        _, sy = self.bandsplit_fwd(y, "bsy", cat, W2, N, save=save)
         z = torch.empty(B, T, K, N, dtype=torch.float32, device=dev)
         ops.gemm_nt(cat.view(B * T * K, W2), pk["cfc.w"], self._p("cfc.b", N), out=z.view(B * T * K, N))
         return z, (cat, sx, sy)
@@ -222,6 +223,8 @@ class FlowBSRNNCore(BSRNNCore):
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         ops.poll_kernel_errors(x_ri.device)      # deferred check (the sampler calls this 15 times: no host stall per call)
         if train:
+            if self.compute_dtype == torch.float16:
+                raise NotImplementedError("compute_dtype f16 is the flow DNN's INFERENCE arithmetic (sampler / enhance); train it in bf16 or f32")
             anchor = self._flat.new_zeros((), requires_grad=True)
             self.mark_used_bands(self._band_tables(x_ri.shape[2], self.compute_dtype, x_ri.device)["K"])
             z = _FlowFrontFn.apply(anchor, x_ri, y_ri, self)
@@ -229,7 +232,7 @@ class FlowBSRNNCore(BSRNNCore):
                 z = _DualPathFn.apply(z, self, l, "t", tembs[l])
                 z = _DualPathFn.apply(z, self, l, "f")
             return _GradDecFn.apply(z, x_ri, self, float(sign))
-        z, _ = self.front_fwd(x_ri, y_ri)
+        z, _ = self.front_fwd(x_ri, y_ri, save=False)
         for l in range(self.num_layer):
             z, _ = self.dualpath_fwd(z, l, "t", False, tembs[l])
             z, _ = self.dualpath_fwd(z, l, "f", False)

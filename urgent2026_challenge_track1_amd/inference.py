@@ -13,31 +13,56 @@ from .dataset import read_audio, write_audio
 from .flow_model import FlowSEModel
 
 
+_INFER_DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
+def _core(model):
+    return model.se_model.core if isinstance(model, SEModel) else model.dnn
+
+
 def load_from_checkpoint(path, map_location="cuda"):
-    """inference.py:30-33: try the discriminative model, fall back to the flow model."""
+    """inference.py:30-33: try the discriminative model, fall back to the flow model.
+
+    Enhanced waveforms are what this entry point produces, and north_star asks them within 1e-3 of the f32 reference arithmetic: a checkpoint
+    trained with bf16 operands is ENHANCED with IEEE-half operands (same bytes, same MFMA rate, 11 instead of 8 significant bits: 5.4e-4 against
+    4.3e-3 at B32 x 4 s, tests/test_c2_fullsize_gpu.py; the flow DNN's 15-step sampler: tests/test_c4_fullsize_gpu.py).  Half has a range of
+    65504: a checkpoint whose activations leave it gives non-finite output, which `enhance_file` detects on every utterance and answers by
+    going back to the checkpoint's own operand type (warning once) - ADVICE r5.  URSE_INFER_DTYPE = bf16 | f16 | f32 overrides the default;
+    f32 checkpoints stay f32."""
+    want = os.environ.get("URSE_INFER_DTYPE", "f16")
+    if want not in _INFER_DTYPES:
+        raise ValueError("URSE_INFER_DTYPE=%r: expected one of %s" % (want, ", ".join(sorted(_INFER_DTYPES))))
     try:
         model = SEModel.load_from_checkpoint(path, map_location=map_location)
     except Exception:
-        return FlowSEModel.load_from_checkpoint(path, map_location=map_location)
-    # Enhanced waveforms are what this entry point produces, and north_star asks them within 1e-3 of the f32 reference arithmetic: a checkpoint
-    # trained with bf16 operands is ENHANCED with f16 operands (same bytes, same MFMA rate, 11 instead of 8 significant bits: 5.4e-4 against
-    # 4.3e-3 at B32 x 4 s, tests/test_c2_fullsize_gpu.py).  URSE_INFER_DTYPE = bf16 | f16 | f32 overrides; f32 checkpoints stay f32.
-    want = os.environ.get("URSE_INFER_DTYPE", "f16")
-    core = model.se_model.core
+        model = FlowSEModel.load_from_checkpoint(path, map_location=map_location)
+    core = _core(model)
+    model._ckpt_dtype = core.compute_dtype
     if core.compute_dtype != torch.float32 or want == "f32":
-        core.compute_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[want]
+        core.compute_dtype = _INFER_DTYPES[want]
     return model
+
+
+def _enhance(model, wav, length, sr):
+    if isinstance(model, SEModel):                           # inference.py:55-58
+        return model.se_model(wav, length, sr)[0].contiguous()
+    return model.enhance(wav, sr, length).contiguous()
 
 
 def enhance_file(model, wav_np, sr, device):
     wav = torch.as_tensor(wav_np).float().to(device).view(1, -1)
     length = torch.tensor([wav.shape[-1]])
     with torch.no_grad():
-        if isinstance(model, SEModel):                       # inference.py:55-58
-            enhanced, _ = model.se_model(wav, length, sr)
-        else:
-            enhanced = model.enhance(wav, sr, length)
-        enhanced = enhanced.contiguous()
+        enhanced = _enhance(model, wav, length, sr)
+        core = _core(model)
+        fallback = getattr(model, "_ckpt_dtype", core.compute_dtype)
+        if core.compute_dtype == torch.float16 and fallback != torch.float16 and not bool(torch.isfinite(enhanced).all()):
+            # (the result is about to be copied to the host anyway: this check is one more small reduction per utterance, not a new stall)
+            import warnings
+            warnings.warn("non-finite enhanced waveform with IEEE-half operands (an activation left half's range): continuing with the "
+                          "checkpoint's own operand type %s" % str(fallback).replace("torch.", ""))
+            core.compute_dtype = fallback
+            enhanced = _enhance(model, wav, length, sr)
         scratch = torch.empty(1, dtype=torch.int32, device=enhanced.device)
         call("peak_normalize", enhanced, enhanced.numel(), 0.9, scratch, stream_ptr())
     return enhanced

@@ -12,6 +12,7 @@ from ._lib import call, require_cuda, stream_ptr
 
 WIN_RECT, WIN_HANN = 0, 1
 F32, BF16, F16 = 0, 1, 2       # include/urse.h: URSE_F32 / URSE_BF16 / URSE_F16
+BF16_ACT_F16 = 3               # URSE_BF16_ACT_F16: weight-gradient GEMMs with bf16 gradients against the forward's f16 activations
 HALF_TYPES = (torch.bfloat16, torch.float16)   # 16-bit operand formats: same kernels, layouts and padding; f16 is the FORWARD-only format
 
 
@@ -50,7 +51,7 @@ def timed_call(tname, name, *args):
 KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_ring", "nt_grouped_128", "tn_ring", "tn_ring_t",
                    "tn_dual", "tn_128", "tn_grouped", "lstm_fwd_stream", "lstm_fwd_wide", "lstm_fwd_cluster",
                    "lstm_fwd_cluster2", "lstm_bwd_stream16", "lstm_bwd_stream32", "lstm_bwd_cluster", "lstm_bwd_split",
-                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "_unused24", "lstm_fwd_rwx", "lstm_bwd_nsplit",
+                   "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "tn_act_f16", "lstm_fwd_rwx", "lstm_bwd_nsplit",
                    "lstm_fwd_clusterx", "lstm_bwd_nsplit3")
 
 
@@ -179,11 +180,30 @@ def gemm_tn(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=
     R = A.shape[0]
     Mo = A.shape[1] if Mo is None else Mo
     No = Bm.shape[1] if No is None else No
-    assert Bm.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and A.dtype == Bm.dtype
+    assert Bm.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1
     assert out.dtype == torch.float32 and out.stride(-1) == 1
     call("gemm_tn", A, A.stride(0), Bm, Bm.stride(0), out, out.stride(0), colsum, R, Mo, No, shift, inner, period,
-         invalid_step, perm_h, _dt(A), int(target_wgs), stream_ptr())
+         invalid_step, perm_h, _tn_dt(A, Bm), int(target_wgs), stream_ptr())
     return out
+
+
+def _tn_dt(A, *Bs):
+    """operand code of a weight-gradient GEMM: the common dtype, or BF16_ACT_F16 for bf16 gradients against f16 activations (f16-forward training:
+    the forward's x_n / h are read where they are and converted to bf16 in the kernel's registers - no second copy is written)."""
+    if A.dtype == torch.bfloat16 and all(b.dtype == torch.float16 for b in Bs):
+        return BF16_ACT_F16
+    assert all(b.dtype == A.dtype for b in Bs), (A.dtype, [b.dtype for b in Bs])
+    return _dt(A)
+
+
+# f16-forward training: weight gradients read the f16 activations directly where the library has the mixed-operand kernel for the shape;
+# 0: the producing kernels write x_n and h a second time in bf16 (round 5: +3 to 4 % on the step, 12.5 GB of extra writes)
+TN_ACT_F16 = os.environ.get("URSE_TN_ACT_F16", "1") != "0"
+
+
+def tn_act_f16_supported(R, Mo, No, No2=0, with_colsum=True, inner=1, period=0):
+    return TN_ACT_F16 and bool(_lib.load().urse_gemm_tn_act_f16_supported(int(R), int(Mo), int(No), int(No2), int(bool(with_colsum)),
+                                                                        int(inner), int(period)))
 
 
 def gemm_tn_dual(A, Bm, out, colsum, B2, out2, Mo, No, No2, shift, inner, period, invalid_step, perm_h=0, target_wgs=0):
@@ -191,9 +211,9 @@ def gemm_tn_dual(A, Bm, out, colsum, B2, out2, Mo, No, No2, shift, inner, period
     require_cuda(A, Bm, B2, out, out2)
     R = A.shape[0]
     assert Bm.shape[0] == R and B2.shape[0] == R and A.stride(1) == 1 and Bm.stride(1) == 1 and B2.stride(1) == 1
-    assert out.dtype == torch.float32 and out2.dtype == torch.float32 and A.dtype == Bm.dtype == B2.dtype
+    assert out.dtype == torch.float32 and out2.dtype == torch.float32
     call("gemm_tn_dual", A, A.stride(0), Bm, Bm.stride(0), out, out.stride(0), colsum, B2, B2.stride(0), out2, out2.stride(0), R,
-         Mo, No, No2, shift, inner, period, invalid_step, perm_h, _dt(A), int(target_wgs), stream_ptr())
+         Mo, No, No2, shift, inner, period, invalid_step, perm_h, _tn_dt(A, Bm, B2), int(target_wgs), stream_ptr())
 
 
 def tn_desc(A, Bm, out, colsum=None, Mo=None, No=None, shift=0, inner=1, period=0, invalid_step=0, perm_h=0):
@@ -481,6 +501,11 @@ PREFETCH_RESERVED_CUS = 0
 # (the flow model's split BPTT; any cluster kernel) is then planned on the CUs that are left - or REFUSED and replaced by its streaming twin -
 # instead of spinning on a workgroup that RCCL keeps off the chip.
 COMM_RESERVED_CUS = 0
+# ranks that share THIS device (bench.py / train_se set it when a non-RCCL backend puts several processes on one GPU, the gloo test path): two
+# processes with a cooperative grid each - clusters that spin until the whole cluster has arrived, ~250 workgroups of 160 KB LDS - cannot be
+# co-resident and would keep each other's partners off the chip until the spin bound trips.  No cooperative plan is made then (round 5
+# guarded the N-split only); the streaming kernels run.
+SHARED_GPU_RANKS = 1
 RCCL_MAX_CHANNELS = int(os.environ.get("URSE_RCCL_MAX_CHANNELS", "32"))
 COOP_REFUSALS = 0                # cooperative plans refused because of reserved CUs (diagnostic: counted, never silent)
 
@@ -542,6 +567,8 @@ def _note_refusal(fits_without_reservation):
 def lstm_cluster_plan(H, Hp, n_seq):
     """None if the persistent cluster kernel does not support this shape."""
     import ctypes
+    if SHARED_GPU_RANKS > 1:
+        return None
     plan = (ctypes.c_int64 * 6)()
     lib = _lib.load()
     if lib.urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus(), plan) != 0:
@@ -620,6 +647,8 @@ CLUSTER2_H = tuple(int(v) for v in os.environ.get("URSE_LSTM_CLUSTER2_H", "768")
 
 def lstm_cluster2_plan(H, Hp, n_seq):
     import ctypes
+    if SHARED_GPU_RANKS > 1:
+        return None
     plan = (ctypes.c_int64 * 4)()
     if _lib.load().urse_lstm_cluster2_plan(H, Hp, n_seq, reserved_cus(), plan) != 0:
         _note_refusal(lambda: _lib.load().urse_lstm_cluster2_plan(H, Hp, n_seq, 0, plan) == 0)
@@ -652,7 +681,7 @@ CLUSTER2_MAX_CHUNKS = int(os.environ.get("URSE_LSTM_CLUSTER2_MAX_CHUNKS", "6"))
 
 
 def lstm_fwd_cluster2(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, save=True):
-    """generalised persistent cluster LSTM forward (bf16): see csrc/lstm_cluster2.hip."""
+    """generalised persistent cluster LSTM forward (bf16 | f16 operands, by gx.dtype): see csrc/lstm_cluster2.hip."""
     chunks = lstm_cluster2_chunks(H, Hp, n_seq, seq_len, inner, outer, stride)
     M, dev = gx.shape[0], gx.device
     ldh = kpad(2 * H, gx.dtype)
@@ -671,7 +700,7 @@ def lstm_fwd_cluster2(gx, whhq, H, Hp, n_seq, seq_len, inner, outer, stride, sav
             r0, r1 = s0 * seq_len, (s0 + n) * seq_len
             g_, h_, c_ = gx[r0:r1], hout[r0:r1], (c[r0:r1] if save else None)
         timed_call("lstm_fwd_time" if stride > 1 else "lstm_fwd_band", "lstm_cluster2_fwd", g_, gx.stride(0), whhq, h_, ldh, c_, hx,
-                   err, H, Hp, n, seq_len, inner, outer, stride, int(save), reserved_cus(), stream_ptr())
+                   err, H, Hp, n, seq_len, inner, outer, stride, int(save), reserved_cus(), _dt(gx), stream_ptr())
     return hout, c, err
 
 
@@ -832,6 +861,8 @@ SPLIT_BWD_MIN_H = int(os.environ.get("URSE_LSTM_SPLIT_BWD_MIN_H", "512"))
 def lstm_split_plan(H, n_seq):
     """None if the split BPTT kernel does not support this shape."""
     import ctypes
+    if SHARED_GPU_RANKS > 1:
+        return None
     plan = (ctypes.c_int64 * 4)()
     if _lib.load().urse_lstm_split_plan(H, n_seq, reserved_cus(), plan) != 0:
         _note_refusal(lambda: _lib.load().urse_lstm_split_plan(H, n_seq, 0, plan) == 0)
@@ -887,9 +918,7 @@ NSPLIT_MAX_SEQ = int(os.environ.get("URSE_LSTM_NSPLIT_MAX_SEQ", "2304"))       #
 NSPLIT_MEMBERS = int(os.environ.get("URSE_NSPLIT_MEMBERS", "2"))
 
 
-# ranks that share THIS device (bench.py / train_se set it when a non-RCCL backend puts several processes on one GPU): two processes with a
-# persistent pair-spinning grid each can keep each other's partners off the chip until the spin bound trips - the N-split is not planned then
-SHARED_GPU_RANKS = 1
+# (SHARED_GPU_RANKS: defined beside the CU reservations above; the N-split is not planned on a shared GPU either)
 
 
 def _nsplit_reserved():

@@ -180,7 +180,9 @@ def fit(cfg, max_steps=None, log_every=50):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("URSE_DIST_BACKEND", "nccl") != "nccl":
         ndev = max(1, torch.cuda.device_count())
-        ops.SHARED_GPU_RANKS = -(-world // ndev)      # ranks per device: pair-spinning grids of two processes on one GPU are not planned (ops.lstm_nsplit_plan)
+        # ranks per device ON THIS NODE (the global world size made a 2 x 8 job look shared): cooperative grids of two processes on one
+        # GPU are not planned (ops.lstm_nsplit_plan, ops.lstm_cluster_plan, ...)
+        ops.SHARED_GPU_RANKS = -(-int(os.environ.get("LOCAL_WORLD_SIZE", world)) // ndev)
         local %= ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -228,20 +230,24 @@ def fit(cfg, max_steps=None, log_every=50):
     policy, warned = getattr(cfg, "unsupported_augmentation", "warn"), False
     for epoch in range(epoch0, cfg.num_train_epochs):
         # the reference never advances the sampler epoch (quirk C.3: on_train_epoch_start is not a DataModule hook)
-        equalise_batch_counts(dm.train_batch_sampler, world, dev)
+        n_batches, in_epoch = equalise_batch_counts(dm.train_batch_sampler, world, dev), 0
         for batch in DevicePrefetcher(train_loader, dev, skipped):
             loss = model.training_step(batch)
             loss.backward()
             model.optimizer_step(opt, reducer)
             step += 1
+            in_epoch += 1
             hit = bool(skipped)
+            # the points at which this rank may leave the loop or write a checkpoint: the agreement below runs there too (a run that
+            # ended by max_steps / its last epoch between two log lines finished without the NotImplementedError the policy promises)
+            leaving = (max_steps is not None and step >= max_steps) or step % cfg.val_check_interval == 0 or in_epoch == n_batches
             if policy == "raise" and world > 1:
                 # every rank must leave the loop in the same step: a rank that raised alone would leave its peers in the next
                 # step's bucket all-reduce until the collective times out - agree on the flag first.  The agreement is a blocking
                 # collective + a host read (it drains the queue: no prefetch / second-queue overlap across it), so it runs when the log line is due,
                 # not every step: under DDP the raise policy stops within log_every steps of the first unsupported draw, on every rank
                 # at the same step
-                if step % log_every == 0:
+                if step % log_every == 0 or leaving:
                     flag = torch.tensor([1.0 if hit else 0.0], device=dev)
                     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                     hit = bool(flag.item() > 0)
