@@ -501,11 +501,20 @@ __device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3)
 // activations against bf16 gradients; a mixed-operand MFMA does not exist).  v_cvt_f32_f16 (+ sdwa for the high halves) and v_cvt_pk_bf16_f32:
 // 12 vector instructions per fragment, issued under the MFMAs - the kernel waits for bytes, not for the vector ALU.  The values differ from the
 // bf16 copy the forward kernels used to write beside the f16 one only by double rounding (f32 -> f16 -> bf16 instead of f32 -> bf16).
+__device__ __forceinline__ unsigned pair_f16_to_bf16(unsigned v) {      // one dword = two elements: two conversions to f32, one packed conversion back
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(__builtin_convertvector(__builtin_bit_cast(f16x2_, v), f32x2_), bf16x2_));
+}
 __device__ __forceinline__ short8_t frag_f16_to_bf16(short8_t v) {
-  typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
-  typedef float f32x8_ __attribute__((ext_vector_type(8)));
-  typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
-  return __builtin_bit_cast(short8_t, __builtin_convertvector(__builtin_convertvector(__builtin_bit_cast(f16x8_, v), f32x8_), bf16x8_));
+  // dword by dword (three instructions and two temporaries each, so that a conversion fits between two MFMAs), the result BUILT from the four dwords:
+  // written as `d[k] = f(d[k])` on the vector in an unrolled loop, this compiler (ROCm 7.2 clang 22) converts element 0 twice and replicates it -
+  // found by tests/test_gemm_gpu.py, reproduced on a four-line kernel
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ d = __builtin_bit_cast(u32x4_, v);
+  const u32x4_ o = u32x4_{pair_f16_to_bf16(d[0]), pair_f16_to_bf16(d[1]), pair_f16_to_bf16(d[2]), pair_f16_to_bf16(d[3])};
+  return __builtin_bit_cast(short8_t, o);
 }
 
 // CVT: 0 both operands bf16; 1 the A operand is IEEE half (the transposed fc gradient: A = h); 2 the B operand is
@@ -973,6 +982,17 @@ __device__ __forceinline__ void glds16u(const char* gsrc, unsigned dst) {
 #pragma clang diagnostic pop
 
 // BH: the right-hand operands [B | B2 | ones] are IEEE half (the forward's f16 activations), converted to bf16 behind the fragment read
+#ifndef URSE_TN224_CVT_INTERLEAVE
+#define URSE_TN224_CVT_INTERLEAVE 1
+#endif
+#ifdef T224STAMP     // timing diagnostics (scripts/stamps.py): shader-clock stamps of wave 0 of workgroup T224STAMP, [iteration = two stages][8]: 0 top, 1 own DMAs
+                     // landed (vmcnt 0), 2 behind the barrier, 3 the next two stages' DMAs issued, 4 first stage computed (fragment reads + 35 MFMAs), 5 second
+                     // stage computed.  T224STAMP_SPLIT: 6 = the first stage's fragment reads complete (an lgkmcnt(0) the shipping kernel does not have)
+__device__ unsigned long long g_t224stamps[512 * 8];
+#define T2ST(slot) do { if (stamp_on && it_ < 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_t224stamps[it_ * 8 + (slot)] = t_; } } while (0)
+#else
+#define T2ST(slot) do { } while (0)
+#endif
 template <int DEPTH, bool BH = false>      // stages in flight: 2 (two stages per barrier) or 3 (one barrier per stage).  A template, not a run-time switch: with both loops in one kernel
                           // the register allocation of BOTH got worse (9 spilled registers where round 4's kernel had none) and the second queue's
                           // weight gradients ran 16 % longer - 5.7 ms per train step that hid the round's other gains until a round-over-round A/B
@@ -996,6 +1016,10 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
   const int nk = (int)((r_end - r_begin) / 32);            // the host guarantees whole 32-row stages (R and the slices are multiples of 32)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 2, wn = w & 3;
+#ifdef T224STAMP
+  const bool stamp_on = blockIdx.x == T224STAMP && w == 0;
+  int it_ = 0;
+#endif
 
   // ---- DMA sources.  The issue path is what bounds a ring kernel of this shape (two waves per SIMD, in-order issue): every lane keeps
   // a 64-bit source pointer and a 32-bit step per DMA; a lane without data (padding columns) points at the zero page with step 0, the
@@ -1111,6 +1135,52 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
   const short8_t ones8 = short8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   (void)ones8;
   const unsigned sA = (unsigned)(wm * MT) << 5, sB = (unsigned)(wn * NT) << 5;
+  auto compute_h = [&](int sl) __attribute__((always_inline)) {
+    // BH: B fragments are read two ahead and converted one ahead of their MFMAs (f16 -> bf16, three vector instructions per dword between two MFMAs);
+    // all five read and converted up front cost the 12 registers this kernel does not have (255 of 256 in the bf16 form)
+    const unsigned st = lds_u + (unsigned)sl * STAGE;
+    short8_t a[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[i] = frag((ba0 ^ (sA + (i << 5))) + st, (ba1 ^ (sA + (i << 5))) + st);
+    // (address selects, not branches: the whole stage stays ONE basic block, which is what lets the scheduler groups below interleave it)
+    const bool w3 = wn == 3;
+    auto bfrag = [&](int j) __attribute__((always_inline)) -> short8_t {
+      const unsigned seg = (w3 ? (j == 0 ? 15u : (unsigned)(j - 1)) : (unsigned)(wn * NT + j)) << 5;
+      const bool small = w3 && j > 0;                      // the 64-column image (columns 256 .. 319)
+      const unsigned x0 = small ? bb0 : ba0, x1 = small ? bb1 : ba1, off = small ? 0u : 16384u;
+      return frag((x0 ^ seg) + st + off, (x1 ^ seg) + st + off);
+    };
+    short8_t bc = bfrag(0), bn = bfrag(1);
+    bc = frag_f16_to_bf16(bc);
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      short8_t bnn = bn;
+      if (j + 2 < NT) bnn = bfrag(j + 2);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], bc, acc[i][j]);
+      if (j + 1 < NT) bc = frag_f16_to_bf16(bn);
+      bn = bnn;
+    }
+#if URSE_TN_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if URSE_TN224_CVT_INTERLEAVE
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 4, 0);         // the A fragments, b[0], b[1]
+    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                 // convert b[0]
+#pragma unroll
+    for (int j = 0; j + 1 < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // b[j + 1]'s conversion (12) and b[j + 2]'s address selects (~10) spread over the gaps
+        if (i == 4 && j + 2 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // b[j + 2]
+      }
+    __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
+#endif
+  };
   auto compute = [&](int sl) __attribute__((always_inline)) {
     const unsigned st = lds_u + (unsigned)sl * STAGE;
     short8_t a[MT], b[NT];
@@ -1141,6 +1211,10 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
       for (int j = 1; j < NT; ++j) b[j] = frag((bb0 ^ ((unsigned)(j - 1) << 5)) + st, (bb1 ^ ((unsigned)(j - 1) << 5)) + st);
 #endif
     }
+#ifdef T224STAMP_SPLIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (sl == 0 || sl == 2) T2ST(6);
+#endif
 #ifdef T224_NO_MFMA
 #pragma unroll
     for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(b[j]));
@@ -1152,10 +1226,8 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
 #endif
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      // BH: one fragment at a time, right in front of its seven MFMAs (all five converted up front held ten more registers live: 2 spills)
-      const short8_t bj = BH ? frag_f16_to_bf16(b[j]) : b[j];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], bj, acc[i][j]);
+      for (int i = 0; i < MT; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
     }
 #if URSE_TN_SETPRIO
     __builtin_amdgcn_s_setprio(0);
@@ -1179,7 +1251,8 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       issue((slot + 3) & 3);
-      compute(slot);
+      if constexpr (BH) compute_h(slot);
+      else compute(slot);
       slot = (slot + 1) & 3;
     }
   } else {
@@ -1187,14 +1260,25 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
   issue(1);
   int slot = 0;
   for (int kt = 0; kt < nk; kt += 2) {
+    T2ST(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    T2ST(1);
     __builtin_amdgcn_s_barrier();
+    T2ST(2);
     issue(slot ^ 2);
     issue((slot ^ 2) + 1);
+    T2ST(3);
     const int nh = kt + 1 < nk ? 2 : 1;
 #pragma unroll 1
-    for (int h = 0; h < nh; ++h) compute(slot + h);
+    for (int h = 0; h < nh; ++h) {
+      if constexpr (BH) compute_h(slot + h);
+      else compute(slot + h);
+      T2ST(4 + h);
+    }
     slot ^= 2;
+#ifdef T224STAMP
+    ++it_;
+#endif
   }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (zero page) DMAs must not outlive the workgroup
@@ -2419,3 +2503,9 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
   URSE_CHECK_LAUNCH("urse_gemm_tn_dual");
   return URSE_OK;
 }
+
+#ifdef T224STAMP
+extern "C" int urse_diag_tn224_stamps(void* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_t224stamps), sizeof(unsigned long long) * 512 * 8);
+}
+#endif

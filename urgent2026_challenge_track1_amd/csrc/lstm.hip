@@ -251,9 +251,20 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_kernel(LstmFwdArgs p) {
 // KH = 2 (f32 operands at H > 624: the [16][4H] f32 tile of the flow model's H = 768 is 196 KB, more than a CU's LDS): the tile holds one HALF of
 // the gate-gradient columns at a time; a wave keeps the gradients of its units in registers, the recurrent product runs half by half over the
 // matching half of the k range into the same accumulators (same k order as one pass: bit-identical to a tile that would fit).
+#ifdef BWSTAMP      // timing diagnostics (scripts/stamps.py): shader-clock stamps of wave 0 of workgroup BWSTAMP, [step][16]: 0 top of the step, 1 .. MAXUT after the cell
+                    // update of unit tile ui (its inputs loaded, the gradients in the LDS tile), 5 at the barrier, 6 behind it, 7 the staged stores issued,
+                    // 8 .. 8 + MAXUT - 1 after the weight pass of unit tile ui
+__device__ unsigned long long g_bwstamps[512 * 16];
+#define BWST(slot) do { if (stamp_on && step < 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_bwstamps[step * 16 + (slot)] = t_; } } while (0)
+#else
+#define BWST(slot) do { } while (0)
+#endif
 template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0, int PF = 0, int STG = 0, int KH = 1>
 __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   static_assert(KH == 1 || (KH == 2 && !HC && !HPC && !PF && !STG), "the half-tile form exists for the plain variant only");
+#ifdef BWSTAMP
+  const bool stamp_on = blockIdx.x == BWSTAMP && (threadIdx.x >> 6) == 0;
+#endif
 #if URSE_BWD_PRIO
   __builtin_amdgcn_s_setprio(URSE_BWD_PRIO);   // the BPTT is on the step's critical path; the wgrad GEMMs it shares CUs with are not
 #endif
@@ -373,6 +384,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   for (int step = 0; step < p.m.seq_len; ++step) {
     const int t = dir ? step : (p.m.seq_len - 1 - step);
     char* tile = smem + (step % nbuf) * R * pitch;
+    BWST(0);
     if constexpr (PF == 2) load_all(t);                 // all unit tiles' inputs in ONE round trip, still inside the step
     if constexpr (PF == 3) {
       if (w * 16 + lc < H) load_step(0, 0, t);
@@ -423,6 +435,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
             }
         }
       }
+      BWST(1 + ui);
     }
     if constexpr (!STG) {
       if (step + 1 == p.m.seq_len) break;
@@ -483,7 +496,9 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
       continue;
     }
     if constexpr (PF == 1) load_all(dir ? t + 1 : t - 1);     // next step's inputs: in flight under the weight pass
+    BWST(5);
     __syncthreads();
+    BWST(6);
     if constexpr (STG) {
 #ifndef BABL_NO_STORE
       constexpr int CPR = 4 * HPC * ES / 16;                    // 16-byte pieces of a row's direction segment
@@ -496,6 +511,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
               *reinterpret_cast<const uint4*>(tile + row * pitch + cc * 16);
       }
 #endif
+      BWST(7);
       if (step + 1 == p.m.seq_len) break;
     }
 #ifdef BABL_NO_MM
@@ -566,6 +582,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) dhr[ui][rt][r] = acc[rt][r];
       }
+      BWST(8 + ui);
     }
     if (nbuf == 1) __syncthreads();
   }
@@ -1112,3 +1129,9 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
   }
   return launch_bwd<float, 1, 16>(p, st);
 }
+
+#ifdef BWSTAMP
+extern "C" int urse_diag_bwd_stamps(void* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(urse::g_bwstamps), sizeof(unsigned long long) * 512 * 16);
+}
+#endif

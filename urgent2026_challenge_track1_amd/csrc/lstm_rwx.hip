@@ -62,6 +62,9 @@ __device__ __forceinline__ void rx_glds16(const char* gsrc, unsigned dst) {
 
 // TI: operand format of both products (bf16_t | f16_t: x_n, W_ih, W_hh, the carried h and hout); the saved gate activations are bf16 in both
 // (they feed the BPTT); H2: also write hout2 (f16 only)
+#ifdef RXSTAMP
+__device__ unsigned long long g_rxstamps[64 * 4];
+#endif
 template <int H, int HP, int NP, bool SAVE, typename TI = bf16_t, bool H2 = false>
 __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p) {
   static_assert(!H2 || __is_same(TI, f16_t), "the bf16 copy of h exists in the f16 mode only");
@@ -171,12 +174,39 @@ __global__ void __launch_bounds__(RX_WAVES * 64, 2) lstm_fwd_rwx_kernel(RxArgs p
     asm volatile("s_waitcnt vmcnt(30)" ::: "memory");                   // stages 0, 1 landed
     issue();
     __builtin_amdgcn_s_barrier();                                       // A_0
+#ifdef RXSTAMP     // timing diagnostics (scripts/stamps.py): the LOADER wave of workgroup RXSTAMP sees both sides of the ring - per time step (200 stages) the
+                   // shader-clock cycles it spent issuing the ten LDS-DMAs of a stage, waiting for stage k + 2 to LAND (vmcnt), and waiting at the stage's
+                   // BARRIER for the seven compute waves; [step][4] = {issue, landing wait, barrier wait, stages}.  (The compute waves cannot be stamped
+                   // without breaking their read-ahead: s_memtime is a scalar memory instruction and its wait drains the LDS reads in flight.)
+    unsigned long long a_issue = 0, a_land = 0, a_bar = 0;
+    const bool stamp_on = blockIdx.x == RXSTAMP;
+#endif
     for (long k = 0; k < total_stages; ++k) {
+#ifdef RXSTAMP
+      const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
       if (k >= 1) issue();                                              // stage k + 5
+#ifdef RXSTAMP
+      const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+#endif
 #ifndef RXABL_NO_DMA_WAIT
       asm volatile("s_waitcnt vmcnt(30)" ::: "memory");                 // stage k + 2 landed
 #endif
+#ifdef RXSTAMP
+      const unsigned long long t2_ = __builtin_amdgcn_s_memtime();
+#endif
       __builtin_amdgcn_s_barrier();                                     // A_{k+1}
+#ifdef RXSTAMP
+      const unsigned long long t3_ = __builtin_amdgcn_s_memtime();
+      a_issue += t1_ - t0_; a_land += t2_ - t1_; a_bar += t3_ - t2_;
+      if ((k + 1) % SPS == 0) {
+        const long st_ = k / SPS;
+        if (stamp_on && lane == 0 && st_ < 64) {
+          g_rxstamps[st_ * 4 + 0] = a_issue; g_rxstamps[st_ * 4 + 1] = a_land; g_rxstamps[st_ * 4 + 2] = a_bar; g_rxstamps[st_ * 4 + 3] = SPS;
+        }
+        a_issue = a_land = a_bar = 0;
+      }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
@@ -518,3 +548,9 @@ extern "C" int urse_lstm_rwx_fwd(const void* xn, int64_t ldx, const void* wx, co
   URSE_CHECK_LAUNCH("urse_lstm_rwx_fwd");
   return URSE_OK;
 }
+
+#ifdef RXSTAMP
+extern "C" int urse_diag_rwx_stamps(void* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(urse::g_rxstamps), sizeof(unsigned long long) * 64 * 4);
+}
+#endif
