@@ -91,7 +91,7 @@ const char* urse_last_error(void);
 #define URSE_KV_LSTM_FWD_RWX 25    /* lstm_fwd_rwx_kernel: row-wave forward with the input projection fused */
 #define URSE_KV_LSTM_BWD_NSPLIT 26 /* lstm_bwd_nsplit_kernel: pairs of workgroups split the output columns of the recurrent product */
 #define URSE_KV_LSTM_FWD_CLUSTERX 27 /* lstm_fwd_clusterx_kernel: cluster forward with the input projection fused */
-#define URSE_KV_LSTM_BWD_NSPLIT3 28  /* lstm_bwd_nsplit3_kernel: three-member N-split BPTT, 48 sequences per group */
+/* (28: unused - the three-member N-split BPTT of round 5 measured slower and left the shipped library: csrc/experiments/lstm_nsplit3.hip) */
 #define URSE_KV_COUNT 32
 int urse_launch_count(int variant);
 int urse_launch_counts_reset(void);
@@ -341,14 +341,6 @@ int urse_lstm_nsplit_plan(int H, int n_seq, int reserved_cus, int64_t* plan);
 int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT, void* flags,
                          void* err_flag, int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride,
                          int reserved_cus, void* stream);
-/* The same with THREE members and 48 sequences per group (csrc/lstm_nsplit3.hip, round 5): a member owns a third of the hidden units (one unit
- * tile per wave, nine waves) and streams a third of W_hh^T, each weight fragment feeds three row tiles - fewer bytes per CU and step on as many
- * CUs (138 workgroups at C2).  Arguments, workspaces and error behaviour as urse_lstm_nsplit_bwd; plan -> {groups per direction, workgroups,
- * flag words}. */
-int urse_lstm_nsplit3_plan(int H, int n_seq, int reserved_cus, int64_t* plan);
-int urse_lstm_nsplit3_bwd(const void* dh, int64_t ldd, void* gates, int64_t ldg, const float* c, const void* whhT, void* flags,
-                          void* err_flag, int H, int n_seq, int seq_len, int64_t inner, int64_t outer, int64_t stride,
-                          int reserved_cus, void* stream);
 /* Backward through time.  dh [M, ldd>=2H] = gradient w.r.t. hout; gates: in = saved activations,
  * out = gradient w.r.t. the gate pre-activations (same interleaved layout); whhT = fragment-ordered
  * transposed recurrent weights from urse_lstm_pack. */

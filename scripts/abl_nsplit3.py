@@ -1,4 +1,4 @@
-"""Ablation timing of the N-split BPTT (diagnostic builds of csrc/lstm_nsplit3.hip; wrong results, timing only)."""
+"""Ablation timing of the N-split BPTT (diagnostic builds of csrc/experiments/lstm_nsplit3.hip: the round-5 three-member N-split, not part of the shipped library; wrong results, timing only)."""
 import ctypes, os, subprocess, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ for name in names:
     fl = [] if name == "base" else [("-D" + x[2:]) if x.startswith("D:") else ("-DN3ABL_" + x) for x in name.split("+")]
     so = "/tmp/ablns3_%s.so" % name.replace("+", "_").replace("=", "").replace(":", "")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-w", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", *fl,
-                           os.path.join(CS, "lstm_nsplit3.hip"), os.path.join(CS, "api.hip"), "-o", so])
+                           os.path.join(CS, "experiments", "lstm_nsplit3.hip"), os.path.join(CS, "api.hip"), "-o", so])
     libs[name] = ctypes.CDLL(so)
 B, T, K, N = 32, 401, 34, 196
 H = 2 * N

@@ -1,4 +1,5 @@
-"""N-split BPTT (csrc/lstm_nsplit.hip) against the streaming BPTT on the time path: agreement of the gate gradients, time per launch."""
+"""(round 6: the touch / wide / helper-wave forms are compiled only with -DURSE_EXPERIMENTS - bash scripts/build_variant.sh nsx lstm_nsplit "-DURSE_EXPERIMENTS", then URSE_LIB_PATH=variants/liburse_nsx.so; the three-member kernel lives in csrc/experiments/ with scripts/abl_nsplit3.py)
+N-split BPTT (csrc/lstm_nsplit.hip) against the streaming BPTT on the time path: agreement of the gate gradients, time per launch."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,15 +46,7 @@ def case(B, T, K, time_runs=0):
     torch.cuda.synchronize()
     os.environ["URSE_NSPLIT_TOUCH"] = "0"
     print("  with the touch wave: err flag %d, == 13-wave form bit for bit: %s" % (int(err6.item()), torch.equal(g6, g3)), flush=True)
-    ops.NSPLIT_MEMBERS = 3
-    g4 = gx.clone()
-    _, err3 = ops.lstm_bwd_nsplit(dh, g4, c, pk["whhT"], H, **sm)
-    torch.cuda.synchronize()
-    ops.NSPLIT_MEMBERS = 2
-    d3 = (g1.float() - g4.float()).abs()
-    print("  three members x 48 rows: err flag %d, max |d| / scale %.2e, mean %.2e, vs two members max %.2e, finite %s" % (
-        int(err3.item()), d3.max().item() / scale, d3.mean().item() / scale, (g4.float() - g3.float()).abs().max().item() / scale, bool(torch.isfinite(g4.float()).all())), flush=True)
-    for name in (("stream16", "nsplit0", "touch", "wide", "members3") * 2 if time_runs else ()):
+    for name in (("stream16", "nsplit0", "touch", "wide") * 2 if time_runs else ()):
         ts = []
         for _ in range(time_runs):
             g2.copy_(gx); torch.cuda.synchronize()
@@ -68,10 +61,6 @@ def case(B, T, K, time_runs=0):
                 os.environ["URSE_NSPLIT_HELPERS"] = "0"; os.environ["URSE_NSPLIT_WIDE"] = "1"
                 ops.lstm_bwd_nsplit(dh, g2, c, pk["whhT"], H, **sm)
                 os.environ["URSE_NSPLIT_WIDE"] = "0"
-            elif name == "members3":
-                ops.NSPLIT_MEMBERS = 3
-                ops.lstm_bwd_nsplit(dh, g2, c, pk["whhT"], H, **sm)
-                ops.NSPLIT_MEMBERS = 2
             else:
                 os.environ["URSE_NSPLIT_HELPERS"] = name[-1]
                 ops.lstm_bwd_nsplit(dh, g2, c, pk["whhT"], H, **sm)

@@ -125,8 +125,9 @@ def short(name):
 
 def collect():
     table = {}
+    csrc = os.path.join(os.path.dirname(BUILD), "csrc")
     for f in sorted(os.listdir(BUILD)):
-        if not f.endswith(".o"):
+        if not f.endswith(".o") or not os.path.exists(os.path.join(csrc, f[:-2] + ".hip")):      # (an object whose source left the tree is not part of the library)
             continue
         ks = object_kernels(os.path.join(BUILD, f))
         names = demangle([n for n, _ in ks])

@@ -340,8 +340,8 @@ def test_cooperative_kernel_timeout_is_reported(lib):
 @pytest.mark.parametrize("save", [True, False])
 def test_row_wave_forward_equals_wide_forward(lib, sm, save):
     """csrc/lstm_rw.hip (16 sequences per wave, W_hh shared through an LDS-DMA ring) == csrc/lstm_wide.hip bit for bit: h, c and the
-    saved gate activations (same bf16 MFMA products in the same order, same f32 cell math), in both kernel forms (one unit / two adjacent
-    units per lane)."""
+    saved gate activations (same bf16 MFMA products in the same order, same f32 cell math).  (The paired form - two adjacent units per lane,
+    round 4, bit-identical too and no faster - is compiled into variant builds only since round 6; the shipped library refuses it.)"""
     from urgent2026_challenge_track1_amd import ops
     torch.manual_seed(3)
     N, dev = 196, "cuda"
@@ -356,14 +356,17 @@ def test_row_wave_forward_equals_wide_forward(lib, sm, save):
     gx = torch.randn(M, 8 * H, device=dev).to(torch.bfloat16)
     g1, g2 = gx.clone(), gx.clone()
     h1, c1 = ops.lstm_fwd_wide(g1, whhb, H, Hp, save=save, **sm)
-    for tw, paired in ((0, False), (16, False), (0, True), (16, True)):
+    from urgent2026_challenge_track1_amd._lib import UrseError
+    with pytest.raises(UrseError):
+        ops.lstm_fwd_rw(g2, whhb_rw, H, Hp, save=save, paired=True, **sm)
+    for tw, paired in ((0, False), (16, False)):
         g2.copy_(gx)
-        h2, c2 = ops.lstm_fwd_rw(g2, whhb_rw if paired else whhb, H, Hp, save=save, target_wgs=tw, paired=paired, **sm)
+        h2, c2 = ops.lstm_fwd_rw(g2, whhb, H, Hp, save=save, target_wgs=tw, paired=paired, **sm)
         assert torch.equal(h1.view(torch.int16), h2.view(torch.int16))
         assert torch.equal(g1.view(torch.int16), g2.view(torch.int16))
         if save:
             assert torch.equal(c1, c2)
-    assert ops.launch_counts()["lstm_fwd_rw"] >= 4
+    assert ops.launch_counts()["lstm_fwd_rw"] >= 2
 
 
 @pytest.mark.parametrize("B,T,K", [(2, 9, 20), (32, 12, 34), (5, 40, 34)])
@@ -463,41 +466,6 @@ def test_fused_row_wave_forward_matches_two_kernel_form_and_lstm(lib, ns, sl, st
     assert ops.launch_counts()["lstm_fwd_rwx"] >= 2
 
 
-@pytest.mark.parametrize("B,T,K", [(1, 7, 34), (2, 21, 20), (3, 9, 34), (5, 40, 34), (32, 101, 34)])
-def test_three_member_nsplit_bptt_matches_streaming_kernel(lib, monkeypatch, B, T, K):
-    """csrc/lstm_nsplit3.hip (round 5, opt-in: measured slower than the two-member kernel): three workgroups share 48 sequences, each owns a third of
-    the unit tiles; vs the one-workgroup streaming kernel, same bound as the two-member form; groups with fewer than 48 sequences included."""
-    from urgent2026_challenge_track1_amd import ops
-    torch.manual_seed(8)
-    N, dev, dt = 196, "cuda", torch.bfloat16
-    H = 2 * N
-    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
-    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
-    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
-                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dt)
-    M = B * T * K
-    sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
-    xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dt)
-    gx = ops.gemm_nt(xr, pk["wih"], pk["bias"])
-    hout, c = ops.lstm_fwd(gx, pk["whh"], H, pk["Hp"], **sm)
-    dh = ops.pack2d(torch.randn(M, 2 * H, device=dev), M, hout.shape[1], dt)
-    g1, g2 = gx.clone(), gx.clone()
-    ops.lstm_bwd(dh, g1, c, pk["whhT"], H, rows16=1, **sm)
-    monkeypatch.setattr(ops, "NSPLIT_MEMBERS", 3)
-    assert ops.lstm_nsplit_plan(H, sm["n_seq"]) is not None
-    ops.launch_counts(reset=True)
-    _, err = ops.lstm_bwd_nsplit(dh, g2, c, pk["whhT"], H, **sm)
-    assert int(err.item()) == 0 and ops.launch_counts()["lstm_bwd_nsplit3"] == 1
-    d = (g1.float() - g2.float()).abs()
-    scale = g1.float().abs().max().item()
-    assert torch.isfinite(g2.float()).all() and d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-4 * scale, (d.max().item(), d.mean().item(), scale)
-    # the units of member 0 (tiles 0 .. 8) see the k-slabs in the streaming kernel's order
-    for dr in range(2):
-        a = g1[:, dr * 4 * H:dr * 4 * H + 9 * 64].view(torch.int16)
-        b = g2[:, dr * 4 * H:dr * 4 * H + 9 * 64].view(torch.int16)
-        assert (a != b).float().mean().item() <= 5e-2
-
-
 @pytest.mark.parametrize("B,T,K", [(1, 7, 34), (2, 21, 20), (3, 9, 34), (5, 40, 34), (32, 401, 34)])
 def test_nsplit_bptt_matches_streaming_kernel(lib, B, T, K):
     """time-path BPTT split over pairs of workgroups by OUTPUT columns (each member streams its half of W_hh^T, the halves of the gate
@@ -531,31 +499,8 @@ def test_nsplit_bptt_matches_streaming_kernel(lib, B, T, K):
         b = g2[:, dr * 4 * H:dr * 4 * H + 13 * 64].view(torch.int16)
         frac = (a != b).float().mean().item()
         assert frac <= (2e-2 if T < 100 else 5e-2), frac          # (their dh_rec is exact; differences enter through the other half's gradients one step later and pile up over 401 steps: 3.2 %)
-    # the helper-wave form (default) against the 13-wave form: the same sums in the same order, bit for bit
-    import os
-    prev = os.environ.get("URSE_NSPLIT_HELPERS")
-    try:
-        os.environ["URSE_NSPLIT_HELPERS"] = "0"
-        g3 = gx.clone()
-        ops.lstm_bwd_nsplit(dh, g3, c, pk["whhT"], H, **sm)
-    finally:
-        if prev is None:
-            os.environ.pop("URSE_NSPLIT_HELPERS", None)
-        else:
-            os.environ["URSE_NSPLIT_HELPERS"] = prev
-    assert torch.equal(g2.view(torch.int16), g3.view(torch.int16))
-    # the seven-wave form with two unit tiles per wave (round 5 experiment, opt-in): the same sums in the same order, bit for bit
-    prevw = os.environ.get("URSE_NSPLIT_WIDE")
-    try:
-        os.environ["URSE_NSPLIT_WIDE"] = "1"
-        g4 = gx.clone()
-        _, err4 = ops.lstm_bwd_nsplit(dh, g4, c, pk["whhT"], H, **sm)
-    finally:
-        if prevw is None:
-            os.environ.pop("URSE_NSPLIT_WIDE", None)
-        else:
-            os.environ["URSE_NSPLIT_WIDE"] = prevw
-    assert int(err4.item()) == 0 and torch.equal(g4.view(torch.int16), g3.view(torch.int16))
+    # (round 6: the helper-wave, seven-wave and touch-wave forms - bit-identical to this one when they were tested here in round 5, and slower -
+    # are compiled into variant builds only: -DURSE_EXPERIMENTS)
 
 
 def test_multi_pack_equals_per_lstm_pack(lib):

@@ -24,7 +24,7 @@
 // streaming kernel), members 1 and 2 add their own range first.
 #include <stdlib.h>
 
-#include "urse_common.h"
+#include "../urse_common.h"
 
 namespace urse {
 

@@ -1882,6 +1882,7 @@ __global__ void __launch_bounds__(512) gemm_nt_bres_kernel(GemmDesc d, int wg_pe
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the last (zero-page) prefetch must not outlive the workgroup
 }
 
+#ifdef URSE_EXPERIMENTS      // round 4's register-stationary gate projection: faster alone, no faster in the step - variant builds only
 // Weights resident in REGISTERS, for K = 224 and wide N with bf16 output (the time path's gate projection: N = 3,136).
 // gemm_nt_bres_kernel keeps a 224-column weight slice in LDS, so a workgroup writes 448-byte pieces of an output row, and 448-byte
 // segments cap the HBM write rate at 3.7 TB/s where 896-byte segments reach 5.4 (scripts/diag/write_pattern.py) - the kernel is bound by its
@@ -2038,6 +2039,7 @@ __global__ void __launch_bounds__(448) gemm_nt_wreg_kernel(GemmDesc d, int parts
   }
   sweep(nst - 1);
 }
+#endif   // URSE_EXPERIMENTS
 
 static int check_desc_host(const GemmDesc& d, int es, const char* who) {
   URSE_CHECK_ARG(d.A && d.B && d.C, "%s: null operand", who);
@@ -2097,6 +2099,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   static const bool no_dma = getenv("URSE_NT_NO_DMA") != nullptr;
   const char* bres_env = getenv("URSE_NT_BRES");
   const int bres_mode = bres_env ? atoi(bres_env) : 1;
+#ifdef URSE_EXPERIMENTS
   // OFF by default (0): 1.11 -> 0.80 ms per launch alone (scripts/bench_gemm.py), but 1.01 ms in the step's profile against 0.96 for the
   // LDS-resident kernel, and no difference in the step (136.1 / 135.1 vs 136.3 / 135.1 ms, profiles/r04_exp_nt_wreg_v1.log): with one barrier
   // per 32-row stage its MFMA phase (0.33 ms, seven waves on four SIMDs) is in series with the memory phases.  Read per call: tests switch it.
@@ -2117,6 +2120,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     URSE_CHECK_LAUNCH("urse_gemm_nt");
     return URSE_OK;
   }
+#endif
   if (bres_mode && in16 && out16 && !no_dma && M >= 8192 && N >= g_nt_bres_min_n && K % 32 == 0 &&
       K >= 96 && K <= 224 && !resid && act != 2 && (ldc * 2) % 16 == 0 && ((uintptr_t)C % 16) == 0) {
     // weight-stationary tiles: see gemm_nt_bres_kernel
@@ -2482,7 +2486,9 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
       note_launch(URSE_KV_TN_DUAL);
       if (act_f16) note_launch(URSE_KV_TN_ACT_F16);
       if (act_f16) hipLaunchKernelGGL((gemm_tn_dual224_kernel<2, true>), dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+#ifdef URSE_EXPERIMENTS      // (three stages in flight: +2 % alone, -2.1 ms LOST in the step, round 5 - variant builds only)
       else if (p.pad_[0] == 3) hipLaunchKernelGGL(gemm_tn_dual224_kernel<3>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+#endif
       else hipLaunchKernelGGL(gemm_tn_dual224_kernel<2>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
       URSE_CHECK_LAUNCH("urse_gemm_tn_dual");
       return URSE_OK;

@@ -872,10 +872,17 @@ static int launch_fwd(const LstmFwdArgs& p, hipStream_t st) {
 }
 
 // URSE_BWD_VARIANT (experiments): 0 = default dispatch, 1 = 16 waves + prefetch, 2 = 8 waves + prefetch on the time path
+// Round 6: the variants (16 waves + prefetch, 13 x 2 / 12 x 3 unit tiles, in-step single round trip, transposed accumulators, two-slot input loads, 48 rows on four
+// 512-register waves) were each measured slower than the default dispatch (docs/HISTORY.md) and are instantiated only in variant builds
+// (-DURSE_EXPERIMENTS through scripts/build_variant.sh): the shipped library holds the kernels the dispatch below can reach without a switch.
+#ifdef URSE_EXPERIMENTS
 static int bwd_variant() {
   const char* e = getenv("URSE_BWD_VARIANT");
   return e ? atoi(e) : 0;
 }
+#else
+static constexpr int bwd_variant() { return 0; }
+#endif
 
 template <typename T, int RT, int NW>
 static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
@@ -920,11 +927,14 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
     if (p.H == 392 && upw <= 4) {
       static const bool stg_on = !(getenv("URSE_BWD_STAGED_STORES") && atoi(getenv("URSE_BWD_STAGED_STORES")) == 0);     // (A/B switch)
       const bool stg = stg_on && (p.ldg * 2) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.gates) % 16) == 0;
+#ifdef URSE_EXPERIMENTS
       if (stg && bwd_variant() == 7) {        // experiment: two-slot pipelined input loads (PF = 3)
         static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 3, 1>), true);
         (void)once;
         hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 3, 1>), grid, dim3(NW * 64), lds + R * sizeof(int), st, pa);
-      } else if (stg) {
+      } else
+#endif
+      if (stg) {
         static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 0, 1>), true);
         (void)once;
         hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 0, 1>), grid, dim3(NW * 64), lds + R * sizeof(int), st, pa);
@@ -937,6 +947,7 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
       return URSE_OK;
     }
   }
+#ifdef URSE_EXPERIMENTS
   if constexpr (sizeof(T) == 2 && NW == 4 && RT == 3) {
     // 48 sequences per workgroup on FOUR waves (one per SIMD: the 512-register budget holds 7 unit tiles x 3 row tiles of per-row state,
     // which spilled at the 256 of two waves per SIMD, profiles/r04_exp_bwd_band_rows48_v1.log): 1.5x the rows per pass over W_hh^T
@@ -946,8 +957,11 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
     hipLaunchKernelGGL((lstm_bwd_kernel<T, 3, 7, 4, 0, 392, 0, 1>), grid, dim3(NW * 64), (size_t)R * lds_frag_pitch(4 * p.H * 2) + R * sizeof(int), st, pa);
     URSE_CHECK_LAUNCH("urse_lstm_bwd");
     return URSE_OK;
-  } else {
+  } else
+#endif
+  {
   if constexpr (sizeof(T) == 2 && NW == 8 && RT == 1) {
+#ifdef URSE_EXPERIMENTS
     if (p.H == 392 && bwd_variant() == 6) {     // transposed accumulator layout: wide loads / stores
       static bool once = (allow_big_lds(lstm_bwd_tr_kernel<1, 4, 8, 392>), true);
       (void)once;
@@ -955,6 +969,7 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
       URSE_CHECK_LAUNCH("urse_lstm_bwd");
       return URSE_OK;
     }
+#endif
     if (p.H == 392) {     // 16 sequences on 8 waves with the next step's inputs prefetched (PF = 1)
       static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 4, 8, 392, 0, 1>), true);
       (void)once;
@@ -964,6 +979,7 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
     }
   }
   if constexpr (sizeof(T) == 2 && NW == 16 && RT == 1) {
+#ifdef URSE_EXPERIMENTS
     if (p.H == 392 && (bwd_variant() == 4 || bwd_variant() == 5)) {     // experiments: 13 x 2 / 12 x 3 unit tiles, prefetched inputs
       const int nw = bwd_variant() == 4 ? 13 : 12;
       if (nw == 13) {
@@ -992,6 +1008,7 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
       URSE_CHECK_LAUNCH("urse_lstm_bwd");
       return URSE_OK;
     }
+#endif
     if (p.H == 392) {     // the model's size on the time path: compile-time geometry (7.2 -> 7.0 ms; the 32-row variant spills with it)
       static bool once = (allow_big_lds(lstm_bwd_kernel<T, 1, 2, 16, 392>), true);
       (void)once;
@@ -1116,11 +1133,13 @@ extern "C" int urse_lstm_bidir_bwd(const void* dh, int64_t ldd, void* gates, int
     nw8 = many && fits2;
   }
   if (rt == 1 && (bwd_variant() == 2 || bwd_variant() == 6)) nw8 = true;
+#ifdef URSE_EXPERIMENTS
   const bool fits3 = (size_t)48 * lds_frag_pitch(8 * H) + 48 * sizeof(int) <= 160 * 1024;
   if (dtype == URSE_BF16 && H == 392 && rt == 2 && fits3 && bwd_variant() == 8 && (ldg * 2) % 16 == 0 && ((uintptr_t)gates % 16) == 0) {
     note_launch(URSE_KV_LSTM_BWD_STREAM32);
     return launch_bwd<bf16_t, 3, 4>(p, st);
   }
+#endif
   note_launch(dtype == URSE_BF16 && rt >= 2 && fits2 ? URSE_KV_LSTM_BWD_STREAM32 : URSE_KV_LSTM_BWD_STREAM16);
   if (dtype == URSE_BF16) {
     if (nw8) return (rt >= 2 && fits2) ? launch_bwd<bf16_t, 2, 8>(p, st) : launch_bwd<bf16_t, 1, 8>(p, st);

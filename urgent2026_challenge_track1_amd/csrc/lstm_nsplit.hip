@@ -482,6 +482,7 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
+#ifdef URSE_EXPERIMENTS      // measured losers of round 5: compiled only into variant builds (scripts/build_variant.sh <name> lstm_nsplit "-DURSE_EXPERIMENTS")
 // Round 5 EXPERIMENT (opt-in, URSE_NSPLIT_WIDE=1): the same pair protocol with SEVEN waves of TWO unit tiles each (8-wave budget: 256 registers).
 // The question: three kernels looked like one law - the 16-wave streaming BPTT keeps 16 x 13 KB of weight fragments in flight and streams at 110 GB/s,
 // the 13-wave kernel above 13 x 9 KB at 62 GB/s, the three-member kernel (lstm_nsplit3.hip) 9 x 11 KB at 52 GB/s: bytes in flight / 1.9 us every time -
@@ -809,6 +810,8 @@ __global__ void __launch_bounds__(NSW_THR) lstm_bwd_nsplitw_kernel(NsplitArgs p)
   }
 }
 
+#endif   // URSE_EXPERIMENTS
+
 }  // namespace urse
 
 using namespace urse;
@@ -856,27 +859,31 @@ extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, in
   (void)hipMemsetAsync(flags, 0, sizeof(unsigned) * plan[2], st);
   const size_t lds = (size_t)32 * lds_frag_pitch(4 * 392 * 2) + 256 + (size_t)NSW * NS_RES * 1024;      // tile, flags + row table, resident fragments
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 0>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 3>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplitw_kernel<392>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 0, 1>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   note_launch(URSE_KV_LSTM_BWD_NSPLIT);
-  // A/B switch.  The helper-wave form (3) is 0.07 ms faster alone and no faster in the step beside the second queue's GEMMs: same-box A/B in both
-  // orders, 133.09 / 130.96 ms per step with helpers against 131.70 / 131.63 without (profiles/r05_ab_nsplit_helpers_v3.log; v1 of that log, 140.83 /
-  // 139.49 against 139.10 / 138.94, was taken while the weight-gradient GEMM spilled): the 13-wave form ships.
+#ifdef URSE_EXPERIMENTS
+  // Variant builds only (round 6: the shipped library instantiates the 13-wave form alone).  What each measured, all in DESIGN 9.6:
+  // URSE_NSPLIT_HELPERS=3, three helper waves own the hand-off: 0.07 ms faster alone, no faster in the step (133.09 / 130.96 with, 131.70 / 131.63 without,
+  // profiles/r05_ab_nsplit_helpers_v3.log); URSE_NSPLIT_WIDE=1, seven waves of two unit tiles: 5.77 vs 5.08 ms; URSE_NSPLIT_TOUCH=1, a wave that warms the
+  // next step's input sectors in L2: 6.41 vs 5.07 ms.
+  static bool once_x = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 3>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplitw_kernel<392>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 0, 1>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once_x;
   const int helpers = getenv("URSE_NSPLIT_HELPERS") ? atoi(getenv("URSE_NSPLIT_HELPERS")) : 0;
-  // URSE_NSPLIT_WIDE: the seven-wave form with two unit tiles per wave (twice the weight fragments in flight)
   const int wide = getenv("URSE_NSPLIT_WIDE") ? atoi(getenv("URSE_NSPLIT_WIDE")) : 0;
   const bool wide_ok = wide && rows < (1L << 24) && ldg * 2 < (1L << 24) && ldd * 2 < (1L << 24) && rows * 2L * H * 4 < 0xFFFFF000L && rows * ldd * 2 < 0xFFFFF000L;
   const int touch = getenv("URSE_NSPLIT_TOUCH") ? atoi(getenv("URSE_NSPLIT_TOUCH")) : 0;
   if (wide_ok) hipLaunchKernelGGL((lstm_bwd_nsplitw_kernel<392>), dim3((unsigned)plan[1]), dim3(NSW_THR), lds, st, p);
   else if (touch > 0 && helpers == 0) hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 0, 1>), dim3((unsigned)plan[1]), dim3(NSTHR + 64), lds, st, p);
   else if (helpers > 0) hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 3>), dim3((unsigned)plan[1]), dim3((NSW + 3) * 64), lds, st, p);
-  else hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 0>), dim3((unsigned)plan[1]), dim3(NSTHR), lds, st, p);
+  else
+#endif
+  hipLaunchKernelGGL((lstm_bwd_nsplit_kernel<392, 0>), dim3((unsigned)plan[1]), dim3(NSTHR), lds, st, p);
   URSE_CHECK_LAUNCH("urse_lstm_nsplit_bwd");
   return URSE_OK;
 }

@@ -700,6 +700,10 @@ extern "C" int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* h
   p.tiles_rem = ntile % G;
   constexpr int HPITCH = lds_frag_pitch(416 * 2);
   const size_t lds = (size_t)RW_NSLOT * 13 * 1024 + (size_t)RW_MAXT * 16 * HPITCH + (paired ? RW_MAXT * 16 * sizeof(int) : 0);
+#ifndef URSE_EXPERIMENTS
+  // (the paired form - two sequences' gates per lane pair, round 4 - measured no faster than this kernel and spills 11 - 13 registers: variant builds only)
+  URSE_CHECK_ARG(!paired, "urse_lstm_rw_fwd: the paired row-wave form is compiled into variant builds only (-DURSE_EXPERIMENTS)");
+#else
   if (paired) {
     static bool once2 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rw2_kernel<392, 416, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
@@ -712,6 +716,7 @@ extern "C" int urse_lstm_rw_fwd(void* gx, int64_t ldg, const void* whhb, void* h
     URSE_CHECK_LAUNCH("urse_lstm_rw_fwd");
     return URSE_OK;
   }
+#endif
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rw_kernel<392, 416, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_rw_kernel<392, 416, false>),

@@ -52,7 +52,7 @@ KERNEL_VARIANTS = ("nt_bres", "nt_ring", "nt_ring_wide", "nt_128", "nt_grouped_r
                    "tn_dual", "tn_128", "tn_grouped", "lstm_fwd_stream", "lstm_fwd_wide", "lstm_fwd_cluster",
                    "lstm_fwd_cluster2", "lstm_bwd_stream16", "lstm_bwd_stream32", "lstm_bwd_cluster", "lstm_bwd_split",
                    "stft960", "stft_generic", "istft_generic", "istft960", "lstm_fwd_rw", "tn_act_f16", "lstm_fwd_rwx", "lstm_bwd_nsplit",
-                   "lstm_fwd_clusterx", "lstm_bwd_nsplit3")
+                   "lstm_fwd_clusterx", "_unused28")
 
 
 _PAGEABLE_UPLOADS = os.environ.get("URSE_PAGEABLE_UPLOADS", "0") == "1"
@@ -795,7 +795,7 @@ def lstm_rw_supported(H, Hp):
 
 
 # the kernel form with two adjacent units per lane and block pair (wider, contiguous accesses); its weights come from lstm_pack_blocks_rw
-RW_PAIRED = os.environ.get("URSE_LSTM_RW_PAIRED", "1") != "0"
+RW_PAIRED = os.environ.get("URSE_LSTM_RW_PAIRED", "0") == "1"      # (round 6: the paired form exists in variant builds only, -DURSE_EXPERIMENTS)
 
 
 def lstm_fwd_rw(gx, whhb, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, target_wgs=0, paired=False):
@@ -914,8 +914,6 @@ def lstm_bwd_split(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride):
 # step and CU; the time path at C2 (1,088 sequences -> 136 workgroups, as many as the streaming kernel uses)
 USE_NSPLIT_LSTM_BWD = os.environ.get("URSE_LSTM_NSPLIT_BWD", "1") != "0"
 NSPLIT_MAX_SEQ = int(os.environ.get("URSE_LSTM_NSPLIT_MAX_SEQ", "2304"))       # beyond that the 32-sequence streaming geometry has the rows it needs
-# three members x 48 sequences instead of two x 32 (csrc/lstm_nsplit3.hip): fewer bytes per CU and step on as many CUs
-NSPLIT_MEMBERS = int(os.environ.get("URSE_NSPLIT_MEMBERS", "2"))
 
 
 # (SHARED_GPU_RANKS: defined beside the CU reservations above; the N-split is not planned on a shared GPU either)
@@ -934,8 +932,7 @@ def lstm_nsplit_plan(H, n_seq):
     if SHARED_GPU_RANKS > 1:
         return None
     plan = (ctypes.c_int64 * 3)()
-    fn = _lib.load().urse_lstm_nsplit3_plan if NSPLIT_MEMBERS == 3 else _lib.load().urse_lstm_nsplit_plan
-    if fn(H, n_seq, _nsplit_reserved(), plan) != 0:
+    if _lib.load().urse_lstm_nsplit_plan(H, n_seq, _nsplit_reserved(), plan) != 0:
         return None
     return list(plan)
 
@@ -962,11 +959,11 @@ def lstm_bwd_nsplit(dh, gates, c, whhT, H, n_seq, seq_len, inner, outer, stride)
     """N-split BPTT (bf16): gates (saved activations) is overwritten with d(pre-activations)."""
     plan = lstm_nsplit_plan(H, n_seq)
     dev = gates.device
-    key = ("nsplit", NSPLIT_MEMBERS, dev, plan[2])
+    key = ("nsplit", dev, plan[2])
     if key not in _cluster_ws:
         _cluster_ws[key] = (torch.zeros(plan[2], device=dev, dtype=torch.int32), kernel_error_flag(dev))
     flags, err = _cluster_ws[key]
-    timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_nsplit3_bwd" if NSPLIT_MEMBERS == 3 else "lstm_nsplit_bwd", dh, dh.stride(0), gates, gates.stride(0), c, whhT,
+    timed_call("lstm_bwd_time" if stride > 1 else "lstm_bwd_band", "lstm_nsplit_bwd", dh, dh.stride(0), gates, gates.stride(0), c, whhT,
                flags, err, H, n_seq, seq_len, inner, outer, stride, _nsplit_reserved(), stream_ptr())
     return gates, err
 
