@@ -1111,6 +1111,28 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
     }
     ++issued;
   };
+  // the same stage, one DMA at a time (DEPTH 4: the issue rides between the MFMA groups of the stage being computed).  Round 6 stamps
+  // (profiles/r06_stamps_tn224_bwdband_rwx_v1.log): of an iteration's 5,176 cycles the eight waves spend 1,866 ISSUING the next two stages' ten DMAs each
+  // right behind the barrier - all at once, blocked on the CU's vector memory path (72 KB at ~39 B/clk), the matrix pipe idle - and 2,276 in MFMAs
+  // with that path idle.  part 0 .. 3: the wave's A / B pieces, part 4: the 64-column image's piece (waves 0 .. 3) and the stage's bookkeeping.
+  auto issue_part = [&](int slot, int part) __attribute__((always_inline)) {
+    const unsigned st = lds_u + (unsigned)slot * STAGE + (unsigned)w * 2048;
+    const bool in = issued < nk;
+    if (part == 0) glds16u(in ? sa0.ptr : zsrc, st);
+    else if (part == 1) glds16u(in ? sa1.ptr : zsrc, st + 1024);
+    else if (part == 2) glds16u((in && rw0.ph != sb0.bad) ? sb0.ptr : zsrc, st + 16384);
+    else if (part == 3) glds16u((in && rw1.ph != sb1.bad) ? sb1.ptr : zsrc, st + 16384 + 1024);
+    else {
+      if (w < 4) glds16u((in && rw2.ph != sb2.bad) ? sb2.ptr : zsrc, lds_u + (unsigned)slot * STAGE + 32768 + (unsigned)w * 1024);
+      if (in) {
+        sa0.ptr += sa0.step; sa1.ptr += sa1.step; sb0.ptr += sb0.step; sb1.ptr += sb1.step;
+        next_row(rw0);
+        next_row(rw1);
+        if (w < 4) { sb2.ptr += sb2.step; next_row(rw2); }
+      }
+      ++issued;
+    }
+  };
 
   f32x4_t acc[MT][NT];
 #pragma unroll
@@ -1181,7 +1203,7 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
     __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
 #endif
   };
-  auto compute = [&](int sl) __attribute__((always_inline)) {
+  auto compute = [&](int sl, int nsl = -1) __attribute__((always_inline)) {
     const unsigned st = lds_u + (unsigned)sl * STAGE;
     short8_t a[MT], b[NT];
 #pragma unroll
@@ -1228,6 +1250,13 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) acc[i][j] = Frag<bf16_t>::mma(a[i], b[j], acc[i][j]);
+      if constexpr (DEPTH == 4) {
+        if (nsl >= 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_part(nsl, j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
 #if URSE_TN_SETPRIO
     __builtin_amdgcn_s_setprio(0);
@@ -1254,6 +1283,19 @@ __global__ void __launch_bounds__(512) gemm_tn_dual224_kernel(TnArgs p) {
       if constexpr (BH) compute_h(slot);
       else compute(slot);
       slot = (slot + 1) & 3;
+    }
+  } else if constexpr (DEPTH == 4) {
+    // two stages per barrier as below, but the DMAs of stages kt + 2 / kt + 3 are issued one by one BETWEEN the MFMA groups of stages kt / kt + 1: a wave
+    // blocked on the memory path leaves the matrix pipe to the other wave of its SIMD instead of all eight queueing behind the barrier
+    issue(0);
+    issue(1);
+    int slot = 0;
+    for (int kt = 0; kt < nk; kt += 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      compute(slot, slot ^ 2);
+      if (kt + 1 < nk) compute(slot + 1, (slot ^ 2) + 1);
+      slot ^= 2;
     }
   } else {
   issue(0);
@@ -2486,6 +2528,7 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
       note_launch(URSE_KV_TN_DUAL);
       if (act_f16) note_launch(URSE_KV_TN_ACT_F16);
       if (act_f16) hipLaunchKernelGGL((gemm_tn_dual224_kernel<2, true>), dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+      else if (p.pad_[0] == 4) hipLaunchKernelGGL(gemm_tn_dual224_kernel<4>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
 #ifdef URSE_EXPERIMENTS      // (three stages in flight: +2 % alone, -2.1 ms LOST in the step, round 5 - variant builds only)
       else if (p.pad_[0] == 3) hipLaunchKernelGGL(gemm_tn_dual224_kernel<3>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
 #endif
