@@ -205,11 +205,29 @@ def flow_bench(dev, steps=3, single_rank_collectives=False):
             out = m.enhance(noisy[:1], fs, lens1, N=15)
             torch.cuda.synchronize()
             de = time.perf_counter() - t0
+        # the same sampler with IEEE-half operands (round 6: the flow DNN's forward in f16 - what inference.py runs by default; its enhanced waveform is
+        # within 1e-3 of the f32 oracle's at full width, the bf16 one is not: tests/test_c4_fullsize_gpu.py)
+        de16, fin16 = None, None
+        try:
+            m.dnn.compute_dtype = torch.float16
+            with torch.no_grad():
+                m.enhance(noisy[:1], fs, lens1, N=15)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out16 = m.enhance(noisy[:1], fs, lens1, N=15)
+                torch.cuda.synchronize()
+                de16 = time.perf_counter() - t0
+                fin16 = bool(torch.isfinite(out16).all())
+        except Exception as ex16:
+            de16 = repr(ex16)[:120]
+        finally:
+            m.dnn.compute_dtype = torch.bfloat16
         T, K, N = L // 384 + 1, 48, 384
         dnn_flops = 2.0 * 6 * 2 * 2 * (4 * 2 * N) * (N + 2 * N) * (T * K)          # gate GEMMs of one DNN evaluation
         res = {"workload": "BSRNN-Flow N=384 L=6 (103 M parameters), B2 x 4 s @ 48 kHz train step; Euler N=15 on 1 x 4 s",
                "train_ms_per_step": dt * 1e3, "train_utt_per_s": B / dt, "final_loss": float(loss.detach()),
                "enhance_ms": de * 1e3, "enhance_rtf": de / 4.0, "enhance_finite": bool(torch.isfinite(out).all()),
+               "enhance_f16_ms": (de16 * 1e3 if isinstance(de16, float) else de16), "enhance_f16_finite": fin16,
                "gate_gemm_tflops_per_dnn_eval": dnn_flops / 1e12, "sampler_gate_gemm_tflops_per_s": 15 * dnn_flops / de / 1e12}
         if coop is not None:
             from urgent2026_challenge_track1_amd import ops
@@ -568,10 +586,12 @@ def f32_mode_step(args, dev, rank, steps=3, dtype="f32"):
     """ms per optimisation step of the SAME workload in the exact-f32 MFMA mode - the arithmetic that meets north_star's 1e-3 on
     every output (waveform, loss, gradients); the headline `value` is the bf16 mode's.  dtype "f16": the f16-forward mode (waveform and loss
     within 1e-3, bf16 backward)."""
+    from urgent2026_challenge_track1_amd import ops
     from urgent2026_challenge_track1_amd.config import Config
     from urgent2026_challenge_track1_amd.d_model import SEModel
     fs, B = 48000, args.batch
     L = int(args.seconds * fs)
+    ops.launch_counts(reset=True)
     cfg = Config(compute_dtype=dtype, model_configs={"num_channel": args.channels, "num_layer": args.layers}, seed=2024)
     torch.manual_seed(cfg.seed)
     model = SEModel(cfg).to(dev)
@@ -596,7 +616,10 @@ def f32_mode_step(args, dev, rank, steps=3, dtype="f32"):
         return {"ms_per_step": dt / steps * 1e3, "utt_per_s": B * steps / dt, "steps": steps, "final_loss": float(loss.detach()),
                 "dtype": "f16 forward operands (v_mfma_f32_16x16x32_f16), bf16 backward operands",
                 "note": "same workload, compute_dtype f16: enhanced waveform and loss within 1e-3 of the f32 oracle at full size "
-                        "(tests/test_c2_fullsize_gpu.py); x_n, h and the mask decoder's tanh layer are written in both formats for the backward"}
+                        "(tests/test_c2_fullsize_gpu.py); round 6: the weight-gradient GEMMs read the forward's f16 x_n / h themselves (bf16 gradients x f16 "
+                        "activations, converted in registers: URSE_BF16_ACT_F16) - no second bf16 copy of them is written; the band split's normalised input "
+                        "and the mask decoder's tanh layer still are",
+                "weight_gradient_launches_in_the_mixed_form": ops.launch_counts().get("tn_act_f16", 0)}
     return {"ms_per_step": dt / steps * 1e3, "utt_per_s": B * steps / dt, "steps": steps, "final_loss": float(loss.detach()),
             "dtype": "f32 (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 MFMA rate)",
             "note": "the mode whose waveform / loss / gradients meet 1e-3 against the f32 oracle at N = 196, L = 6"}

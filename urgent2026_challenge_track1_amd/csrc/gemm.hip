@@ -2528,7 +2528,9 @@ extern "C" int urse_gemm_tn_dual(const void* A, int64_t lda, const void* B, int6
       note_launch(URSE_KV_TN_DUAL);
       if (act_f16) note_launch(URSE_KV_TN_ACT_F16);
       if (act_f16) hipLaunchKernelGGL((gemm_tn_dual224_kernel<2, true>), dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+#ifdef URSE_EXPERIMENTS      // (DMA issue between the MFMA groups, round 6: -8.5 % alone, neutral in the step, profiles/r06_ab_tn224_interleave_v1 / _v2.log - variant builds only)
       else if (p.pad_[0] == 4) hipLaunchKernelGGL(gemm_tn_dual224_kernel<4>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
+#endif
 #ifdef URSE_EXPERIMENTS      // (three stages in flight: +2 % alone, -2.1 ms LOST in the step, round 5 - variant builds only)
       else if (p.pad_[0] == 3) hipLaunchKernelGGL(gemm_tn_dual224_kernel<3>, dim3((unsigned)(tl * slices)), dim3(512), 0, (hipStream_t)stream, p);
 #endif

@@ -24,6 +24,8 @@
 // alone, but 28.3 against 25.6 ms per step beside the weight-gradient GEMMs of the second queue.
 // Same math, layouts and outputs as lstm_bwd_kernel; member 0 adds the k-slabs in ascending order (bit-identical), member 1 adds
 // its own (upper) range first, i.e. the f32 sums of its units see the slabs in another order.
+#include <type_traits>
+
 #include "urse_common.h"
 
 namespace urse {
@@ -37,9 +39,30 @@ constexpr int NSTHR = NSW * 64;
 #define NS_PUB 1                  // the batch of the own-range product in front of which the wave publishes (0 .. 2)
 #endif
 constexpr int NS_KB = 9;           // weight fragments in flight per wave (13 waves: 128-VGPR cap)
+#ifndef NS_PFI
+#define NS_PFI 0                  // round 6 EXPERIMENT (compile-time, off: scripts/build_variant.sh pfi lstm_nsplit "-DNS_PFI=1"): the NEXT step's inputs requested before the
+#endif                            // second product of this step - the saved gates of the wave's unit tile by LDS-DMA into 4 KB per wave (the 52 KB the tile leaves free),
+                                  // c_{t-1} and dh into 16 registers - so that the cell phase starts on data that is there (round 5's stamps: 6,000 + 2,500..4,400 of a
+                                  // step's 30,400 cycles are that one exposed round trip + its barrier).  Parity-green, no spill at 6 fragments in flight in the second
+                                  // product - and SLOWER: 6.23 against 5.65 ms per launch, 131.8 against 129.2 ms per step, same box both orders
+                                  // (profiles/r06_ab_nsplit_pfi_v1.log).  A wave's loads return in order: the twenty prefetch loads (HBM latency) sit in front of the
+                                  // second product's weight fragments (L2 hits), which now wait for them - the round trip moved from the cell phase into the product,
+                                  // and the resident fragments + three fragments in flight were paid for it.  Only ANOTHER wave's queue could carry the prefetch, and the
+                                  // LDS a helper would fill (gates 53 + c 27 + dh 13 KB) is not there (58 KB free).
 #ifndef NS_RES
-#define NS_RES 4                  // weight fragments per wave that stay in LDS for the whole launch (the first slabs of the partner's K range): the 60 KB
-#endif                            // the tile leaves free take 8 % of the weight stream off the CU's L2 port
+#define NS_RES (NS_PFI ? 0 : 4)   // weight fragments per wave that stay in LDS for the whole launch (the first slabs of the partner's K range): -0.3 ms per train step
+#endif                            // in round 5; the prefetch above takes the same LDS and pays more
+#ifndef NS_KB2
+#define NS_KB2 (NS_PFI ? 6 : 9)   // fragments in flight in the SECOND product, across which the prefetched c / dh registers are live (128-register cap)
+#endif
+
+// one LDS-DMA wave-instruction (64 lanes x 16 B, lane-linear at the LDS byte address dst; m0 declared clobbered, as in gemm.hip)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void ns_glds16(const char* gsrc, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(dst) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 
 struct NsplitArgs {
   const void* dh; long ldd;
@@ -130,6 +153,8 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
     rowtab[tid] = seq < p.n_seq ? (int)((seq / p.inner) * p.outer + (seq % p.inner)) : -1;
   }
   for (int i = tid; i < 32 * PITCH / 16; i += NTHR_ALL) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);
+  // NS_PFI: 4 KB per wave behind the tile: [32 rows][16 units x 4 gates] bf16 of the wave's unit tile, the next step's saved gate activations
+  char* pfg = smem + 32 * PITCH + 256 + (w < NSW ? w : 0) * 4096;
   // resident weight fragments: the first NS_RES k-slabs of the PARTNER's K range of this wave's unit tile, read from LDS every step
   char* resw = smem + 32 * PITCH + 256 + (w < NSW ? w : 0) * (NS_RES * 1024) + lane * 16;
   if (NS_RES > 0 && active) {
@@ -282,6 +307,45 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
       return;
     }
   }
+  // ---- NS_PFI: the inputs of time index tt for this wave's unit tile: gates -> pfg by LDS-DMA (four instructions: lane l of instruction i moves the 16-byte
+  // piece l % 8 of row 8 i + l / 8, i.e. lane-linear in the wave's 4 KB), c_{t-1} and dh -> cn / dhn.  Issued in front of the second product's fragment loads:
+  // older than every one of them in the in-order vmcnt queue, so complete when the last fragment is.
+  float cn[2][4];
+  bf16_t dhn[2][4];
+  const unsigned pfg_u = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)pfg);
+  auto prefetch_inputs = [&](int tt) __attribute__((always_inline)) {
+    if (!active) {          // (assigned on every path: a value carried over from the previous step would be live through the whole step - 16 registers)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cn[rt][r] = 0.f; dhn[rt][r] = 0; }
+      return;
+    }
+    const int toffn = tt * stride_i;
+    const bool firstn = dir ? (tt == p.seq_len - 1) : (tt == 0);
+    // (the tile of the last 8 units: its pieces 4 .. 7 would lie past the direction's 4H columns - they re-read piece 3, nobody reads them back)
+    const int pc = (ut * 16 + (lane & 7) * 2 < H) ? (lane & 7) : ((H - ut * 16) / 2 - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int grow = rowtab[i * 8 + (lane >> 3)];
+      grow = grow < 0 ? rowtab[0] : grow;                                // (rows past n_seq: any row of the pair, never stored)
+      const char* src = reinterpret_cast<const char*>(gates) + ((long)(grow + toffn) * ldg_i + (gcol_i + ut * 64)) * 2 + pc * 16;
+      ns_glds16(src, __builtin_amdgcn_readfirstlane(pfg_u + (unsigned)i * 1024u));
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rowb(rt, r) + toffn;
+        cn[rt][r] = firstn ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + uc)];
+        dhn[rt][r] = dh[(long)row * ldd_i + (hcol_i + uc)];
+      }
+  };
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cn[rt][r] = 0.f; dhn[rt][r] = 0; }
+  if constexpr (NS_PFI && HELP == 0 && TCH == 0) prefetch_inputs(dir ? 0 : p.seq_len - 1);
   for (int step = 0; step < p.seq_len; ++step) {
     const int t = dir ? step : (p.seq_len - 1 - step);
     const int toff = t * stride_i;
@@ -289,6 +353,7 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
     const bool last = step + 1 == p.seq_len;
     NST_(0);
     // ---- 1. gate gradients of the owned units: LDS tile (own columns) + the gates output (write-through: the partner reads them)
+    if constexpr (NS_PFI && HELP == 0 && TCH == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the prefetch's LDS-DMAs (the compiler does not count them): long landed
     if (active) {
       uint2 gpre[2][4];
       float cpre[2][4];
@@ -301,9 +366,15 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
 #ifdef NSABL_NO_LOAD      // timing diagnostics (wrong results): NSABL_NO_LOAD, NSABL_NO_STORE, NSABL_NO_MM, NSABL_NO_POLL, NSABL_NO_COPY (scripts/abl_nsplit.py)
           gpre[rt][r] = make_uint2((unsigned)row, 0x3f003f00u); cpre[rt][r] = (float)(row & 3); dhpre[rt][r] = (bf16_t)(0x3c00 + (row & 7));
 #else
-          gpre[rt][r] = *reinterpret_cast<const uint2*>(gates + ((long)row * ldg_i + (gcol_i + uc * 4)));
-          cpre[rt][r] = first_ ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + uc)];
-          dhpre[rt][r] = dh[(long)row * ldd_i + (hcol_i + uc)];
+          if constexpr (NS_PFI && HELP == 0 && TCH == 0) {
+            gpre[rt][r] = *reinterpret_cast<const uint2*>(pfg + (rt * 16 + lr * 4 + r) * 128 + lc * 8);      // (requested a product ago: see prefetch_inputs)
+            cpre[rt][r] = cn[rt][r];
+            dhpre[rt][r] = dhn[rt][r];
+          } else {
+            gpre[rt][r] = *reinterpret_cast<const uint2*>(gates + ((long)row * ldg_i + (gcol_i + uc * 4)));
+            cpre[rt][r] = first_ ? 0.f : p.c[(long)(row + prev_i) * ldc_i + (hcol_i + uc)];
+            dhpre[rt][r] = dh[(long)row * ldd_i + (hcol_i + uc)];
+          }
 #endif
         }
 #pragma unroll
@@ -359,16 +430,17 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
     const char* ar = tile + lc * PITCH + 16 * lr;
     // k-slabs [k0, k1) of this wave's unit tile against the tile in LDS, NS_KB fragments in flight; `publish`: after the first batch
     // of fragment loads is issued, wait for this wave's gate-gradient stores (older in the in-order vmcnt queue) and count the wave in
-    auto product = [&](int k0, int k1, bool publish) {
+    auto product = [&](auto kbc, int k0, int k1, bool publish) {
+      constexpr int KB = decltype(kbc)::value;      // fragments in flight (the publishing product: NS_KB = 9, what its counted wait is written for)
 #pragma unroll 1
-      for (int kb = k0; kb < k1; kb += NS_KB) {
-        uint4 b[NS_KB];
+      for (int kb = k0; kb < k1; kb += KB) {
+        uint4 b[KB];
 #pragma unroll
-        for (int i = 0; i < NS_KB; ++i) {
+        for (int i = 0; i < KB; ++i) {
           const int ks = (kb + i < k1) ? kb + i : k1 - 1;
           b[i] = *reinterpret_cast<const uint4*>(whhT + (long)ks * 1024);
         }
-        if (publish && kb == k0 + NS_PUB * NS_KB) {
+        if (publish && kb == k0 + NS_PUB * KB) {
           // this batch's NS_KB fragment loads may stay in flight; everything older - the earlier batches and, before them, this wave's
           // gate-gradient stores - is then complete.  (In front of the FIRST batch this wait put the write-through stores' ~2 us of
           // acknowledge latency on the critical path: profiles/r04_abl_nsplit_v1.log, 14.5 -> 11.6 us per step without the stores.)
@@ -386,7 +458,7 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
         for (int i = 0; i < 1; ++i) acc[0][0] += __uint_as_float(b[0].x);
         if (false)
 #endif
-        for (int i = 0; i < NS_KB; ++i) {
+        for (int i = 0; i < KB; ++i) {
           if (kb + i < k1) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -402,14 +474,14 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
       // ---- 2 + 3 (helper form). compute waves: the own K range.  Helper waves: wait for the own half's stores, raise the flag, wait for the
       // partner's, copy its half into the tile.  One barrier ends both.
       if (active) {
-        product(ks_own0, ks_own1, false);
+        product(std::integral_constant<int, NS_KB>{}, ks_own0, ks_own1, false);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     } else {
     // ---- 2. the own K range (in LDS already); the hand-off to the partner travels meanwhile
     if (active) {
-      product(ks_own0, ks_own1, true);
+      product(std::integral_constant<int, NS_KB>{}, ks_own0, ks_own1, true);
     } else {                                                             // a wave without a unit tile stored its share of the rows too
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) {
@@ -451,6 +523,7 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
     __builtin_amdgcn_s_barrier();
     }
     NST_(6);
+    if constexpr (NS_PFI && HELP == 0 && TCH == 0) prefetch_inputs(dir ? t + 1 : t - 1);      // (this is not the last step: that one left the loop above)
     // ---- 4. the other K range
     if (active) {
       // the first NS_RES k-slabs of the partner's range come from LDS (resident for the whole launch), the rest is streamed
@@ -468,7 +541,7 @@ __global__ void __launch_bounds__((NSW + HELP + TCH) * 64) lstm_bwd_nsplit_kerne
       }
 #endif
 #endif
-      product(k0o + NS_RES, k1o, false);
+      product(std::integral_constant<int, NS_KB2>{}, k0o + NS_RES, k1o, false);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -857,7 +930,7 @@ extern "C" int urse_lstm_nsplit_bwd(const void* dh, int64_t ldd, void* gates, in
   p.g_bytes = (unsigned)(rows * ldg * 2); p.c_bytes = (unsigned)(rows * 2L * H * 4); p.d_bytes = (unsigned)(rows * ldd * 2);
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(flags, 0, sizeof(unsigned) * plan[2], st);
-  const size_t lds = (size_t)32 * lds_frag_pitch(4 * 392 * 2) + 256 + (size_t)NSW * NS_RES * 1024;      // tile, flags + row table, resident fragments
+  const size_t lds = (size_t)32 * lds_frag_pitch(4 * 392 * 2) + 256 + (size_t)NSW * (NS_PFI ? 4096 : NS_RES * 1024);      // tile, flags + row table, the prefetched gates (or the resident fragments)
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_nsplit_kernel<392, 0>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
