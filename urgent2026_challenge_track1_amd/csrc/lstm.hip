@@ -259,6 +259,13 @@ __device__ unsigned long long g_bwstamps[512 * 16];
 #else
 #define BWST(slot) do { } while (0)
 #endif
+// one LDS-DMA wave-instruction (64 lanes x 16 B, lane-linear at the LDS byte address dst; m0 declared clobbered, as in gemm.hip)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void bw_glds16(const char* gsrc, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(dst) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 template <typename T, int RT, int MAXUT, int NW, int HC = 0, int HPC = 0, int PF = 0, int STG = 0, int KH = 1>
 __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   static_assert(KH == 1 || (KH == 2 && !HC && !HPC && !PF && !STG), "the half-tile form exists for the plain variant only");
@@ -329,7 +336,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   // PF = 3: two register slots - the loads of unit tile ui + 1 are issued before tile ui is computed, so a step costs ONE exposed round trip
   // to HBM plus what the compute of a tile does not cover, instead of MAXUT dependent ones (band path, 4 tiles per wave: the input loads are
   // 1.2 of the launch's 3.8 ms, scripts/abl_lstm.py); the registers come out of the weight fragments in flight (URSE_BWD_KB2_PF3)
-  constexpr int PU = PF == 3 ? 2 : (PF ? MAXUT : 1);
+  constexpr int PU = PF == 3 ? 2 : (PF == 4 ? 1 : (PF ? MAXUT : 1));
+  static_assert(PF != 4 || (STG && RT == 2 && sizeof(T) == 2 && KH == 1 && HPC), "PF 4: the 32-row staged-store bf16 form (row table in LDS)");
   V4 gpf[PU][RT][4];
   float cpf[PU][RT][4];
   T dhpf[PU][RT][4];
@@ -380,7 +388,52 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
     for (int ui = 0; ui < MAXUT; ++ui)
       if ((w + NW * ui) * 16 + lc < H) load_step(ui, PF ? ui : 0, tt);
   };
+  // PF = 4 (round 6; the stamps put 35 % of a step on FOUR dependent input round trips, one per unit tile): the unit tiles of a wave go in PAIRS - the even
+  // one's inputs are requested into registers as before and, in the same breath, the odd one's by LDS-DMA into 7 KB per wave behind the row table
+  // ([32 rows][128 B] saved gates, [32][64 B] c_{t-1}, [32][32 B] dh; no register is spent on them): one round trip per pair.  Requested inside the cell
+  // phase, consumed before the weight pass starts: nothing of this sits in front of a weight fragment in the wave's in-order load queue (what sank the
+  // N-split's prefetch, csrc/lstm_nsplit.hip NS_PFI).
+  char* pfb = smem + nbuf * R * pitch + R * (int)sizeof(int) + w * 7168;
+  const unsigned pfb_u = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)pfb);
+  auto dma_tile = [&](int ui, int tt) __attribute__((always_inline)) {
+    const int utd = __builtin_amdgcn_readfirstlane(w) + NW * ui;          // (wave-uniform, and told so: what is built on it is scalar arithmetic; the caller checked utd < nut)
+    // the row table is read again every step through an index the compiler cannot see through: left visible, the seven row lookups and the address
+    // arithmetic built on them are hoisted out of the time loop and stay live across the weight pass - 22 spilled registers
+    int opq = 0;
+    asm volatile("" : "+v"(opq));
+    const int* rowtab = reinterpret_cast<const int*>(smem + nbuf * R * pitch);
+    const int ln = lane + opq;                                            // (the lane id too: piece indices and clamps are per-lane loop invariants)
+    const int toff_ = tt * stride_i;
+    const bool first_ = dir ? (tt == p.m.seq_len - 1) : (tt == 0);
+    const int nu = H - utd * 16 < 16 ? H - utd * 16 : 16;                 // units of this tile that exist (the last tile of H = 392: 8): pieces past them re-read the last one
+    {
+      const int ch = ln & 7, chc = ch < nu / 2 ? ch : nu / 2 - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int grow = rowtab[i * 8 + (ln >> 3)];
+        grow = grow < 0 ? rowtab[0] : grow;
+        bw_glds16(reinterpret_cast<const char*>(gates) + ((long)(grow + toff_) * ldg_i + (gcol_i + utd * 64)) * 2 + chc * 16, __builtin_amdgcn_readfirstlane(pfb_u + (unsigned)i * 1024u));
+      }
+    }
+    {
+      const int ch = ln & 3, chc = ch < nu / 4 ? ch : nu / 4 - 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int grow = rowtab[i * 16 + (ln >> 2)];
+        grow = grow < 0 ? rowtab[0] : grow;
+        const int crow = grow + toff_ + (first_ ? 0 : prev_i);           // (first step of the forward recurrence: c_{-1} = 0, the value read is not used)
+        bw_glds16(reinterpret_cast<const char*>(p.c) + ((long)crow * ldc_i + (hcol_i + utd * 16)) * 4 + chc * 16, __builtin_amdgcn_readfirstlane(pfb_u + 4096u + (unsigned)i * 1024u));
+      }
+    }
+    {
+      const int ch = ln & 1, chc = ch < nu / 8 ? ch : nu / 8 - 1;
+      int grow = rowtab[ln >> 1];
+      grow = grow < 0 ? rowtab[0] : grow;
+      bw_glds16(reinterpret_cast<const char*>(dh) + ((long)(grow + toff_) * ldd_i + (hcol_i + utd * 16)) * 2 + chc * 16, __builtin_amdgcn_readfirstlane(pfb_u + 6144u));
+    }
+  };
   if constexpr (PF == 1) load_all(dir ? 0 : p.m.seq_len - 1);
+  if constexpr (PF == 4) __syncthreads();                                 // (the row table is complete before the first DMA reads it)
   for (int step = 0; step < p.m.seq_len; ++step) {
     const int t = dir ? step : (p.m.seq_len - 1 - step);
     char* tile = smem + (step % nbuf) * R * pitch;
@@ -394,12 +447,37 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
       const int ut = w + NW * ui;
       if (ut < nut) {
         const int u = ut * 16 + lc;
+        if constexpr (PF == 4) {
+          // (wave-uniform part; the per-lane loads and reads stay inside the one `u < H` block below with the arithmetic that consumes them - assigned in a
+          // block of their own, the input registers are live through the whole step for the lanes that skip it: 82 spills)
+          if ((ui & 1) == 0) {
+            if (ui + 1 < MAXUT && w + NW * (ui + 1) < nut) dma_tile(ui + 1, t);      // the odd partner's inputs travel with this tile's
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile's DMAs (the compiler does not count them); nothing younger is in flight
+          }
+        }
         if (u < H) {
           if constexpr (!PF) load_step(ui, 0, t);
+          if constexpr (PF == 4) {
+            if ((ui & 1) == 0) {
+              load_step(ui, 0, t);
+            } else {
+              const bool first_ = dir ? (t == p.m.seq_len - 1) : (t == 0);
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int lrow = rt * 16 + lr * 4 + r;
+                  gpf[0][rt][r] = *reinterpret_cast<const V4*>(pfb + lrow * 128 + lc * 8);
+                  cpf[0][rt][r] = first_ ? 0.f : *reinterpret_cast<const float*>(pfb + 4096 + lrow * 64 + lc * 4);
+                  dhpf[0][rt][r] = *reinterpret_cast<const T*>(pfb + 6144 + lrow * 32 + lc * 2);
+                }
+            }
+          }
           if constexpr (PF == 3) {
             if (ui + 1 < MAXUT && (w + NW * (ui + 1)) * 16 + lc < H) load_step(ui + 1, (ui + 1) & 1, t);
           }
-          const int SL = PF == 3 ? (ui & 1) : (PF ? ui : 0);         // (a constant after unrolling)
+          const int SL = PF == 3 ? (ui & 1) : ((PF && PF != 4) ? ui : 0);         // (a constant after unrolling)
           V4 (&gpre)[RT][4] = gpf[SL];
           float (&cpre)[RT][4] = cpf[SL];
           T (&dhpre)[RT][4] = dhpf[SL];
@@ -550,10 +628,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
 #define URSE_BWD_KB2_STG 25   // the staged-store form of the 32-sequence geometry has the registers for 49 = 25 + 24 fragments in flight (246 VGPRs, no
                               // spill): 3.69 -> 3.61 ms per launch, same bits (scripts/diag/kb2_sweep.sh; 19 and 21 leave ragged last batches and lose)
 #endif
+#ifndef URSE_BWD_KB2_PF4
+#define URSE_BWD_KB2_PF4 17   // the paired-tile form: what its DMA addresses and LDS pointer leave for fragments in flight (49 = 17 + 17 + 15)
+#endif
 #ifndef URSE_BWD_KB3
 #define URSE_BWD_KB3 13   // 48 rows on four waves (512 registers per wave): what the per-row state of 7 x 3 tiles leaves for fragments in flight
 #endif
-        constexpr int KB = (sizeof(T) == 2) ? (RT >= 3 ? URSE_BWD_KB3 : RT >= 2 ? (PF == 3 ? URSE_BWD_KB2_PF3 : (STG ? URSE_BWD_KB2_STG : URSE_BWD_KB2)) : (NW == 8 ? URSE_BWD_KB8 : (PF == 1 ? (NW == 12 ? URSE_BWD_KBPF12 : URSE_BWD_KBPF16) : URSE_BWD_KB))) : 8;
+        constexpr int KB = (sizeof(T) == 2) ? (RT >= 3 ? URSE_BWD_KB3 : RT >= 2 ? (PF == 3 ? URSE_BWD_KB2_PF3 : (PF == 4 ? URSE_BWD_KB2_PF4 : (STG ? URSE_BWD_KB2_STG : URSE_BWD_KB2))) : (NW == 8 ? URSE_BWD_KB8 : (PF == 1 ? (NW == 12 ? URSE_BWD_KBPF12 : URSE_BWD_KBPF16) : URSE_BWD_KB))) : 8;
         #pragma unroll 1
         for (int k0 = 0; k0 < nslab; k0 += KB) {
           uint4 b[KB];
@@ -932,6 +1013,19 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
         static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 3, 1>), true);
         (void)once;
         hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 3, 1>), grid, dim3(NW * 64), lds + R * sizeof(int), st, pa);
+      } else
+#endif
+#ifdef URSE_EXPERIMENTS
+      // round 6, measured and dropped (variant builds only): unit tiles in PAIRS, the odd one's inputs by LDS-DMA beside the even one's register loads (PF = 4; parity-green,
+      // no spill at 17 fragments in flight).  3.65 vs 3.48 ms alone, 25.8 vs 24.4 ms of band BPTT per step (profiles/r06_ab_bwd_pairs_v1.log): the stamps of the paired form
+      // show the first tile's wait growing from 8.1 k to 12.4 k cycles - what looked like four dependent LATENCIES is the throughput of small-sector HBM gathers (8 + 4 + 2
+      // bytes per row and unit): asking for two tiles at once takes as long as asking twice.
+      static const bool pairs = getenv("URSE_BWD_PAIRS") && atoi(getenv("URSE_BWD_PAIRS")) != 0;
+      if (stg && pairs && !pa.dbuf && lds + R * sizeof(int) + NW * 7168 <= 160 * 1024 && (p.ldd * 2) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.dh) % 16) == 0 &&
+          (reinterpret_cast<uintptr_t>(p.c) % 16) == 0) {
+        static bool once = (allow_big_lds(lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 4, 1>), true);
+        (void)once;
+        hipLaunchKernelGGL((lstm_bwd_kernel<T, 2, 4, 8, 0, 392, 4, 1>), grid, dim3(NW * 64), lds + R * sizeof(int) + NW * 7168, st, pa);
       } else
 #endif
       if (stg) {
