@@ -669,6 +669,176 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(LstmBwdArgs p) {
   }
 }
 
+// ---- BPTT with the waves of a workgroup in two ROLES (bf16, H = 392, 32 sequences per workgroup; round 6) ---------------------------------
+// lstm_bwd_kernel uses two resources one after the other inside a workgroup: the cell phase waits for HBM (the step's saved gates, c_{t-1} and dh:
+// 179 KB per step and workgroup; over the launch 6.0 GB read + 2.75 GB written = half its time at 5 TB/s) with the L2-bound weight pass idle, then the
+// weight pass (1.57 MB of W_hh^T per step through the CU's memory path) runs with HBM idle - stamps: 35 % / 59 % of a step, profiles/
+// r06_stamps_tn224_bwdband_rwx_v1.log.  The inputs do not depend on the recurrence, only the arithmetic does; but a wave's loads return in ORDER, so a wave
+// that prefetches them makes its own weight fragments (L2 hits) wait for HBM (the N-split's prefetch, the paired tiles: both measured slower).  So the two
+// streams get their own waves:
+//   seven CELL waves own the per-element state (unit w * 56 .. + 55 of wave w, 28 elements per lane: dc and c in registers) and everything that touches HBM:
+//     after the step's barrier they store the gate gradients (16-byte row pieces out of the LDS tile) and request the NEXT step's inputs into registers -
+//     both travel while the product runs; at the top of a step they read dh_rec from LDS, do the cell arithmetic and write the tile;
+//   one PRODUCT wave streams W_hh^T (25 unit tiles x 49 fragments, a whole tile's 49 in flight, refilled slot by slot across tiles and steps) against the
+//     tile and writes dh_rec [32][392] f32 to LDS.
+// Two barriers per step (tile complete / dh_rec complete).  Arithmetic and summation order are lstm_bwd_kernel's: bit-identical gate gradients.
+template <int H>
+__global__ void __launch_bounds__(512) lstm_bwd_roles_kernel(LstmBwdArgs p) {
+  constexpr int R = 32, NUT = (H + 15) / 16, G4 = 4 * H, NSLAB = G4 * 2 / 64, PITCH = lds_frag_pitch(G4 * 2);
+  constexpr int NCW = 7, UPW = H / NCW, EPL = R * UPW / 64, KC = UPW / 8;        // cell waves, units per cell wave (56), elements per lane (28), 8-unit groups per wave (7)
+  constexpr int DP = H + 12;                                                    // dh_rec row pitch in floats (404: the product wave's 4-row groups fall on different banks)
+  static_assert(H % NCW == 0 && UPW % 8 == 0 && EPL * 64 == R * UPW && EPL == 4 * KC, "element map: row = (k / KC) * 8 + lane / 8, unit = (k % KC) * 8 + lane % 8");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                                            // [32][PITCH] bf16 gate gradients of the step (MFMA A operand)
+  float* dhrec = reinterpret_cast<float*>(smem + R * PITCH);                   // [32][DP] f32
+  int* rowtab = reinterpret_cast<int*>(smem + R * PITCH + R * DP * 4);         // [32] row of (sequence, t = 0), -1 beyond n_seq
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int dir, tile_;
+  xcd_dir_tile(p.xcd, dir, tile_);
+  const int s0 = tile_ * R;
+  const int ldg_i = (int)p.ldg, ldd_i = (int)p.ldd, ldc_i = 2 * H, stride_i = (int)p.m.stride;
+  const int gcol_i = dir * G4, hcol_i = dir * H, prev_i = dir ? stride_i : -stride_i;
+  if (tid < R) {
+    const int seq = s0 + tid;
+    rowtab[tid] = seq < p.m.n_seq ? (int)((seq / p.m.inner) * p.m.outer + (seq % p.m.inner)) : -1;
+  }
+  for (int i = tid; i < R * DP; i += 512) dhrec[i] = 0.f;                       // dh_rec of the first step
+  for (int i = tid; i < R * PITCH / 16; i += 512) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0, 0, 0, 0);      // (the K padding past 4H stays zero)
+  __syncthreads();
+  const bf16_t* dh = reinterpret_cast<const bf16_t*>(p.dh);
+  bf16_t* gates = reinterpret_cast<bf16_t*>(p.gates);
+
+  if (w < NCW) {
+    // ================= cell waves =================
+    const int r8 = lane >> 3, c8 = lane & 7;
+    int rowb[4];                                                                // row of this lane's sequences (kr = 0 .. 3: sequence kr * 8 + r8) at t = 0, clamped beyond n_seq
+#pragma unroll
+    for (int kr = 0; kr < 4; ++kr) {
+      int seq = s0 + kr * 8 + r8;
+      if (seq >= p.m.n_seq) seq = p.m.n_seq - 1;
+      rowb[kr] = (int)((seq / p.m.inner) * p.m.outer + (seq % p.m.inner));
+    }
+    const int u0 = w * UPW + c8;                                                // unit of element k: u0 + (k % KC) * 8
+    float dcs[EPL], ccur[EPL];
+    uint2 gp[EPL];
+    float cp[EPL];
+    bf16_t dp[EPL];
+    // buffer descriptors over the three input matrices (32-bit byte offsets: checked on the host): a lane's 28 elements are FOUR row bases + an
+    // instruction's immediate (element k: row base k / KC, 8-unit group k % KC) - twelve address registers per step instead of 84 64-bit pointers
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)0xFFFFF000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c), 0, (int)0xFFFFF000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dh), 0, (int)0xFFFFF000u, 0x00020000);
+    auto load_inputs = [&](int tt) __attribute__((always_inline)) {
+      const int toff_ = tt * stride_i;
+      const bool first_ = dir ? (tt == p.m.seq_len - 1) : (tt == 0);          // first step of the forward recurrence: c_{-1} = 0
+      unsigned og[4], oc[4], od[4];
+#pragma unroll
+      for (int kr = 0; kr < 4; ++kr) {
+        const int row = rowb[kr] + toff_;
+        og[kr] = (unsigned)(row * ldg_i + gcol_i + u0 * 4) * 2u;
+        oc[kr] = (unsigned)((row + (first_ ? 0 : prev_i)) * ldc_i + hcol_i + u0) * 4u;
+        od[kr] = (unsigned)(row * ldd_i + hcol_i + u0) * 2u;
+      }
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        const u32x2_ g2 = __builtin_amdgcn_raw_buffer_load_b64(rs_g, (int)(og[k / KC] + (unsigned)((k % KC) * 64)), 0, 0);
+        gp[k] = make_uint2(g2[0], g2[1]);
+        const float cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)(oc[k / KC] + (unsigned)((k % KC) * 32)), 0, 0));
+        cp[k] = first_ ? 0.f : cv;
+        dp[k] = (bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_d, (int)(od[k / KC] + (unsigned)((k % KC) * 16)), 0, 0);
+      }
+    };
+    {
+      const int t0 = dir ? 0 : p.m.seq_len - 1;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        dcs[k] = 0.f;
+        ccur[k] = p.c[(long)(rowb[k / KC] + t0 * stride_i) * ldc_i + (hcol_i + u0 + (k % KC) * 8)];
+      }
+      load_inputs(t0);
+    }
+    constexpr int CPR = G4 * 2 / 16, CTHR = NCW * 64;                           // 16-byte pieces of a row's direction segment (196), cell threads (448)
+    for (int step = 0; step < p.m.seq_len; ++step) {
+      const int t = dir ? step : (p.m.seq_len - 1 - step);
+      const int toff = t * stride_i;
+      // ---- cell arithmetic on inputs that were requested a product ago; dh_rec from the product wave
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        const int lrow = (k / KC) * 8 + r8, u = u0 + (k % KC) * 8;
+        float a[4];
+        Vec4<bf16_t>::unpack(gp[k], a);
+        const float iv = a[0], fv = a[1], gv = a[2], ov = a[3];
+        const float dht = bf16_to_f32(dp[k]) + dhrec[lrow * DP + u];
+        const float tc = tanhf_(ccur[k]);
+        const float dct = dcs[k] + dht * ov * (1.f - tc * tc);
+        float dg[4];
+        dg[0] = dct * gv * iv * (1.f - iv);
+        dg[1] = dct * cp[k] * fv * (1.f - fv);
+        dg[2] = dct * iv * (1.f - gv * gv);
+        dg[3] = dht * tc * ov * (1.f - ov);
+        dcs[k] = dct * fv;
+        ccur[k] = cp[k];                                                        // c_{t-1} is the next processed step's c_t
+        *reinterpret_cast<uint2*>(tile + lrow * PITCH + u * 8) = Vec4<bf16_t>::pack(dg);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                             // A: the tile is complete, dh_rec has been consumed
+      // ---- the step's gate gradients leave (16-byte row pieces), the next step's inputs are requested: both under the product
+      for (int idx = tid; idx < R * CPR; idx += CTHR) {
+        const int row = idx / CPR, cc = idx - row * CPR;
+        const int grow = rowtab[row];
+        if (grow >= 0)
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gates) + ((long)(grow + toff) * ldg_i + gcol_i) * 2 + cc * 16) =
+              *reinterpret_cast<const uint4*>(tile + row * PITCH + cc * 16);
+      }
+      if (step + 1 == p.m.seq_len) break;
+      load_inputs(dir ? t + 1 : t - 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // (the tile reads of the stores are done before the barrier lets the next step write it)
+      __builtin_amdgcn_s_barrier();                                             // B: dh_rec of this step is complete
+    }
+    return;
+  }
+
+  // ================= product wave =================
+  const int lr = lane >> 4, lc = lane & 15;
+  const char* whhT = reinterpret_cast<const char*>(p.whhT) + ((long)dir * NUT * NSLAB) * 1024 + lane * 16;
+  const char* ar = tile + lc * PITCH + 16 * lr;
+  // ONE wave has to keep the CU's memory path busy (68 GB/s x ~0.7 us = 48 KB in flight): a whole unit tile's 49 fragments sit in registers, and the slot of
+  // a fragment is refilled with the NEXT tile's fragment the moment its MFMAs have issued - 49 KB in flight without a gap between tiles, nor between steps
+  // (the weights do not depend on the step: the first tile of step t + 1 is requested while the last tile of step t is multiplied)
+  uint4 b[NSLAB];
+#pragma unroll
+  for (int i = 0; i < NSLAB; ++i) b[i] = *reinterpret_cast<const uint4*>(whhT + (long)i * 1024);
+  for (int step = 0; step < p.m.seq_len; ++step) {
+    __builtin_amdgcn_s_barrier();                                               // A
+    if (step + 1 == p.m.seq_len) break;
+#pragma unroll 1
+    for (int ut = 0; ut < NUT; ++ut) {
+      f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+      const char* wn = whhT + (long)(ut + 1 < NUT ? ut + 1 : 0) * NSLAB * 1024;  // the tile that follows (tile 0 of the next step behind the last one)
+#pragma unroll
+      for (int i = 0; i < NSLAB; ++i) {
+        uint4 a[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) a[rt] = *reinterpret_cast<const uint4*>(ar + rt * 16 * PITCH + i * 64);
+        mma_slab<bf16_t, 2>(a, b[i], acc);
+        b[i] = *reinterpret_cast<const uint4*>(wn + (long)i * 1024);
+      }
+      const int u = ut * 16 + lc;
+      if (u < H) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dhrec[(rt * 16 + lr * 4 + r) * DP + u] = acc[rt][r];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                               // B
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // (the last refills are never consumed; they must not outlive the wave)
+}
+
 // ---- BPTT, transposed accumulator layout (bf16) -------------------------------------------------------------------------------
 // lstm_bwd_kernel multiplies dgates (A operand, rows = sequences) with W_hh fragments (B operand, columns = units): the MFMA C
 // layout then gives a lane ONE unit and FOUR sequences, and every per-(sequence, unit) input of the cell update - saved gates
@@ -1016,6 +1186,21 @@ static int launch_bwd(const LstmBwdArgs& p, hipStream_t st) {
       } else
 #endif
 #ifdef URSE_EXPERIMENTS
+      // round 6, measured and dropped (variant builds only; URSE_BWD_ROLES=1): lstm_bwd_roles_kernel - parity-green (1 bf16 ulp from this kernel: other fma contractions), no
+      // spill, and TWICE as slow: 8.15 against 4.08 ms per launch (profiles/r06_ab_bwd_roles_v1.log).  Its one product wave keeps a whole tile's 49 fragments in flight and
+      // refills them across tiles and steps - and that is all ONE wave's load queue holds (vmcnt counts to 63): 49 KB against the ~200 KB the eight waves of this kernel keep
+      // in flight to reach the CU's 68 GB/s.  The weight stream needs the registers of many waves, the per-element state needs them too, and 32 rows leave no LDS for either.
+      const bool roles = getenv("URSE_BWD_ROLES") && atoi(getenv("URSE_BWD_ROLES")) != 0;
+      // (its cell waves address the three input matrices with 32-bit byte offsets)
+      const long rows_ = p.m.stride * (p.m.seq_len - 1) + ((long)(p.m.n_seq - 1) / p.m.inner) * p.m.outer + (p.m.n_seq - 1) % p.m.inner + 1;
+      if (stg && roles && (size_t)R * lds_frag_pitch(4 * 392 * 2) + R * (392 + 12) * 4 + R * sizeof(int) <= 160 * 1024 &&
+          rows_ * p.ldg * 2 < 0xFFFFF000L && rows_ * 2L * p.H * 4 < 0xFFFFF000L && rows_ * p.ldd * 2 < 0xFFFFF000L && rows_ * p.ldg < (1L << 31)) {
+        static bool once = (allow_big_lds(lstm_bwd_roles_kernel<392>), true);
+        (void)once;
+        hipLaunchKernelGGL((lstm_bwd_roles_kernel<392>), grid, dim3(512), (size_t)R * lds_frag_pitch(4 * 392 * 2) + R * (392 + 12) * 4 + R * sizeof(int), st, pa);
+        URSE_CHECK_LAUNCH("urse_lstm_bwd");
+        return URSE_OK;
+      }
       // round 6, measured and dropped (variant builds only): unit tiles in PAIRS, the odd one's inputs by LDS-DMA beside the even one's register loads (PF = 4; parity-green,
       // no spill at 17 fragments in flight).  3.65 vs 3.48 ms alone, 25.8 vs 24.4 ms of band BPTT per step (profiles/r06_ab_bwd_pairs_v1.log): the stamps of the paired form
       // show the first tile's wait growing from 8.1 k to 12.4 k cycles - what looked like four dependent LATENCIES is the throughput of small-sector HBM gathers (8 + 4 + 2
