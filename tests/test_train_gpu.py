@@ -253,3 +253,27 @@ def test_inference_half_default_on_a_trained_checkpoint_validated_and_with_a_way
         y = inference.enhance_file(m, noisy[0], fs, "cuda")
     assert any("checkpoint's own operand type" in str(x.message) for x in w), [str(x.message) for x in w]
     assert core.compute_dtype == torch.bfloat16 and bool(torch.isfinite(y).all())
+
+
+@pytest.mark.gpu
+def test_default_bench_line_carries_the_one_rccl_rank_leg():
+    """`python bench.py` (no --no-dist-leg): after the timed steps the parent starts the SAME workload once more as the only rank of an RCCL process
+    group (child process, timeout) and reports it under `config.dist`: `reserved_step_ms`, its ratio to the plain step, the buckets, the
+    cooperative kernels' error flag and refusals.  Toy size here; the full-size figures are in the driver's line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NCCL_MAX_NCHANNELS")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--pretouch-gib", "0", "--batch", "2", "--seconds", "1",
+           "--channels", "32", "--layers", "2", "--no-flow", "--no-metrics", "--no-cpu-baseline", "--no-f32-mode"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    dist = d["config"]["dist"]
+    assert "error" not in dist, dist
+    assert d["config"]["dist_backend"] is None                      # the headline run itself used no process group
+    assert dist["backend"] == "nccl" and dist["world_size"] == 1 and dist["comm_reserved_cus"] == 32
+    assert dist["reserved_step_ms"] > 0 and abs(dist["reserved_vs_plain"] - dist["reserved_step_ms"] / d["ms_per_step"]) < 1e-9
+    assert dist["kernel_error_flag"] == 0 and dist["ranks_hold_identical_weights"] is True
+    gb = dist["gradient_buckets"]
+    assert gb["collectives_issued"] == gb["buckets"] * (3 + 2)        # 3 timed + 2 warm-up steps of the leg
