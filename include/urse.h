@@ -257,8 +257,12 @@ int urse_lstm_cluster_fwd(void* gx, int64_t ldg, const void* whhq, void* hout, i
  * [M, ldg >= 8H] RECEIVES the bf16 gate activations (save != 0; NULL otherwise); plan / hx / counters / err_flag / reserved_cus / xcd_aware / dtype /
  * hout_bf16 as urse_lstm_cluster_fwd.  urse_lstm_clusterx_supported: Np == 224, Hp == 416 (N = 196, H = 392). */
 int urse_lstm_clusterx_supported(int N, int Np, int H, int Hp);
-/* 16-bit elements of the hx workspace of urse_lstm_clusterx_fwd (its exchange planes keep rows at the LDS tile's pitch: 27 / 26 of the plan's hx);
- * fails where urse_lstm_cluster_plan fails */
+/* Geometry / workspace of urse_lstm_clusterx_fwd: plan[7] = {C, clusters per direction, sequences per cluster, rows_pad, hx elements (16-bit; the exchange
+ * planes keep rows at the LDS tile's pitch), counters, ROUNDS}.  Up to (clusters per direction) * 64 sequences per direction the clusters are
+ * urse_lstm_cluster_plan's and rounds = 1 (the time path).  Round 6: with more sequences (the band path, rnn_band of the same reference lines: 12,832
+ * per direction x 34 steps at C2) every co-resident cluster keeps its weights and takes 64 sequences per ROUND, rounds = ceil(n_seq / (clusters * 64));
+ * urse_lstm_clusterx_fwd accepts any n_seq for which this call succeeds.  urse_lstm_clusterx_hx_elems = plan[4]. */
+int urse_lstm_clusterx_plan(int H, int Hp, int n_seq, int reserved_cus, int64_t* plan);
 int urse_lstm_clusterx_hx_elems(int H, int Hp, int n_seq, int reserved_cus, int64_t* elems);
 int urse_lstm_pack_quads_x(const float* wih, void* out, int N, int Np, int H, int dtype, void* stream);
 int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* wihq, const float* bias, const void* whhq, void* gates, int64_t ldg, void* hout,

@@ -572,3 +572,63 @@ def test_cluster_forward_with_fused_projection_matches_two_kernel_form(lib, dtyp
     # inference form: nothing saved
     g3, h3, c3, e3 = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], save=False, **sm)
     assert g3 is None and c3 is None and torch.equal(h3, h2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n_seq,K", [(2400, 34), (1300, 5), (1153, 8), (12832, 34)])
+def test_cluster_forward_in_rounds_on_the_band_path(lib, dtype, n_seq, K):
+    """Round 6: the band path (espnet2 BSRNN's rnn_band, reference twin baseline_code/models/bsrnn_flowse.py:296-299: many short sequences) through the
+    fused cluster forward in ROUNDS - every co-resident cluster keeps its weights and takes 64 sequences per round; the hand-off's step counter runs on
+    across rounds, a round's first step waits for the previous round's last publication and starts from h = 0.  Checked (a) against nn.LSTM in f32,
+    (b) BIT for bit against the same kernel run one round at a time on slabs of at most clusters x 64 sequences (a sequence's arithmetic does not
+    depend on which cluster, round or row it gets), incl. a last round that only some clusters take part in, a partial last chunk, an odd sequence
+    length (the LDS tiles' parity restarts per round, the exchange planes' does not) and the full C2 shape (12 rounds); (c) forward-only form."""
+    from urgent2026_challenge_track1_amd import ops
+    N, H, dev = 196, 392, "cuda"
+    torch.manual_seed(11)
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    plan = ops.lstm_clusterx_plan(H, pk["Hp"], n_seq)
+    cap = plan[1] * 64
+    assert plan[6] == -(-n_seq // cap) and plan[6] > 1 and ops.lstm_cluster_plan(H, pk["Hp"], n_seq) is None
+    M = n_seq * K
+    x = torch.randn(n_seq, K, N)
+    xr = ops.pack2d(x.reshape(M, N).to(dev), M, pk["Np"], dtype)
+    sm = dict(n_seq=n_seq, seq_len=K, inner=1, outer=K, stride=1)
+    ops.launch_counts(reset=True)
+    g, h, c, e = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], **sm)
+    assert ops.launch_counts()["lstm_fwd_clusterx"] == 1 and int(e.item()) == 0
+    if n_seq <= 2400:
+        y = lstm(x)[0].detach().reshape(-1, 2 * H)
+        assert (h[:, :2 * H].float().cpu() - y).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 2.5e-3)
+    for s0 in range(0, n_seq, cap):
+        s1 = min(n_seq, s0 + cap)
+        sl = slice(s0 * K, s1 * K)
+        g1, h1, c1, e1 = ops.lstm_fwd_clusterx(xr[sl], pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], n_seq=s1 - s0, seq_len=K, inner=1, outer=K, stride=1)
+        assert int(e1.item()) == 0
+        assert torch.equal(h1, h[sl]) and torch.equal(c1, c[sl]) and torch.equal(g1, g[sl]), (s0, s1)
+    g3, h3, c3, e3 = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], save=False, **sm)
+    assert g3 is None and c3 is None and torch.equal(h3, h) and int(e3.item()) == 0
+
+
+def test_cluster_forward_in_rounds_on_the_time_geometry(lib):
+    """the same rounds with the time path's strides (sequence (b, k), step stride K): 1,360 sequences of 7 steps = 2 rounds, against nn.LSTM."""
+    from urgent2026_challenge_track1_amd import ops
+    N, H, dev, dtype = 196, 392, "cuda", torch.bfloat16
+    B, T, K = 40, 7, 34
+    torch.manual_seed(12)
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    M = B * T * K
+    x = torch.randn(B, T, K, N)
+    sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K)
+    assert ops.lstm_clusterx_plan(H, pk["Hp"], sm["n_seq"])[6] == 2
+    y = lstm(x.permute(0, 2, 1, 3).reshape(B * K, T, N))[0].detach().reshape(B, K, T, 2 * H).permute(0, 2, 1, 3).reshape(-1, 2 * H)
+    xr = ops.pack2d(x.reshape(M, N).to(dev), M, pk["Np"], dtype)
+    g, h, c, e = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], **sm)
+    assert int(e.item()) == 0
+    assert (h[:, :2 * H].float().cpu() - y).abs().max().item() <= 2e-2

@@ -401,8 +401,8 @@ class BSRNNCore(nn.Module):
         if self.H == 392 and path == "t":
             lay -= {"wx", "whhb_rw"}
         d = self._dims
-        if (self.H == 392 and path == "f") or not ops.lstm_clusterx_supported(self.N, d["Np"], self.H, d["Hp"]):
-            lay -= {"wihq"}          # (the fused cluster forward serves the time path; other shapes have no such kernel)
+        if (self.H == 392 and path == "f" and not ops.BAND_CLUSTERX) or not ops.lstm_clusterx_supported(self.N, d["Np"], self.H, d["Hp"]):
+            lay -= {"wihq"}          # (the fused cluster forward: the time path, and - round 6, in rounds - the band path; other shapes have no such kernel)
         return lay
 
     def _band_tables(self, F, dtype, device):
@@ -526,13 +526,16 @@ class BSRNNCore(nn.Module):
             two = False
         xn, stats, xn_b = ops.groupnorm_fwd(skip, self._p(p + "gamma", N), self._p(p + "beta", N), B, T, 1, K * N, N,
                                             d["Np"], 0, dt, GN_EPS, add=temb, stats=pre, bf16_copy=two or None)
-        fused = (ops.USE_RWX_LSTM and ops.USE_RW_LSTM and dt in ops.HALF_TYPES and pk.get(p + "wx") is not None and
+        cx_ok = (ops.USE_CLUSTERX_LSTM and ops.USE_CLUSTER_LSTM and dt in ops.HALF_TYPES and pk.get(p + "wihq") is not None and
+                 pk.get(p + "whhq") is not None and H not in ops.CLUSTER2_H and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
+                 ops.lstm_clusterx_supported(N, d["Np"], H, d["Hp"]))
+        # the band path in ROUNDS through the fused cluster forward (round 6), where the plan's rounds x steps price below the row-wave kernel
+        band_cx = cx_ok and path == "f" and ops.BAND_CLUSTERX and ops.band_clusterx_pays(H, d["Hp"], sm["n_seq"])
+        fused = (not band_cx and ops.USE_RWX_LSTM and ops.USE_RW_LSTM and dt in ops.HALF_TYPES and pk.get(p + "wx") is not None and
                  sm["n_seq"] >= ops.RW_MIN_SEQ and not (ops.USE_CLUSTER_LSTM and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
                                                       ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None))
         # (fused: the input projection runs inside the recurrence kernel - no gate GEMM, no [M, 8H] pre-activation matrix)
-        fused_c = (not fused and ops.USE_CLUSTERX_LSTM and ops.USE_CLUSTER_LSTM and dt in ops.HALF_TYPES and pk.get(p + "wihq") is not None and
-                   pk.get(p + "whhq") is not None and H not in ops.CLUSTER2_H and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
-                   ops.lstm_clusterx_supported(N, d["Np"], H, d["Hp"]) and ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None)
+        fused_c = not fused and cx_ok and (band_cx or ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None)
         gx = None if (fused or fused_c) else ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
         hout_b = None
         if fused_c:

@@ -80,6 +80,7 @@ struct ClusterXArgs {
   long inner, outer, stride;
   int n_seq, seq_len;
   int C, ncl, rows_per_cluster, rows_pad;
+  int rounds;                     // > 1: more sequences than the co-resident clusters hold at once - every cluster takes 64 per round, round after round
   unsigned g_bytes, c_bytes, h_bytes, x_bytes;
   unsigned* xws;                  // XCD-aware formation (null = static clusters): [0..7] arrivals per XCD, [8] arrivals, zeroed per launch
 };
@@ -160,7 +161,8 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         const int ns = S / 2, nm = Mx / 2;
         int rows_m = 0;
         if (nm > 0 && XROWS * ns < p.n_seq) rows_m = (p.n_seq - XROWS * ns + nm - 1) / nm;
-        const int rows_s = (p.n_seq - rows_m * nm + ns - 1) / ns;
+        int rows_s = (p.n_seq - rows_m * nm + ns - 1) / ns;
+        if (p.rounds > 1) rows_s = rows_m = XROWS;                         // (rounds: 64 sequences per cluster and round, the single-XCD clusters first)
         if (rows_m <= XROWS && rows_s <= XROWS && rows_s > 0) {
           mode = 1;
           int ci, jj, lc_;
@@ -181,28 +183,16 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     if (xs[0] == 1) { dir = xs[1]; clx = xs[2]; j = xs[3]; seq0 = xs[4]; nrows_x = xs[5]; local = xs[6] != 0; cl = clx; }
     __syncthreads();
   }
-  int seq1 = seq0 + nrows_x;
-  if (seq1 > p.n_seq) seq1 = p.n_seq;
-  const int nrows = seq1 > seq0 ? seq1 - seq0 : 0;
+  // ROUNDS (the band path: 12,832 sequences per direction, 34 steps): the cluster keeps its weights and takes 64 sequences per round, ncl * 64 sequences
+  // apart.  The step counter of the hand-off runs on across rounds (gs): every step publishes, also a round's last one, and the first step of the next
+  // round WAITS for that publication before it starts from h = 0 - a member that ran ahead would otherwise overwrite the plane its partner still gathers.
+  const int seq0_first = seq0, rstride = p.ncl * XROWS;
+  const int nrounds = (p.rounds > 1 && seq0_first < p.n_seq) ? (p.n_seq - seq0_first + rstride - 1) / rstride : 1;
   const int nq = (H + 3) >> 2;
   const int ldg_i = (int)p.ldg, ldh_i = (int)p.ldh, ldc_i = 2 * H, stride_i = (int)p.stride, gcol_i = dir * 4 * H, hcol_i = dir * H;
   constexpr unsigned COOB = 0xFFFFF000u;
 
-  // ---- common set-up: row table, bias of this workgroup's units, zeroed staging
-  if (tid < XROWS) {
-    int seq = seq0 + tid;
-    if (seq >= p.n_seq) seq = p.n_seq - 1;
-    const int r0 = (int)((seq / p.inner) * p.outer + (seq % p.inner));
-    rowtab[tid] = r0;
-    xrow[tid] = tid < nrows ? (unsigned)r0 * (unsigned)((int)p.ldx * 2) : 0xFFFFF000u;
-  }
-  if (tid < XTHR) {                                                       // (the h piece of working thread tid: row tid / 7, units 8 (tid % 7) ..)
-    const int sr = tid / (XUW * 2 / 16), sc = tid - sr * (XUW * 2 / 16), ucol = j * XUW + sc * 8;
-    int seq = seq0 + sr;
-    if (seq >= p.n_seq) seq = p.n_seq - 1;
-    const int r0 = (int)((seq / p.inner) * p.outer + (seq % p.inner));
-    hrow[tid] = (sr < nrows && ucol < H) ? ((unsigned)r0 * (unsigned)ldh_i + (unsigned)(hcol_i + ucol)) * 2u : 0xFFFFF000u;
-  }
+  // ---- common set-up: bias of this workgroup's units, zeroed staging
   for (int i = tid; i < XUW * 4; i += XTHR + 64) {
     const int u = j * XUW + (i >> 2);
     bias_s[i] = u < H ? p.bias[(long)dir * 4 * H + u * 4 + (i & 3)] : 0.f;
@@ -210,11 +200,9 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   for (int i = tid; i < 2 * XROWS * XUW * 2 / 4; i += XTHR + 64) reinterpret_cast<unsigned*>(hstage0)[i] = 0u;      // pad units stay 0
   for (int i = tid; i < XROWS * lds_frag_pitch(XNSH * 64) / 16; i += XTHR + 64) reinterpret_cast<uint4*>(htile)[i] = make_uint4(0, 0, 0, 0);   // (K padding stays 0)
   if (tid == 0) *deadflag = 0u;
-  __syncthreads();
   const int nvu = (H - j * XUW) < XUW ? (H - j * XUW > 0 ? H - j * XUW : 0) : XUW;     // valid units of this workgroup (a multiple of 8)
   const __amdgpu_buffer_rsrc_t rs_gs = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)p.g_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
-
   // ---- x rows by LDS-DMA: one instruction brings TWO rows - lanes 0 .. 27 the 28 pieces of row 2 i, lanes 30 .. 57 those of row 2 i + 1 (the destination
   // is lane-linear: lane 30 lands at byte 480 = the tile's pitch), the other lanes are masked off.  EVERY wave issues some of the 32 instructions of a
   // step (XDW per working wave, the rest the helper) right behind barrier 1: issued by the helper wave alone they took 9,000 cycles of a 15,700-cycle step (in-kernel stamps,
@@ -250,22 +238,46 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #endif
     }
   };
-  fetch4(0, (dir ? p.seq_len - 1 : 0) * stride_i, lane);                 // x_0 -> tile 0 (every wave its rows; B0 below)
-
   if (w == XW) {
     // ================= helper wave: saved gates / c_t of every step out; the working waves' two barriers per step =================
+    // (its own copy of the round loop, in front of the working waves' weight loads: inside ONE loop the compiler keeps the 160 weight registers live across the
+    //  helper's 220 registers of store offsets and pieces - 438 scratch instructions)
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
+    const int seq0r = seq0_first + rnd * rstride;
+    int seq1 = seq0r + nrows_x;
+    if (seq1 > p.n_seq) seq1 = p.n_seq;
+    const int nrows = seq1 > seq0r ? seq1 - seq0r : 0;
+    int lane_h = lane;                                                    // (opaque per round: what is derived from it is not to be hoisted out of the round loop)
+    asm volatile("" : "+v"(lane_h));
+    // the round's row tables, for all eight waves (behind the previous round's closing barrier: nobody reads the old ones any more)
+    {
+      int seq = seq0r + lane_h;
+      if (seq >= p.n_seq) seq = p.n_seq - 1;
+      const int r0 = (int)((seq / p.inner) * p.outer + (seq % p.inner));
+      rowtab[lane_h] = r0;
+      xrow[lane_h] = lane_h < nrows ? (unsigned)r0 * (unsigned)((int)p.ldx * 2) : 0xFFFFF000u;
+      for (int tt = lane_h; tt < XTHR; tt += 64) {                          // (the h piece of working thread tt: row tt / 7, units 8 (tt % 7) ..)
+        const int sr = tt / (XUW * 2 / 16), sc = tt - sr * (XUW * 2 / 16), ucol = j * XUW + sc * 8;
+        int sq = seq0r + sr;
+        if (sq >= p.n_seq) sq = p.n_seq - 1;
+        const int rr = (int)((sq / p.inner) * p.outer + (sq % p.inner));
+        hrow[tt] = (sr < nrows && ucol < H) ? ((unsigned)rr * (unsigned)ldh_i + (unsigned)(hcol_i + ucol)) * 2u : 0xFFFFF000u;
+      }
+    }
+    __syncthreads();                                                      // the round's row tables are written
+    fetch4(0, (dir ? p.seq_len - 1 : 0) * stride_i, lane_h);                 // x_0 -> tile 0 (every wave its rows; B0 below)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int NG = XROWS * GPC / 64, NC = XROWS * (XUW * 4 / 16) / 64;     // 30 gates pieces, 14 c pieces per lane and step
+    constexpr int NG = XROWS * GPC / 64, NC = XROWS * (XUW * 4 / 16) / 64;     // 30 gates pieces, 14 c pieces per lane_h and step
     constexpr int GC = XUW * 8 / 16, CC = XUW * 4 / 16;
     unsigned og[NG], oc[NC];
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-      const int idx = lane + i * 64, row = idx / GPC, cc = idx - row * GPC;
+      const int idx = lane_h + i * 64, row = idx / GPC, cc = idx - row * GPC;
       og[i] = (row < nrows && cc < GC && cc * 2 < nvu) ? ((unsigned)rowtab[row] * (unsigned)ldg_i + (unsigned)(gcol_i + (j * XUW + cc * 2) * 4)) * 2u : COOB;
     }
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-      const int idx = lane + i * 64, row = idx / CC, cc = idx - row * CC;
+      const int idx = lane_h + i * 64, row = idx / CC, cc = idx - row * CC;
       oc[i] = (row < nrows && cc * 4 < nvu) ? ((unsigned)rowtab[row] * (unsigned)ldc_i + (unsigned)(hcol_i + j * XUW + cc * 4)) * 4u : COOB;
     }
     uint4 vg[NG], vc[NC];
@@ -322,12 +334,11 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         store_pieces();
       }
     }
+    __builtin_amdgcn_s_barrier();                                         // end of the round: tables and tiles may be rewritten (the last step's pieces are in registers)
+    }
     return;
   }
-
-  // ================= working waves =================
-  // operands swapped as in lstm_cluster.hip: A = the resident weight fragment (rows = the quad's 16 gate columns), B = the h / x fragment (columns =
-  // sequences): lane (lr, lc) then holds the FOUR GATES of unit lr of the quad for sequence lc of the row tile
+  // resident weight fragments of the working waves: loaded once, kept over every round
   uint4 breg[XQ][XNSH], wreg[XQ][XNSP];
   const int lu0 = w * XQ * 4 + lr;                                        // unit index inside the workgroup of quad 0 (quad 1: + 4); H % 56 == 0: all valid
   (void)lu0;
@@ -348,9 +359,39 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
                                  (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)w6.z), (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)w6.w));
     if (lr == 1) breg[q][XNSH - 1] = w6s;
   }
+  // The resident weight fragments are USED once here, in front of the time loop: the compiler's wait-count bookkeeping then knows their loads are done.
+  // Without this the loads of the last fragments count as outstanding at the loop's entry, the merge with the back edge keeps that state for every
+  // iteration, and the first MFMAs that read those registers carry `s_waitcnt vmcnt(4) ... vmcnt(0)` - which, from the second step on, wait for the
+  // seven loads of the h GATHER issued just before: the projection ran BEHIND the gather's round trip instead of under it (found in the ISA after the
+  // stamps put 2,900 - 3,250 cycles on a projection whose MFMAs need 1,500).
+#pragma unroll
+  for (int q = 0; q < XQ; ++q) {
+#pragma unroll
+    for (int ks = 0; ks < XNSH; ++ks) asm volatile("" :: "v"(breg[q][ks].x), "v"(breg[q][ks].y), "v"(breg[q][ks].z), "v"(breg[q][ks].w));
+#pragma unroll
+    for (int ks = 0; ks < XNSP; ++ks) asm volatile("" :: "v"(wreg[q][ks].x), "v"(wreg[q][ks].y), "v"(wreg[q][ks].z), "v"(wreg[q][ks].w));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bool dead = false;
+  for (int rnd = 0; rnd < nrounds; ++rnd) {
+  // ---- the round's sequences (their row tables are the HELPER wave's work: the integer divisions need two dozen registers, and here 160 hold weights);
+  // the thread id is made opaque per round: left visible, everything derived from it is hoisted out of the round loop and stays live over every step
+  int tid_o = tid;
+  asm volatile("" : "+v"(tid_o));
+  seq0 = seq0_first + rnd * rstride;
+  int seq1 = seq0 + nrows_x;
+  if (seq1 > p.n_seq) seq1 = p.n_seq;
+  const int nrows = seq1 > seq0 ? seq1 - seq0 : 0;
+  __syncthreads();                                                        // the round's row tables are written
+  fetch4(0, (dir ? p.seq_len - 1 : 0) * stride_i, tid_o & 63);                 // x_0 -> tile 0 (every wave its rows; B0 below)
+
+
+  // ================= working waves =================
+  // operands swapped as in lstm_cluster.hip: A = the resident weight fragment (rows = the quad's 16 gate columns), B = the h / x fragment (columns =
+  // sequences): lane (lr, lc) then holds the FOUR GATES of unit lr of the quad for sequence lc of the row tile
   // c_{t-1} is read back from the previous step's c staging tile (LDS, written every step), not carried in registers: the budget is 256 and the
   // resident weights take 160
-  for (int i = tid; i < 2 * XROWS * XUW; i += XTHR) reinterpret_cast<float*>(cstage0)[i] = 0.f;
+  for (int i = tid_o; i < 2 * XROWS * XUW; i += XTHR) reinterpret_cast<float*>(cstage0)[i] = 0.f;
 
   // exchange planes: rows at the LDS tile's pitch (864 B), so that a chunk sits at the same byte offset of the plane AND of the tile, and a chunk walk whose
   // offsets are the lane's base + a compile-time multiple of the pass: pass i of thread tid < 441 takes chunk tid % 49 of row 9 i + tid / 49 (nine rows of
@@ -392,6 +433,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   //   gather chunk / staged piece  tid * 16
   int toff_d = 0;
   bool have_d = false;
+  const int gs0 = rnd * p.seq_len, gs_end = nrounds * p.seq_len;        // the hand-off's step counter runs on across rounds
   // (returns the registers the stores read: a 16-byte buffer store fetches its data some time AFTER it has issued, and an LDS read that the compiler
   //  places a few instructions behind it into the same registers can land first - seen here as the first dword of a piece replaced in the waves that
   //  issue last, and in lstm_cluster.hip's helper waves in round 4; the caller keeps the registers occupied until the MFMA block behind has issued)
@@ -409,23 +451,10 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       keep1 = vb;
     }
   };
-  // The resident weight fragments are USED once here, in front of the time loop: the compiler's wait-count bookkeeping then knows their loads are done.
-  // Without this the loads of the last fragments count as outstanding at the loop's entry, the merge with the back edge keeps that state for every
-  // iteration, and the first MFMAs that read those registers carry `s_waitcnt vmcnt(4) ... vmcnt(0)` - which, from the second step on, wait for the
-  // seven loads of the h GATHER issued just before: the projection ran BEHIND the gather's round trip instead of under it (found in the ISA after the
-  // stamps put 2,900 - 3,250 cycles on a projection whose MFMAs need 1,500).
-#pragma unroll
-  for (int q = 0; q < XQ; ++q) {
-#pragma unroll
-    for (int ks = 0; ks < XNSH; ++ks) asm volatile("" :: "v"(breg[q][ks].x), "v"(breg[q][ks].y), "v"(breg[q][ks].z), "v"(breg[q][ks].w));
-#pragma unroll
-    for (int ks = 0; ks < XNSP; ++ks) asm volatile("" :: "v"(wreg[q][ks].x), "v"(wreg[q][ks].y), "v"(wreg[q][ks].z), "v"(wreg[q][ks].w));
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                           // B0: x_0 is in tile 0 (every wave fetched its rows)
 
   int lane_v = lane;
-  bool dead = false;
   volatile __attribute__((address_space(3))) unsigned* dead_lds = (volatile __attribute__((address_space(3))) unsigned*)deadflag;
   for (int step = 0; step < p.seq_len; ++step) {
     // The lane's indices are made opaque per step (and again per phase): left visible as loop invariants the compiler hoists every address derived
@@ -446,9 +475,10 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     const int t = dir ? (p.seq_len - 1 - step) : step;
     const int toff = t * stride_i;
     const int par = step & 1;
-    const unsigned pprev = (unsigned)((step + 1) & 1), pcur = (unsigned)par;
-    const unsigned tag_cur = (((unsigned)step >> 1) & 1u) ^ 1u;
-    const unsigned tag_prev = (((unsigned)(step - 1) >> 1) & 1u) ^ 1u;
+    const int gs = gs0 + step;
+    const unsigned pprev = (unsigned)((gs + 1) & 1), pcur = (unsigned)(gs & 1);
+    const unsigned tag_cur = (((unsigned)gs >> 1) & 1u) ^ 1u;
+    const unsigned tag_prev = (((unsigned)(gs - 1) >> 1) & 1u) ^ 1u;
     const int xg = G0 + par * GS + (lane_v & 15) * GP + (lane_v >> 4) * 16;
     const int bq = B0 + w * (XQ * 64) + (lane_v >> 4) * 16;
     // ---- 0. x_t W_ih^T + b (independent of h) + 1. the h gather.  The gather's loads are issued in front of the projection.
@@ -461,7 +491,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       // is not rewritten before every member has passed this step), so the loop carries no per-lane bookkeeping
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       uint4 hn[HL];
-      bool live = step > 0 && !dead && nact > 0;                          // (dead: this wave has seen a hand-off time out - it stops waiting;
+      bool live = gs > 0 && !dead && nact > 0;                            // (dead: this wave has seen a hand-off time out - it stops waiting;
                                                                           //  nact == 0: a cluster the XCD-aware formation left without sequences)
 #ifdef XABL_NO_GATHER
       live = false;
@@ -550,9 +580,12 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         }
       }
       XST(2);
-      if (live && tag_prev) {                                             // (tags of the other parity are zero bits: nothing to clear)
+      // (tags of the other parity are zero bits: nothing to clear.  A later round's first step: the wait was for the PLANE, the round starts from h = 0 -
+      //  the same AND with a mask of zeros; written as a separate `if (step == 0) hn = 0` the compiler spilled four weight fragments for the whole loop)
+      const unsigned km = step == 0 ? 0u : ~TAGM;
+      if (live && (tag_prev || step == 0)) {
 #pragma unroll
-        for (int i = 0; i < HL; ++i) { hn[i].x &= ~TAGM; hn[i].y &= ~TAGM; hn[i].z &= ~TAGM; hn[i].w &= ~TAGM; }
+        for (int i = 0; i < HL; ++i) { hn[i].x &= km; hn[i].y &= km; hn[i].z &= km; hn[i].w &= km; }
       }
       if (!tailw) {
 #pragma unroll
@@ -685,7 +718,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     __builtin_amdgcn_s_barrier();                                         // barrier 2
     XST(6);
     // ---- 3. h_t of this workgroup's units -> exchange buffer (tagged)
-    if (step + 1 < p.seq_len) {
+    if (gs + 1 < gs_end) {
       const unsigned tagv = tag_cur ? TAGM : 0u;
       const uint4 v = *reinterpret_cast<const uint4*>(smem + H0 + par * HS + tv);
       const uint4 vt = make_uint4(v.x | tagv, v.y | tagv, v.z | tagv, v.w | tagv);
@@ -707,8 +740,13 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     have_d = true;
   }
   {
-    uint4 k0, k1;
-    if (have_d) deferred_hout((p.seq_len + 1) & 1, w * 1024 + lane * 16, k0, k1);
+    uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
+    if (have_d) deferred_hout((p.seq_len + 1) & 1, w * 1024 + lane_v * 16, k0, k1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // end of the round: tables and tiles may be rewritten
+    asm volatile("" :: "v"(k0.x), "v"(k0.y), "v"(k0.z), "v"(k0.w));      // (the store's data registers stay occupied until then, see deferred_hout)
+    if constexpr (H2) asm volatile("" :: "v"(k1.x), "v"(k1.y), "v"(k1.z), "v"(k1.w));
+  }
   }
 }
 
@@ -779,13 +817,34 @@ extern "C" int urse_lstm_clusterx_supported(int N, int Np, int H, int Hp) {
   return (N > 0 && N <= 200 && Np == 224 && H == 392 && Hp == 416) ? 1 : 0;
 }
 
+// workspace / geometry query of the fused cluster forward: {C, ncl, rows_per_cluster, rows_pad, hx_elems (16-bit elements of the exchange planes at the LDS
+// tile's pitch), n_counters, rounds}.  Up to ncl * 64 sequences per direction: urse_lstm_cluster_plan's clusters, one round.  More (the band path:
+// 12,832 per direction): every co-resident cluster takes 64 sequences per round, rounds = ceil(n_seq / (ncl * 64)).
+extern "C" int urse_lstm_clusterx_plan(int H, int Hp, int n_seq, int reserved_cus, int64_t* plan) {
+  URSE_CHECK_ARG(plan && n_seq > 0 && reserved_cus >= 0, "urse_lstm_clusterx_plan: bad argument");
+  URSE_CHECK_ARG(urse_lstm_clusterx_supported(196, 224, H, Hp), "urse_lstm_clusterx_plan: unsupported H=%d Hp=%d", H, Hp);
+  int64_t one[6];
+  int rc = urse_lstm_cluster_plan(H, Hp, n_seq < XROWS ? n_seq : XROWS, reserved_cus, one);      // (C, and whether a cluster fits beside the reservation at all)
+  if (rc) return rc;
+  const int ncl_max = (device_cu_count() - reserved_cus - 4) / 2 / (int)one[0];
+  if (n_seq <= ncl_max * XROWS) {
+    rc = urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus, plan);
+    if (rc) return rc;
+    plan[6] = 1;
+  } else {
+    plan[0] = one[0]; plan[1] = ncl_max; plan[2] = XROWS; plan[3] = XROWS; plan[5] = 2 * ncl_max;
+    plan[6] = (n_seq + ncl_max * XROWS - 1) / (ncl_max * XROWS);
+  }
+  plan[4] = (int64_t)2 * 2 * plan[1] * plan[3] * (lds_frag_pitch(XNSH * 64) / 2);
+  return URSE_OK;
+}
+
 extern "C" int urse_lstm_clusterx_hx_elems(int H, int Hp, int n_seq, int reserved_cus, int64_t* elems) {
   URSE_CHECK_ARG(elems, "urse_lstm_clusterx_hx_elems: null pointer");
-  URSE_CHECK_ARG(urse_lstm_clusterx_supported(196, 224, H, Hp), "urse_lstm_clusterx_hx_elems: unsupported H=%d Hp=%d", H, Hp);
-  int64_t plan[6];
-  const int rc = urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus, plan);
+  int64_t plan[7];
+  const int rc = urse_lstm_clusterx_plan(H, Hp, n_seq, reserved_cus, plan);
   if (rc) return rc;
-  *elems = (int64_t)2 * 2 * plan[1] * plan[3] * (lds_frag_pitch(XNSH * 64) / 2);
+  *elems = plan[4];
   return URSE_OK;
 }
 
@@ -797,8 +856,8 @@ extern "C" int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* w
   URSE_CHECK_ARG(urse_lstm_clusterx_supported(N, Np, H, Hp), "urse_lstm_clusterx_fwd: unsupported N=%d Np=%d H=%d Hp=%d", N, Np, H, Hp);
   URSE_CHECK_ARG(dtype == URSE_BF16 || dtype == URSE_F16, "urse_lstm_clusterx_fwd: operands are bf16 or f16 (dtype %d)", dtype);
   URSE_CHECK_ARG(!hout_bf16 || (dtype == URSE_F16 && ((uintptr_t)hout_bf16 % 16) == 0), "urse_lstm_clusterx_fwd: the bf16 copy of h goes with f16 operands only");
-  int64_t plan[6];
-  int rc = urse_lstm_cluster_plan(H, Hp, n_seq, reserved_cus, plan);       // the same clusters as urse_lstm_cluster_fwd: 7 workgroups x 56 units, 64 sequences
+  int64_t plan[7];
+  int rc = urse_lstm_clusterx_plan(H, Hp, n_seq, reserved_cus, plan);      // the same clusters as urse_lstm_cluster_fwd: 7 workgroups x 56 units, 64 sequences (per round)
   if (rc) return rc;
   URSE_CHECK_ARG((!save || (ldg >= 8L * H && ldg % 8 == 0 && ((uintptr_t)gates % 16) == 0)) && ldh >= 2L * H && (ldh * 2) % 16 == 0 && ((uintptr_t)hout % 16) == 0 &&
                      ((uintptr_t)hx % 16) == 0 && ldx >= Np && (ldx * 2) % 16 == 0 && ((uintptr_t)xn % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0),
@@ -816,7 +875,7 @@ extern "C" int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* w
   p.gates = save ? gates : hout; p.ldg = save ? ldg : 8L * H; p.hout = hout; p.hout2 = hout_bf16; p.ldh = ldh; p.c = (save && c) ? c : reinterpret_cast<float*>(hout);
   p.hx = (bf16_t*)hx; p.err = (unsigned*)err_flag; p.H = H; p.save = save;
   p.inner = inner; p.outer = outer; p.stride = stride; p.n_seq = n_seq; p.seq_len = seq_len;
-  p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2]; p.rows_pad = (int)plan[3];
+  p.C = (int)plan[0]; p.ncl = (int)plan[1]; p.rows_per_cluster = (int)plan[2]; p.rows_pad = (int)plan[3]; p.rounds = (int)plan[6];
   hipStream_t st = (hipStream_t)stream;
   // the exchange planes start with every tag bit clear; their rows sit at the LDS tile's pitch: plan[4] * 27 / 26 elements (urse_lstm_clusterx_hx_elems)
   (void)hipMemsetAsync(hx, 0, (size_t)2 * 2 * plan[1] * plan[3] * lds_frag_pitch(XNSH * 64), st);

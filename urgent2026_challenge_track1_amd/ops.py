@@ -611,17 +611,45 @@ def lstm_clusterx_supported(N, Np, H, Hp):
     return bool(_lib.load().urse_lstm_clusterx_supported(N, Np, H, Hp))
 
 
+# the band path through the same kernel in ROUNDS (round 6): every co-resident cluster keeps its weights and takes 64 sequences per round
+BAND_CLUSTERX = os.environ.get("URSE_LSTM_BAND_CLUSTERX", "1") != "0"
+
+
+def lstm_clusterx_plan(H, Hp, n_seq):
+    """[C, clusters per direction, sequences per cluster, rows_pad, hx elements, counters, rounds] of the fused cluster forward, or None (unsupported
+    shape, ranks sharing the GPU, or the reservation leaves no room for a cluster).  rounds > 1: more sequences than the clusters hold at once."""
+    import ctypes
+    if SHARED_GPU_RANKS > 1:
+        return None
+    plan = (ctypes.c_int64 * 7)()
+    lib = _lib.load()
+    if lib.urse_lstm_clusterx_plan(H, Hp, n_seq, reserved_cus(), plan) != 0:
+        _note_refusal(lambda: lib.urse_lstm_clusterx_plan(H, Hp, n_seq, 0, plan) == 0)
+        return None
+    return list(plan)
+
+
+# what the two band-path forwards cost per launch, from the step profile (r06_trainstep_v2_kernel_stats.csv): the cluster kernel 6.1 us per step whatever the
+# number of sequences a round carries, the row-wave kernel 3.0 ms for 2 x 12,832 sequences x 34 steps = 3.4 ns per sequence and step
+CLUSTERX_US_PER_STEP, RWX_NS_PER_SEQ_STEP = 6.1, 3.4
+
+
+def band_clusterx_pays(H, Hp, n_seq):
+    """True where the plan exists, needs more than one round, and rounds x 6.1 us prices at least 10 % below the row-wave kernel's 2 n_seq x 3.4 ns
+    (C2 without a reservation: 12 rounds against a break-even of 14.3; beside 32 reserved CUs: 14 rounds - the row-wave kernel keeps the launch)."""
+    plan = lstm_clusterx_plan(H, Hp, n_seq)
+    return plan is not None and plan[6] > 1 and plan[6] * CLUSTERX_US_PER_STEP * 1e3 < 0.9 * 2 * n_seq * RWX_NS_PER_SEQ_STEP
+
+
 def lstm_fwd_clusterx(xn, wihq, whhq, bias, N, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, xcd_aware=None, bf16_copy=False):
     """cluster LSTM forward with the input projection fused (bf16 | f16 operands): xn [M, Np] -> (gates [M, 8H] bf16 activations or None, hout, c, err);
-    bf16_copy (f16): one more element, hout_bf16.  The plan and the workspaces are lstm_fwd_cluster's."""
+    bf16_copy (f16): one more element, hout_bf16.  Any n_seq lstm_clusterx_plan accepts (in rounds above clusters * 64 sequences per direction)."""
     xcd_aware = CLUSTER_XCD_AWARE if xcd_aware is None else xcd_aware
-    plan = lstm_cluster_plan(H, Hp, n_seq)
-    M, Np, dev = xn.shape[0], xn.shape[1], xn.device
-    import ctypes
-    n_hx_ = ctypes.c_int64()
-    if _lib.load().urse_lstm_clusterx_hx_elems(H, Hp, n_seq, reserved_cus(), ctypes.byref(n_hx_)) != 0:
+    plan = lstm_clusterx_plan(H, Hp, n_seq)
+    if plan is None:
         raise RuntimeError("lstm_fwd_clusterx: no cluster plan for H=%d n_seq=%d" % (H, n_seq))
-    n_hx = int(n_hx_.value)
+    M, Np, dev = xn.shape[0], xn.shape[1], xn.device
+    n_hx = int(plan[4])
     key = ("x", dev, H, Hp, n_seq, n_hx, plan[5])
     if key not in _cluster_ws:
         _cluster_ws[key] = (torch.zeros(n_hx, device=dev, dtype=torch.bfloat16),
