@@ -827,7 +827,7 @@ def main():
     traffic, traffic_src = None, None
     pmc_names = {"lstm_bwd_time": "lstm_bwd_nsplit_kernel" if ops.launch_counts().get("lstm_bwd_nsplit", 0) else "lstm_bwd_kernel<unsigned short, 1, 2, 16",
                  "lstm_bwd_band": "lstm_bwd_kernel<unsigned short, 2, 4, 8",
-                 "lstm_fwd_time": "lstm_fwd_cluster_kernel", "lstm_fwd_band": "lstm_fwd_rwx_kernel"}
+                 "lstm_fwd_time": "lstm_fwd_clusterx_kernel", "lstm_fwd_band": "lstm_fwd_clusterx_kernel"}
     if (B, args.seconds, args.channels, args.layers, args.dtype) == (32, 4.0, 196, 6, "bf16"):
         import glob
         import re

@@ -64,5 +64,8 @@ for name, lib in libs.items():
         print("   %-18s -> %-18s %8.0f" % (lab[i - 1], lab[i], np.median(sa[:, i] - sa[:, i - 1])))
     print("   %-18s -> %-18s %8.0f" % ("published", "next top", np.median(nx[:, 0] - sa[:, 7])))
     print("   step                                   %8.0f" % np.median(nx[:, 0] - sa[:, 0]))
+    if np.median(sa[:, 12]) > 0:      # phase 2 by parts (XPIPE): head = row tile 0's MFMAs, three interleaved phases, tail = row tile 3's cell update
+        print("   phase 2: head %.0f | tile 1 MFMAs + tile 0 cells %.0f | tile 2 + 1 %.0f | tile 3 + 2 %.0f | tail (tile 3 cells) %.0f" % (
+            np.median(sa[:, 12] - sa[:, 4]), np.median(sa[:, 13] - sa[:, 12]), np.median(sa[:, 14] - sa[:, 13]), np.median(sa[:, 15] - sa[:, 14]), np.median(sa[:, 5] - sa[:, 15])))
     print("   helper: arrives at b1 %.0f cycles after worker 0 | b1 -> DMAs issued %.0f | -> landed %.0f | arrives at b2 %.0f after worker 0 | b2 -> next b1 arrival (pieces read + stored) %.0f" % (
         np.median(sa[:, 8] - sa[:, 3]), np.median(sa[:, 10] - sa[:, 9]), np.median(sa[:, 11] - sa[:, 10]), np.median(sa[:, 11] - sa[:, 5]), np.median(nx[:, 8] - sa[:, 11])))

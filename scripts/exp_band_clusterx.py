@@ -1,11 +1,12 @@
 """The band path's forward at C2 (2 x 12,832 sequences x 34 steps) through the fused cluster forward in rounds against the fused row-wave kernel:
 each alone, 5 launches after a warm-up, ms per launch (host clock around a synchronised launch; the step A/B decides)."""
-import time
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from urgent2026_challenge_track1_amd import ops
 N, H, dev = 196, 392, "cuda"
-B, T, K = 32, 401, 34
-for dtype in (torch.bfloat16, torch.float16):
+T, K = 401, 34
+for B, dtype in ((32, torch.bfloat16), (32, torch.float16), (16, torch.bfloat16), (8, torch.bfloat16), (4, torch.bfloat16), (3, torch.bfloat16)):
     torch.manual_seed(0)
     lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
     cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
@@ -14,7 +15,7 @@ for dtype in (torch.bfloat16, torch.float16):
     M = B * T * K
     xr = ops.pack2d(torch.randn(M, N, device=dev), M, pk["Np"], dtype)
     sm = dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
-    print(dtype, "plan", ops.lstm_clusterx_plan(H, pk["Hp"], sm["n_seq"]), "pays", ops.band_clusterx_pays(H, pk["Hp"], sm["n_seq"]))
+    print("B", B, dtype, "plan", ops.lstm_clusterx_plan(H, pk["Hp"], sm["n_seq"]), "pays", ops.band_clusterx_pays(H, pk["Hp"], sm["n_seq"]))
 
     def timed(fn, n=5):
         fn(); torch.cuda.synchronize()

@@ -80,9 +80,11 @@ def test_fullsize_forward_matches_f32_oracle_and_runs_the_c2_kernels(lib, dtype)
     torch.cuda.synchronize()
     ops.poll_kernel_errors(torch.device("cuda", torch.cuda.current_device()), sync=True)
     counts = ops.launch_counts()
-    for k in ("lstm_fwd_clusterx", "lstm_fwd_rwx", "lstm_bwd_nsplit", "lstm_bwd_stream32", "tn_dual", "nt_bres", "stft960"):
+    for k in ("lstm_fwd_clusterx", "lstm_bwd_nsplit", "lstm_bwd_stream32", "tn_dual", "nt_bres", "stft960"):
         assert counts[k] > 0, (k, counts)
     assert counts["lstm_fwd_stream"] == 0 and counts["lstm_fwd_wide"] == 0, counts
+    # round 6: BOTH paths of every layer go through the fused cluster forward - the time path in one round, the band path (12,832 sequences per direction) in 12
+    assert counts["lstm_fwd_clusterx"] == 12 and counts["lstm_fwd_rwx"] == 0, counts
     wav_c = wav.detach().cpu()
     e_loss = abs(float(loss) - loss_r) / abs(loss_r)
     l2 = _rel(wav_c, wav_r)
@@ -240,7 +242,7 @@ def test_full_length_gradients_match_f32_oracle(lib, monkeypatch):
     torch.cuda.synchronize()
     ops.poll_kernel_errors(torch.device("cuda", torch.cuda.current_device()), sync=True)
     counts = ops.launch_counts()
-    for k in ("lstm_fwd_clusterx", "lstm_fwd_rwx", "lstm_bwd_nsplit", "lstm_bwd_stream32", "tn_dual", "nt_bres", "stft960"):
+    for k in ("lstm_fwd_clusterx", "lstm_bwd_nsplit", "lstm_bwd_stream32", "tn_dual", "nt_bres", "stft960"):
         assert counts[k] > 0, (k, counts)
     mine = dict(model.se_model.named_parameters())
     worst, wn, per_group = 0.0, None, {}

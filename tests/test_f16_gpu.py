@@ -202,7 +202,7 @@ def test_f16_c2_kernel_set_forward_and_gradients(lib, monkeypatch, fs, B, Ls):
     model.se_model.core._flush_deferred_wgrads()
     torch.cuda.synchronize()
     counts = ops.launch_counts()
-    for k in ("nt_bres", "nt_ring", "lstm_fwd_clusterx", "lstm_fwd_rwx", "nt_grouped_ring", "lstm_bwd_nsplit"):
+    for k in ("nt_bres", "nt_ring", "lstm_fwd_clusterx", "nt_grouped_ring", "lstm_bwd_nsplit"):
         assert counts[k] > 0, (k, counts)
     assert counts["tn_dual"] > 0 or fs != 48000, counts       # (K = 27 bands at 16 kHz: the dual weight-gradient kernel's whole-block condition does not hold)
     # 12 half layers x (2 dual launches + 1 fc gradient) in the mixed form, or none of them

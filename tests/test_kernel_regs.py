@@ -17,7 +17,9 @@ C2_STEP = [
     "gemm_tn_dual224_kernel<2, false>",
     "urse::lstm_bwd_nsplit_kernel<392, 0, 0>",
     "urse::lstm_bwd_kernel<unsigned short, 2, 4, 8, 0, 392, 0, 1, 1>",
-    "urse::lstm_fwd_rwx_kernel<392, 416, 224, true, unsigned short, false>",
+    "urse::lstm_fwd_rwx_kernel<392, 416, 224, true, unsigned short, false>",      # the band path's forward beside a CU reservation (otherwise: the cluster forward in rounds)
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true>",
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, false>",
     "gemm_tn_dma_kernel<7, 2, 0>",
     "gemm_tn_dma_kernel<7, 2, 1>",          # f16-forward training: fc gradient against the f16 h (round 6)
     "gemm_nt_dma_gnb_kernel",
@@ -54,14 +56,12 @@ C4_STEP = [
     "urse::lstm_bwd_split_kernel<1, 3>",      # the cooperative split BPTT at H = 768: 16 rows per cluster (urse_lstm_split_plan(768, 96) -> rows 16), three unit tiles per wave
 ]
 # Spills that exist, where they sit, and the bound they are held to (a regression of any of them fails this test):
-#  * the fused cluster forward allocates all 256 registers (160 of them resident weights); ONE register (a lane predicate of the prologue's x
-#    DMAs) is stored and reloaded before the time loop starts - llvm-objdump shows no scratch instruction inside the loop that holds the MFMAs;
-#    its SGPR spills go to lanes of v255 (v_writelane / v_readlane, no memory).
+#  * (the fused cluster forward - all 256 registers, 160 of them resident weights - had ONE spilled register until round 6; in its rounds form, with the
+#    helper wave's loop in front of the weight loads and the thread id opaque per round, it has none and sits in C2_STEP; its SGPR spills go to
+#    lanes of a VGPR - v_writelane / v_readlane, no memory)
 #  * the 32-ROW forms of the split BPTT (<2, *>: H <= 512, no benchmarked configuration dispatches them - C4's H = 768 runs <1, 3>, spill-free, in the
 #    list above) spill ~50 registers inside their step loop on the 128-register budget of 16 waves: tracked so that it cannot grow unnoticed.
 KNOWN = {
-    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true>": dict(vgpr_spill_count=1, scratch_ops_in_mfma_loops=0),
-    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, false>": dict(vgpr_spill_count=1, scratch_ops_in_mfma_loops=0),
     "urse::lstm_bwd_split_kernel<2, 3>": dict(vgpr_spill_count=50, scratch_ops_in_mfma_loops=88),
     "urse::lstm_bwd_split_kernel<2, 2>": dict(vgpr_spill_count=52, scratch_ops_in_mfma_loops=90),
     #  * the mixed-operand dual weight-gradient GEMM (f16-forward training): two registers of its set-up are parked in scratch before the K loop

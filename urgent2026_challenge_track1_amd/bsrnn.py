@@ -530,7 +530,7 @@ class BSRNNCore(nn.Module):
                  pk.get(p + "whhq") is not None and H not in ops.CLUSTER2_H and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
                  ops.lstm_clusterx_supported(N, d["Np"], H, d["Hp"]))
         # the band path in ROUNDS through the fused cluster forward (round 6), where the plan's rounds x steps price below the row-wave kernel
-        band_cx = cx_ok and path == "f" and ops.BAND_CLUSTERX and ops.band_clusterx_pays(H, d["Hp"], sm["n_seq"])
+        band_cx = cx_ok and path == "f" and ops.BAND_CLUSTERX and ops.band_clusterx_pays(H, d["Hp"], sm["n_seq"], sm["seq_len"])
         fused = (not band_cx and ops.USE_RWX_LSTM and ops.USE_RW_LSTM and dt in ops.HALF_TYPES and pk.get(p + "wx") is not None and
                  sm["n_seq"] >= ops.RW_MIN_SEQ and not (ops.USE_CLUSTER_LSTM and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
                                                       ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None))

@@ -58,8 +58,17 @@ constexpr int XNSP = 6;            // k-slabs of W_ih the PROJECTION multiplies:
 #ifndef XDW
 #define XDW 2                      // LDS-DMA instructions of x_{t+1} per working wave and step, the helper takes the other 18 (in the step: 14.70 ms of cluster forward per train step with 2, 14.84 with 3, 15.16 with 4, profiles/r05_ab_xdw_v1.log)
 #endif
+#ifndef XDWA
+#define XDWA XDW                   // ... of waves 0 .. 3
+#endif
+#ifndef XDWB
+#define XDWB XDW                   // ... of waves 4 .. 6
+#endif
 #ifndef XMIDPOLL
 #define XMIDPOLL 0x2               // behind which row tiles of the projection the wave looks at the gather (bit rt)
+#endif
+#ifndef XPIPE
+#define XPIPE 1                    // phase 2 of a step interleaved by hand (round 6), 0: the compiler's order
 #endif
 #ifndef XPD
 #define XPD 4                      // A fragments of the x tile read ahead in the projection (registers: 4 each)
@@ -114,7 +123,10 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H;
 #ifdef XSTAMP
-  const bool stamp_on = blockIdx.x == XSTAMP && blockIdx.y == 0 && (w == 0 || w == XW);
+#ifndef XSTAMP_W
+#define XSTAMP_W 0                 // which working wave is stamped
+#endif
+  const bool stamp_on = blockIdx.x == XSTAMP && blockIdx.y == 0 && (w == XSTAMP_W || w == XW);
 #endif
   constexpr int Hp = XNSH * 32, pitch = lds_frag_pitch(Hp * 2);          // h tile row pitch (864)
   constexpr int GP = lds_frag_pitch(XNSX * 64);                           // x / gates tile row pitch (480): conflict-free A fragment reads
@@ -219,12 +231,17 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     const unsigned xpiece = (unsigned)((lane_ < 30 ? lane_ : lane_ - 30) * 16);
     // (XDW instructions per working wave, the other 32 - 7 XDW by the helper, which has the time: it reaches barrier 2 ~1,700 cycles before the working
     //  waves when all eight take four)
-    constexpr int HDW = XROWS / 2 - XW * XDW;
+    // round 6: waves 0 .. 3 take XDWA each, waves 4 .. 6 XDWB (the second-dispatched half is the arbitration loser of every SIMD pair and the LAST at
+    // barrier 2 by ~1,500 cycles - per-wave stamps; an LDS-DMA costs its wave 100 - 130 cycles of issue), the helper the rest
+    constexpr int HDW = XROWS / 2 - 4 * XDWA - (XW - 4) * XDWB;
     static_assert(HDW >= 0, "DMA split");
+    constexpr int MAXDW = XDWA > XDWB ? (XDWA > HDW ? XDWA : HDW) : (XDWB > HDW ? XDWB : HDW);
+    const int ndw = w == XW ? HDW : (w < 4 ? XDWA : XDWB);
+    const int pr0 = w == XW ? 4 * XDWA + (XW - 4) * XDWB : (w < 4 ? w * XDWA : 4 * XDWA + (w - 4) * XDWB);
 #pragma unroll
-    for (int i = 0; i < (XDW > HDW ? XDW : HDW); ++i) {
-      if (i >= (w == XW ? HDW : XDW)) continue;
-      const int pr = (w == XW ? XW * XDW : w * XDW) + i;                   // row pair
+    for (int i = 0; i < MAXDW; ++i) {
+      if (i >= ndw) continue;
+      const int pr = pr0 + i;                                              // row pair
       const unsigned vo = xrow[2 * pr + (lane_ < 30 ? 0 : 1)] + xpiece;
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds_g0 + (unsigned)(par * (XROWS * GP) + 2 * pr * GP));
 #ifndef XABL_NO_DMA      // timing diagnostics (wrong results): XABL_NO_DMA, XABL_NO_HSTORE, XABL_NO_PROJ, XABL_NO_REC, XABL_NO_AREAD (no A fragment reads), XABL_NO_CELL, XABL_NO_GATHER, XABL_NO_XSTORE, XABL_NO_HOUT
@@ -671,6 +688,87 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         }
       }
     };
+#if XPIPE
+    {
+      // Round 6: ONE row tile ahead, interleaved by hand.  The cell update of row tile rt is cut into 13 stages (one per k-slab: a handful of vector
+      // instructions each, the same operations in the same order as sigmoidf_ / tanhf_ - bit-identical results) and stage ks is issued right behind
+      // the two MFMAs of k-slab ks of row tile rt + 1, with a scheduling fence between slabs.  Left to the compiler (the form below) a step's phase 2
+      // is blocks of 18 - 26 MFMAs followed by blocks of 60 - 170 vector instructions: the two working waves of a SIMD run in lockstep behind
+      // barrier 1, so both want the matrix pipe, then both want the vector ALU - 7,700 cycles for 3,300 of MFMA and 3,600 of VALU per SIMD.
+      f32x4_t accS[2][XQ];
+      float sx0[XQ], sx1[XQ], sx2[XQ], sx3[XQ], scp[XQ], scv[XQ], sec[XQ];
+      auto mm_slab = [&](int rt, int ks, f32x4_t (&acc)[XQ]) __attribute__((always_inline)) {
+        if (ks == 0) {
+#pragma unroll
+          for (int q = 0; q < XQ; ++q) {
+            float a0, a1, a2, a3;
+            unpack2<TI>(accp[rt][q].x, a0, a1);
+            unpack2<TI>(accp[rt][q].y, a2, a3);
+            acc[q] = f32x4_t{a0, a1, a2, a3};
+          }
+        }
+        const int idx = rt * XNSH + ks;
+        const uint4 a = ab[idx % XAD];
+        if (idx + XAD < 4 * XNSH) ab[idx % XAD] = rd(idx + XAD);
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) acc[q] = mfma16<TI>(breg[q][ks], a, acc[q]);
+      };
+      auto cell_stage = [&](int rt, int st, const f32x4_t (&acc)[XQ]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+          if (st == 0) { scp[q] = *reinterpret_cast<const float*>(smem + c_prev + rt * 16 * XUW * 4 + q * 16); sx0[q] = __expf(-acc[q][0]); }
+          else if (st == 1) sx1[q] = __expf(-acc[q][1]);
+          else if (st == 2) sx3[q] = __expf(-acc[q][3]);
+          else if (st == 3) sx2[q] = __expf(2.0f * acc[q][2]);
+          else if (st == 4) sx0[q] = __builtin_amdgcn_rcpf(1.0f + sx0[q]);                    // i
+          else if (st == 5) sx1[q] = __builtin_amdgcn_rcpf(1.0f + sx1[q]);                    // f
+          else if (st == 6) sx3[q] = __builtin_amdgcn_rcpf(1.0f + sx3[q]);                    // o
+          else if (st == 7) sx2[q] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(sx2[q] + 1.0f);      // g
+          else if (st == 8) {
+            scv[q] = __builtin_fmaf(sx1[q], scp[q], __fmul_rn(sx0[q], sx2[q]));
+            *reinterpret_cast<float*>(smem + c_cur + rt * 16 * XUW * 4 + q * 16) = scv[q];    // (also the next step's c_{t-1})
+          } else if (st == 9) sec[q] = __expf(2.0f * scv[q]);
+          else if (st == 10) sec[q] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(sec[q] + 1.0f);
+          else if (st == 11) *reinterpret_cast<TI*>(smem + h_cur + rt * 16 * XUW * 2 + q * 8) = from_f32<TI>(sx3[q] * sec[q]);
+          else if (st == 12) {
+            if constexpr (SAVE) {
+              uint2 gs_;
+              gs_.x = pack2<bf16_t>(sx0[q], sx1[q]);
+              gs_.y = pack2<bf16_t>(sx2[q], sx3[q]);
+              *reinterpret_cast<uint2*>(smem + g_cur + rt * 16 * GP + q * 32) = gs_;
+            }
+          }
+        }
+      };
+#pragma unroll
+      for (int ks = 0; ks < XNSH; ++ks) mm_slab(0, ks, accS[0]);
+#if XFETCH_POS == 1
+      if (step + 1 < p.seq_len) fetch4(par ^ 1, (dir ? t - 1 : t + 1) * stride_i, lane_v);
+#endif
+#ifndef XNO_KEEP
+      asm volatile("" :: "v"(keep0.x), "v"(keep0.y), "v"(keep0.z), "v"(keep0.w));      // (see deferred_hout)
+      if constexpr (H2) asm volatile("" :: "v"(keep1.x), "v"(keep1.y), "v"(keep1.z), "v"(keep1.w));
+#endif
+      XST(12);
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) {
+#pragma unroll
+        for (int ks = 0; ks < XNSH; ++ks) {
+          __builtin_amdgcn_sched_barrier(0);
+          mm_slab(rt + 1, ks, accS[(rt + 1) & 1]);
+          cell_stage(rt, ks, accS[rt & 1]);
+        }
+        if (rt == 0) XST(13);
+        if (rt == 1) XST(14);
+        if (rt == 2) XST(15);
+      }
+#pragma unroll
+      for (int st = 0; st < 13; ++st) {
+        __builtin_amdgcn_sched_barrier(0);
+        cell_stage(3, st, accS[1]);
+      }
+    }
+#else
     {
       f32x4_t accA[XQ], accB[XQ];
       mm(0, accA);
@@ -713,6 +811,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #endif
       cell(3, accB);
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         // (its rows of x_{t+1} have landed)
     XST(5);
     __builtin_amdgcn_s_barrier();                                         // barrier 2

@@ -629,16 +629,21 @@ def lstm_clusterx_plan(H, Hp, n_seq):
     return list(plan)
 
 
-# what the two band-path forwards cost per launch, from the step profile (r06_trainstep_v2_kernel_stats.csv): the cluster kernel 6.1 us per step whatever the
-# number of sequences a round carries, the row-wave kernel 3.0 ms for 2 x 12,832 sequences x 34 steps = 3.4 ns per sequence and step
-CLUSTERX_US_PER_STEP, RWX_NS_PER_SEQ_STEP = 6.1, 3.4
+# what the two band-path forwards cost per launch, each alone at T = 401, K = 34 (profiles/r06_exp_band_clusterx_v2.log): the cluster kernel 6.3 us per step whatever
+# a round carries (B 32: 12 rounds 2.62 ms, B 8: 3 rounds 0.70 ms, B 4: 2 rounds 0.46 ms) + ~50 us of launch prologue; the row-wave kernel 3.5 ns per
+# sequence and step (B 32: 3.07 ms) with a floor of 36 us per step (B 8: 1.38 ms, B 4: 1.23 ms - a workgroup's pass over the weights per step)
+CLUSTERX_US_PER_STEP, CLUSTERX_US_PROLOGUE, RWX_NS_PER_SEQ_STEP, RWX_US_PER_STEP_FLOOR = 6.3, 50.0, 3.5, 36.0
 
 
-def band_clusterx_pays(H, Hp, n_seq):
-    """True where the plan exists, needs more than one round, and rounds x 6.1 us prices at least 10 % below the row-wave kernel's 2 n_seq x 3.4 ns
-    (C2 without a reservation: 12 rounds against a break-even of 14.3; beside 32 reserved CUs: 14 rounds - the row-wave kernel keeps the launch)."""
+def band_clusterx_pays(H, Hp, n_seq, seq_len=34):
+    """True where the plan exists, needs more than one round (one round is lstm_cluster_plan's business), and prices at least 5 % below the row-wave
+    kernel (C2 without a reservation: 12 rounds, 2.6 against 3.1 ms; beside 32 reserved CUs: 15 clusters, 14 rounds - the row-wave kernel keeps the launch)."""
     plan = lstm_clusterx_plan(H, Hp, n_seq)
-    return plan is not None and plan[6] > 1 and plan[6] * CLUSTERX_US_PER_STEP * 1e3 < 0.9 * 2 * n_seq * RWX_NS_PER_SEQ_STEP
+    if plan is None or plan[6] <= 1:
+        return False
+    cx = plan[6] * seq_len * CLUSTERX_US_PER_STEP + CLUSTERX_US_PROLOGUE
+    rwx = seq_len * max(RWX_US_PER_STEP_FLOOR, 2 * n_seq * RWX_NS_PER_SEQ_STEP * 1e-3)
+    return cx < 0.95 * rwx
 
 
 def lstm_fwd_clusterx(xn, wihq, whhq, bias, N, H, Hp, n_seq, seq_len, inner, outer, stride, save=True, xcd_aware=None, bf16_copy=False):
