@@ -208,3 +208,31 @@ def test_bf16_c2_train_step_matches_oracle(lib, c2_dispatch):
     assert flipped <= 2e-2 * tot, (flipped, tot)
     counts = ops.launch_counts()
     assert counts["tn_dual"] > 0 and counts["lstm_fwd_clusterx"] > 0 and counts["lstm_bwd_stream32"] > 0, counts
+
+
+def test_both_paths_in_rounds_through_the_model_are_bit_identical_to_one_round(lib, monkeypatch):
+    """Round 6: the fused cluster forward takes any number of sequences in ROUNDS (the band path at C2: 12; the time path above 33 utterances per GPU: 2).
+    A sequence's arithmetic does not depend on the cluster, round or row it gets, so the model's enhanced waveform must not change by a bit when the SAME
+    batch is forced into rounds: a reservation of 200 CUs leaves 3 clusters per direction = 192 slots for the time path's 204 and the band path's 606
+    sequences (2 and 4 rounds).  Also: the dispatch really went that way (launch counts; no row-wave, no streaming forward)."""
+    from urgent2026_challenge_track1_amd import ops
+    L = 2
+    ref, model = _models(L)
+    model.eval()
+    clean, noisy, lens = _batch()
+    H, Hp = 2 * N, ops.kpad(ops.pad_to(2 * N, 16), torch.bfloat16)
+    monkeypatch.setattr(ops, "band_clusterx_pays", lambda H_, Hp_, n_seq, seq_len=34: (ops.lstm_clusterx_plan(H_, Hp_, n_seq) or [0] * 7)[6] > 1)
+    with torch.no_grad():
+        ops.launch_counts(reset=True)
+        wav0 = model.se_model(noisy[:, 0].cuda(), lens, FS)[0].clone()
+        c0 = dict(ops.launch_counts())
+        assert ops.lstm_clusterx_plan(H, Hp, B * 34)[6] == 1 and c0["lstm_fwd_clusterx"] == 2 * L, c0
+        with ops.reserve_cus(co_resident=200):
+            pt, pb = ops.lstm_clusterx_plan(H, Hp, B * 34), ops.lstm_clusterx_plan(H, Hp, B * 101)
+            assert pt[1] == 3 and pt[6] == 2 and pb[6] == 4, (pt, pb)
+            ops.launch_counts(reset=True)
+            wav1 = model.se_model(noisy[:, 0].cuda(), lens, FS)[0].clone()
+            c1 = dict(ops.launch_counts())
+    ops.poll_kernel_errors(torch.device("cuda", torch.cuda.current_device()), sync=True)
+    assert c1["lstm_fwd_clusterx"] == 2 * L and c1["lstm_fwd_rwx"] == 0 and c1["lstm_fwd_stream"] == 0 and c1["lstm_fwd_cluster"] == 0, c1
+    assert torch.isfinite(wav1).all() and torch.equal(wav0, wav1)

@@ -535,7 +535,10 @@ class BSRNNCore(nn.Module):
                  sm["n_seq"] >= ops.RW_MIN_SEQ and not (ops.USE_CLUSTER_LSTM and not (path == "f" and ops.BAND_PATH_NO_CLUSTER) and
                                                       ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None))
         # (fused: the input projection runs inside the recurrence kernel - no gate GEMM, no [M, 8H] pre-activation matrix)
-        fused_c = not fused and cx_ok and (band_cx or ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None)
+        # (the time path above the clusters' capacity - more than 33 utterances per GPU at 48 kHz - in rounds too, instead of gate GEMM + streaming forward)
+        time_cx = (cx_ok and path == "t" and ops.TIME_CLUSTERX_ROUNDS and ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is None and
+                   ops.lstm_clusterx_plan(H, d["Hp"], sm["n_seq"]) is not None)
+        fused_c = not fused and cx_ok and (band_cx or time_cx or ops.lstm_cluster_plan(H, d["Hp"], sm["n_seq"]) is not None)
         gx = None if (fused or fused_c) else ops.gemm_nt(xn, pk[p + "wih"], pk[p + "bias"])
         hout_b = None
         if fused_c:

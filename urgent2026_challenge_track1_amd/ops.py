@@ -613,6 +613,8 @@ def lstm_clusterx_supported(N, Np, H, Hp):
 
 # the band path through the same kernel in ROUNDS (round 6): every co-resident cluster keeps its weights and takes 64 sequences per round
 BAND_CLUSTERX = os.environ.get("URSE_LSTM_BAND_CLUSTERX", "1") != "0"
+# ... and the time path above 1,152 sequences per direction (batches of more than 33 utterances at 48 kHz)
+TIME_CLUSTERX_ROUNDS = os.environ.get("URSE_LSTM_TIME_CLUSTERX_ROUNDS", "1") != "0"
 
 
 def lstm_clusterx_plan(H, Hp, n_seq):
