@@ -29,6 +29,12 @@
 //   * a 16-byte buffer store reads its data registers some time after it has issued: an LDS read a few instructions behind it into the same
 //     registers can land first (first dword of the stored piece replaced, in the waves that issue last) - the registers stay occupied until the
 //     MFMA block behind the store has issued (deferred_hout).
+// Round 6: (i) ROUNDS - more sequences than the co-resident clusters hold (the band path: rnn_band of the same reference lines, 12,832 sequences x 34 steps per
+// direction) go through the resident clusters 64 per cluster and round (urse_lstm_clusterx_plan; the protocol's step counter runs on across rounds, a round's first
+// step waits for the previous round's last publication and starts from h = 0): 2.46 against the row-wave kernel's 2.90 ms per launch in the step, 0.46 against 1.23 ms
+// at B = 4; (ii) phase 2 of a step (barrier 1 -> barrier 2) interleaved by hand, one row tile ahead (XPIPE), and the projection's fragment reads as one ring
+// (XPROJ_RING); no spilled register.  Per-wave stamps (profiles/r06_abl_clusterx_waves_v1.log): the second-dispatched wave of each SIMD pair is the last at barrier 2
+// (6,670 cycles against 5,100 / 4,600), and the x rows' DMA chain (issue 2,300 + landing 3,500) is right behind it - phase 2 without ANY arithmetic is 0.3 us shorter.
 // Same math / layouts / protocol as lstm_cluster.hip, and the same rounding points as the two-kernel form for 192 of the 196 input channels:
 // x W_ih^T + b is rounded to the 16-bit operand format before h W_hh^T is added to it (there: the gx matrix; here: the register pairs that wait for
 // the gather); the last four channels are added unrounded.  N = 196 (Np 224), H = 392 (Hp 416).
@@ -66,6 +72,9 @@ constexpr int XNSP = 6;            // k-slabs of W_ih the PROJECTION multiplies:
 #endif
 #ifndef XMIDPOLL
 #define XMIDPOLL 0x2               // behind which row tiles of the projection the wave looks at the gather (bit rt)
+#endif
+#ifndef XPROJ_RING
+#define XPROJ_RING 1                // the projection's fragment reads as one ring across the row tiles (round 6: top -> projected 2,620 -> 2,370 cycles, forward 28.2 -> 27.5 ms per train step; with a scheduling fence per k-slab and six ahead: 2,200 cycles, 28.4 ms), 0: groups of XPD per row tile
 #endif
 #ifndef XPIPE
 #define XPIPE 1                    // phase 2 of a step interleaved by hand (round 6), 0: the compiler's order
@@ -548,6 +557,47 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       // Between row tiles the wave looks at what has arrived and asks again for what has not: the members of a cluster publish within a few hundred
       // cycles of each other, so the first request usually comes back with the old tags, and a wave that only looked again after the whole projection
       // (4,100 cycles, in-kernel stamps) found out 2,600 cycles late.
+#if XPROJ_RING
+      // round 6: the A fragments of the x tile (4 row tiles x 6 k-slabs) through ONE rotating set of XPD registers across the row tiles, as the h tile's in
+      // phase 2: in groups of XPD per row tile (below) every group waited out an LDS round trip - 2,800 cycles for 768 of MFMA per wave, and the gather
+      // is back after ~2,050
+      uint4 pa[XPD];
+      auto prd = [&](int idx) __attribute__((always_inline)) {
+#ifndef XABL_NO_AREAD
+        return *reinterpret_cast<const uint4*>(smem + xg + (idx / XNSP) * 16 * GP + (idx % XNSP) * 64);
+#else
+        return make_uint4(xg, idx, 0, 0);
+#endif
+      };
+#pragma unroll
+      for (int i = 0; i < XPD; ++i) pa[i] = prd(i);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        f32x4_t accx[XQ];
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) accx[q] = *reinterpret_cast<const f32x4_t*>(smem + bq + q * 64);
+#pragma unroll
+        for (int k = 0; k < XNSP; ++k) {
+          const int idx = rt * XNSP + k;
+          const uint4 a = pa[idx % XPD];
+          if (idx + XPD < 4 * XNSP) pa[idx % XPD] = prd(idx + XPD);
+#pragma unroll
+#ifndef XABL_NO_PROJ
+          for (int q = 0; q < XQ; ++q) accx[q] = mfma16<TI>(wreg[q][k], a, accx[q]);
+#else
+          for (int q = 0; q < XQ; ++q) accx[q][k & 3] += __uint_as_float(wreg[q][k].x ^ a.x);
+#endif
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) accp[rt][q] = make_uint2(pack2<TI>(accx[q][0], accx[q][1]), pack2<TI>(accx[q][2], accx[q][3]));
+#ifndef XNO_MIDPOLL
+        if (((XMIDPOLL >> rt) & 1) && pendu) {
+          check();
+          if (pendu) reissue();
+        }
+#endif
+      }
+#else
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         f32x4_t accx[XQ];
@@ -583,6 +633,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         }
 #endif
       }
+#endif
       XST(1);
       if (pendu) {
         unsigned spins = 0;
