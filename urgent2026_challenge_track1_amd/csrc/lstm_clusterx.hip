@@ -35,9 +35,9 @@
 // at B = 4; (ii) phase 2 of a step (barrier 1 -> barrier 2) interleaved by hand, one row tile ahead (XPIPE), and the projection's fragment reads as one ring
 // (XPROJ_RING); no spilled register.  Per-wave stamps (profiles/r06_abl_clusterx_waves_v1.log): the second-dispatched wave of each SIMD pair is the last at barrier 2
 // (6,670 cycles against 5,100 / 4,600), and the x rows' DMA chain (issue 2,300 + landing 3,500) is right behind it - phase 2 without ANY arithmetic is 0.3 us shorter.
-// Same math / layouts / protocol as lstm_cluster.hip, and the same rounding points as the two-kernel form for 192 of the 196 input channels:
-// x W_ih^T + b is rounded to the 16-bit operand format before h W_hh^T is added to it (there: the gx matrix; here: the register pairs that wait for
-// the gather); the last four channels are added unrounded.  N = 196 (Np 224), H = 392 (Hp 416).
+// Same math / layouts / protocol as lstm_cluster.hip.  Round 5 kept the two-kernel form's rounding point (x W_ih^T + b rounded to the 16-bit operand format before h W_hh^T is
+// added: there the gx matrix, here register pairs that waited for the gather; four channels unrounded); round 6 keeps the sum in f32 (XPROJ_F32) - nn.LSTM's own accumulation.
+// N = 196 (Np 224), H = 392 (Hp 416).
 #include "urse_common.h"
 
 namespace urse {
@@ -73,6 +73,12 @@ constexpr int XNSP = 6;            // k-slabs of W_ih the PROJECTION multiplies:
 #ifndef XMIDPOLL
 #define XMIDPOLL 0x2               // behind which row tiles of the projection the wave looks at the gather (bit rt)
 #endif
+#ifndef XPROJ_F32
+#define XPROJ_F32 1                 // x W_ih^T + b waits for the gather in f32 (round 6: the hand-interleaved phase 2 left the 16 registers; no pack / unpack: 48 vector instructions per wave
+                                    // and step less on a SIMD whose vector ISSUE is phase 2's bound - forward 28.4 -> 27.7 ms per train step, four A/B pairs).  The sum is then not rounded
+                                    // to the 16-bit operand format before h W_hh^T is added: what nn.LSTM's f32 accumulation does, one rounding less than the two-kernel form (whose gx
+                                    // matrix is stored in 16 bits): h differs from it by 1.1e-4 on average (bf16), 1.4e-5 (f16).  0: the packed pairs of round 5
+#endif
 #ifndef XPROJ_RING
 #define XPROJ_RING 1                // the projection's fragment reads as one ring across the row tiles (round 6: top -> projected 2,620 -> 2,370 cycles, forward 28.2 -> 27.5 ms per train step; with a scheduling fence per k-slab and six ahead: 2,200 cycles, 28.4 ms), 0: groups of XPD per row tile
 #endif
@@ -102,6 +108,20 @@ struct ClusterXArgs {
   unsigned g_bytes, c_bytes, h_bytes, x_bytes;
   unsigned* xws;                  // XCD-aware formation (null = static clusters): [0..7] arrivals per XCD, [8] arrivals, zeroed per launch
 };
+
+#if XPROJ_F32
+#define PROJ_KEEP(v) (v)
+#define PROJ_TAKE(v) (v)
+#else
+#define PROJ_KEEP(v) make_uint2(pack2<TI>((v)[0], (v)[1]), pack2<TI>((v)[2], (v)[3]))
+#define PROJ_TAKE(v) proj_take<TI>(v)
+template <typename TI> __device__ __forceinline__ f32x4_t proj_take(uint2 v) {
+  float a0, a1, a2, a3;
+  unpack2<TI>(v.x, a0, a1);
+  unpack2<TI>(v.y, a2, a3);
+  return f32x4_t{a0, a1, a2, a3};
+}
+#endif
 
 __device__ __forceinline__ void xstore_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off, uint4 v) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -510,7 +530,11 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     // ---- 0. x_t W_ih^T + b (independent of h) + 1. the h gather.  The gather's loads are issued in front of the projection.
     // (the projection's sums wait for the gather as 16-bit pairs of the operand format - what the two-kernel form stores in gx - : 16 registers
     //  instead of 32 across barrier 1)
+#if XPROJ_F32
+    f32x4_t accp[4][XQ];
+#else
     uint2 accp[4][XQ];
+#endif
     {
       // the thread's chunks of the cluster's h_{t-1}, all of them in flight at once.  Which chunks are still awaited is kept per WAVE (a scalar mask:
       // a chunk index is re-requested for the whole wave while any of its lanes misses a tag - re-reading a piece that has arrived is harmless, the plane
@@ -589,7 +613,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #endif
         }
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) accp[rt][q] = make_uint2(pack2<TI>(accx[q][0], accx[q][1]), pack2<TI>(accx[q][2], accx[q][3]));
+        for (int q = 0; q < XQ; ++q) accp[rt][q] = PROJ_KEEP(accx[q]);
 #ifndef XNO_MIDPOLL
         if (((XMIDPOLL >> rt) & 1) && pendu) {
           check();
@@ -625,7 +649,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
             }
         }
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) accp[rt][q] = make_uint2(pack2<TI>(accx[q][0], accx[q][1]), pack2<TI>(accx[q][2], accx[q][3]));
+        for (int q = 0; q < XQ; ++q) accp[rt][q] = PROJ_KEEP(accx[q]);
 #ifndef XNO_MIDPOLL
         if (((XMIDPOLL >> rt) & 1) && pendu) {
           check();
@@ -698,10 +722,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     auto mm = [&](int rt, f32x4_t (&acc)[XQ]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < XQ; ++q) {
-        float a0, a1, a2, a3;
-        unpack2<TI>(accp[rt][q].x, a0, a1);
-        unpack2<TI>(accp[rt][q].y, a2, a3);
-        acc[q] = f32x4_t{a0, a1, a2, a3};
+        acc[q] = PROJ_TAKE(accp[rt][q]);
       }
 #pragma unroll
       for (int ks = 0; ks < XNSH; ++ks) {
@@ -752,10 +773,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         if (ks == 0) {
 #pragma unroll
           for (int q = 0; q < XQ; ++q) {
-            float a0, a1, a2, a3;
-            unpack2<TI>(accp[rt][q].x, a0, a1);
-            unpack2<TI>(accp[rt][q].y, a2, a3);
-            acc[q] = f32x4_t{a0, a1, a2, a3};
+            acc[q] = PROJ_TAKE(accp[rt][q]);
           }
         }
         const int idx = rt * XNSH + ks;
