@@ -575,7 +575,7 @@ def test_cluster_forward_with_fused_projection_matches_two_kernel_form(lib, dtyp
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("n_seq,K", [(2400, 34), (1300, 5), (1153, 8), (12832, 34)])
+@pytest.mark.parametrize("n_seq,K", [(2400, 34), (1300, 5), (1153, 8), (1300, 1), (2305, 2), (12832, 34)])
 def test_cluster_forward_in_rounds_on_the_band_path(lib, dtype, n_seq, K):
     """Round 6: the band path (espnet2 BSRNN's rnn_band, reference twin baseline_code/models/bsrnn_flowse.py:296-299: many short sequences) through the
     fused cluster forward in ROUNDS - every co-resident cluster keeps its weights and takes 64 sequences per round; the hand-off's step counter runs on
@@ -611,6 +611,10 @@ def test_cluster_forward_in_rounds_on_the_band_path(lib, dtype, n_seq, K):
         assert torch.equal(h1, h[sl]) and torch.equal(c1, c[sl]) and torch.equal(g1, g[sl]), (s0, s1)
     g3, h3, c3, e3 = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], save=False, **sm)
     assert g3 is None and c3 is None and torch.equal(h3, h) and int(e3.item()) == 0
+    if dtype == torch.float16 and n_seq <= 2400:      # the instance that writes h once more in bf16 (f16-forward training without the mixed-operand weight gradients)
+        g4, h4, c4, e4, h4b = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], bf16_copy=True, **sm)
+        assert int(e4.item()) == 0 and torch.equal(h4, h) and torch.equal(g4, g) and torch.equal(c4, c)
+        assert torch.equal(h4b[:, :2 * H], h[:, :2 * H].float().to(torch.bfloat16)) and torch.all(h4b[:, 2 * H:] == 0)
 
 
 def test_cluster_forward_in_rounds_on_the_time_geometry(lib):
