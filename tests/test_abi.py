@@ -99,3 +99,22 @@ def test_product_package_calls_no_vendor_math_library():
         needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
         for libname in ("rocblas", "hipblas", "rocfft", "hipfft", "MIOpen", "rccl"):
             assert libname not in needed, libname
+
+
+def test_cluster_forward_plan_in_rounds(lib):
+    """Round 6: urse_lstm_clusterx_plan = {C, clusters per direction, sequences per cluster, rows_pad, hx elements, counters, rounds}.  Up to clusters x 64
+    sequences per direction it is urse_lstm_cluster_plan's geometry in one round; above, every cluster takes 64 per round.  (No GPU here: the library plans
+    for 256 CUs; a reservation leaves fewer clusters and more rounds.)"""
+    plan = (ctypes.c_int64 * 7)()
+    one = (ctypes.c_int64 * 6)()
+    assert lib.urse_lstm_clusterx_plan(392, 416, 1088, 0, plan) == 0 and lib.urse_lstm_cluster_plan(392, 416, 1088, 0, one) == 0
+    assert list(plan)[:4] == list(one)[:4] and plan[5] == one[5] and plan[6] == 1 and plan[0] == 7 and plan[1] == 18
+    assert lib.urse_lstm_clusterx_plan(392, 416, 1152, 0, plan) == 0 and plan[6] == 1
+    assert lib.urse_lstm_cluster_plan(392, 416, 1153, 0, one) != 0                           # the one-round plan refuses ...
+    assert lib.urse_lstm_clusterx_plan(392, 416, 1153, 0, plan) == 0 and list(plan)[1:4] == [18, 64, 64] and plan[6] == 2      # ... this one takes a second round
+    assert lib.urse_lstm_clusterx_plan(392, 416, 12832, 0, plan) == 0 and plan[6] == 12      # the band path at C2
+    hx = ctypes.c_int64()
+    assert lib.urse_lstm_clusterx_hx_elems(392, 416, 12832, 0, ctypes.byref(hx)) == 0 and hx.value == plan[4] == 2 * 2 * 18 * 64 * 432
+    assert lib.urse_lstm_clusterx_plan(392, 416, 12832, 32, plan) == 0 and plan[1] == 15 and plan[6] == 14      # beside 32 reserved CUs
+    assert lib.urse_lstm_clusterx_plan(392, 416, 12832, 250, plan) != 0                      # no room for a single cluster
+    assert lib.urse_lstm_clusterx_plan(768, 768, 100, 0, plan) != 0                          # not this kernel's shape
