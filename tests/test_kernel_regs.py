@@ -18,8 +18,12 @@ C2_STEP = [
     "urse::lstm_bwd_nsplit_kernel<392, 0, 0>",
     "urse::lstm_bwd_kernel<unsigned short, 2, 4, 8, 0, 392, 0, 1, 1>",
     "urse::lstm_fwd_rwx_kernel<392, 416, 224, true, unsigned short, false>",      # the band path's forward beside a CU reservation (otherwise: the cluster forward in rounds)
-    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true>",
-    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, false>",
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true, 4>",
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, false, 4>",
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, false, 1>",      # small-batch inference: one / two row tiles per step (round 6)
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, false, 2>",
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true, 1>",
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true, 2>",
     "gemm_tn_dma_kernel<7, 2, 0>",
     "gemm_tn_dma_kernel<7, 2, 1>",          # f16-forward training: fc gradient against the f16 h (round 6)
     "gemm_nt_dma_gnb_kernel",

@@ -636,3 +636,39 @@ def test_cluster_forward_in_rounds_on_the_time_geometry(lib):
     g, h, c, e = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], **sm)
     assert int(e.item()) == 0
     assert (h[:, :2 * H].float().cpu() - y).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,K,path,nt", [(2, 30, 34, "time", 1), (12, 12, 34, "time", 2), (1, 250, 34, "band", 1), (7, 401, 34, "time", 1), (8, 40, 34, "time", 2), (14, 9, 34, "time", 2)])
+def test_cluster_forward_instances_of_one_and_two_row_tiles(lib, monkeypatch, dtype, B, T, K, path, nt):
+    """Round 6: launches whose plan gives a cluster at most 16 / 32 sequences (small batches: the time path of B <= 8 / 16 utterances at 48 kHz, where an inference
+    forward is 401 steps of hand-off latency) run instances of the fused cluster forward that gather, fetch, multiply and store ONE / TWO row tiles of 16 per step
+    (template parameter NT).  A sequence's arithmetic is the same in every instance: h, c and the saved gates are bit-identical to the full instance (forced with
+    URSE_CLUSTERX_NT=4), with and without saving."""
+    from urgent2026_challenge_track1_amd import ops
+    N, H, dev = 196, 392, "cuda"
+    torch.manual_seed(13)
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True)
+    cat = lambda a, b: torch.cat([a, b]).detach().to(dev).contiguous()
+    pk = ops.lstm_pack(cat(lstm.weight_ih_l0, lstm.weight_ih_l0_reverse), cat(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse),
+                       cat(lstm.bias_ih_l0, lstm.bias_ih_l0_reverse), cat(lstm.bias_hh_l0, lstm.bias_hh_l0_reverse), N, H, dtype)
+    M = B * T * K
+    x = torch.randn(B, T, K, N)
+    sm = dict(n_seq=B * K, seq_len=T, inner=K, outer=T * K, stride=K) if path == "time" else dict(n_seq=B * T, seq_len=K, inner=1, outer=K, stride=1)
+    plan = ops.lstm_clusterx_plan(H, pk["Hp"], sm["n_seq"])
+    bound = -(-sm["n_seq"] // (plan[1] - 2))      # the instance is chosen for the rows a cluster can get once the XCD-aware formation has left two clusters per direction empty
+    assert plan[6] == 1 and (bound <= 16 if nt == 1 else 16 < bound <= 32), (plan, bound)
+    xr = ops.pack2d(x.reshape(M, N).to(dev), M, pk["Np"], dtype)
+    monkeypatch.delenv("URSE_CLUSTERX_NT", raising=False)
+    g1, h1, c1, e1 = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], **sm)
+    _, h1i, _, e1i = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], save=False, **sm)
+    monkeypatch.setenv("URSE_CLUSTERX_NT", "4")
+    g4, h4, c4, e4 = ops.lstm_fwd_clusterx(xr, pk["wihq"], pk["whhq"], pk["bias"], N, H, pk["Hp"], **sm)
+    assert int(e1.item()) == 0 and int(e1i.item()) == 0 and int(e4.item()) == 0
+    assert torch.equal(h1, h4) and torch.equal(c1, c4) and torch.equal(g1, g4) and torch.equal(h1i, h4)
+    if M <= 40000:
+        if path == "time":
+            y = lstm(x.permute(0, 2, 1, 3).reshape(B * K, T, N))[0].detach().reshape(B, K, T, 2 * H).permute(0, 2, 1, 3).reshape(-1, 2 * H)
+        else:
+            y = lstm(x.reshape(B * T, K, N))[0].detach().reshape(-1, 2 * H)
+        assert (h1[:, :2 * H].float().cpu() - y).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 2.5e-3)

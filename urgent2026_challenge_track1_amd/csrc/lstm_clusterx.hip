@@ -144,8 +144,12 @@ __device__ unsigned long long g_xstamps[512 * 16];
 #define XST(slot) do { } while (0)
 #endif
 
-template <typename TI, bool H2, bool SAVE>
+// NT (round 6): row tiles of 16 sequences a cluster multiplies per step - 4 (64 sequences per cluster), or 1 / 2 for launches whose plan gives a cluster at most 16 / 32
+// (small batches: the time path of B <= 8 / 16 utterances); everything per row - gather passes, x DMAs, projection, recurrent product, cell update, the helper's
+// pieces - is bounded by it at compile time, a sequence's arithmetic is the same in every instance (bit-identical results)
+template <typename TI, bool H2, bool SAVE, int NT = 4>
 __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXArgs p) {
+  static_assert(NT == 1 || NT == 2 || NT == 4, "row tiles per step");
   static_assert(!H2 || __is_same(TI, f16_t), "the bf16 copy of h exists in the f16 mode only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         if (nm > 0 && XROWS * ns < p.n_seq) rows_m = (p.n_seq - XROWS * ns + nm - 1) / nm;
         int rows_s = (p.n_seq - rows_m * nm + ns - 1) / ns;
         if (p.rounds > 1) rows_s = rows_m = XROWS;                         // (rounds: 64 sequences per cluster and round, the single-XCD clusters first)
-        if (rows_m <= XROWS && rows_s <= XROWS && rows_s > 0) {
+        if (rows_m <= NT * 16 && rows_s <= NT * 16 && rows_s > 0) {         // (what this instance's row tiles hold; otherwise the static clusters of the plan)
           mode = 1;
           int ci, jj, lc_;
           if ((int)rank < f_me * p.C) { ci = before_full + (int)rank / p.C; jj = (int)rank % p.C; lc_ = 1; }
@@ -271,6 +275,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     for (int i = 0; i < MAXDW; ++i) {
       if (i >= ndw) continue;
       const int pr = pr0 + i;                                              // row pair
+      if (NT < 4 && pr >= NT * 8) continue;                                // (rows past the instance's row tiles are never read)
       const unsigned vo = xrow[2 * pr + (lane_ < 30 ? 0 : 1)] + xpiece;
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds_g0 + (unsigned)(par * (XROWS * GP) + 2 * pr * GP));
 #ifndef XABL_NO_DMA      // timing diagnostics (wrong results): XABL_NO_DMA, XABL_NO_HSTORE, XABL_NO_PROJ, XABL_NO_REC, XABL_NO_AREAD (no A fragment reads), XABL_NO_CELL, XABL_NO_GATHER, XABL_NO_XSTORE, XABL_NO_HOUT
@@ -313,7 +318,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     __syncthreads();                                                      // the round's row tables are written
     fetch4(0, (dir ? p.seq_len - 1 : 0) * stride_i, lane_h);                 // x_0 -> tile 0 (every wave its rows; B0 below)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int NG = XROWS * GPC / 64, NC = XROWS * (XUW * 4 / 16) / 64;     // 30 gates pieces, 14 c pieces per lane_h and step
+    constexpr int NG = (NT * 16 * GPC + 63) / 64, NC = (NT * 16 * (XUW * 4 / 16) + 63) / 64;     // 30 gates pieces, 14 c pieces per lane and step (NT = 4)
     constexpr int GC = XUW * 8 / 16, CC = XUW * 4 / 16;
     unsigned og[NG], oc[NC];
 #pragma unroll
@@ -458,6 +463,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
   // clusters of the XCD-aware formation have 32 - moves 36 rows, not 64; the rows past its last sequence compute on zero inputs and are stored nowhere),
   // so that "which chunks does this thread wait for" is a scalar, not a per-lane mask.  With fewer than 64 rows the seven left-over threads
   // duplicate threads 0 .. 6 (same loads, same LDS writes) instead of taking row 63.
+  constexpr int HLt = NT == 4 ? HL : (NT * 16 + HRP - 1) / HRP;           // passes an instance of fewer row tiles can need (2 / 4)
   const int nact = nrows >= XROWS ? HL : (nrows + HRP - 1) / HRP;
   const bool full = nrows >= XROWS;
   (void)tailt;
@@ -531,16 +537,16 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
     // (the projection's sums wait for the gather as 16-bit pairs of the operand format - what the two-kernel form stores in gx - : 16 registers
     //  instead of 32 across barrier 1)
 #if XPROJ_F32
-    f32x4_t accp[4][XQ];
+    f32x4_t accp[NT][XQ];
 #else
-    uint2 accp[4][XQ];
+    uint2 accp[NT][XQ];
 #endif
     {
       // the thread's chunks of the cluster's h_{t-1}, all of them in flight at once.  Which chunks are still awaited is kept per WAVE (a scalar mask:
       // a chunk index is re-requested for the whole wave while any of its lanes misses a tag - re-reading a piece that has arrived is harmless, the plane
       // is not rewritten before every member has passed this step), so the loop carries no per-lane bookkeeping
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      uint4 hn[HL];
+      uint4 hn[HLt];
       bool live = gs > 0 && !dead && nact > 0;                            // (dead: this wave has seen a hand-off time out - it stops waiting;
                                                                           //  nact == 0: a cluster the XCD-aware formation left without sequences)
 #ifdef XABL_NO_GATHER
@@ -552,7 +558,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       //  a scalar select of the offset; per-chunk branches around the loads made the compiler keep two generations of the 28 registers alive)
       auto load_all = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < HL; ++i) {
+        for (int i = 0; i < HLt; ++i) {
           const int so = (int)(sbase + (unsigned)(i < nact ? HRP * pitch * i : 0));
           const u32x4 r = tailw ? __builtin_amdgcn_raw_buffer_load_b128(rs, i < nact ? gb - i * gcorr : gb, so, 16)
                                 : __builtin_amdgcn_raw_buffer_load_b128(rs, gb, so, 16);
@@ -562,14 +568,14 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       if (live) load_all();
       else {
 #pragma unroll
-        for (int i = 0; i < HL; ++i) hn[i] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < HLt; ++i) hn[i] = make_uint4(0, 0, 0, 0);
       }
       unsigned pendu = live ? 1u : 0u;
       // a chunk has arrived when all eight tags are the previous step's: AND / OR trees over the round's chunks, one ballot per round
       auto check = [&]() __attribute__((always_inline)) {
         unsigned acc_and = hn[0].x & hn[0].y & hn[0].z & hn[0].w, acc_or = hn[0].x | hn[0].y | hn[0].z | hn[0].w;
 #pragma unroll
-        for (int i = 1; i < HL; ++i) {
+        for (int i = 1; i < HLt; ++i) {
           acc_and &= hn[i].x & hn[i].y & hn[i].z & hn[i].w;
           acc_or |= hn[i].x | hn[i].y | hn[i].z | hn[i].w;
         }
@@ -596,7 +602,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #pragma unroll
       for (int i = 0; i < XPD; ++i) pa[i] = prd(i);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
+      for (int rt = 0; rt < NT; ++rt) {
         f32x4_t accx[XQ];
 #pragma unroll
         for (int q = 0; q < XQ; ++q) accx[q] = *reinterpret_cast<const f32x4_t*>(smem + bq + q * 64);
@@ -604,7 +610,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         for (int k = 0; k < XNSP; ++k) {
           const int idx = rt * XNSP + k;
           const uint4 a = pa[idx % XPD];
-          if (idx + XPD < 4 * XNSP) pa[idx % XPD] = prd(idx + XPD);
+          if (idx + XPD < NT * XNSP) pa[idx % XPD] = prd(idx + XPD);
 #pragma unroll
 #ifndef XABL_NO_PROJ
           for (int q = 0; q < XQ; ++q) accx[q] = mfma16<TI>(wreg[q][k], a, accx[q]);
@@ -622,6 +628,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #endif
       }
 #else
+      static_assert(NT == 4, "the grouped projection exists for the full instance only");
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         f32x4_t accx[XQ];
@@ -677,14 +684,14 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
       const unsigned km = step == 0 ? 0u : ~TAGM;
       if (live && (tag_prev || step == 0)) {
 #pragma unroll
-        for (int i = 0; i < HL; ++i) { hn[i].x &= km; hn[i].y &= km; hn[i].z &= km; hn[i].w &= km; }
+        for (int i = 0; i < HLt; ++i) { hn[i].x &= km; hn[i].y &= km; hn[i].z &= km; hn[i].w &= km; }
       }
       if (!tailw) {
 #pragma unroll
-        for (int i = 0; i < HL; ++i) *reinterpret_cast<uint4*>(smem + gb + HRP * pitch * i) = hn[i];      // (a dead pass wrote a copy of pass 0 into rows nobody stores)
+        for (int i = 0; i < HLt; ++i) *reinterpret_cast<uint4*>(smem + gb + HRP * pitch * i) = hn[i];      // (a dead pass wrote a copy of pass 0 into rows nobody stores)
       } else {
 #pragma unroll
-        for (int i = 0; i < HL; ++i) *reinterpret_cast<uint4*>(smem + gb - i * gcorr + HRP * pitch * i) = hn[i];
+        for (int i = 0; i < HLt; ++i) *reinterpret_cast<uint4*>(smem + gb - i * gcorr + HRP * pitch * i) = hn[i];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -778,7 +785,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
         }
         const int idx = rt * XNSH + ks;
         const uint4 a = ab[idx % XAD];
-        if (idx + XAD < 4 * XNSH) ab[idx % XAD] = rd(idx + XAD);
+        if (idx + XAD < NT * XNSH) ab[idx % XAD] = rd(idx + XAD);
 #pragma unroll
         for (int q = 0; q < XQ; ++q) acc[q] = mfma16<TI>(breg[q][ks], a, acc[q]);
       };
@@ -820,7 +827,7 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #endif
       XST(12);
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt) {
+      for (int rt = 0; rt < NT - 1; ++rt) {
 #pragma unroll
         for (int ks = 0; ks < XNSH; ++ks) {
           __builtin_amdgcn_sched_barrier(0);
@@ -834,11 +841,12 @@ __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXAr
 #pragma unroll
       for (int st = 0; st < 13; ++st) {
         __builtin_amdgcn_sched_barrier(0);
-        cell_stage(3, st, accS[1]);
+        cell_stage(NT - 1, st, accS[(NT - 1) & 1]);
       }
     }
 #else
     {
+      static_assert(NT == 4, "the compiler-ordered phase 2 exists for the full instance only");
       f32x4_t accA[XQ], accB[XQ];
       mm(0, accA);
       mm(1, accB);
@@ -1052,19 +1060,31 @@ extern "C" int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* w
     (void)hipMemsetAsync(counters, 0, sizeof(unsigned) * plan[5], st);
     p.xws = (unsigned*)counters;
   }
-#define URSE_CLX_ATTR(...) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_clusterx_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-  static bool once = (URSE_CLX_ATTR(bf16_t, false, true), URSE_CLX_ATTR(bf16_t, false, false), URSE_CLX_ATTR(f16_t, false, true), URSE_CLX_ATTR(f16_t, false, false),
-                      URSE_CLX_ATTR(f16_t, true, true), true);
-  (void)once;
-#undef URSE_CLX_ATTR
+  // row tiles per step: 64 sequences per cluster (and every launch in rounds) take the full instance; a plan of at most 16 / 32 per cluster - the time path of a small
+  // batch: B <= 8 / 16 utterances at 48 kHz - the instances that gather, fetch, multiply and store one / two row tiles (URSE_CLUSTERX_NT = 1 | 2 | 4 forces one that fits)
+  // (the XCD-aware formation re-balances the sequences over the clusters that sit inside one XCD - two mixed clusters per direction without any is its usual case -,
+  //  so the instance is chosen for n_seq over two clusters fewer; a formation that still needs more rows per cluster falls back to the plan's static clusters)
+  const int rows_bound = (xcd_aware && plan[5] >= 9 && plan[1] > 2) ? (int)((n_seq + plan[1] - 3) / (plan[1] - 2)) : (int)plan[2];
+  int nt = (plan[6] > 1 || rows_bound > 32) ? 4 : (rows_bound > 16 ? 2 : 1);
+  if (const char* e = getenv("URSE_CLUSTERX_NT")) {
+    const int f = atoi(e);
+    if ((f == 1 || f == 2 || f == 4) && f >= nt) nt = f;
+  }
   const size_t lds = clusterx_lds();
   dim3 grid(p.C * p.ncl, 2), blk(XTHR + 64);
   note_launch(URSE_KV_LSTM_FWD_CLUSTERX);
-  if (dtype == URSE_F16 && hout_bf16 && save) hipLaunchKernelGGL((lstm_fwd_clusterx_kernel<f16_t, true, true>), grid, blk, lds, st, p);
-  else if (dtype == URSE_F16 && save) hipLaunchKernelGGL((lstm_fwd_clusterx_kernel<f16_t, false, true>), grid, blk, lds, st, p);
-  else if (dtype == URSE_F16) hipLaunchKernelGGL((lstm_fwd_clusterx_kernel<f16_t, false, false>), grid, blk, lds, st, p);
-  else if (save) hipLaunchKernelGGL((lstm_fwd_clusterx_kernel<bf16_t, false, true>), grid, blk, lds, st, p);
-  else hipLaunchKernelGGL((lstm_fwd_clusterx_kernel<bf16_t, false, false>), grid, blk, lds, st, p);
+#define URSE_CLX_GO(...) do { \
+    static bool once_ = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_clusterx_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); \
+    (void)once_; \
+    hipLaunchKernelGGL((lstm_fwd_clusterx_kernel<__VA_ARGS__>), grid, blk, lds, st, p); } while (0)
+#define URSE_CLX_NT(...) do { if (nt == 1) URSE_CLX_GO(__VA_ARGS__, 1); else if (nt == 2) URSE_CLX_GO(__VA_ARGS__, 2); else URSE_CLX_GO(__VA_ARGS__, 4); } while (0)
+  if (dtype == URSE_F16 && hout_bf16 && save) URSE_CLX_NT(f16_t, true, true);
+  else if (dtype == URSE_F16 && save) URSE_CLX_NT(f16_t, false, true);
+  else if (dtype == URSE_F16) URSE_CLX_NT(f16_t, false, false);
+  else if (save) URSE_CLX_NT(bf16_t, false, true);
+  else URSE_CLX_NT(bf16_t, false, false);
+#undef URSE_CLX_NT
+#undef URSE_CLX_GO
   URSE_CHECK_LAUNCH("urse_lstm_clusterx_fwd");
   return URSE_OK;
 }
