@@ -24,6 +24,8 @@ C2_STEP = [
     "urse::lstm_fwd_clusterx_kernel<unsigned short, false, false, 2>",
     "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true, 1>",
     "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true, 2>",
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, false, 3>",
+    "urse::lstm_fwd_clusterx_kernel<unsigned short, false, true, 3>",
     "gemm_tn_dma_kernel<7, 2, 0>",
     "gemm_tn_dma_kernel<7, 2, 1>",          # f16-forward training: fc gradient against the f16 h (round 6)
     "gemm_nt_dma_gnb_kernel",

@@ -144,12 +144,12 @@ __device__ unsigned long long g_xstamps[512 * 16];
 #define XST(slot) do { } while (0)
 #endif
 
-// NT (round 6): row tiles of 16 sequences a cluster multiplies per step - 4 (64 sequences per cluster), or 1 / 2 for launches whose plan gives a cluster at most 16 / 32
-// (small batches: the time path of B <= 8 / 16 utterances); everything per row - gather passes, x DMAs, projection, recurrent product, cell update, the helper's
+// NT (round 6): row tiles of 16 sequences a cluster multiplies per step - 4 (64 sequences per cluster), or 1 / 2 / 3 for launches whose plan gives a cluster at most 16 / 32 / 48
+// (small batches: the time path of up to 7 / 14 / 21 utterances); everything per row - gather passes, x DMAs, projection, recurrent product, cell update, the helper's
 // pieces - is bounded by it at compile time, a sequence's arithmetic is the same in every instance (bit-identical results)
 template <typename TI, bool H2, bool SAVE, int NT = 4>
 __global__ void __launch_bounds__(XTHR + 64) lstm_fwd_clusterx_kernel(ClusterXArgs p) {
-  static_assert(NT == 1 || NT == 2 || NT == 4, "row tiles per step");
+  static_assert(NT >= 1 && NT <= 4, "row tiles per step");
   static_assert(!H2 || __is_same(TI, f16_t), "the bf16 copy of h exists in the f16 mode only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
@@ -1061,14 +1061,14 @@ extern "C" int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* w
     p.xws = (unsigned*)counters;
   }
   // row tiles per step: 64 sequences per cluster (and every launch in rounds) take the full instance; a plan of at most 16 / 32 per cluster - the time path of a small
-  // batch: B <= 8 / 16 utterances at 48 kHz - the instances that gather, fetch, multiply and store one / two row tiles (URSE_CLUSTERX_NT = 1 | 2 | 4 forces one that fits)
+  // batch: B <= 8 / 16 utterances at 48 kHz - the instances that gather, fetch, multiply and store one / two row tiles (URSE_CLUSTERX_NT = 1 .. 4 forces one that fits)
   // (the XCD-aware formation re-balances the sequences over the clusters that sit inside one XCD - two mixed clusters per direction without any is its usual case -,
   //  so the instance is chosen for n_seq over two clusters fewer; a formation that still needs more rows per cluster falls back to the plan's static clusters)
   const int rows_bound = (xcd_aware && plan[5] >= 9 && plan[1] > 2) ? (int)((n_seq + plan[1] - 3) / (plan[1] - 2)) : (int)plan[2];
-  int nt = (plan[6] > 1 || rows_bound > 32) ? 4 : (rows_bound > 16 ? 2 : 1);
+  int nt = (plan[6] > 1 || rows_bound > 48) ? 4 : (rows_bound > 32 ? 3 : (rows_bound > 16 ? 2 : 1));
   if (const char* e = getenv("URSE_CLUSTERX_NT")) {
     const int f = atoi(e);
-    if ((f == 1 || f == 2 || f == 4) && f >= nt) nt = f;
+    if (f >= 1 && f <= 4 && f >= nt) nt = f;
   }
   const size_t lds = clusterx_lds();
   dim3 grid(p.C * p.ncl, 2), blk(XTHR + 64);
@@ -1077,7 +1077,7 @@ extern "C" int urse_lstm_clusterx_fwd(const void* xn, int64_t ldx, const void* w
     static bool once_ = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_clusterx_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); \
     (void)once_; \
     hipLaunchKernelGGL((lstm_fwd_clusterx_kernel<__VA_ARGS__>), grid, blk, lds, st, p); } while (0)
-#define URSE_CLX_NT(...) do { if (nt == 1) URSE_CLX_GO(__VA_ARGS__, 1); else if (nt == 2) URSE_CLX_GO(__VA_ARGS__, 2); else URSE_CLX_GO(__VA_ARGS__, 4); } while (0)
+#define URSE_CLX_NT(...) do { if (nt == 1) URSE_CLX_GO(__VA_ARGS__, 1); else if (nt == 2) URSE_CLX_GO(__VA_ARGS__, 2); else if (nt == 3) URSE_CLX_GO(__VA_ARGS__, 3); else URSE_CLX_GO(__VA_ARGS__, 4); } while (0)
   if (dtype == URSE_F16 && hout_bf16 && save) URSE_CLX_NT(f16_t, true, true);
   else if (dtype == URSE_F16 && save) URSE_CLX_NT(f16_t, false, true);
   else if (dtype == URSE_F16) URSE_CLX_NT(f16_t, false, false);
