@@ -160,6 +160,35 @@ def cpu_baseline(budget_s=170.0):
                                                               d["threads"], os.cpu_count() or 1)}
 
 
+def inference_forward_bench(args, dev):
+    """forward only, what inference.py's enhance_file runs per batch: BSRNN_SE at the benchmarked width on B x 4 s @ 48 kHz, ms per forward.
+    Small batches run the fused cluster forward's one- / two- / three-row-tile instances; extra key, not the headline."""
+    from urgent2026_challenge_track1_amd.bsrnn import BSRNN_SE
+    from urgent2026_challenge_track1_amd import ops
+    res = {"workload": "BSRNN_SE N=%d L=%d forward (eval, no_grad), B x 4 s @ 48 kHz, random weights" % (args.channels, args.layers), "ms_per_forward": {}}
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        m = BSRNN_SE(num_channel=args.channels, num_layer=args.layers, compute_dtype=dt).to(dev).eval()
+        row = {}
+        for B in (1, 4, 16, 32):
+            x = 0.1 * torch.randn(B, 192000, device=dev)
+            lens = torch.full((B,), 192000)
+            with torch.no_grad():
+                m(x, lens, 48000)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    m(x, lens, 48000)
+                torch.cuda.synchronize()
+            row["B%d" % B] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+        ops.poll_kernel_errors(dev if isinstance(dev, torch.device) else torch.device(dev), sync=True)
+        res["ms_per_forward"][name] = row
+        del m
+        torch.cuda.empty_cache()
+    res["utt_per_s_B32_bf16"] = round(32e3 / res["ms_per_forward"]["bf16"]["B32"], 1)
+    res["real_time_factor_B1_f16"] = round(res["ms_per_forward"]["f16"]["B1"] / 4e3, 5)
+    return res
+
+
 def flow_bench(dev, steps=3, single_rank_collectives=False):
     """BASELINE.json configs[3]: BSRNN-Flow (n_fft 1536 / hop 384, N = 384, 6 layers) generative train step at the
     yaml's batch (2 x 4 s @ 48 kHz: forward_step + backward + clip + AdamW + EMA) and the Euler sampler (N = 15) on one utterance."""
@@ -914,6 +943,10 @@ def main():
             torch.cuda.empty_cache()
         if not args.no_flow:
             out["flow_c4"] = flow_bench(dev)
+            try:
+                out["inference_forward"] = inference_forward_bench(args, dev)
+            except Exception as e:
+                out["inference_forward"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_metrics:
         out["metrics_bench"] = metrics_bench(dev, batches=max(1, args.metric_pairs // 2048))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
