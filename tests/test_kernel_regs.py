@@ -56,8 +56,9 @@ C2_STEP = [
 ]
 # C4 (BSRNN-Flow, H = 768): the cluster forward and the other kernels of its step that C2 does not launch
 C4_STEP = [
-    "urse::lstm_fwd_cluster2_kernel<24, 8, 1, unsigned short>",
-    "_ZN4urse24lstm_fwd_cluster2_kernelILi24ELi8ELi1EDF16_EEvNS_12Cluster2ArgsE",      # its f16 instance (this c++filt does not know DF16_)
+    "urse::lstm_fwd_cluster2_kernel<24, 8, 1, unsigned short, false>",      # training (saves): without the step's third barrier (round 6)
+    "urse::lstm_fwd_cluster2_kernel<24, 8, 1, unsigned short, true>",       # forward only: with it
+    "_ZN4urse24lstm_fwd_cluster2_kernelILi24ELi8ELi1EDF16_Lb1EEEvNS_12Cluster2ArgsE",      # the f16 forward-only instance (this c++filt does not know DF16_)
     "gemm_tn_dma_kernel<8, 2, 0>",
     "urse::lstm_bwd_split_kernel<1, 3>",      # the cooperative split BPTT at H = 768: 16 rows per cluster (urse_lstm_split_plan(768, 96) -> rows 16), three unit tiles per wave
 ]

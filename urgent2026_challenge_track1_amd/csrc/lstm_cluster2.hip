@@ -59,7 +59,7 @@ __device__ __forceinline__ uint4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned of
 
 }  // namespace c2
 
-template <int NSLAB, int NW, int QPW, typename TI = bf16_t>
+template <int NSLAB, int NW, int QPW, typename TI = bf16_t, bool SYNC3 = true>
 __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args p) {
   using namespace c2;
   constexpr int NTHR = NW * 64, UW = NW * QPW * 4, HPB = NSLAB * 64;       // units per workgroup, bytes per h row
@@ -279,20 +279,27 @@ __global__ void __launch_bounds__(NW * 64) lstm_fwd_cluster2_kernel(Cluster2Args
         }
       }
     }
-    __syncthreads();   // hstage / htile are rewritten by the next step
+    // (round 6: the third barrier of a step is not needed for correctness - the h tile is rewritten by the next step's gather, and every reader finished its MFMAs before
+    //  barrier 2; the staging tile by the next step's cell update behind ITS barrier 1, and every reader has published before it arrives there.  Measured on the flow leg,
+    //  both orders twice (profiles/r06_ab_c2_sync3_v1.log): without it the train step 87.6 -> 86.4 ms, but the sampler 257.7 -> 267 ms: in the forward-only step it holds
+    //  the early waves back from polling while the last ones publish.  So it stays where nothing is saved: template parameter SYNC3 = !save - as a run-time
+    //  `if (!p.save)` the forward-only step lost the same 3 %, barrier and all: `r06_ab_c2_sync3_cond_v1.log`.)
+    if constexpr (SYNC3) __syncthreads();
   }
 }
 
 template <int NSLAB, int NW, int QPW>
 static int launch_cluster2(const Cluster2Args& p, int f16, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, bf16_t>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, f16_t>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-  (void)once;
   const size_t lds = (size_t)C2ROWS * lds_frag_pitch(NSLAB * 64) + (size_t)C2ROWS * NW * QPW * 4 * 2 + 16;
-  if (f16) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, f16_t>), dim3(p.C * p.ncl, 2), dim3(NW * 64), lds, st, p);
-  else hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, bf16_t>), dim3(p.C * p.ncl, 2), dim3(NW * 64), lds, st, p);
+#define URSE_C2_GO(...) do { \
+    static bool once_ = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, __VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); \
+    (void)once_; \
+    hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<NSLAB, NW, QPW, __VA_ARGS__>), dim3(p.C * p.ncl, 2), dim3(NW * 64), lds, st, p); } while (0)
+  if (f16 && p.save) URSE_C2_GO(f16_t, false);
+  else if (f16) URSE_C2_GO(f16_t, true);
+  else if (p.save) URSE_C2_GO(bf16_t, false);
+  else URSE_C2_GO(bf16_t, true);
+#undef URSE_C2_GO
   URSE_CHECK_LAUNCH("urse_lstm_cluster2_fwd");
   return URSE_OK;
 }
