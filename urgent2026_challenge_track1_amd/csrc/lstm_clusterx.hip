@@ -71,7 +71,7 @@ constexpr int XNSP = 6;            // k-slabs of W_ih the PROJECTION multiplies:
 #define XDWB XDW                   // ... of waves 4 .. 6
 #endif
 #ifndef XMIDPOLL
-#define XMIDPOLL 0x2               // behind which row tiles of the projection the wave looks at the gather (bit rt)
+#define XMIDPOLL 0x2               // behind which row tiles of the projection the wave looks at the gather (bit rt); round 6 re-measured with the shorter projection: one look behind tile 0, 1 or 2 is the same step (28.1 - 28.6 ms of forward per train step), two or three looks cost 10 ms (profiles/r06_ab_midpoll_v1.log)
 #endif
 #ifndef XPROJ_F32
 #define XPROJ_F32 1                 // x W_ih^T + b waits for the gather in f32 (round 6: the hand-interleaved phase 2 left the 16 registers; no pack / unpack: 48 vector instructions per wave
